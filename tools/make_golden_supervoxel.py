@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/supervoxel_*.npz by RUNNING the reference's own codelibrary templates.
+
+Runs only in the build container: needs oracle/_ref/libf4l_ref.so, which oracle/Makefile compiles from
+the headers where they lie under /root/reference/cpp_core/supervoxel_segmentation (see
+oracle/ref_harness.cpp).  Output is data only: the float32 input cloud and what the reference computed
+for it (kNN indices / squared distances, PCA normals, #grid cells, #supervoxels, labels).
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, ROOT)
+from oracle import oracle as O  # noqa: E402
+
+
+def surface_cloud(seed, n, extent=1.0, noise=0.002):
+    rng = np.random.default_rng(seed)
+    xy = rng.uniform(0, extent, (n, 2))
+    z = 0.1 * np.sin(6 * xy[:, 0] / extent) * np.cos(5 * xy[:, 1] / extent) + 0.03 * np.sin(23 * xy[:, 0] / extent)
+    z = z + rng.normal(0, noise, n)
+    return np.c_[xy, z].astype(np.float32)
+
+
+def volume_cloud(seed, n):
+    rng = np.random.default_rng(seed)
+    return rng.uniform(-1, 1, (n, 3)).astype(np.float32)
+
+
+def lattice_cloud(m):
+    g = np.arange(m, dtype=np.float32) * np.float32(0.125)  # exactly representable -> exact distance ties
+    x, y = np.meshgrid(g, g, indexing="ij")
+    return np.stack([x.ravel(), y.ravel(), np.zeros(m * m, np.float32)], axis=1)
+
+
+def main():
+    if not O.have_ref():
+        raise SystemExit("oracle/_ref/libf4l_ref.so missing: run `make -C oracle` in the build container")
+    out_dir = os.path.join(ROOT, "tests", "golden")
+    cases = [
+        ("surf_s0_n2000_k15", surface_cloud(0, 2000), 15, 0.15, True),
+        ("surf_s1_n2000_k30", surface_cloud(1, 2000), 30, 0.2, True),
+        ("vol_s2_n2000_k15", volume_cloud(2, 2000), 15, 0.5, True),
+        ("georef_s3_n3000_k30", surface_cloud(3, 3000, extent=20.0, noise=0.01) + np.array([2647.0, 1177.0, 1500.0], np.float32), 30, 2.5, True),
+        ("lattice_m24_k9", lattice_cloud(24), 9, 0.5, True),
+        ("surf_s4_n20000_k30", surface_cloud(4, 20000), 30, 0.1, False),
+    ]
+    for name, xyz, k, res, with_d2 in cases:
+        r = O.ref_supervoxel(xyz, k, res)
+        arrays = dict(xyz=xyz, k=np.int32(k), resolution=np.float64(res), knn_idx=r["knn_idx"],
+                      normals=r["normals"], labels=r["labels"], n_supervoxels=np.int32(r["n_supervoxels"]),
+                      n_grid_cells=np.int32(r["n_grid_cells"]))
+        if with_d2:
+            arrays["knn_d2"] = r["knn_d2"]
+        path = os.path.join(out_dir, f"supervoxel_{name}.npz")
+        np.savez_compressed(path, **arrays)
+        print(f"{name}: n={xyz.shape[0]} k={k} res={res} K={r['n_supervoxels']} cells={r['n_grid_cells']} "
+              f"-> {os.path.getsize(path)} bytes")
+
+
+if __name__ == "__main__":
+    main()
