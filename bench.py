@@ -1,0 +1,176 @@
+#!/usr/bin/env python3
+"""bench.py -- M source-points/s through 20-iteration piecewise ICP on a synthetic two-epoch cloud.
+
+Contract (driver):  python bench.py --gpus N --steps K --warmup W   (N > 1 via torch.distributed.run, one rank per GPU)
+prints ONE JSON line on rank 0.
+
+A "step" is one pass of the hot path over one tile, inputs resident in HBM when the clock starts:
+    per-patch weighted Kabsch init (f4l_kabsch_batched on the 1-NN correspondences)
+ -> 20 fixed point-to-point ICP iterations per patch (f4l_piecewise_icp, max_corr_dist 0.1 m, no early exit)
+ -> dense displacement rows [s, T s] for every source point (f4l_apply_transform)
+ -> (N > 1) RCCL all-gather of the per-patch results (T, fitness, rmse, iters: 152 B per patch).
+Workload at N = 1: BASELINE.json configs[1] ("C2_1M_2k": 1 M points per epoch, 45 x 45 = 2025 patches).
+Scaling is weak: tiles are the reference's independent units (<= 1 M points each, configs/landslide/*.yaml
+max_pts_per_tile), every rank owns one tile and only the per-patch results are exchanged.
+
+Extra objects on the JSON line:
+  roofline     dominant kernel = icp_kernel; achieved = algorithmic bytes per launch (20 iters x 24 B per source
+               point) / its mean duration measured with events on the launch stream; peak = 8 TB/s.
+  cpu_baseline the C oracle (oracle/f4l_oracle.c, 1 thread, "port") timed on a bounded sample of the same patches.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is what a copy achieves
+ICP_BYTES_PER_PT_ITER = 24  # 12 B source point + 12 B share of the target patch
+MAX_ITER = 20
+MAX_CORR = 0.1
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="C2_1M_2k")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline budget (0 disables)")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from fusion4landslide_amd import engine, synthetic
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an AMD GPU (no CPU fallback exists for the product path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    cfg = synthetic.CONFIGS[args.config]
+    n, cells, res = cfg["n"], cfg["cells"], cfg["resolution"]
+    d = synthetic.make_patches(n, cells, res, seed=10 * rank)  # every rank owns its own tile
+    P = d["P"]
+    src, tgt = torch.from_numpy(d["src"]).to(dev), torch.from_numpy(d["tgt"]).to(dev)
+    so, to = torch.from_numpy(d["src_off"]).to(dev), torch.from_numpy(d["tgt_off"]).to(dev)
+    eye = torch.eye(4, dtype=torch.float64, device=dev).repeat(P, 1, 1)
+
+    # Kabsch-init correspondences (inputs of the path, produced upstream by matching in the reference):
+    # 1-NN of each source point inside its target patch within 2 x max_corr_dist.  Untimed setup.
+    nn, _ = engine.nn_refine(src, so, tgt, to, eye, torch.full((P,), 2 * MAX_CORR, dtype=torch.float64, device=dev),
+                             max_tgt_patch=d["max_tgt"], return_rows=False)
+    cs_h, ct_h, coff_h = synthetic.correspondences_from_nn(d["src"], d["src_off"], d["tgt"], d["tgt_off"], nn.cpu().numpy())
+    cs, ct, coff = torch.from_numpy(cs_h).to(dev), torch.from_numpy(ct_h).to(dev), torch.from_numpy(coff_h).to(dev)
+
+    gathered = [torch.empty((P, 19), dtype=torch.float64, device=dev) for _ in range(world)] if world > 1 else None
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+
+    def step(i_timed=None):
+        R, t = engine.kabsch_batched(cs, ct, coff, eps=1e-6)
+        T0 = eye.clone()
+        T0[:, :3, :3] = R
+        T0[:, :3, 3] = t
+        if i_timed is not None:
+            ev[i_timed][0].record()
+        out = engine.piecewise_icp(src, so, tgt, to, init_T=T0, max_corr_dist=MAX_CORR, max_iter=MAX_ITER,
+                                   fixed_iters=True, max_src_patch=d["max_src"], max_tgt_patch=d["max_tgt"])
+        if i_timed is not None:
+            ev[i_timed][1].record()
+        rows = engine.apply_transform(src, so, out["T"])
+        if world > 1:
+            packed = torch.cat([out["T"].reshape(P, 16), out["fitness"][:, None], out["rmse"][:, None],
+                                out["iters"].to(torch.float64)[:, None]], dim=1)
+            dist.all_gather(gathered, packed)
+        return out, rows
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out, rows = step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    icp_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if args.steps > 0 else float("nan")
+
+    if rank == 0:
+        ms_per_step = 1e3 * elapsed / max(args.steps, 1)
+        value = world * n / (ms_per_step * 1e-3) / 1e6
+        alg_bytes = ICP_BYTES_PER_PT_ITER * MAX_ITER * n
+        achieved = alg_bytes / (icp_ms * 1e-3) / 1e9
+        line = {
+            "metric": "M-points/sec piecewise ICP (20 iters, two-epoch cloud)",
+            "value": round(value, 3), "unit": "Mpts/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": args.config, "points_per_epoch_per_gpu": n, "patches_per_gpu": P,
+                       "icp": "point2point, 20 fixed iters, max_corr_dist 0.1 m", "parallelism": f"tiles x{world}",
+                       "mean_fitness": round(float(out["fitness"].mean().item()), 4)},
+            "roofline": {"bound": "hbm", "kernel": "icp_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "kernel_ms": round(icp_ms, 4), "algorithmic_bytes": alg_bytes},
+        }
+        if args.cpu_seconds > 0:
+            line["cpu_baseline"] = cpu_baseline(d, cs_h, ct_h, coff_h, args.cpu_seconds)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(d, cs, ct, coff, budget_s):
+    """The oracle (single-thread C port of the same step) on a bounded prefix of the tile's patches."""
+    import numpy as np
+
+    from oracle import oracle as O
+
+    P = d["P"]
+    # calibrate on a few patches, then size the sample to the budget
+    def run(p_lo, p_hi):
+        s0, s1, t0, t1 = d["src_off"][p_lo], d["src_off"][p_hi], d["tgt_off"][p_lo], d["tgt_off"][p_hi]
+        so, to = d["src_off"][p_lo:p_hi + 1] - s0, d["tgt_off"][p_lo:p_hi + 1] - t0
+        co = coff[p_lo:p_hi + 1] - coff[p_lo]
+        c0, c1 = coff[p_lo], coff[p_hi]
+        t = time.perf_counter()
+        R, tt = O.kabsch_batched(cs[c0:c1], ct[c0:c1], co, eps=1e-6)
+        T0 = np.tile(np.eye(4), (p_hi - p_lo, 1, 1))
+        T0[:, :3, :3] = R
+        T0[:, :3, 3] = tt
+        res = O.piecewise_icp(d["src"][s0:s1], so, d["tgt"][t0:t1], to, init_T=T0, max_corr_dist=MAX_CORR,
+                              max_iter=MAX_ITER, fixed_iters=True)
+        s = d["src"][s0:s1].astype(np.float64)
+        pid = np.repeat(np.arange(p_hi - p_lo), np.diff(so))
+        _ = np.einsum("nij,nj->ni", res["T"][pid, :3, :3], s) + res["T"][pid, :3, 3]
+        return time.perf_counter() - t, int(s1 - s0)
+
+    probe = min(P, 16)
+    dt, npts = run(0, probe)
+    rate = npts / dt
+    want = int(min(P, max(probe, budget_s * rate / (d["src"].shape[0] / P))))
+    dt, npts = run(0, want)
+    return {"value": round(npts / dt / 1e6, 5), "unit": "Mpts/s", "cores": 1, "kind": "port",
+            "sample": f"first {want} of {P} patches ({npts} source points), same Kabsch+ICP(20)+apply step, {dt:.1f} s"}
+
+
+if __name__ == "__main__":
+    main()

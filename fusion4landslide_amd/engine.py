@@ -1,0 +1,240 @@
+"""Tensor-level host API over the C ABI (include/f4l.h): torch tensors in, torch tensors out.
+
+PyTorch is plumbing here (device memory, streams); every computation below is one call into
+libf4l_hip.so on the current torch stream.  Inputs must live on the GPU; nothing falls back to the CPU.
+
+Ragged patches are CSR: ``pts`` is (n, 3) float32 with the points of patch p in rows
+``off[p]:off[p+1]`` (``off`` int64, length P+1).  This is the layout that replaces the reference's Python
+lists of index tensors (src/coarse_to_fine_matching_base.py:3156-3157, 3254).
+"""
+import ctypes as C
+
+from . import _lib
+from ._lib import check, lib, ptr, require_gpu, stream_ptr
+
+_ICP_MODES = {"point2point": _lib.ICP_POINT2POINT, "point2plane": _lib.ICP_POINT2PLANE}
+
+
+def _dev(t, dtype, name, shape_tail=None):
+    torch = require_gpu()
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name} must be a torch.Tensor on the GPU")
+    if not t.is_cuda:
+        raise _lib.F4LError(f"{name} must be a CUDA (ROCm) tensor; there is no CPU path")
+    if t.dtype != dtype:
+        t = t.to(dtype)
+    if not t.is_contiguous():
+        t = t.contiguous()
+    if shape_tail is not None and tuple(t.shape[1:]) != tuple(shape_tail):
+        raise ValueError(f"{name} must have shape (n, {', '.join(map(str, shape_tail))}), got {tuple(t.shape)}")
+    return t
+
+
+def _max_patch(off):
+    if off.numel() < 2:
+        return 0
+    return int((off[1:] - off[:-1]).max().item())
+
+
+def kabsch_batched(src, ref, off, weights=None, weight_thresh=0.0, eps=1e-7):
+    """Batched ragged weighted Kabsch (scripts/weighted_svd.py:58-129 per patch).
+
+    src, ref: (n, 3) float32 or float64; off: (P+1,) int64; weights: (n,) or None.
+    Returns R (P, 3, 3) float64, t (P, 3) float64.
+    """
+    torch = require_gpu()
+    f64 = src.dtype == torch.float64
+    dt = torch.float64 if f64 else torch.float32
+    src = _dev(src, dt, "src", (3,))
+    ref = _dev(ref, dt, "ref", (3,))
+    off = _dev(off, torch.int64, "off")
+    w = None if weights is None else _dev(weights, dt, "weights")
+    n, P = src.shape[0], off.shape[0] - 1
+    if ref.shape[0] != n or (w is not None and w.shape[0] != n):
+        raise ValueError("src, ref and weights must have the same number of rows")
+    R = torch.empty((P, 3, 3), dtype=torch.float64, device=src.device)
+    t = torch.empty((P, 3), dtype=torch.float64, device=src.device)
+    fn = lib().f4l_kabsch_batched_f64 if f64 else lib().f4l_kabsch_batched
+    check(fn(ptr(src), ptr(ref), ptr(w), ptr(off), P, n, float(weight_thresh), float(eps), ptr(R), ptr(t),
+             stream_ptr()), "f4l_kabsch_batched")
+    return R, t
+
+
+def kabsch_residuals(src, ref, off, R, t):
+    """|| R_p s_i + t_p - r_i || per row (scripts/weighted_svd.py:143-146) -> (n,) float64."""
+    torch = require_gpu()
+    src = _dev(src, torch.float32, "src", (3,))
+    ref = _dev(ref, torch.float32, "ref", (3,))
+    off = _dev(off, torch.int64, "off")
+    R = _dev(R, torch.float64, "R")
+    t = _dev(t, torch.float64, "t")
+    n, P = src.shape[0], off.shape[0] - 1
+    res = torch.empty((n,), dtype=torch.float64, device=src.device)
+    check(lib().f4l_kabsch_residuals(ptr(src), ptr(ref), ptr(off), P, n, ptr(R), ptr(t), ptr(res), stream_ptr()),
+          "f4l_kabsch_residuals")
+    return res
+
+
+def patch_normals(pts, off, knn=30, max_patch=None):
+    """Per-patch `estimate_normals()` (utils/o3d_tools.py:29-30) -> (n, 3) float32."""
+    torch = require_gpu()
+    pts = _dev(pts, torch.float32, "pts", (3,))
+    off = _dev(off, torch.int64, "off")
+    P = off.shape[0] - 1
+    if max_patch is None:
+        max_patch = _max_patch(off)
+    out = torch.empty_like(pts)
+    check(lib().f4l_patch_normals(ptr(pts), ptr(off), P, int(knn), int(max_patch), ptr(out), stream_ptr()),
+          "f4l_patch_normals")
+    return out
+
+
+def piecewise_icp(src, src_off, tgt, tgt_off, init_T=None, max_corr_dist=0.1, max_iter=30, rel_fitness=1e-6,
+                  rel_rmse=1e-6, icp_type="point2point", fixed_iters=False, tgt_normals=None, return_corr=False,
+                  max_src_patch=None, max_tgt_patch=None):
+    """Batched per-patch ICP (utils/o3d_tools.py:12-71 for P patch pairs in one launch).
+
+    Returns dict(T (P,4,4) f64, fitness (P,) f64, rmse (P,) f64, iters (P,) i32[, corr (n_src,) i32]).
+    ``fixed_iters=True`` is the benchmark mode (exactly ``max_iter`` updates, no early exit).
+    """
+    torch = require_gpu()
+    if icp_type not in _ICP_MODES:
+        raise ValueError("ICP type not supported")  # utils/o3d_tools.py:43
+    mode = _ICP_MODES[icp_type]
+    src = _dev(src, torch.float32, "src", (3,))
+    tgt = _dev(tgt, torch.float32, "tgt", (3,))
+    src_off = _dev(src_off, torch.int64, "src_off")
+    tgt_off = _dev(tgt_off, torch.int64, "tgt_off")
+    P = src_off.shape[0] - 1
+    if tgt_off.shape[0] - 1 != P:
+        raise ValueError("src_off and tgt_off must describe the same number of patches")
+    if max_src_patch is None:
+        max_src_patch = _max_patch(src_off)
+    if max_tgt_patch is None:
+        max_tgt_patch = _max_patch(tgt_off)
+    T0 = None
+    if init_T is not None:
+        T0 = _dev(init_T, torch.float64, "init_T")
+        if T0.numel() != P * 16:
+            raise ValueError("init_T must be (P, 4, 4)")
+    tn = None
+    if mode == _lib.ICP_POINT2PLANE:
+        tn = patch_normals(tgt, tgt_off, 30, max_tgt_patch) if tgt_normals is None else _dev(
+            tgt_normals, torch.float32, "tgt_normals", (3,))
+    dev = src.device
+    T = torch.empty((P, 4, 4), dtype=torch.float64, device=dev)
+    fit = torch.empty((P,), dtype=torch.float64, device=dev)
+    rmse = torch.empty((P,), dtype=torch.float64, device=dev)
+    iters = torch.empty((P,), dtype=torch.int32, device=dev)
+    corr = torch.empty((src.shape[0],), dtype=torch.int32, device=dev) if return_corr else None
+    check(lib().f4l_piecewise_icp(ptr(src), ptr(src_off), ptr(tgt), ptr(tgt_off), P, ptr(T0), ptr(tn),
+                                  float(max_corr_dist), int(max_iter), float(rel_fitness), float(rel_rmse), mode,
+                                  int(bool(fixed_iters)), int(max_src_patch), int(max_tgt_patch), ptr(T), ptr(fit),
+                                  ptr(rmse), ptr(iters), ptr(corr), stream_ptr()), "f4l_piecewise_icp")
+    out = dict(T=T, fitness=fit, rmse=rmse, iters=iters)
+    if return_corr:
+        out["corr"] = corr
+    return out
+
+
+def apply_transform(pts, off, T, inverse=False):
+    """Rows [s, T_p s] (src/coarse_to_fine_matching_base.py:3371-3374,3408) -> (n, 6) float32."""
+    torch = require_gpu()
+    pts = _dev(pts, torch.float32, "pts", (3,))
+    off = _dev(off, torch.int64, "off")
+    T = _dev(T, torch.float64, "T")
+    n, P = pts.shape[0], off.shape[0] - 1
+    out = torch.empty((n, 6), dtype=torch.float32, device=pts.device)
+    check(lib().f4l_apply_transform(ptr(pts), ptr(off), P, n, ptr(T), int(bool(inverse)), ptr(out), stream_ptr()),
+          "f4l_apply_transform")
+    return out
+
+
+def nn_refine(src, src_off, tgt, tgt_off, T, thr, max_tgt_patch=None, return_rows=True):
+    """`refine_dvfs_with_threshold` for all patches (src/coarse_to_fine_matching_base.py:48-97).
+
+    Returns (nn (n_src,) int32 index inside the target patch or -1, rows (n_src, 6) float32 or None)."""
+    torch = require_gpu()
+    src = _dev(src, torch.float32, "src", (3,))
+    tgt = _dev(tgt, torch.float32, "tgt", (3,))
+    src_off = _dev(src_off, torch.int64, "src_off")
+    tgt_off = _dev(tgt_off, torch.int64, "tgt_off")
+    T = _dev(T, torch.float64, "T")
+    thr = _dev(thr, torch.float64, "thr")
+    P = src_off.shape[0] - 1
+    if max_tgt_patch is None:
+        max_tgt_patch = _max_patch(tgt_off)
+    nn = torch.empty((src.shape[0],), dtype=torch.int32, device=src.device)
+    rows = torch.empty((src.shape[0], 6), dtype=torch.float32, device=src.device) if return_rows else None
+    check(lib().f4l_nn_refine(ptr(src), ptr(src_off), ptr(tgt), ptr(tgt_off), P, ptr(T), ptr(thr),
+                              int(max_tgt_patch), ptr(nn), ptr(rows), stream_ptr()), "f4l_nn_refine")
+    return nn, rows
+
+
+def knn(xyz, k, return_d2=False):
+    """Exact kNN of every point inside the cloud (kd_tree.h:266-280 semantics) -> (n, k) int32[, (n, k) f64]."""
+    torch = require_gpu()
+    xyz = _dev(xyz, torch.float32, "xyz", (3,))
+    n = xyz.shape[0]
+    idx = torch.empty((n, k), dtype=torch.int32, device=xyz.device)
+    d2 = torch.empty((n, k), dtype=torch.float64, device=xyz.device) if return_d2 else None
+    nbytes = lib().f4l_knn_workspace_bytes(n, k)
+    ws = torch.empty((max(int(nbytes), 1),), dtype=torch.uint8, device=xyz.device)
+    check(lib().f4l_knn(ptr(xyz), n, int(k), ptr(idx), ptr(d2), ptr(ws), C.c_size_t(nbytes), stream_ptr()), "f4l_knn")
+    return (idx, d2) if return_d2 else idx
+
+
+def normals(xyz, knn_idx):
+    """PCA normals from neighbour lists (pca_estimate_normals.h:43-108) -> (n, 3) float64."""
+    torch = require_gpu()
+    xyz = _dev(xyz, torch.float32, "xyz", (3,))
+    knn_idx = _dev(knn_idx, torch.int32, "knn_idx")
+    n, k = knn_idx.shape
+    out = torch.empty((n, 3), dtype=torch.float64, device=xyz.device)
+    check(lib().f4l_normals(ptr(xyz), n, ptr(knn_idx), int(k), ptr(out), stream_ptr()), "f4l_normals")
+    return out
+
+
+def supervoxel(xyz, k, resolution, return_intermediates=False):
+    """Whole partition (supervoxel.cpp:92-133 without file I/O). Returns labels (n,) int32 on the GPU and K.
+
+    kNN and normals run on the GPU; the order-dependent segmentation runs on the host inside the library,
+    so this call synchronises the current stream."""
+    torch = require_gpu()
+    xyz = _dev(xyz, torch.float32, "xyz", (3,))
+    n = xyz.shape[0]
+    labels = torch.empty((n,), dtype=torch.int32, device=xyz.device)
+    knn_out = torch.empty((n, k), dtype=torch.int32, device=xyz.device) if return_intermediates else None
+    nrm_out = torch.empty((n, 3), dtype=torch.float64, device=xyz.device) if return_intermediates else None
+    nbytes = lib().f4l_supervoxel_workspace_bytes(n, k)
+    ws = torch.empty((max(int(nbytes), 1),), dtype=torch.uint8, device=xyz.device)
+    nsv = C.c_int32(0)
+    check(lib().f4l_supervoxel(ptr(xyz), n, int(k), float(resolution), ptr(labels), C.byref(nsv), ptr(knn_out),
+                               ptr(nrm_out), ptr(ws), C.c_size_t(nbytes), stream_ptr()), "f4l_supervoxel")
+    if return_intermediates:
+        return labels, nsv.value, knn_out, nrm_out
+    return labels, nsv.value
+
+
+def labels_to_csr(labels, K):
+    """Sort-by-label -> (order (n,) int32, off (K+1,) int64); replaces prepare_pts2spt_dict's mask loop
+    (src/coarse_to_fine_matching_base.py:1327-1332)."""
+    torch = require_gpu()
+    labels = _dev(labels, torch.int32, "labels")
+    n = labels.shape[0]
+    order = torch.empty((n,), dtype=torch.int32, device=labels.device)
+    off = torch.empty((K + 1,), dtype=torch.int64, device=labels.device)
+    nbytes = lib().f4l_labels_to_csr_workspace_bytes(n, K)
+    ws = torch.empty((max(int(nbytes), 1),), dtype=torch.uint8, device=labels.device)
+    check(lib().f4l_labels_to_csr(ptr(labels), n, int(K), ptr(order), ptr(off), ptr(ws), C.c_size_t(nbytes),
+                                  stream_ptr()), "f4l_labels_to_csr")
+    return order, off
+
+
+def gather_points(pts, order):
+    torch = require_gpu()
+    pts = _dev(pts, torch.float32, "pts", (3,))
+    order = _dev(order, torch.int32, "order")
+    out = torch.empty((order.shape[0], 3), dtype=torch.float32, device=pts.device)
+    check(lib().f4l_gather_points(ptr(pts), ptr(order), order.shape[0], ptr(out), stream_ptr()), "f4l_gather_points")
+    return out

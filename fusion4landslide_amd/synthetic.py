@@ -1,0 +1,114 @@
+"""Seeded synthetic two-epoch clouds for tests and bench.py.
+
+Epoch 1: N points, (x, y) ~ U([0, L]^2), z = sum_j a_j sin(2 pi f_j x + phi_j) sin(2 pi g_j y + psi_j) with
+a_j = 2 / 2^j m, f_j = g_j = 2^j / 100 1/m (j = 1..4), plus N(0, 5 mm) range noise.
+Epoch 2: independently re-sampled on the same surface, then moved by a piecewise-rigid field: square blocks
+of side 4 x resolution, each with a rotation <= 0.5 deg about a random axis through the block centre and a
+translation U(-0.05, 0.05) m ("stable", 70 % of the blocks) or U(0.2, 0.5) m with random sign (the rest),
+plus N(0, 5 mm).  float32 storage.
+
+The ICP-timing partition is the (x, y) grid at `resolution` (independent of the supervoxel implementation):
+patch c holds the source points of cell c and the target points of cell c, as CSR arrays.
+
+Everything here is host numpy (PCG64) so that the CPU oracle and the GPU see bit-identical inputs; it is data
+generation, not part of the measured path.
+"""
+import numpy as np
+
+# configs of BASELINE.json: name -> (N per epoch, grid cells per side, resolution [m])
+CONFIGS = {
+    "C1_50k_64": dict(n=50_000, cells=8, resolution=1.386),
+    "C2_1M_2k": dict(n=1_000_000, cells=45, resolution=1.386),
+    "C3_10M_20k": dict(n=10_000_000, cells=141, resolution=0.1),
+    "C4_50M_100k": dict(n=50_000_000, cells=316, resolution=1.386),
+}
+
+
+def _surface(x, y, phases):
+    z = np.zeros_like(x)
+    for j in range(1, 5):
+        a, f = 2.0 / 2 ** j, 2 ** j / 100.0
+        z += a * np.sin(2 * np.pi * f * x + phases[j - 1, 0]) * np.sin(2 * np.pi * f * y + phases[j - 1, 1])
+    return z
+
+
+def _rodrigues(axis, angle):
+    axis = axis / np.linalg.norm(axis, axis=1, keepdims=True)
+    K = np.zeros((axis.shape[0], 3, 3))
+    K[:, 0, 1], K[:, 0, 2] = -axis[:, 2], axis[:, 1]
+    K[:, 1, 0], K[:, 1, 2] = axis[:, 2], -axis[:, 0]
+    K[:, 2, 0], K[:, 2, 1] = -axis[:, 1], axis[:, 0]
+    s, c = np.sin(angle)[:, None, None], np.cos(angle)[:, None, None]
+    return np.eye(3)[None] + s * K + (1 - c) * (K @ K)
+
+
+def two_epoch_cloud(n, cells, resolution, noise=0.005, seed=0, origin=(0.0, 0.0, 0.0)):
+    """Returns dict(src (n,3) f32, tgt (n,3) f32, L, block_R, block_t, block_of_tgt)."""
+    L = cells * resolution
+    phases = np.random.Generator(np.random.PCG64(seed)).uniform(0, 2 * np.pi, (4, 2))
+    r0 = np.random.Generator(np.random.PCG64(seed))
+    r0.uniform(0, 2 * np.pi, (4, 2))  # keep the stream aligned with `phases`
+    xy = r0.uniform(0, L, (n, 2))
+    src = np.c_[xy, _surface(xy[:, 0], xy[:, 1], phases) + r0.normal(0, noise, n)]
+    r1 = np.random.Generator(np.random.PCG64(seed + 1))
+    xy2 = r1.uniform(0, L, (n, 2))
+    tgt0 = np.c_[xy2, _surface(xy2[:, 0], xy2[:, 1], phases)]
+    # piecewise-rigid field on square blocks of side 4 x resolution
+    r2 = np.random.Generator(np.random.PCG64(seed + 2))
+    nb = int(np.ceil(cells / 4.0))
+    B = nb * nb
+    ang = np.deg2rad(r2.uniform(0, 0.5, B))
+    R = _rodrigues(r2.normal(size=(B, 3)), ang)
+    stable = r2.uniform(size=B) < 0.7
+    t_small = r2.uniform(-0.05, 0.05, (B, 3))
+    t_big = r2.uniform(0.2, 0.5, (B, 3)) * np.where(r2.uniform(size=(B, 3)) < 0.5, -1.0, 1.0)
+    t = np.where(stable[:, None], t_small, t_big)
+    bs = 4.0 * resolution
+    bx = np.minimum((tgt0[:, 0] / bs).astype(np.int64), nb - 1)
+    by = np.minimum((tgt0[:, 1] / bs).astype(np.int64), nb - 1)
+    bid = by * nb + bx
+    centre = np.c_[(bx + 0.5) * bs, (by + 0.5) * bs, np.zeros(n)]
+    tgt = np.einsum("nij,nj->ni", R[bid], tgt0 - centre) + centre + t[bid]
+    tgt[:, 2] += r1.normal(0, noise, n)
+    off = np.asarray(origin, dtype=np.float64)
+    return dict(src=(src + off).astype(np.float32), tgt=(tgt + off).astype(np.float32), L=L, block_R=R, block_t=t,
+                block_of_tgt=bid, origin=off)
+
+
+def grid_partition(pts, cells, resolution, origin=(0.0, 0.0, 0.0)):
+    """(x, y) grid-cell partition -> (order (n,) int64, off (cells^2 + 1,) int64): points of patch c are
+    pts[order[off[c]:off[c+1]]]. Points outside [0, L)^2 are clamped into the border cells."""
+    o = np.asarray(origin, dtype=np.float64)
+    cx = np.clip(((pts[:, 0].astype(np.float64) - o[0]) / resolution).astype(np.int64), 0, cells - 1)
+    cy = np.clip(((pts[:, 1].astype(np.float64) - o[1]) / resolution).astype(np.int64), 0, cells - 1)
+    cid = cy * cells + cx
+    order = np.argsort(cid, kind="stable")
+    counts = np.bincount(cid, minlength=cells * cells)
+    off = np.zeros(cells * cells + 1, dtype=np.int64)
+    np.cumsum(counts, out=off[1:])
+    return order, off
+
+
+def make_patches(n, cells, resolution, seed=0, noise=0.005, origin=(0.0, 0.0, 0.0)):
+    """Two-epoch cloud already grouped into patch-contiguous CSR arrays.
+
+    Returns dict(src, src_off, tgt, tgt_off, P, max_src, max_tgt, meta)."""
+    c = two_epoch_cloud(n, cells, resolution, noise=noise, seed=seed, origin=origin)
+    so, soff = grid_partition(c["src"], cells, resolution, origin)
+    to, toff = grid_partition(c["tgt"], cells, resolution, origin)
+    return dict(src=np.ascontiguousarray(c["src"][so]), src_off=soff, tgt=np.ascontiguousarray(c["tgt"][to]), tgt_off=toff,
+                P=cells * cells, max_src=int(np.diff(soff).max()), max_tgt=int(np.diff(toff).max()), meta=c)
+
+
+def correspondences_from_nn(src, src_off, tgt, tgt_off, nn):
+    """Kabsch-init correspondences: rows (s_i, t_nn[i]) for every source point with nn[i] >= 0, as CSR over patches.
+    `nn` holds the index INSIDE the target patch (output of engine.nn_refine / oracle.nn_within). numpy in/out."""
+    P = src_off.shape[0] - 1
+    pid = np.repeat(np.arange(P), np.diff(src_off))
+    keep = nn >= 0
+    cs = src[keep]
+    ct = tgt[tgt_off[pid[keep]] + nn[keep]]
+    counts = np.bincount(pid[keep], minlength=P)
+    off = np.zeros(P + 1, dtype=np.int64)
+    np.cumsum(counts, out=off[1:])
+    return np.ascontiguousarray(cs), np.ascontiguousarray(ct), off

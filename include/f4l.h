@@ -1,0 +1,163 @@
+/*
+ * f4l.h -- C ABI of the MI355X-native piecewise-ICP displacement-field engine (libf4l_hip.so).
+ *
+ * This is the drop-in boundary for the hot path of gseg-ethz/fusion4landslide.  Each entry point
+ * names the reference interface it replaces (file:line relative to the reference checkout).  The
+ * reference has no FFI of its own on this path except the SWIG module `supervoxel`
+ * (cpp_core/supervoxel_segmentation/supervoxel.i:15,22); the other boundaries are Python call sites
+ * (utils/o3d_tools.py:12, scripts/weighted_svd.py:58,132) which the host-side mirror in
+ * fusion4landslide_amd/ re-implements on top of these functions via ctypes.
+ *
+ * Conventions
+ *  - All array arguments are DEVICE pointers (HBM resident, e.g. torch tensor .data_ptr()) unless the
+ *    parameter name ends in `_host`.  The caller owns every buffer.
+ *  - Point clouds are packed float32 [n][3] (x,y,z), exactly the (N,3) tensors the reference keeps
+ *    (src/coarse_to_fine_matching_base.py:906-912).  Ragged patches are CSR: `off` is int64 [P+1].
+ *  - Transforms are row-major double [4][4]; rotations row-major double [3][3]  (Open3D returns
+ *    float64 4x4, utils/o3d_tools.py:66).
+ *  - `stream` is a hipStream_t (NULL = default stream).  Work is enqueued asynchronously on it; no
+ *    call synchronises the device unless documented.  No global state; re-entrant.
+ *  - Return value: F4L_OK (0) or a negative F4L_E* code; nothing throws.
+ *  - Functions taking `workspace` need a caller-provided scratch buffer of at least the byte count the
+ *    matching *_workspace_bytes() query returns (so that nothing allocates inside a launch and the
+ *    sequence can be captured into a hipGraph).
+ */
+#ifndef F4L_H_
+#define F4L_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define F4L_OK 0
+#define F4L_EINVAL (-1)       /* bad argument (NULL pointer, negative size, k out of range ...) */
+#define F4L_EWORKSPACE (-2)   /* workspace too small */
+#define F4L_EHIP (-3)         /* HIP runtime error, see f4l_last_hip_error() */
+#define F4L_EUNSUPPORTED (-4) /* valid request this build cannot serve (e.g. k > 64) */
+#define F4L_ENOMEM (-5)       /* host allocation failed */
+
+#define F4L_ICP_POINT2POINT 0 /* o3d TransformationEstimationPointToPoint(False), utils/o3d_tools.py:34 */
+#define F4L_ICP_POINT2PLANE 1 /* o3d TransformationEstimationPointToPlane(),     utils/o3d_tools.py:39 */
+
+#define F4L_MAX_K 64 /* neighbour-list capacity of the wave-resident top-k (one slot per lane) */
+
+int f4l_version(void);
+const char *f4l_strerror(int code);
+/* hipError_t of the most recent failing HIP call on this thread (0 when none). */
+int f4l_last_hip_error(void);
+/* CU count, LDS bytes per workgroup, total HBM bytes, gcnArchName of the current device. */
+int f4l_device_info(int *cu_count, int *lds_bytes, int64_t *hbm_bytes, char *arch, int arch_len);
+
+/* ------------------------------------------------------------------------------------------------
+ * B3  weighted Kabsch / Procrustes, batched over ragged correspondence lists.
+ * Replaces scripts/weighted_svd.py:58-129 `weighted_procrustes` (dup src/rgb_guided.py:25-96) as it is
+ * called once per patch at src/coarse_to_fine_matching_base.py:3341 (via :132-142):
+ *   w <- where(w < w_thresh, 0, w);  w <- w / (sum w + eps)      (eps stays in the denominator)
+ *   cs, ct weighted centroids;  H = sum w (s - cs)(t - ct)^T;  U S V^T = svd(H)
+ *   R = V diag(1,1,sign det(V U^T)) U^T;  t = ct - R cs
+ * src/ref: float32 [n_total][3]; w: float32 [n_total] or NULL (all ones); off: int64 [P+1].
+ * R_out: double [P][9]; t_out: double [P][3].  A patch with zero rows yields R = I, t = 0.
+ * The _f64 variant takes double clouds/weights (the reference function is dtype generic).
+ * ---------------------------------------------------------------------------------------------- */
+int f4l_kabsch_batched(const float *src, const float *ref, const float *w, const int64_t *off, int64_t P,
+                       int64_t n_total, double w_thresh, double eps, double *R_out, double *t_out,
+                       void *stream);
+int f4l_kabsch_batched_f64(const double *src, const double *ref, const double *w, const int64_t *off,
+                           int64_t P, int64_t n_total, double w_thresh, double eps, double *R_out,
+                           double *t_out, void *stream);
+
+/* Residual norms || R_p s_i + t_p - r_i || per row (scripts/weighted_svd.py:143-146), float64 [n_total].
+ * The caller prunes rows (res < 1 m at :147, or 2.5 x median at src/rgb_guided.py:113-118). */
+int f4l_kabsch_residuals(const float *src, const float *ref, const int64_t *off, int64_t P, int64_t n_total,
+                         const double *R, const double *t, double *res_out, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * B2  per-patch ICP, batched: the loop body of src/coarse_to_fine_matching_base.py:3353-3367, i.e.
+ * utils/o3d_tools.py:12-71 `icp_registration` -> Open3D 0.19 registration_icp, for P independent
+ * (source patch, target patch) pairs in one launch, with zero host round trips.
+ *   src/src_off, tgt/tgt_off : CSR patches (float32 [.][3], int64 [P+1])
+ *   init_T      : double [P][16] or NULL (identity)              (o3d `init`, utils/o3d_tools.py:47)
+ *   tgt_normals : float32 [n_tgt][3]; required for POINT2PLANE (see f4l_patch_normals), else NULL
+ *   max_corr_dist, max_iter, rel_fitness, rel_rmse : o3d ICPConvergenceCriteria (utils/o3d_tools.py:47-50)
+ *   fixed_iters != 0 disables the early exit: exactly max_iter updates (benchmark mode)
+ *   max_src_patch_host / max_tgt_patch_host : largest patch sizes (host-known; size LDS and pick the path)
+ * Outputs (any may be NULL except T_out):
+ *   T_out double [P][16]; fitness_out, rmse_out double [P]; iters_out int32 [P];
+ *   corr_out int32 [n_src]: index INSIDE the target patch of each source point's final correspondence,
+ *   or -1 (utils/o3d_tools.py:64 `correspondence_set`).
+ * ---------------------------------------------------------------------------------------------- */
+int f4l_piecewise_icp(const float *src, const int64_t *src_off, const float *tgt, const int64_t *tgt_off,
+                      int64_t P, const double *init_T, const float *tgt_normals, double max_corr_dist,
+                      int max_iter, double rel_fitness, double rel_rmse, int mode, int fixed_iters,
+                      int64_t max_src_patch_host, int64_t max_tgt_patch_host, double *T_out,
+                      double *fitness_out, double *rmse_out, int32_t *iters_out, int32_t *corr_out,
+                      void *stream);
+
+/* Per-patch normal estimation as utils/o3d_tools.py:29-30 (`pcd.estimate_normals()` on the patch cloud:
+ * kNN(knn=30) inside the patch, self included; smallest-eigenvector of the neighbourhood covariance;
+ * (0,0,1) when degenerate; unoriented).  normals_out float32 [n][3]. */
+int f4l_patch_normals(const float *pts, const int64_t *off, int64_t P, int knn, int64_t max_patch_host,
+                      float *normals_out, void *stream);
+
+/* a14: dense displacement rows [s, T_p s] for every point of every patch
+ * (src/coarse_to_fine_matching_base.py:3371-3374,3408); out6 float32 [n][6].
+ * inverse != 0 writes [T_p^-1 q, q] instead (tgt2src, :3393-3397). */
+int f4l_apply_transform(const float *pts, const int64_t *off, int64_t P, int64_t n_total, const double *T,
+                        int inverse, float *out6, void *stream);
+
+/* a15: `refine_dvfs_with_threshold` (src/coarse_to_fine_matching_base.py:48-97) for all patches at once:
+ * for each source point, transform by T_p, take the nearest point of the target patch; valid when
+ * d^2 < thr_p^2.  thr double [P].  nn_out int32 [n_src] (index inside the target patch, or -1);
+ * out6 float32 [n_src][6] = [s, nearest target] (rows of invalid points are zero filled); both nullable. */
+int f4l_nn_refine(const float *src, const int64_t *src_off, const float *tgt, const int64_t *tgt_off, int64_t P,
+                  const double *T, const double *thr, int64_t max_tgt_patch_host, int32_t *nn_out, float *out6,
+                  void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * B1  supervoxel partition.  Replaces the SWIG export
+ *   std::vector<int> computeSupervoxel(std::string input_file, int k_neighbors, double resolution,
+ *                                      std::string save_file)     cpp_core/supervoxel_segmentation/supervoxel.h:11-12
+ * (body supervoxel.cpp:83-143) minus its file I/O, which the host-side shim does.
+ *
+ * f4l_knn: exact k nearest neighbours of every point within the cloud, squared Euclidean distance in
+ *   double, self included in slot 0, ascending (codelibrary/util/tree/kd_tree.h:266-280); exact-distance
+ *   ties are ordered by point index.  idx_out int32 [n][k]; d2_out double [n][k] or NULL.  1 <= k <= 64, k <= n.
+ * f4l_normals: PCA normal of each point's neighbour list (codelibrary/geometry/point_cloud/
+ *   pca_estimate_normals.h:43-108, unit weights), double [n][3].
+ * f4l_supervoxel: kNN + normals on the device, then the sequential boundary-preserving segmentation
+ *   (codelibrary/geometry/point_cloud/supervoxel_segmentation.h:65-265, metric supervoxel.cpp:27-40) on the
+ *   host: this call SYNCHRONISES `stream`.  labels_out int32 [n] (device); n_supervoxels_host is a HOST int.
+ *   knn_out / normals_out (device, nullable) receive the intermediate products.
+ * ---------------------------------------------------------------------------------------------- */
+size_t f4l_knn_workspace_bytes(int64_t n, int k);
+int f4l_knn(const float *xyz, int64_t n, int k, int32_t *idx_out, double *d2_out, void *workspace,
+            size_t workspace_bytes, void *stream);
+int f4l_normals(const float *xyz, int64_t n, const int32_t *knn_idx, int k, double *normals_out, void *stream);
+size_t f4l_supervoxel_workspace_bytes(int64_t n, int k);
+int f4l_supervoxel(const float *xyz, int64_t n, int k, double resolution, int32_t *labels_out,
+                   int32_t *n_supervoxels_host, int32_t *knn_out, double *normals_out, void *workspace,
+                   size_t workspace_bytes, void *stream);
+
+/* Host-only helper (no device work): the sequential segmentation stage on host arrays.  Exposed so the
+ * Python shim can re-segment cached kNN/normals; same semantics as inside f4l_supervoxel. */
+int f4l_supervoxel_segment_host(const float *xyz_host, const double *normals_host, const int32_t *knn_host,
+                                int64_t n, int k, double resolution, int32_t *labels_host,
+                                int32_t *n_supervoxels_host);
+
+/* Sort-by-label -> CSR (replaces the O(K*N) mask loop of prepare_pts2spt_dict,
+ * src/coarse_to_fine_matching_base.py:1327-1332).  labels int32 [n] in [0,K); order_out int32 [n] = point ids
+ * grouped by label (stable); off_out int64 [K+1]. */
+size_t f4l_labels_to_csr_workspace_bytes(int64_t n, int64_t K);
+int f4l_labels_to_csr(const int32_t *labels, int64_t n, int64_t K, int32_t *order_out, int64_t *off_out,
+                      void *workspace, size_t workspace_bytes, void *stream);
+
+/* Gather rows: out[i] = pts[order[i]] (float32 [n][3]); builds patch-contiguous clouds from a CSR order. */
+int f4l_gather_points(const float *pts, const int32_t *order, int64_t n, float *out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* F4L_H_ */
