@@ -12,6 +12,8 @@ LIB_PATH = os.path.join(_HERE, "lib", "libf4l_hip.so")
 F4L_OK = 0
 ICP_POINT2POINT = 0
 ICP_POINT2PLANE = 1
+SEARCH_F32 = 0
+SEARCH_F64 = 1
 MAX_K = 64
 
 # every symbol include/f4l.h declares, with its ctypes signature (all pointers as void*)
@@ -24,8 +26,8 @@ SIGNATURES = {
     "f4l_kabsch_batched": (C.c_int, [_P, _P, _P, _P, _I64, _I64, _D, _D, _P, _P, _P]),
     "f4l_kabsch_batched_f64": (C.c_int, [_P, _P, _P, _P, _I64, _I64, _D, _D, _P, _P, _P]),
     "f4l_kabsch_residuals": (C.c_int, [_P, _P, _P, _I64, _I64, _P, _P, _P, _P]),
-    "f4l_piecewise_icp": (C.c_int, [_P, _P, _P, _P, _I64, _P, _P, _D, _I, _D, _D, _I, _I, _I64, _I64, _P, _P, _P,
-                                    _P, _P, _P]),
+    "f4l_piecewise_icp": (C.c_int, [_P, _P, _P, _P, _I64, _P, _P, _D, _I, _D, _D, _I, _I, _I, _I64, _I64, _P, _P,
+                                    _P, _P, _P, _P]),
     "f4l_patch_normals": (C.c_int, [_P, _P, _I64, _I, _I64, _P, _P]),
     "f4l_apply_transform": (C.c_int, [_P, _P, _I64, _I64, _P, _I, _P, _P]),
     "f4l_nn_refine": (C.c_int, [_P, _P, _P, _P, _I64, _P, _P, _I64, _P, _P, _P]),

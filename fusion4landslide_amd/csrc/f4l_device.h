@@ -148,30 +148,42 @@ __device__ __forceinline__ void svd3(const double *A, double *U, double *S, doub
     S[0] = s0; S[1] = s1; S[2] = s2;
 #pragma unroll
     for (int i = 0; i < 9; ++i) V[i] = Vm[i];
+    // U: first column by normalisation, second by Gram-Schmidt, third as a cross product.  Directions that
+    // carry no signal (rank-deficient A) are completed from the matching columns of V, so that U V^T is the
+    // identity on the null space (a zero matrix gives U = V, like a Jacobi SVD that never rotates).
     double u0[3], u1[3], u2[3];
     if (s0 > 0.0) {
         u0[0] = W[0] / s0; u0[1] = W[3] / s0; u0[2] = W[6] / s0;
     } else {
-        u0[0] = 1.0; u0[1] = 0.0; u0[2] = 0.0;
+        u0[0] = Vm[0]; u0[1] = Vm[3]; u0[2] = Vm[6];
     }
-    const double pr = u0[0] * W[1] + u0[1] * W[4] + u0[2] * W[7];
+    double pr = u0[0] * W[1] + u0[1] * W[4] + u0[2] * W[7];
     u1[0] = W[1] - pr * u0[0]; u1[1] = W[4] - pr * u0[1]; u1[2] = W[7] - pr * u0[2];
     double n1 = sqrt(u1[0] * u1[0] + u1[1] * u1[1] + u1[2] * u1[2]);
     if (!(n1 > 1e-14 * s0 && n1 > 0.0)) {
-        const double ax = fabs(u0[0]), ay = fabs(u0[1]), az = fabs(u0[2]);
-        double e0 = 0.0, e1 = 0.0, e2 = 0.0;
-        if (ax <= ay) { if (ax <= az) e0 = 1.0; else e2 = 1.0; }
-        else { if (ay <= az) e1 = 1.0; else e2 = 1.0; }
-        u1[0] = u0[1] * e2 - u0[2] * e1;
-        u1[1] = u0[2] * e0 - u0[0] * e2;
-        u1[2] = u0[0] * e1 - u0[1] * e0;
+        pr = u0[0] * Vm[1] + u0[1] * Vm[4] + u0[2] * Vm[7];
+        u1[0] = Vm[1] - pr * u0[0]; u1[1] = Vm[4] - pr * u0[1]; u1[2] = Vm[7] - pr * u0[2];
         n1 = sqrt(u1[0] * u1[0] + u1[1] * u1[1] + u1[2] * u1[2]);
+        if (!(n1 > 1e-8)) {
+            const double ax = fabs(u0[0]), ay = fabs(u0[1]), az = fabs(u0[2]);
+            double e0 = 0.0, e1 = 0.0, e2 = 0.0;
+            if (ax <= ay) { if (ax <= az) e0 = 1.0; else e2 = 1.0; }
+            else { if (ay <= az) e1 = 1.0; else e2 = 1.0; }
+            u1[0] = u0[1] * e2 - u0[2] * e1;
+            u1[1] = u0[2] * e0 - u0[0] * e2;
+            u1[2] = u0[0] * e1 - u0[1] * e0;
+            n1 = sqrt(u1[0] * u1[0] + u1[1] * u1[1] + u1[2] * u1[2]);
+        }
     }
     u1[0] /= n1; u1[1] /= n1; u1[2] /= n1;
     u2[0] = u0[1] * u1[2] - u0[2] * u1[1];
     u2[1] = u0[2] * u1[0] - u0[0] * u1[2];
     u2[2] = u0[0] * u1[1] - u0[1] * u1[0];
-    if (u2[0] * W[2] + u2[1] * W[5] + u2[2] * W[8] < 0.0) { u2[0] = -u2[0]; u2[1] = -u2[1]; u2[2] = -u2[2]; }
+    {
+        const bool sig = s2 > 1e-14 * s0 && s2 > 0.0;
+        const double r0 = sig ? W[2] : Vm[2], r1 = sig ? W[5] : Vm[5], r2 = sig ? W[8] : Vm[8];
+        if (u2[0] * r0 + u2[1] * r1 + u2[2] * r2 < 0.0) { u2[0] = -u2[0]; u2[1] = -u2[1]; u2[2] = -u2[2]; }
+    }
     U[0] = u0[0]; U[1] = u1[0]; U[2] = u2[0];
     U[3] = u0[1]; U[4] = u1[1]; U[5] = u2[1];
     U[6] = u0[2]; U[7] = u1[2]; U[8] = u2[2];

@@ -39,7 +39,7 @@ struct IcpArgs {
     int64_t P;
     const double *init_T;
     const float *tgt_normals;
-    float r2;
+    double r2;
     int max_iter;
     double rel_fitness, rel_rmse;
     int fixed_iters;
@@ -48,34 +48,44 @@ struct IcpArgs {
     int32_t *iters_out, *corr_out;
 };
 
-// Nearest target of up to two query points; targets in LDS (float4, origin-relative).
-template <int SPT>
-__device__ __forceinline__ void nn_lds(const float4 *__restrict__ tl, int nt, const float (&px)[2], const float (&py)[2],
-                                       const float (&pz)[2], float (&best)[2], int (&bj)[2]) {
+// Target point as staged in LDS: float4 (16 B, one ds_read_b128) for the float32 search, 3 doubles for the
+// float64 ("reference arithmetic") search.
+template <typename F> struct TgtPt;
+template <> struct TgtPt<float> { float x, y, z, w; };
+template <> struct TgtPt<double> { double x, y, z; };
+
+template <typename F> __device__ __forceinline__ F f_inf();
+template <> __device__ __forceinline__ float f_inf<float>() { return __builtin_inff(); }
+template <> __device__ __forceinline__ double f_inf<double>() { return __builtin_inf(); }
+
+// Nearest target of up to two query points; targets in LDS (origin-relative).
+template <int SPT, typename F>
+__device__ __forceinline__ void nn_lds(const TgtPt<F> *__restrict__ tl, int nt, const F (&px)[2], const F (&py)[2],
+                                       const F (&pz)[2], F (&best)[2], int (&bj)[2]) {
 #pragma unroll 8
     for (int j = 0; j < nt; ++j) {
-        const float4 q = tl[j];
+        const TgtPt<F> q = tl[j];
 #pragma unroll
         for (int s = 0; s < SPT; ++s) {
-            const float dx = px[s] - q.x, dy = py[s] - q.y, dz = pz[s] - q.z;
-            const float d = dx * dx + dy * dy + dz * dz;
+            const F dx = px[s] - q.x, dy = py[s] - q.y, dz = pz[s] - q.z;
+            const F d = dx * dx + dy * dy + dz * dz;
             if (d < best[s]) { best[s] = d; bj[s] = j; }
         }
     }
 }
 
 // Same with targets in global memory (patches larger than the LDS budget): wave-uniform addresses.
-template <int SPT>
+template <int SPT, typename F>
 __device__ __forceinline__ void nn_global(const float *__restrict__ tg, int nt, float ox, float oy, float oz,
-                                          const float (&px)[2], const float (&py)[2], const float (&pz)[2],
-                                          float (&best)[2], int (&bj)[2]) {
+                                          const F (&px)[2], const F (&py)[2], const F (&pz)[2], F (&best)[2],
+                                          int (&bj)[2]) {
 #pragma unroll 4
     for (int j = 0; j < nt; ++j) {
-        const float qx = tg[3 * j] - ox, qy = tg[3 * j + 1] - oy, qz = tg[3 * j + 2] - oz;
+        const F qx = (F)tg[3 * j] - (F)ox, qy = (F)tg[3 * j + 1] - (F)oy, qz = (F)tg[3 * j + 2] - (F)oz;
 #pragma unroll
         for (int s = 0; s < SPT; ++s) {
-            const float dx = px[s] - qx, dy = py[s] - qy, dz = pz[s] - qz;
-            const float d = dx * dx + dy * dy + dz * dz;
+            const F dx = px[s] - qx, dy = py[s] - qy, dz = pz[s] - qz;
+            const F d = dx * dx + dy * dy + dz * dz;
             if (d < best[s]) { best[s] = d; bj[s] = j; }
         }
     }
@@ -119,13 +129,13 @@ __device__ __forceinline__ bool solve6(double (&M)[6][7], double (&x)[6]) {
 // LDS layout (dynamic): [ scratch doubles | state doubles | float4 targets ]
 //   scratch : ICP_NW * NV partial sums
 //   state   : Rc[9], tc[3], flag      (flag: 0 continue, 1 finished)
-template <int MODE, int SPT>
+template <int MODE, int SPT, typename F>
 __global__ __launch_bounds__(ICP_NT, 4) void icp_kernel(IcpArgs a) {
     constexpr int NV = (MODE == F4L_ICP_POINT2POINT) ? 17 : 29;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     double *scratch = reinterpret_cast<double *>(smem_raw);
     double *state = scratch + ICP_NW * 32;  // 32 >= NV keeps the float4 region 16-byte aligned
-    float4 *tl = reinterpret_cast<float4 *>(state + 16);
+    TgtPt<F> *tl = reinterpret_cast<TgtPt<F> *>(state + 16);
 
     const int64_t p = blockIdx.x;
     if (p >= a.P) return;
@@ -142,8 +152,11 @@ __global__ __launch_bounds__(ICP_NT, 4) void icp_kernel(IcpArgs a) {
     else if (ns > 0) { ox = sg[0]; oy = sg[1]; oz = sg[2]; }
 
     if (in_lds) {
-        for (int j = tid; j < nt; j += ICP_NT)
-            tl[j] = make_float4(tg[3 * j] - ox, tg[3 * j + 1] - oy, tg[3 * j + 2] - oz, 0.f);
+        for (int j = tid; j < nt; j += ICP_NT) {
+            TgtPt<F> q;
+            q.x = (F)tg[3 * j] - (F)ox; q.y = (F)tg[3 * j + 1] - (F)oy; q.z = (F)tg[3 * j + 2] - (F)oz;
+            tl[j] = q;
+        }
     }
 
     // running transform in origin-relative coordinates, p' = Rc s' + tc, lives in LDS `state`
@@ -165,43 +178,43 @@ __global__ __launch_bounds__(ICP_NT, 4) void icp_kernel(IcpArgs a) {
     }
     __syncthreads();
 
-    const bool active = ns > 0 && a.r2 > 0.f;  // o3d returns the init untouched when max_corr_dist <= 0
+    const bool active = ns > 0 && a.r2 > 0.0;
+    const F r2 = (F)a.r2;  // o3d returns the init untouched when max_corr_dist <= 0
     const int n_pass = active ? a.max_iter + 1 : 0;
 
     for (int pass = 0; pass < n_pass; ++pass) {
-        const float R0 = (float)state[0], R1 = (float)state[1], R2 = (float)state[2], R3 = (float)state[3],
-                    R4 = (float)state[4], R5 = (float)state[5], R6 = (float)state[6], R7 = (float)state[7],
-                    R8 = (float)state[8];
-        const float t0f = (float)state[9], t1f = (float)state[10], t2f = (float)state[11];
+        const F R0 = (F)state[0], R1 = (F)state[1], R2 = (F)state[2], R3 = (F)state[3], R4 = (F)state[4],
+                R5 = (F)state[5], R6 = (F)state[6], R7 = (F)state[7], R8 = (F)state[8];
+        const F t0f = (F)state[9], t1f = (F)state[10], t2f = (F)state[11];
         double acc[NV];
 #pragma unroll
         for (int i = 0; i < NV; ++i) acc[i] = 0.0;
 
         for (int base = 0; base < ns; base += ICP_NT * SPT) {
-            float px[2], py[2], pz[2], best[2];
+            F px[2], py[2], pz[2], best[2];
             int bj[2], si[2];
 #pragma unroll
             for (int s = 0; s < SPT; ++s) {
                 si[s] = base + s * ICP_NT + tid;
                 const int ii = si[s] < ns ? si[s] : ns - 1;  // clamp: inactive lanes recompute the last point
-                const float x = sg[3 * ii] - ox, y = sg[3 * ii + 1] - oy, z = sg[3 * ii + 2] - oz;
+                const F x = (F)sg[3 * ii] - (F)ox, y = (F)sg[3 * ii + 1] - (F)oy, z = (F)sg[3 * ii + 2] - (F)oz;
                 px[s] = R0 * x + R1 * y + R2 * z + t0f;
                 py[s] = R3 * x + R4 * y + R5 * z + t1f;
                 pz[s] = R6 * x + R7 * y + R8 * z + t2f;
-                best[s] = __builtin_inff();
+                best[s] = f_inf<F>();
                 bj[s] = -1;
             }
-            if (in_lds) nn_lds<SPT>(tl, nt, px, py, pz, best, bj);
-            else nn_global<SPT>(tg, nt, ox, oy, oz, px, py, pz, best, bj);
+            if (in_lds) nn_lds<SPT, F>(tl, nt, px, py, pz, best, bj);
+            else nn_global<SPT, F>(tg, nt, ox, oy, oz, px, py, pz, best, bj);
 #pragma unroll
             for (int s = 0; s < SPT; ++s) {
                 const bool valid = si[s] < ns;
-                const bool hit = valid && bj[s] >= 0 && best[s] < a.r2;  // SearchHybrid: d2 < r^2
+                const bool hit = valid && bj[s] >= 0 && best[s] < r2;  // SearchHybrid: d2 < r^2
                 if (a.corr_out && valid) a.corr_out[s0 + si[s]] = hit ? bj[s] : -1;
                 if (hit) {
-                    float qx, qy, qz;
-                    if (in_lds) { const float4 q = tl[bj[s]]; qx = q.x; qy = q.y; qz = q.z; }
-                    else { qx = tg[3 * bj[s]] - ox; qy = tg[3 * bj[s] + 1] - oy; qz = tg[3 * bj[s] + 2] - oz; }
+                    F qx, qy, qz;
+                    if (in_lds) { const TgtPt<F> q = tl[bj[s]]; qx = q.x; qy = q.y; qz = q.z; }
+                    else { qx = (F)tg[3 * bj[s]] - (F)ox; qy = (F)tg[3 * bj[s] + 1] - (F)oy; qz = (F)tg[3 * bj[s] + 2] - (F)oz; }
                     const double dpx = px[s], dpy = py[s], dpz = pz[s], dqx = qx, dqy = qy, dqz = qz;
                     acc[0] += 1.0;
                     acc[1] += (double)best[s];
@@ -358,46 +371,54 @@ __global__ __launch_bounds__(ICP_NT, 4) void icp_kernel(IcpArgs a) {
 
 }  // namespace f4l
 
+namespace f4l {
+template <typename F>
+static int launch_icp(const IcpArgs &a, int mode, bool two, size_t lds, hipStream_t st) {
+    dim3 grid((unsigned)a.P), block(ICP_NT);
+    const void *fn;
+    if (mode == F4L_ICP_POINT2POINT) fn = two ? (const void *)icp_kernel<0, 2, F> : (const void *)icp_kernel<0, 1, F>;
+    else fn = two ? (const void *)icp_kernel<1, 2, F> : (const void *)icp_kernel<1, 1, F>;
+    if (lds > 64 * 1024)  // opt in to > 64 KiB of dynamic LDS
+        F4L_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (mode == F4L_ICP_POINT2POINT) {
+        if (two) hipLaunchKernelGGL((icp_kernel<0, 2, F>), grid, block, lds, st, a);
+        else hipLaunchKernelGGL((icp_kernel<0, 1, F>), grid, block, lds, st, a);
+    } else {
+        if (two) hipLaunchKernelGGL((icp_kernel<1, 2, F>), grid, block, lds, st, a);
+        else hipLaunchKernelGGL((icp_kernel<1, 1, F>), grid, block, lds, st, a);
+    }
+    F4L_LAUNCH_CHECK();
+    return F4L_OK;
+}
+}  // namespace f4l
+
 extern "C" int f4l_piecewise_icp(const float *src, const int64_t *src_off, const float *tgt, const int64_t *tgt_off,
                                  int64_t P, const double *init_T, const float *tgt_normals, double max_corr_dist,
                                  int max_iter, double rel_fitness, double rel_rmse, int mode, int fixed_iters,
-                                 int64_t max_src_patch_host, int64_t max_tgt_patch_host, double *T_out,
-                                 double *fitness_out, double *rmse_out, int32_t *iters_out, int32_t *corr_out,
-                                 void *stream) {
+                                 int search_precision, int64_t max_src_patch_host, int64_t max_tgt_patch_host,
+                                 double *T_out, double *fitness_out, double *rmse_out, int32_t *iters_out,
+                                 int32_t *corr_out, void *stream) {
     using namespace f4l;
     if (P < 0 || !src_off || !tgt_off || !T_out || max_iter < 0 || max_src_patch_host < 0 || max_tgt_patch_host < 0)
         return F4L_EINVAL;
     if (mode != F4L_ICP_POINT2POINT && mode != F4L_ICP_POINT2PLANE) return F4L_EINVAL;
+    if (search_precision != F4L_SEARCH_F32 && search_precision != F4L_SEARCH_F64) return F4L_EINVAL;
     if (mode == F4L_ICP_POINT2PLANE && max_tgt_patch_host > 0 && !tgt_normals) return F4L_EINVAL;
     if ((max_src_patch_host > 0 && !src) || (max_tgt_patch_host > 0 && !tgt)) return F4L_EINVAL;
     if (P == 0) return F4L_OK;
     if (P > 0x7fffffffLL || max_src_patch_host > 0x3fffffffLL || max_tgt_patch_host > 0x3fffffffLL)
         return F4L_EUNSUPPORTED;
+    const bool f64 = search_precision == F4L_SEARCH_F64;
+    const int cap_max = f64 ? ICP_LDS_TGT_MAX * 2 / 3 : ICP_LDS_TGT_MAX;  // 24 B vs 16 B per staged target
     IcpArgs a;
     a.src = src; a.src_off = src_off; a.tgt = tgt; a.tgt_off = tgt_off; a.P = P;
     a.init_T = init_T; a.tgt_normals = tgt_normals;
-    a.r2 = max_corr_dist > 0.0 ? (float)(max_corr_dist * max_corr_dist) : 0.f;
+    a.r2 = max_corr_dist > 0.0 ? max_corr_dist * max_corr_dist : 0.0;
     a.max_iter = max_iter; a.rel_fitness = rel_fitness; a.rel_rmse = rel_rmse; a.fixed_iters = fixed_iters;
-    a.lds_cap = (int)(max_tgt_patch_host < ICP_LDS_TGT_MAX ? max_tgt_patch_host : ICP_LDS_TGT_MAX);
+    a.lds_cap = (int)(max_tgt_patch_host < cap_max ? max_tgt_patch_host : cap_max);
     a.T_out = T_out; a.fitness_out = fitness_out; a.rmse_out = rmse_out; a.iters_out = iters_out; a.corr_out = corr_out;
-    const size_t lds = (size_t)(ICP_NW * 32 + 16) * sizeof(double) + (size_t)a.lds_cap * sizeof(float4);
-    hipStream_t st = (hipStream_t)stream;
+    const size_t lds = (size_t)(ICP_NW * 32 + 16) * sizeof(double) + (size_t)a.lds_cap * (f64 ? 24 : 16);
     const bool two = max_src_patch_host > ICP_NT;  // two source points per lane once patches exceed one pass
-    dim3 grid((unsigned)P), block(ICP_NT);
-    if (lds > 64 * 1024) {
-        // opt in to > 64 KiB dynamic LDS
-        const void *fn;
-        if (mode == F4L_ICP_POINT2POINT) fn = two ? (const void *)icp_kernel<0, 2> : (const void *)icp_kernel<0, 1>;
-        else fn = two ? (const void *)icp_kernel<1, 2> : (const void *)icp_kernel<1, 1>;
-        F4L_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    }
-    if (mode == F4L_ICP_POINT2POINT) {
-        if (two) hipLaunchKernelGGL((icp_kernel<0, 2>), grid, block, lds, st, a);
-        else hipLaunchKernelGGL((icp_kernel<0, 1>), grid, block, lds, st, a);
-    } else {
-        if (two) hipLaunchKernelGGL((icp_kernel<1, 2>), grid, block, lds, st, a);
-        else hipLaunchKernelGGL((icp_kernel<1, 1>), grid, block, lds, st, a);
-    }
-    F4L_LAUNCH_CHECK();
-    return F4L_OK;
+    return f64 ? launch_icp<double>(a, mode, two, lds, (hipStream_t)stream)
+               : launch_icp<float>(a, mode, two, lds, (hipStream_t)stream);
 }

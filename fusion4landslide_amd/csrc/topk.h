@@ -65,10 +65,11 @@ struct WaveTopK {
 // Squared Euclidean distance in double from float coordinates, accumulated x, y, z with separately rounded
 // multiply and add (no FMA), as codelibrary/util/metric/squared_euclidean.h:25-36 compiled for x86-64.
 __device__ __forceinline__ double dist2_exact(float ax, float ay, float az, float bx, float by, float bz) {
+#pragma clang fp contract(off)  // HIP's __dmul_rn/__dadd_rn are plain operators: keep hipcc from fusing them
     const double dx = (double)ax - (double)bx, dy = (double)ay - (double)by, dz = (double)az - (double)bz;
-    double t = __dmul_rn(dx, dx);
-    t = __dadd_rn(t, __dmul_rn(dy, dy));
-    t = __dadd_rn(t, __dmul_rn(dz, dz));
+    double t = dx * dx;
+    t = t + dy * dy;
+    t = t + dz * dz;
     return t;
 }
 

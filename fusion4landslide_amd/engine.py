@@ -91,11 +91,13 @@ def patch_normals(pts, off, knn=30, max_patch=None):
 
 def piecewise_icp(src, src_off, tgt, tgt_off, init_T=None, max_corr_dist=0.1, max_iter=30, rel_fitness=1e-6,
                   rel_rmse=1e-6, icp_type="point2point", fixed_iters=False, tgt_normals=None, return_corr=False,
-                  max_src_patch=None, max_tgt_patch=None):
+                  max_src_patch=None, max_tgt_patch=None, search="f32"):
     """Batched per-patch ICP (utils/o3d_tools.py:12-71 for P patch pairs in one launch).
 
     Returns dict(T (P,4,4) f64, fitness (P,) f64, rmse (P,) f64, iters (P,) i32[, corr (n_src,) i32]).
     ``fixed_iters=True`` is the benchmark mode (exactly ``max_iter`` updates, no early exit).
+    ``search="f64"`` evaluates the nearest-neighbour search in double like the reference's Open3D path (parity
+    mode, ~2x the time); ``"f32"`` searches in float32 on patch-relative coordinates.
     """
     torch = require_gpu()
     if icp_type not in _ICP_MODES:
@@ -129,7 +131,8 @@ def piecewise_icp(src, src_off, tgt, tgt_off, init_T=None, max_corr_dist=0.1, ma
     corr = torch.empty((src.shape[0],), dtype=torch.int32, device=dev) if return_corr else None
     check(lib().f4l_piecewise_icp(ptr(src), ptr(src_off), ptr(tgt), ptr(tgt_off), P, ptr(T0), ptr(tn),
                                   float(max_corr_dist), int(max_iter), float(rel_fitness), float(rel_rmse), mode,
-                                  int(bool(fixed_iters)), int(max_src_patch), int(max_tgt_patch), ptr(T), ptr(fit),
+                                  int(bool(fixed_iters)), {"f32": _lib.SEARCH_F32, "f64": _lib.SEARCH_F64}[search],
+                                  int(max_src_patch), int(max_tgt_patch), ptr(T), ptr(fit),
                                   ptr(rmse), ptr(iters), ptr(corr), stream_ptr()), "f4l_piecewise_icp")
     out = dict(T=T, fitness=fit, rmse=rmse, iters=iters)
     if return_corr:

@@ -24,11 +24,14 @@ CONFIGS = {
 }
 
 
-def _surface(x, y, phases):
+def _surface(x, y, phases, roughness=0.0):
     z = np.zeros_like(x)
     for j in range(1, 5):
         a, f = 2.0 / 2 ** j, 2 ** j / 100.0
         z += a * np.sin(2 * np.pi * f * x + phases[j - 1, 0]) * np.sin(2 * np.pi * f * y + phases[j - 1, 1])
+    if roughness:
+        # metre-scale relief so that a single patch constrains all six degrees of freedom (tests only)
+        z += roughness * np.sin(2 * np.pi * x / 0.9 + phases[0, 0]) * np.sin(2 * np.pi * y / 1.1 + phases[0, 1])
     return z
 
 
@@ -42,17 +45,17 @@ def _rodrigues(axis, angle):
     return np.eye(3)[None] + s * K + (1 - c) * (K @ K)
 
 
-def two_epoch_cloud(n, cells, resolution, noise=0.005, seed=0, origin=(0.0, 0.0, 0.0)):
+def two_epoch_cloud(n, cells, resolution, noise=0.005, seed=0, origin=(0.0, 0.0, 0.0), roughness=0.0):
     """Returns dict(src (n,3) f32, tgt (n,3) f32, L, block_R, block_t, block_of_tgt)."""
     L = cells * resolution
     phases = np.random.Generator(np.random.PCG64(seed)).uniform(0, 2 * np.pi, (4, 2))
     r0 = np.random.Generator(np.random.PCG64(seed))
     r0.uniform(0, 2 * np.pi, (4, 2))  # keep the stream aligned with `phases`
     xy = r0.uniform(0, L, (n, 2))
-    src = np.c_[xy, _surface(xy[:, 0], xy[:, 1], phases) + r0.normal(0, noise, n)]
+    src = np.c_[xy, _surface(xy[:, 0], xy[:, 1], phases, roughness) + r0.normal(0, noise, n)]
     r1 = np.random.Generator(np.random.PCG64(seed + 1))
     xy2 = r1.uniform(0, L, (n, 2))
-    tgt0 = np.c_[xy2, _surface(xy2[:, 0], xy2[:, 1], phases)]
+    tgt0 = np.c_[xy2, _surface(xy2[:, 0], xy2[:, 1], phases, roughness)]
     # piecewise-rigid field on square blocks of side 4 x resolution
     r2 = np.random.Generator(np.random.PCG64(seed + 2))
     nb = int(np.ceil(cells / 4.0))
@@ -89,11 +92,11 @@ def grid_partition(pts, cells, resolution, origin=(0.0, 0.0, 0.0)):
     return order, off
 
 
-def make_patches(n, cells, resolution, seed=0, noise=0.005, origin=(0.0, 0.0, 0.0)):
+def make_patches(n, cells, resolution, seed=0, noise=0.005, origin=(0.0, 0.0, 0.0), roughness=0.0):
     """Two-epoch cloud already grouped into patch-contiguous CSR arrays.
 
     Returns dict(src, src_off, tgt, tgt_off, P, max_src, max_tgt, meta)."""
-    c = two_epoch_cloud(n, cells, resolution, noise=noise, seed=seed, origin=origin)
+    c = two_epoch_cloud(n, cells, resolution, noise=noise, seed=seed, origin=origin, roughness=roughness)
     so, soff = grid_partition(c["src"], cells, resolution, origin)
     to, toff = grid_partition(c["tgt"], cells, resolution, origin)
     return dict(src=np.ascontiguousarray(c["src"][so]), src_off=soff, tgt=np.ascontiguousarray(c["tgt"][to]), tgt_off=toff,

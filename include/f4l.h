@@ -42,6 +42,9 @@ extern "C" {
 #define F4L_ICP_POINT2POINT 0 /* o3d TransformationEstimationPointToPoint(False), utils/o3d_tools.py:34 */
 #define F4L_ICP_POINT2PLANE 1 /* o3d TransformationEstimationPointToPlane(),     utils/o3d_tools.py:39 */
 
+#define F4L_SEARCH_F32 0 /* nearest-neighbour search in float32 on patch-relative coordinates (fast path)   */
+#define F4L_SEARCH_F64 1 /* ... in float64, the arithmetic of the reference's Open3D path (parity mode)     */
+
 #define F4L_MAX_K 64 /* neighbour-list capacity of the wave-resident top-k (one slot per lane) */
 
 int f4l_version(void);
@@ -83,6 +86,8 @@ int f4l_kabsch_residuals(const float *src, const float *ref, const int64_t *off,
  *   tgt_normals : float32 [n_tgt][3]; required for POINT2PLANE (see f4l_patch_normals), else NULL
  *   max_corr_dist, max_iter, rel_fitness, rel_rmse : o3d ICPConvergenceCriteria (utils/o3d_tools.py:47-50)
  *   fixed_iters != 0 disables the early exit: exactly max_iter updates (benchmark mode)
+ *   search_precision : F4L_SEARCH_F32 | F4L_SEARCH_F64.  The transform, all sums and the solves are double in
+ *                 both; F64 also evaluates point positions and squared distances in double, like Open3D.
  *   max_src_patch_host / max_tgt_patch_host : largest patch sizes (host-known; size LDS and pick the path)
  * Outputs (any may be NULL except T_out):
  *   T_out double [P][16]; fitness_out, rmse_out double [P]; iters_out int32 [P];
@@ -92,9 +97,9 @@ int f4l_kabsch_residuals(const float *src, const float *ref, const int64_t *off,
 int f4l_piecewise_icp(const float *src, const int64_t *src_off, const float *tgt, const int64_t *tgt_off,
                       int64_t P, const double *init_T, const float *tgt_normals, double max_corr_dist,
                       int max_iter, double rel_fitness, double rel_rmse, int mode, int fixed_iters,
-                      int64_t max_src_patch_host, int64_t max_tgt_patch_host, double *T_out,
-                      double *fitness_out, double *rmse_out, int32_t *iters_out, int32_t *corr_out,
-                      void *stream);
+                      int search_precision, int64_t max_src_patch_host, int64_t max_tgt_patch_host,
+                      double *T_out, double *fitness_out, double *rmse_out, int32_t *iters_out,
+                      int32_t *corr_out, void *stream);
 
 /* Per-patch normal estimation as utils/o3d_tools.py:29-30 (`pcd.estimate_normals()` on the patch cloud:
  * kNN(knn=30) inside the patch, self included; smallest-eigenvector of the neighbourhood covariance;

