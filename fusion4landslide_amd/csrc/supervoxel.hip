@@ -13,6 +13,9 @@
 #include <cfloat>
 #include <cmath>
 #include <cstring>
+#include <fstream>
+#include <iomanip>
+#include <random>
 #include <vector>
 
 #include "f4l_device.h"
@@ -304,4 +307,27 @@ extern "C" int f4l_supervoxel(const float *xyz, int64_t n, int k, double resolut
     F4L_HIP_CHECK(hipStreamSynchronize(st));
     if (n_supervoxels_host) *n_supervoxels_host = nsv;
     return F4L_OK;
+}
+
+// Partition text file `x y z r g b label` exactly as the reference writes it (supervoxel.cpp:45-64 ->
+// codelibrary/geometry/io/xyz_io.h:192-221): 12 significant digits, one random colour per supervoxel drawn from
+// a default-seeded std::mt19937.  `load_partition` re-reads column 6 (src/coarse_to_fine_matching_base.py:1275).
+extern "C" int f4l_write_partition_txt(const char *path, const float *xyz_host, const int32_t *labels_host, int64_t n,
+                                       int32_t n_supervoxels) {
+    if (!path || n < 0 || n_supervoxels < 0 || (n > 0 && (!xyz_host || !labels_host))) return F4L_EINVAL;
+    std::vector<uint32_t> colour((size_t)n_supervoxels);
+    std::mt19937 random;
+    for (int32_t i = 0; i < n_supervoxels; ++i) colour[(size_t)i] = (uint32_t)random();
+    std::ofstream out(path);
+    if (!out) return F4L_EINVAL;
+    out << std::setprecision(12);
+    for (int64_t i = 0; i < n; ++i) {
+        const int32_t l = labels_host[i];
+        if (l < 0 || l >= n_supervoxels) return F4L_EINVAL;
+        const uint32_t c = colour[(size_t)l];
+        out << (double)xyz_host[3 * i] << " " << (double)xyz_host[3 * i + 1] << " " << (double)xyz_host[3 * i + 2] << " "
+            << (int)((c >> 16) & 0xff) << " " << (int)((c >> 8) & 0xff) << " " << (int)(c & 0xff) << " " << (int)l << "\n";
+    }
+    out.close();
+    return out.good() ? F4L_OK : F4L_EINVAL;
 }

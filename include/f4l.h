@@ -152,6 +152,12 @@ int f4l_supervoxel_segment_host(const float *xyz_host, const double *normals_hos
                                 int64_t n, int k, double resolution, int32_t *labels_host,
                                 int32_t *n_supervoxels_host);
 
+/* Host-only: write the partition text file `x y z r g b label` byte-for-byte as the reference does
+ * (supervoxel.cpp:45-64 -> codelibrary/geometry/io/xyz_io.h:192-221); `load_partition`
+ * (src/coarse_to_fine_matching_base.py:1257,1275) re-reads column 6. */
+int f4l_write_partition_txt(const char *path, const float *xyz_host, const int32_t *labels_host, int64_t n,
+                            int32_t n_supervoxels);
+
 /* Sort-by-label -> CSR (replaces the O(K*N) mask loop of prepare_pts2spt_dict,
  * src/coarse_to_fine_matching_base.py:1327-1332).  labels int32 [n] in [0,K); order_out int32 [n] = point ids
  * grouped by label (stable); off_out int64 [K+1]. */
