@@ -23,6 +23,8 @@
 // Numerics: coordinates are taken relative to a per-patch origin (first target point) so that float32
 // distance arithmetic works at ~1 m magnitudes even for georeferenced clouds; the running transform and all
 // sums are double.
+#include <stdlib.h>
+
 #include "f4l_device.h"
 
 namespace f4l {
@@ -46,6 +48,7 @@ struct IcpArgs {
     int lds_cap;  // number of float4 target slots in dynamic LDS
     double *T_out, *fitness_out, *rmse_out;
     int32_t *iters_out, *corr_out;
+    int debug;  // F4L_ICP_DEBUG env: 1 = skip the solve, 2 = skip the search (timing experiments only)
 };
 
 // Target point as staged in LDS: float4 (16 B, one ds_read_b128) for the float32 search, 3 doubles for the
@@ -204,7 +207,8 @@ __global__ __launch_bounds__(ICP_NT, 4) void icp_kernel(IcpArgs a) {
                 best[s] = f_inf<F>();
                 bj[s] = -1;
             }
-            if (in_lds) nn_lds<SPT, F>(tl, nt, px, py, pz, best, bj);
+            if (a.debug & 2) { bj[0] = 0; bj[1] = 0; best[0] = (F)1e-4; best[1] = (F)1e-4; }
+            else if (in_lds) nn_lds<SPT, F>(tl, nt, px, py, pz, best, bj);
             else nn_global<SPT, F>(tg, nt, ox, oy, oz, px, py, pz, best, bj);
 #pragma unroll
             for (int s = 0; s < SPT; ++s) {
@@ -271,7 +275,7 @@ __global__ __launch_bounds__(ICP_NT, 4) void icp_kernel(IcpArgs a) {
                     done = true;
             }
             if (pass == a.max_iter) done = true;
-            if (!done && m > 0.0) {
+            if (!done && m > 0.0 && !(a.debug & 1)) {
                 double Ru[9], tu[3];
                 bool have = true;
                 if (MODE == F4L_ICP_POINT2POINT) {
@@ -416,6 +420,7 @@ extern "C" int f4l_piecewise_icp(const float *src, const int64_t *src_off, const
     a.r2 = max_corr_dist > 0.0 ? max_corr_dist * max_corr_dist : 0.0;
     a.max_iter = max_iter; a.rel_fitness = rel_fitness; a.rel_rmse = rel_rmse; a.fixed_iters = fixed_iters;
     a.lds_cap = (int)(max_tgt_patch_host < cap_max ? max_tgt_patch_host : cap_max);
+    { const char *dbg = getenv("F4L_ICP_DEBUG"); a.debug = dbg ? atoi(dbg) : 0; }
     a.T_out = T_out; a.fitness_out = fitness_out; a.rmse_out = rmse_out; a.iters_out = iters_out; a.corr_out = corr_out;
     const size_t lds = (size_t)(ICP_NW * 32 + 16) * sizeof(double) + (size_t)a.lds_cap * (f64 ? 24 : 16);
     const bool two = max_src_patch_host > ICP_NT;  // two source points per lane once patches exceed one pass
