@@ -79,3 +79,14 @@ def test_host_segmentation_matches_oracle_and_golden(golden_dir):
         assert rc == 0
         assert nsv.value == int(g["n_supervoxels"])
         assert np.array_equal(labels, g["labels"])
+
+
+def test_reference_module_layout_is_importable():
+    """The mirrors of the reference's modules import without a GPU (compute raises, importing does not)."""
+    import importlib
+    for mod in ["fusion4landslide_amd.cpp_core.supervoxel_segmentation.build.supervoxel",
+                "fusion4landslide_amd.utils.o3d_tools", "fusion4landslide_amd.scripts.weighted_svd",
+                "fusion4landslide_amd.src.piecewise_icp", "fusion4landslide_amd.main_piecewise_icp"]:
+        importlib.import_module(mod)
+    sv = importlib.import_module("fusion4landslide_amd.cpp_core.supervoxel_segmentation.build.supervoxel")
+    assert callable(sv.computeSupervoxel) and callable(sv.WritePoints)
