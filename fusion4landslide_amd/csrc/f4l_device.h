@@ -50,6 +50,60 @@ __device__ __forceinline__ int wave_sum(int v) {
     return v;
 }
 
+// ---- DPP reductions (VALU only: no LDS round trips, unlike __shfl which lowers to ds_bpermute) --------
+// The classic GCN wave64 pattern: two quad permutes, row_half_mirror, row_mirror, row_bcast15, row_bcast31;
+// the total lands in lane 63 and is handed to every lane through an SGPR (v_readlane).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_mov(double v) {
+    const long long b = __double_as_longlong(v);
+    // bound_ctrl = true: lanes without a source (masked rows keep `old` = 0) read zero
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffLL), CTRL, ROW_MASK, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, ROW_MASK, 0xf, true);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ double bcast_lane63(double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffLL), 63);
+    const int hi = __builtin_amdgcn_readlane((int)(b >> 32), 63);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+// Sum over the 64 lanes, result uniform in every lane.
+__device__ __forceinline__ double wave_sum_dpp(double v) {
+    v += dpp_mov<0xB1, 0xf>(v);   // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4E, 0xf>(v);   // quad_perm [2,3,0,1]
+    v += dpp_mov<0x141, 0xf>(v);  // row_half_mirror
+    v += dpp_mov<0x140, 0xf>(v);  // row_mirror: every lane of a 16-lane row holds the row total
+    v += dpp_mov<0x142, 0xa>(v);  // row_bcast15 into rows 1 and 3
+    v += dpp_mov<0x143, 0xc>(v);  // row_bcast31 into rows 2 and 3: lane 63 holds the wave total
+    return bcast_lane63(v);
+}
+
+// The same for N independent values, stage by stage in groups of at most 6, so that the dependency chains of a
+// group interleave without keeping 2 N temporaries alive.
+template <int N, int LO, int HI>
+__device__ __forceinline__ void wave_sum_dpp_group(double (&v)[N]) {
+#pragma unroll
+    for (int i = LO; i < HI; ++i) v[i] += dpp_mov<0xB1, 0xf>(v[i]);
+#pragma unroll
+    for (int i = LO; i < HI; ++i) v[i] += dpp_mov<0x4E, 0xf>(v[i]);
+#pragma unroll
+    for (int i = LO; i < HI; ++i) v[i] += dpp_mov<0x141, 0xf>(v[i]);
+#pragma unroll
+    for (int i = LO; i < HI; ++i) v[i] += dpp_mov<0x140, 0xf>(v[i]);
+#pragma unroll
+    for (int i = LO; i < HI; ++i) v[i] += dpp_mov<0x142, 0xa>(v[i]);
+#pragma unroll
+    for (int i = LO; i < HI; ++i) v[i] += dpp_mov<0x143, 0xc>(v[i]);
+#pragma unroll
+    for (int i = LO; i < HI; ++i) v[i] = bcast_lane63(v[i]);
+}
+template <int N, int LO = 0>
+__device__ __forceinline__ void wave_sum_dpp_n(double (&v)[N]) {
+    constexpr int HI = LO + 6 < N ? LO + 6 : N;
+    wave_sum_dpp_group<N, LO, HI>(v);
+    if constexpr (HI < N) wave_sum_dpp_n<N, HI>(v);
+}
+
 // Sum NV doubles across a workgroup of NW waves; every thread receives the totals in v[].
 // scratch: NW*NV doubles of LDS.  Contains two barriers.
 template <int NV, int NW>
@@ -117,19 +171,9 @@ __device__ __forceinline__ bool jacobi_rotate(double *W, double *V) {
     return true;
 }
 
-// One-sided (Hestenes) Jacobi SVD of a 3x3: A = U diag(S) V^T, S descending, U and V orthogonal also for
-// rank-deficient A (free directions completed by Gram-Schmidt / cross product).
-__device__ __forceinline__ void svd3(const double *A, double *U, double *S, double *V) {
-    double W[9], Vm[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-#pragma unroll
-    for (int i = 0; i < 9; ++i) W[i] = A[i];
-    for (int sweep = 0; sweep < 60; ++sweep) {
-        bool any = false;
-        any |= jacobi_rotate<0, 1>(W, Vm);
-        any |= jacobi_rotate<0, 2>(W, Vm);
-        any |= jacobi_rotate<1, 2>(W, Vm);
-        if (!any) break;
-    }
+// Second half of the one-sided Jacobi SVD: W = A V has mutually orthogonal columns; sort them by norm
+// (descending), normalise into U, complete the directions that carry no signal.
+__device__ __forceinline__ void svd3_finish(double *W, double *Vm, double *U, double *S, double *V) {
     double s0 = sqrt(W[0] * W[0] + W[3] * W[3] + W[6] * W[6]);
     double s1 = sqrt(W[1] * W[1] + W[4] * W[4] + W[7] * W[7]);
     double s2 = sqrt(W[2] * W[2] + W[5] * W[5] + W[8] * W[8]);
@@ -187,6 +231,83 @@ __device__ __forceinline__ void svd3(const double *A, double *U, double *S, doub
     U[0] = u0[0]; U[1] = u1[0]; U[2] = u2[0];
     U[3] = u0[1]; U[4] = u1[1]; U[5] = u2[1];
     U[6] = u0[2]; U[7] = u1[2]; U[8] = u2[2];
+}
+
+// One-sided (Hestenes) Jacobi SVD of a 3x3: A = U diag(S) V^T, S descending, U and V orthogonal also for
+// rank-deficient A (free directions completed by Gram-Schmidt / cross product).
+__device__ __forceinline__ void svd3(const double *A, double *U, double *S, double *V) {
+    double W[9], Vm[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+#pragma unroll
+    for (int i = 0; i < 9; ++i) W[i] = A[i];
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        bool any = false;
+        any |= jacobi_rotate<0, 1>(W, Vm);
+        any |= jacobi_rotate<0, 2>(W, Vm);
+        any |= jacobi_rotate<1, 2>(W, Vm);
+        if (!any) break;
+    }
+    svd3_finish(W, Vm, U, S, V);
+}
+
+// ---- the same SVD for the per-iteration solve of the ICP kernel, built for latency ------------------------
+// A rotation only has to (a) be orthogonal to working precision and (b) shrink the off-diagonal term; how
+// accurately its ANGLE is computed merely steers convergence.  So the angle uses the raw v_rcp_f64 /
+// v_sqrt_f64 estimates (~1e-7 relative, one instruction each instead of a ~12-instruction IEEE sequence), and
+// only c = (1 + t^2)^(-1/2) is polished by two Newton steps to full double precision; s = c t then makes
+// c^2 + s^2 = 1 to rounding.  Columns count as orthogonal at |gamma| <= 8 eps sqrt(alpha beta): the exit
+// test of svd3 (eps / 4) sits below the rounding noise of gamma and usually burns all 60 sweeps.
+template <int P, int Q>
+__device__ __forceinline__ bool jacobi_rotate_fast(double *W, double *V) {
+    double alpha = 0.0, beta = 0.0, gamma = 0.0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        alpha += W[3 * i + P] * W[3 * i + P];
+        beta += W[3 * i + Q] * W[3 * i + Q];
+        gamma += W[3 * i + P] * W[3 * i + Q];
+    }
+    const double tol = 8.0 * 2.220446049250313e-16;
+    if (!(gamma * gamma > (tol * tol) * (alpha * beta))) return false;  // converged pair (also gamma == 0, NaN)
+    const double zeta = (beta - alpha) * 0.5 * __builtin_amdgcn_rcp(gamma);
+    double t = __builtin_amdgcn_rcp(fabs(zeta) + __builtin_amdgcn_sqrt(__builtin_fma(zeta, zeta, 1.0)));
+    t = zeta < 0.0 ? -t : t;
+    const double x = __builtin_fma(t, t, 1.0);
+    double c = __builtin_amdgcn_rsq(x);
+    c = c * __builtin_fma(-0.5 * x * c, c, 1.5);
+    c = c * __builtin_fma(-0.5 * x * c, c, 1.5);
+    const double sn = c * t;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const double wp = W[3 * i + P], wq = W[3 * i + Q];
+        W[3 * i + P] = c * wp - sn * wq;
+        W[3 * i + Q] = sn * wp + c * wq;
+        const double vp = V[3 * i + P], vq = V[3 * i + Q];
+        V[3 * i + P] = c * vp - sn * vq;
+        V[3 * i + Q] = sn * vp + c * vq;
+    }
+    return true;
+}
+
+// A = U diag(S) V^T with the sweeps WARM-STARTED from V0 (orthogonal; the V of the previous ICP iteration, or I):
+// W = A V0 already has nearly orthogonal columns when A moved little, so one or two sweeps finish it.
+__device__ __forceinline__ int svd3_warm(const double *A, const double *V0, double *U, double *S, double *V) {
+    double W[9], Vm[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) Vm[i] = V0[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            W[3 * i + j] = A[3 * i] * V0[j] + A[3 * i + 1] * V0[3 + j] + A[3 * i + 2] * V0[6 + j];
+    int sweeps = 0;
+    for (; sweeps < 16; ++sweeps) {
+        bool any = false;
+        any |= jacobi_rotate_fast<0, 1>(W, Vm);
+        any |= jacobi_rotate_fast<0, 2>(W, Vm);
+        any |= jacobi_rotate_fast<1, 2>(W, Vm);
+        if (!any) break;
+    }
+    svd3_finish(W, Vm, U, S, V);
+    return sweeps;  // rotating sweeps (the final, idle one not counted)
 }
 
 // R = A diag(1,1,d) B^T for row-major 3x3 A, B.

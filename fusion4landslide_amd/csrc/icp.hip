@@ -7,31 +7,34 @@
 // the 4x4 back (two device crossings per patch).
 //
 // Mapping to CDNA4
-//   * one 256-thread workgroup (4 waves) per patch pair;
-//   * the target patch is staged ONCE into LDS as float4 (x,y,z relative to a per-patch origin) and stays
-//     resident for every iteration; all 64 lanes of a wave read the same candidate -> LDS broadcast reads,
-//     conflict free (ds_read_b128, one per candidate per wave);
-//   * each lane owns one or two source points per pass (registers), brute-force nearest neighbour inside the
-//     patch: 3 sub + 1 mul + 2 fma + compare/select per pair, no MFMA (the contraction is 3x3);
+//   * one workgroup of NW waves (1, 2 or 4; chosen by the host from the patch count and size) per patch pair;
+//   * the target patch is counting-sorted ONCE into an LDS-resident uniform grid with cell edge >= the
+//     correspondence radius (patch_grid.h) and stays there for every iteration; the source patch is staged in
+//     LDS as well, so after the prologue an iteration touches no global memory at all;
+//   * each lane owns one source point at a time and walks the <= 9 grid rows around it (float4 LDS reads),
+//     instead of the whole patch: ~25 candidates per query instead of ~500;
 //   * per pass the correspondence sums (17 doubles for Umeyama, 29 for the 6x6 point-to-plane system) are
-//     reduced with wavefront __shfl butterflies, then across the 4 waves through LDS; wave 0 solves the 3x3
+//     reduced with DPP row operations (no LDS traffic), then across the waves through LDS; wave 0 solves the 3x3
 //     Jacobi SVD / 6x6 system in double and broadcasts the new transform through LDS;
 //   * convergence test, iteration count, fitness and rmse are evaluated on the device.
-// Source points are re-read from global memory each pass (12 B/pt/iter, L2 resident after the first pass);
-// with the target share this is the 24 B/pt/iter algorithmic traffic of SURVEY.md 8(d).
+// HBM traffic per patch is one read of both clouds (plus two re-reads of the target from L2 while the grid
+// is built); the ALGORITHMIC traffic the roofline is priced with stays the reference's dataflow, 24 B per
+// source point per iteration.
 //
 // Numerics: coordinates are taken relative to a per-patch origin (first target point) so that float32
 // distance arithmetic works at ~1 m magnitudes even for georeferenced clouds; the running transform and all
-// sums are double.
+// sums are double.  The grid search returns exactly the brute-force answer: the minimiser of (d2, index).
+#include <stdio.h>
 #include <stdlib.h>
 
 #include "f4l_device.h"
+#include "patch_grid.h"
 
 namespace f4l {
 
-constexpr int ICP_NW = 4;             // waves per workgroup
-constexpr int ICP_NT = ICP_NW * 64;   // threads per workgroup
-constexpr int ICP_LDS_TGT_MAX = 8192; // target points kept in LDS at most (128 KiB of the 160 KiB)
+constexpr int ICP_LDS_BUDGET = 160 * 1024 - 512;  // dynamic LDS a single workgroup may ask for on gfx950
+constexpr int ICP_TGT_MAX = 8192;                 // target points kept in LDS at most
+constexpr int ICP_CELL_MAX = 16384;               // grid cells at most (uint16 prefix table)
 
 struct IcpArgs {
     const float *src;
@@ -41,56 +44,38 @@ struct IcpArgs {
     int64_t P;
     const double *init_T;
     const float *tgt_normals;
-    double r2;
+    double r, r2;
     int max_iter;
     double rel_fitness, rel_rmse;
     int fixed_iters;
-    int lds_cap;  // number of float4 target slots in dynamic LDS
+    int tgt_cap;   // target slots in LDS (patches with more targets take the brute-force global path)
+    int src_cap;   // source slots in LDS (0: sources are re-read from global memory each pass)
+    int cell_cap;  // grid cells the prefix table can hold
     double *T_out, *fitness_out, *rmse_out;
     int32_t *iters_out, *corr_out;
-    int debug;  // F4L_ICP_DEBUG env: 1 = skip the solve, 2 = skip the search (timing experiments only)
+    int debug;  // F4L_ICP_DEBUG env: 1 = skip the solve, 2 = skip the search, 4 = no row pruning (experiments)
+    unsigned long long *prof;  // F4L_ICP_PROF builds only: per-phase shader-clock totals (see f4l_piecewise_icp)
 };
 
-// Target point as staged in LDS: float4 (16 B, one ds_read_b128) for the float32 search, 3 doubles for the
-// float64 ("reference arithmetic") search.
-template <typename F> struct TgtPt;
-template <> struct TgtPt<float> { float x, y, z, w; };
-template <> struct TgtPt<double> { double x, y, z; };
+#ifdef F4L_ICP_PROF
+#define PROF_T(var) const unsigned long long var = __builtin_readcyclecounter()
+#define PROF_ADD(slot, t1, t0) do { prof_acc[slot] += (unsigned long long)((t1) - (t0)); } while (0)
+#define PROF_CNT(slot, v) do { if (a.prof) atomicAdd(&a.prof[slot], (unsigned long long)(v)); } while (0)
+#else
+#define PROF_T(var)
+#define PROF_ADD(slot, t1, t0)
+#define PROF_CNT(slot, v)
+#endif
 
-template <typename F> __device__ __forceinline__ F f_inf();
-template <> __device__ __forceinline__ float f_inf<float>() { return __builtin_inff(); }
-template <> __device__ __forceinline__ double f_inf<double>() { return __builtin_inf(); }
-
-// Nearest target of up to two query points; targets in LDS (origin-relative).
-template <int SPT, typename F>
-__device__ __forceinline__ void nn_lds(const TgtPt<F> *__restrict__ tl, int nt, const F (&px)[2], const F (&py)[2],
-                                       const F (&pz)[2], F (&best)[2], int (&bj)[2]) {
-#pragma unroll 8
-    for (int j = 0; j < nt; ++j) {
-        const TgtPt<F> q = tl[j];
-#pragma unroll
-        for (int s = 0; s < SPT; ++s) {
-            const F dx = px[s] - q.x, dy = py[s] - q.y, dz = pz[s] - q.z;
-            const F d = dx * dx + dy * dy + dz * dz;
-            if (d < best[s]) { best[s] = d; bj[s] = j; }
-        }
-    }
-}
-
-// Same with targets in global memory (patches larger than the LDS budget): wave-uniform addresses.
-template <int SPT, typename F>
-__device__ __forceinline__ void nn_global(const float *__restrict__ tg, int nt, float ox, float oy, float oz,
-                                          const F (&px)[2], const F (&py)[2], const F (&pz)[2], F (&best)[2],
-                                          int (&bj)[2]) {
+// Brute-force fallback with targets in global memory (patches larger than the LDS budget): wave-uniform
+// addresses, ascending index, so the (d2, index) minimiser is the same as the grid's.
+template <typename F>
+__device__ __forceinline__ void nn_global(const float *__restrict__ tg, int nt, float ox, float oy, float oz, F px, F py,
+                                          F pz, Best<F> &best) {
 #pragma unroll 4
     for (int j = 0; j < nt; ++j) {
         const F qx = (F)tg[3 * j] - (F)ox, qy = (F)tg[3 * j + 1] - (F)oy, qz = (F)tg[3 * j + 2] - (F)oz;
-#pragma unroll
-        for (int s = 0; s < SPT; ++s) {
-            const F dx = px[s] - qx, dy = py[s] - qy, dz = pz[s] - qz;
-            const F d = dx * dx + dy * dy + dz * dz;
-            if (d < best[s]) { best[s] = d; bj[s] = j; }
-        }
+        best.offer(grid_d2(px - qx, py - qy, pz - qz), j, j);
     }
 }
 
@@ -129,16 +114,29 @@ __device__ __forceinline__ bool solve6(double (&M)[6][7], double (&x)[6]) {
     return ok;
 }
 
-// LDS layout (dynamic): [ scratch doubles | state doubles | float4 targets ]
-//   scratch : ICP_NW * NV partial sums
-//   state   : Rc[9], tc[3], flag      (flag: 0 continue, 1 finished)
-template <int MODE, int SPT, typename F>
-__global__ __launch_bounds__(ICP_NT, 4) void icp_kernel(IcpArgs a) {
+// uniform double held in LDS -> scalar registers
+__device__ __forceinline__ double uniform_f64(double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readfirstlane((int)(b & 0xffffffffLL));
+    const int hi = __builtin_amdgcn_readfirstlane((int)(b >> 32));
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+// LDS layout (dynamic): [ scratch | state | targets tl | sources sl | prefix table E ]
+//   scratch : NW * 32 doubles (partial sums; doubles as the scratch of grid_build)
+//   state   : Rc[9], tc[3], done flag, fitness, rmse, iterations, V[9] of the last SVD (warm start)  (32 doubles)
+template <int MODE, int NW, typename F>
+__global__ __launch_bounds__(NW * 64, 4) void icp_kernel(IcpArgs a) {
     constexpr int NV = (MODE == F4L_ICP_POINT2POINT) ? 17 : 29;
+    constexpr int NT = NW * 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     double *scratch = reinterpret_cast<double *>(smem_raw);
-    double *state = scratch + ICP_NW * 32;  // 32 >= NV keeps the float4 region 16-byte aligned
-    TgtPt<F> *tl = reinterpret_cast<TgtPt<F> *>(state + 16);
+    double *state = scratch + NW * 32;
+    GridPt<F> *tl = reinterpret_cast<GridPt<F> *>(state + 32);
+    GridPt<F> *sl = tl + a.tgt_cap;
+    unsigned int *rl = reinterpret_cast<unsigned int *>(sl + a.src_cap);          // per-lane row lists of grid_nn
+    unsigned short *E = reinterpret_cast<unsigned short *>(rl + (GRID_ROWS + 1) * NT);
+    unsigned short *prev = E + a.cell_cap + 8;  // sorted position of each source point's last correspondence
 
     const int64_t p = blockIdx.x;
     if (p >= a.P) return;
@@ -147,18 +145,31 @@ __global__ __launch_bounds__(ICP_NT, 4) void icp_kernel(IcpArgs a) {
     const int ns = (int)(a.src_off[p + 1] - s0), nt = (int)(a.tgt_off[p + 1] - t0);
     const float *__restrict__ sg = a.src + 3 * s0;
     const float *__restrict__ tg = a.tgt + 3 * t0;
-    const bool in_lds = nt <= a.lds_cap;
+    const bool active = ns > 0 && a.r2 > 0.0;  // o3d returns the init untouched when max_corr_dist <= 0
+    const bool tgt_in_lds = nt > 0 && nt <= a.tgt_cap;
+    const bool src_in_lds = ns <= a.src_cap;
 
     // per-patch origin: first target point (else first source point, else 0)
     float ox = 0.f, oy = 0.f, oz = 0.f;
     if (nt > 0) { ox = tg[0]; oy = tg[1]; oz = tg[2]; }
     else if (ns > 0) { ox = sg[0]; oy = sg[1]; oz = sg[2]; }
 
-    if (in_lds) {
-        for (int j = tid; j < nt; j += ICP_NT) {
-            TgtPt<F> q;
-            q.x = (F)tg[3 * j] - (F)ox; q.y = (F)tg[3 * j + 1] - (F)oy; q.z = (F)tg[3 * j + 2] - (F)oz;
-            tl[j] = q;
+#ifdef F4L_ICP_PROF
+    unsigned long long prof_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    PROF_T(pt_start);
+    PatchGrid<F> g;
+    g.minx = g.miny = g.minz = (F)0; g.h = (F)1; g.inv_h = (F)1; g.nx = g.ny = g.nz = 1;
+    if (active) {  // uniform across the workgroup
+        if (tgt_in_lds) grid_build<F, NT>(tg, nt, ox, oy, oz, (F)a.r, a.cell_cap, tl, E, reinterpret_cast<F *>(scratch), g);
+        if (src_in_lds) {
+            for (int i = tid; i < ns; i += NT) {
+                GridPt<F> q;
+                q.x = (F)sg[3 * i] - (F)ox; q.y = (F)sg[3 * i + 1] - (F)oy; q.z = (F)sg[3 * i + 2] - (F)oz;
+                q.id = i;
+                sl[i] = q;
+                prev[i] = 0xffffu;
+            }
         }
     }
 
@@ -178,87 +189,122 @@ __global__ __launch_bounds__(ICP_NT, 4) void icp_kernel(IcpArgs a) {
             state[6] = 0; state[7] = 0; state[8] = 1; state[9] = 0; state[10] = 0; state[11] = 0;
         }
         state[12] = 0.0; state[13] = 0.0; state[14] = 0.0; state[15] = 0.0;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) state[16 + i] = (i % 4 == 0) ? 1.0 : 0.0;
     }
     __syncthreads();
 
-    const bool active = ns > 0 && a.r2 > 0.0;
-    const F r2 = (F)a.r2;  // o3d returns the init untouched when max_corr_dist <= 0
+    PROF_T(pt_built);
+    PROF_ADD(1, pt_built, pt_start);
+    const F r2 = (F)a.r2;
     const int n_pass = active ? a.max_iter + 1 : 0;
+    const bool use_prev = src_in_lds && !(a.debug & 4);
 
     for (int pass = 0; pass < n_pass; ++pass) {
-        const F R0 = (F)state[0], R1 = (F)state[1], R2 = (F)state[2], R3 = (F)state[3], R4 = (F)state[4],
-                R5 = (F)state[5], R6 = (F)state[6], R7 = (F)state[7], R8 = (F)state[8];
-        const F t0f = (F)state[9], t1f = (F)state[10], t2f = (F)state[11];
+        // the transform is uniform: keep it in scalar registers
+        const F R0 = (F)uniform_f64(state[0]), R1 = (F)uniform_f64(state[1]), R2 = (F)uniform_f64(state[2]),
+                R3 = (F)uniform_f64(state[3]), R4 = (F)uniform_f64(state[4]), R5 = (F)uniform_f64(state[5]),
+                R6 = (F)uniform_f64(state[6]), R7 = (F)uniform_f64(state[7]), R8 = (F)uniform_f64(state[8]);
+        const F t0f = (F)uniform_f64(state[9]), t1f = (F)uniform_f64(state[10]), t2f = (F)uniform_f64(state[11]);
         double acc[NV];
 #pragma unroll
         for (int i = 0; i < NV; ++i) acc[i] = 0.0;
+        PROF_T(pt_p0);
 
-        for (int base = 0; base < ns; base += ICP_NT * SPT) {
-            F px[2], py[2], pz[2], best[2];
-            int bj[2], si[2];
+        for (int base = 0; base < ns; base += NT) {
+            const int si = base + tid;
+            const bool valid = si < ns;
+            const int ii = valid ? si : ns - 1;  // idle lanes recompute the last point (keeps loads in bounds)
+            F x, y, z;
+            if (src_in_lds) { const GridPt<F> s = sl[ii]; x = s.x; y = s.y; z = s.z; }
+            else { x = (F)sg[3 * ii] - (F)ox; y = (F)sg[3 * ii + 1] - (F)oy; z = (F)sg[3 * ii + 2] - (F)oz; }
+            const F px = R0 * x + R1 * y + R2 * z + t0f;
+            const F py = R3 * x + R4 * y + R5 * z + t1f;
+            const F pz = R6 * x + R7 * y + R8 * z + t2f;
+            Best<F> best;
+            best.init(r2);
+            if (a.debug & 2) { if (nt > 0) best.offer((F)1e-4, 0, 0); }
+            else if (tgt_in_lds) {
+                // last pass's correspondence, re-measured, bounds the search from the start
+                const int pv = (use_prev && valid) ? (int)prev[ii] : 0xffff;
+                if (pv != 0xffff) {
+                    const GridPt<F> q = tl[pv];
+                    best.offer(grid_d2(px - q.x, py - q.y, pz - q.z), q.id, pv);
+                }
+#ifdef F4L_ICP_PROF
+                grid_nn<F, NT>(g, tl, E, rl, valid, px, py, pz, best, (a.debug & 64) ? a.prof : nullptr);
+#else
+                grid_nn<F, NT>(g, tl, E, rl, valid, px, py, pz, best);
+#endif
+                if (use_prev && valid) prev[ii] = (unsigned short)(best.pos >= 0 ? best.pos : 0xffff);
+            } else nn_global<F>(tg, nt, ox, oy, oz, px, py, pz, best);
+            const bool hit = valid && best.pos >= 0 && best.d2() < r2;  // SearchHybrid: d2 < r^2
+            const int bj = best.id();  // index inside the target patch
+            if (a.corr_out && valid) a.corr_out[s0 + si] = hit ? bj : -1;
+            if (hit) {
+                F qx, qy, qz;
+                if (tgt_in_lds) { const GridPt<F> q = tl[best.pos]; qx = q.x; qy = q.y; qz = q.z; }
+                else { qx = (F)tg[3 * bj] - (F)ox; qy = (F)tg[3 * bj + 1] - (F)oy; qz = (F)tg[3 * bj + 2] - (F)oz; }
+                const double dpx = px, dpy = py, dpz = pz, dqx = qx, dqy = qy, dqz = qz;
+                acc[0] += 1.0;
+                acc[1] += (double)best.d2();
+                if (MODE == F4L_ICP_POINT2POINT) {
+                    acc[2] += dpx; acc[3] += dpy; acc[4] += dpz;
+                    acc[5] += dqx; acc[6] += dqy; acc[7] += dqz;
+                    acc[8] += dqx * dpx; acc[9] += dqx * dpy; acc[10] += dqx * dpz;
+                    acc[11] += dqy * dpx; acc[12] += dqy * dpy; acc[13] += dqy * dpz;
+                    acc[14] += dqz * dpx; acc[15] += dqz * dpy; acc[16] += dqz * dpz;
+                } else {
+                    const float *nn = a.tgt_normals + 3 * (t0 + bj);
+                    const double nx = nn[0], ny = nn[1], nz = nn[2];
+                    const double r = (dpx - dqx) * nx + (dpy - dqy) * ny + (dpz - dqz) * nz;
+                    double J[6];
+                    J[0] = dpy * nz - dpz * ny; J[1] = dpz * nx - dpx * nz; J[2] = dpx * ny - dpy * nx;
+                    J[3] = nx; J[4] = ny; J[5] = nz;
+                    int k = 2;
 #pragma unroll
-            for (int s = 0; s < SPT; ++s) {
-                si[s] = base + s * ICP_NT + tid;
-                const int ii = si[s] < ns ? si[s] : ns - 1;  // clamp: inactive lanes recompute the last point
-                const F x = (F)sg[3 * ii] - (F)ox, y = (F)sg[3 * ii + 1] - (F)oy, z = (F)sg[3 * ii + 2] - (F)oz;
-                px[s] = R0 * x + R1 * y + R2 * z + t0f;
-                py[s] = R3 * x + R4 * y + R5 * z + t1f;
-                pz[s] = R6 * x + R7 * y + R8 * z + t2f;
-                best[s] = f_inf<F>();
-                bj[s] = -1;
-            }
-            if (a.debug & 2) { bj[0] = 0; bj[1] = 0; best[0] = (F)1e-4; best[1] = (F)1e-4; }
-            else if (in_lds) nn_lds<SPT, F>(tl, nt, px, py, pz, best, bj);
-            else nn_global<SPT, F>(tg, nt, ox, oy, oz, px, py, pz, best, bj);
+                    for (int u = 0; u < 6; ++u)
 #pragma unroll
-            for (int s = 0; s < SPT; ++s) {
-                const bool valid = si[s] < ns;
-                const bool hit = valid && bj[s] >= 0 && best[s] < r2;  // SearchHybrid: d2 < r^2
-                if (a.corr_out && valid) a.corr_out[s0 + si[s]] = hit ? bj[s] : -1;
-                if (hit) {
-                    F qx, qy, qz;
-                    if (in_lds) { const TgtPt<F> q = tl[bj[s]]; qx = q.x; qy = q.y; qz = q.z; }
-                    else { qx = (F)tg[3 * bj[s]] - (F)ox; qy = (F)tg[3 * bj[s] + 1] - (F)oy; qz = (F)tg[3 * bj[s] + 2] - (F)oz; }
-                    const double dpx = px[s], dpy = py[s], dpz = pz[s], dqx = qx, dqy = qy, dqz = qz;
-                    acc[0] += 1.0;
-                    acc[1] += (double)best[s];
-                    if (MODE == F4L_ICP_POINT2POINT) {
-                        acc[2] += dpx; acc[3] += dpy; acc[4] += dpz;
-                        acc[5] += dqx; acc[6] += dqy; acc[7] += dqz;
-                        acc[8] += dqx * dpx; acc[9] += dqx * dpy; acc[10] += dqx * dpz;
-                        acc[11] += dqy * dpx; acc[12] += dqy * dpy; acc[13] += dqy * dpz;
-                        acc[14] += dqz * dpx; acc[15] += dqz * dpy; acc[16] += dqz * dpz;
-                    } else {
-                        const float *nn = a.tgt_normals + 3 * (t0 + bj[s]);
-                        const double nx = nn[0], ny = nn[1], nz = nn[2];
-                        const double r = (dpx - dqx) * nx + (dpy - dqy) * ny + (dpz - dqz) * nz;
-                        double J[6];
-                        J[0] = dpy * nz - dpz * ny; J[1] = dpz * nx - dpx * nz; J[2] = dpx * ny - dpy * nx;
-                        J[3] = nx; J[4] = ny; J[5] = nz;
-                        int k = 2;
+                        for (int v = u; v < 6; ++v) acc[k++] += J[u] * J[v];  // 21 upper-triangular terms
 #pragma unroll
-                        for (int u = 0; u < 6; ++u)
-#pragma unroll
-                            for (int v = u; v < 6; ++v) acc[k++] += J[u] * J[v];  // 21 upper-triangular terms
-#pragma unroll
-                        for (int u = 0; u < 6; ++u) acc[23 + u] += J[u] * r;
-                    }
+                    for (int u = 0; u < 6; ++u) acc[23 + u] += J[u] * r;
                 }
             }
         }
 
-        // wave butterflies, then the 4 partials through LDS; wave 0 solves
+        PROF_T(pt_p1);
+        PROF_ADD(2, pt_p1, pt_p0);
+        // DPP reduction inside the wave, then the NW partials through LDS; wave 0 solves
+        wave_sum_dpp_n<NV>(acc);
+        if (NW > 1) {
+            if (lane == 0) {
 #pragma unroll
-        for (int i = 0; i < NV; ++i) acc[i] = wave_sum(acc[i]);
-        if (lane == 0) {
-#pragma unroll
-            for (int i = 0; i < NV; ++i) scratch[wave * 32 + i] = acc[i];
+                for (int i = 0; i < NV; ++i) scratch[wave * 32 + i] = acc[i];
+            }
+            PROF_T(pt_p1b);
+            PROF_ADD(12, pt_p1b, pt_p1);
+            __syncthreads();
         }
-        __syncthreads();
+        PROF_T(pt_p2);
+        PROF_ADD(3, pt_p2, pt_p1);
         if (wave == 0) {
+            // The solve is one long dependent chain executed by a single wave while the rest of the workgroup
+            // waits: let it win the issue arbitration against the other workgroups' waves on this SIMD.
+            __builtin_amdgcn_s_setprio(3);
+            if (NW > 1) {
+                // lane i sums the NW partials of value i (one LDS read per wave), then the totals go to scalar
+                // registers: keeps NW * NV partial sums from being live at once
+                double t = scratch[lane & 31];
 #pragma unroll
-            for (int i = 0; i < NV; ++i)
-                acc[i] = scratch[i] + scratch[32 + i] + scratch[64 + i] + scratch[96 + i];
+                for (int w = 1; w < NW; ++w) t += scratch[w * 32 + (lane & 31)];
+                const long long tb = __double_as_longlong(t);
+                const int tlo = (int)(tb & 0xffffffffLL), thi = (int)(tb >> 32);
+#pragma unroll
+                for (int i = 0; i < NV; ++i) {
+                    const int lo = __builtin_amdgcn_readlane(tlo, i), hi = __builtin_amdgcn_readlane(thi, i);
+                    acc[i] = __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+                }
+            }
             double Rc[9], tc[3];
 #pragma unroll
             for (int i = 0; i < 9; ++i) Rc[i] = state[i];
@@ -287,8 +333,19 @@ __global__ __launch_bounds__(ICP_NT, 4) void icp_kernel(IcpArgs a) {
                     sg9[0] = acc[8] * im - mq0 * mp0; sg9[1] = acc[9] * im - mq0 * mp1; sg9[2] = acc[10] * im - mq0 * mp2;
                     sg9[3] = acc[11] * im - mq1 * mp0; sg9[4] = acc[12] * im - mq1 * mp1; sg9[5] = acc[13] * im - mq1 * mp2;
                     sg9[6] = acc[14] * im - mq2 * mp0; sg9[7] = acc[15] * im - mq2 * mp1; sg9[8] = acc[16] * im - mq2 * mp2;
-                    double U[9], S[3], V[9];
-                    svd3(sg9, U, S, V);
+                    double U[9], S[3], V[9], V0[9];
+#pragma unroll
+                    for (int i = 0; i < 9; ++i) V0[i] = state[16 + i];
+                    const int n_sweeps = svd3_warm(sg9, V0, U, S, V);
+#ifdef F4L_ICP_PROF
+                    (void)n_sweeps;
+#else
+                    (void)n_sweeps;
+#endif
+                    if (lane == 0) {
+#pragma unroll
+                        for (int i = 0; i < 9; ++i) state[16 + i] = V[i];
+                    }
                     const double sgn = (det3(U) * det3(V) < 0.0) ? -1.0 : 1.0;
                     mul_diag_bt(U, sgn, V, Ru);
                     tu[0] = mq0 - (Ru[0] * mp0 + Ru[1] * mp1 + Ru[2] * mp2);
@@ -341,12 +398,26 @@ __global__ __launch_bounds__(ICP_NT, 4) void icp_kernel(IcpArgs a) {
                 state[12] = done ? 1.0 : 0.0;
                 state[13] = fit_new; state[14] = rmse_new; state[15] = (double)iters;
             }
+            __builtin_amdgcn_s_setprio(0);
         }
+
+        PROF_T(pt_p3);
+        PROF_ADD(4, pt_p3, pt_p2);
         __syncthreads();
+        PROF_T(pt_p4);
+        PROF_ADD(5, pt_p4, pt_p3);
         const bool finished = state[12] != 0.0;
         if (finished) break;  // uniform across the workgroup
     }
 
+    PROF_T(pt_end);
+    PROF_ADD(0, pt_end, pt_start);
+#ifdef F4L_ICP_PROF
+    if (a.prof && tid == 0) {
+        const int slots[7] = {0, 1, 2, 3, 4, 5, 12};
+        for (int i = 0; i < 7; ++i) atomicAdd(&a.prof[slots[i]], prof_acc[slots[i]]);
+    }
+#endif
     if (tid == 0) {
         // back to global coordinates: t = tc - Rc o + o
         const double o0 = ox, o1 = oy, o2 = oz;
@@ -370,29 +441,39 @@ __global__ __launch_bounds__(ICP_NT, 4) void icp_kernel(IcpArgs a) {
         if (a.iters_out) a.iters_out[p] = iters;
     }
     if (!active && a.corr_out)
-        for (int i = tid; i < ns; i += ICP_NT) a.corr_out[s0 + i] = -1;
+        for (int i = tid; i < ns; i += NT) a.corr_out[s0 + i] = -1;
 }
 
 }  // namespace f4l
 
 namespace f4l {
-template <typename F>
-static int launch_icp(const IcpArgs &a, int mode, bool two, size_t lds, hipStream_t st) {
-    dim3 grid((unsigned)a.P), block(ICP_NT);
-    const void *fn;
-    if (mode == F4L_ICP_POINT2POINT) fn = two ? (const void *)icp_kernel<0, 2, F> : (const void *)icp_kernel<0, 1, F>;
-    else fn = two ? (const void *)icp_kernel<1, 2, F> : (const void *)icp_kernel<1, 1, F>;
+
+template <int MODE, int NW, typename F>
+static int launch_icp_one(const IcpArgs &a, size_t lds, hipStream_t st) {
     if (lds > 64 * 1024)  // opt in to > 64 KiB of dynamic LDS
-        F4L_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    if (mode == F4L_ICP_POINT2POINT) {
-        if (two) hipLaunchKernelGGL((icp_kernel<0, 2, F>), grid, block, lds, st, a);
-        else hipLaunchKernelGGL((icp_kernel<0, 1, F>), grid, block, lds, st, a);
-    } else {
-        if (two) hipLaunchKernelGGL((icp_kernel<1, 2, F>), grid, block, lds, st, a);
-        else hipLaunchKernelGGL((icp_kernel<1, 1, F>), grid, block, lds, st, a);
-    }
+        F4L_HIP_CHECK(hipFuncSetAttribute((const void *)icp_kernel<MODE, NW, F>,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((icp_kernel<MODE, NW, F>), dim3((unsigned)a.P), dim3(NW * 64), lds, st, a);
     F4L_LAUNCH_CHECK();
     return F4L_OK;
+}
+
+template <typename F>
+static int launch_icp(const IcpArgs &a, int mode, int nw, size_t lds, hipStream_t st) {
+    if (mode == F4L_ICP_POINT2POINT) {
+        if (nw == 1) return launch_icp_one<0, 1, F>(a, lds, st);
+        if (nw == 2) return launch_icp_one<0, 2, F>(a, lds, st);
+        return launch_icp_one<0, 4, F>(a, lds, st);
+    }
+    if (nw == 1) return launch_icp_one<1, 1, F>(a, lds, st);
+    if (nw == 2) return launch_icp_one<1, 2, F>(a, lds, st);
+    return launch_icp_one<1, 4, F>(a, lds, st);
+}
+
+static inline int pow2_ceil(int64_t v) {
+    int r = 1;
+    while (r < v) r <<= 1;
+    return r;
 }
 }  // namespace f4l
 
@@ -413,17 +494,55 @@ extern "C" int f4l_piecewise_icp(const float *src, const int64_t *src_off, const
     if (P > 0x7fffffffLL || max_src_patch_host > 0x3fffffffLL || max_tgt_patch_host > 0x3fffffffLL)
         return F4L_EUNSUPPORTED;
     const bool f64 = search_precision == F4L_SEARCH_F64;
-    const int cap_max = f64 ? ICP_LDS_TGT_MAX * 2 / 3 : ICP_LDS_TGT_MAX;  // 24 B vs 16 B per staged target
+    const size_t pt = f64 ? sizeof(GridPt<double>) : sizeof(GridPt<float>);
     IcpArgs a;
     a.src = src; a.src_off = src_off; a.tgt = tgt; a.tgt_off = tgt_off; a.P = P;
     a.init_T = init_T; a.tgt_normals = tgt_normals;
-    a.r2 = max_corr_dist > 0.0 ? max_corr_dist * max_corr_dist : 0.0;
+    a.r = max_corr_dist > 0.0 ? max_corr_dist : 0.0;
+    a.r2 = a.r * a.r;
     a.max_iter = max_iter; a.rel_fitness = rel_fitness; a.rel_rmse = rel_rmse; a.fixed_iters = fixed_iters;
-    a.lds_cap = (int)(max_tgt_patch_host < cap_max ? max_tgt_patch_host : cap_max);
     { const char *dbg = getenv("F4L_ICP_DEBUG"); a.debug = dbg ? atoi(dbg) : 0; }
     a.T_out = T_out; a.fitness_out = fitness_out; a.rmse_out = rmse_out; a.iters_out = iters_out; a.corr_out = corr_out;
-    const size_t lds = (size_t)(ICP_NW * 32 + 16) * sizeof(double) + (size_t)a.lds_cap * (f64 ? 24 : 16);
-    const bool two = max_src_patch_host > ICP_NT;  // two source points per lane once patches exceed one pass
-    return f64 ? launch_icp<double>(a, mode, two, lds, (hipStream_t)stream)
-               : launch_icp<float>(a, mode, two, lds, (hipStream_t)stream);
+
+    // waves per patch: enough waves to fill the 1024 SIMDs a few times over, as few barriers as possible
+    int nw = 4;
+    if (P >= 8192 && max_src_patch_host <= 1024) nw = 1;
+    else if (P >= 4096 && max_src_patch_host <= 2048) nw = 2;
+    { const char *e = getenv("F4L_ICP_WAVES"); if (e) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) nw = v; } }
+
+    // LDS plan: targets first (they make the grid possible), then the prefix table, then the sources
+    const size_t fixed = (size_t)(nw * 32 + 32) * sizeof(double) + (size_t)(GRID_ROWS + 1) * nw * 64 * sizeof(unsigned int);
+    int tgt_cap = (int)(max_tgt_patch_host < ICP_TGT_MAX ? max_tgt_patch_host : ICP_TGT_MAX);
+    if (tgt_cap < 1) tgt_cap = 1;
+    int cell_cap = pow2_ceil(2 * (int64_t)tgt_cap);
+    cell_cap = cell_cap < 512 ? 512 : (cell_cap > ICP_CELL_MAX ? ICP_CELL_MAX : cell_cap);
+    auto table_bytes = [](int cells) { return ((size_t)cells + 8) * 2; };
+    while (fixed + (size_t)tgt_cap * pt + table_bytes(cell_cap) > (size_t)ICP_LDS_BUDGET && cell_cap > 512) cell_cap >>= 1;
+    while (fixed + (size_t)tgt_cap * pt + table_bytes(cell_cap) > (size_t)ICP_LDS_BUDGET) tgt_cap -= 256;
+    size_t lds = fixed + (size_t)tgt_cap * pt + table_bytes(cell_cap);
+    int src_cap = 0;
+    if (lds + (size_t)max_src_patch_host * (pt + 2) + 16 <= (size_t)ICP_LDS_BUDGET) src_cap = (int)max_src_patch_host;
+    lds += (size_t)src_cap * (pt + 2) + 16;
+    lds = (lds + 15) & ~(size_t)15;
+    a.tgt_cap = tgt_cap; a.src_cap = src_cap; a.cell_cap = cell_cap;
+    a.prof = nullptr;
+#ifdef F4L_ICP_PROF
+    if (getenv("F4L_ICP_PROF")) {
+        unsigned long long *dp = nullptr, hp[16];
+        F4L_HIP_CHECK(hipMalloc(&dp, sizeof(hp)));
+        F4L_HIP_CHECK(hipMemset(dp, 0, sizeof(hp)));
+        a.prof = dp;
+        int rc = f64 ? launch_icp<double>(a, mode, nw, lds, (hipStream_t)stream) : launch_icp<float>(a, mode, nw, lds, (hipStream_t)stream);
+        F4L_HIP_CHECK(hipDeviceSynchronize());
+        F4L_HIP_CHECK(hipMemcpy(hp, dp, sizeof(hp), hipMemcpyDeviceToHost));
+        hipFree(dp);
+        fprintf(stderr, "[icp prof] P=%lld nw=%d lds=%zu tgt_cap=%d src_cap=%d cell_cap=%d | per-WG mean cycles: total %.0f build %.0f search %.0f reduce %.0f solve %.0f barrier %.0f dpp %.0f sweeps/solve %.2f | per query: steps %.2f rows %.2f rows_taken %.2f wave-steps/batch %.2f\n",
+                (long long)P, nw, lds, tgt_cap, src_cap, cell_cap, hp[0] / (double)P, hp[1] / (double)P, hp[2] / (double)P,
+                hp[3] / (double)P, hp[4] / (double)P, hp[5] / (double)P, hp[12] / (double)P, hp[13] / (double)(hp[14] ? hp[14] : 1), hp[6] / (double)(hp[9] ? hp[9] : 1),
+                hp[7] / (double)(hp[9] ? hp[9] : 1), hp[8] / (double)(hp[9] ? hp[9] : 1), hp[10] / (double)(hp[11] ? hp[11] : 1));
+        return rc;
+    }
+#endif
+    return f64 ? launch_icp<double>(a, mode, nw, lds, (hipStream_t)stream)
+               : launch_icp<float>(a, mode, nw, lds, (hipStream_t)stream);
 }

@@ -1,0 +1,356 @@
+// patch_grid.h -- a uniform grid over ONE target patch, resident in LDS, and the exact nearest-neighbour
+// query against it.  Shared by icp_kernel (icp.hip) and nn_refine_kernel (patch_ops.hip).
+//
+// The reference answers "nearest target point within radius r" with an Open3D KD-tree per patch
+// (utils/o3d_tools.py:46-50 -> registration_icp -> KDTreeFlann::SearchHybrid(p, r, 1), and
+// src/coarse_to_fine_matching_base.py:70-80 for refine_dvfs_with_threshold).  A pointer-chasing tree is the
+// wrong shape for a 64-wide wavefront; a patch is small (hundreds to a few thousand points) and the radius is
+// known, so the whole patch is counting-sorted ONCE into cubic cells of edge h >= r that live in LDS for all
+// ICP iterations:
+//
+//   tl[0..nt)      target points in cell order, {x, y, z, original index}  (coordinates relative to the patch origin)
+//   E[0..ncell]    packed uint16 prefix table: points of cell c are tl[E[c] .. E[c+1])
+//
+// Cells are numbered x-fastest, so the three x-neighbours of a cell form ONE contiguous run ("row") of tl; a
+// query therefore scans at most 9 rows (3 y x 3 z), each a linear run of float4 LDS reads.  Every lane owns
+// one query and walks its own rows; rows whose distance to the query already exceeds the best candidate are
+// skipped.  The result is the exact minimiser of (d2, original index) among the targets with d2 < r^2: the same
+// point a brute-force scan in index order (and the oracle's KD-tree) returns, independent of the order in
+// which the counting sort happened to place points inside a cell.
+//
+// Exactness of the 3x3x3 stencil: cell coordinates are floor((x - min) / h) evaluated in floating point for
+// targets and queries alike (a monotone function of x); h = r * (1 + 2^-7) leaves 7e-3 cells of slack for its
+// rounding (float32 cell coordinates below 16384 are good to 3e-3), so |q - t| < r implies |cell(q) - cell(t)| <= 1 on every axis.
+#pragma once
+#include "f4l_device.h"
+
+namespace f4l {
+
+// ---- point records as staged in LDS ------------------------------------------------------------------
+template <typename F> struct GridPt;
+template <> struct __attribute__((aligned(16))) GridPt<float> { float x, y, z; int id; };              // 16 B
+template <> struct __attribute__((aligned(16))) GridPt<double> { double x, y, z; int id; int pad; };   // 32 B
+
+template <typename F> struct PatchGrid {
+    F minx, miny, minz, h, inv_h;
+    int nx, ny, nz;  // nx * ny * nz <= cell capacity
+};
+
+template <typename F> __device__ __forceinline__ F grid_inf();
+template <> __device__ __forceinline__ float grid_inf<float>() { return __builtin_inff(); }
+template <> __device__ __forceinline__ double grid_inf<double>() { return __builtin_inf(); }
+
+__device__ __forceinline__ int floor_to_int(float v) { return __float2int_rd(v); }
+__device__ __forceinline__ int floor_to_int(double v) { return __double2int_rd(v); }
+
+template <typename F>
+__device__ __forceinline__ void grid_cell(const PatchGrid<F> &g, F x, F y, F z, int &cx, int &cy, int &cz) {
+    cx = floor_to_int((x - g.minx) * g.inv_h);
+    cy = floor_to_int((y - g.miny) * g.inv_h);
+    cz = floor_to_int((z - g.minz) * g.inv_h);
+}
+
+// Squared distance: float32 with the fused chain fma(dz,dz, fma(dy,dy, dx*dx)); float64 with separately rounded
+// multiply/add in x, y, z order, i.e. the bits Eigen's (a - b).squaredNorm() produces on x86-64 without FMA
+// contraction (what the oracle and Open3D's CPU path evaluate).
+__device__ __forceinline__ float grid_d2(float dx, float dy, float dz) {
+    return __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+}
+__device__ __forceinline__ double grid_d2(double dx, double dy, double dz) {
+#pragma clang fp contract(off)
+    double t = dx * dx;
+    t = t + dy * dy;
+    t = t + dz * dz;
+    return t;
+}
+
+// ---- best-candidate record: lexicographic (d2, original index) ------------------------------------------
+// float32: one 64-bit key {bits(d2) : id}; d2 >= 0, so the IEEE bit pattern orders like the value.
+template <typename F> struct Best;
+template <> struct Best<float> {
+    unsigned long long key;
+    int pos;
+    __device__ __forceinline__ void init(float r2) {
+        key = ((unsigned long long)__float_as_uint(r2) << 32) | 0xffffffffULL;
+        pos = -1;
+    }
+    __device__ __forceinline__ void offer(float d, int id, int j) {
+        const unsigned long long k = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned int)id;
+        const bool better = k < key;
+        key = better ? k : key;
+        pos = better ? j : pos;
+    }
+    // predicated form for the flat scan loop (no branch: every lane executes the same instructions)
+    __device__ __forceinline__ void offer_if(bool act, float d, int id, int j) {
+        const unsigned long long k = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned int)id;
+        const bool better = act && k < key;
+        key = better ? k : key;
+        pos = better ? j : pos;
+    }
+    __device__ __forceinline__ float d2() const { return __uint_as_float((unsigned int)(key >> 32)); }
+    __device__ __forceinline__ int id() const { return (int)(unsigned int)(key & 0xffffffffULL); }
+};
+template <> struct Best<double> {
+    double d;
+    int i, pos;
+    __device__ __forceinline__ void init(double r2) { d = r2; i = 0x7fffffff; pos = -1; }
+    __device__ __forceinline__ void offer(double dd, int id, int j) {
+        if (dd < d || (dd == d && id < i)) { d = dd; i = id; pos = j; }
+    }
+    __device__ __forceinline__ void offer_if(bool act, double dd, int id, int j) {
+        const bool better = act && (dd < d || (dd == d && id < i));
+        d = better ? dd : d;
+        i = better ? id : i;
+        pos = better ? j : pos;
+    }
+    __device__ __forceinline__ double d2() const { return d; }
+    __device__ __forceinline__ int id() const { return i; }
+};
+
+// ---- build ---------------------------------------------------------------------------------------------
+// Called by all NT threads of the workgroup.  tg: packed float32 [nt][3] of the patch in global memory;
+// (ox, oy, oz): patch origin; r: search radius (> 0); cell_cap: capacity of E in cells (E holds cell_cap + 2
+// uint16, 4-byte aligned); red: NT/64 * 8 values of F scratch in LDS.  On return (after a barrier) tl and E
+// are complete and g describes the grid.  nt >= 1, nt <= 65535.
+template <typename F, int NT>
+__device__ __forceinline__ void grid_build(const float *__restrict__ tg, int nt, float ox, float oy, float oz, F r,
+                                           int cell_cap, GridPt<F> *__restrict__ tl, unsigned short *__restrict__ E,
+                                           F *__restrict__ red, PatchGrid<F> &g) {
+    constexpr int NW = NT / 64;
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    // 1. bounding box of the patch (origin-relative)
+    F mn[3] = {grid_inf<F>(), grid_inf<F>(), grid_inf<F>()}, mx[3] = {-grid_inf<F>(), -grid_inf<F>(), -grid_inf<F>()};
+    for (int j = tid; j < nt; j += NT) {
+        const F x = (F)tg[3 * j] - (F)ox, y = (F)tg[3 * j + 1] - (F)oy, z = (F)tg[3 * j + 2] - (F)oz;
+        mn[0] = x < mn[0] ? x : mn[0]; mn[1] = y < mn[1] ? y : mn[1]; mn[2] = z < mn[2] ? z : mn[2];
+        mx[0] = x > mx[0] ? x : mx[0]; mx[1] = y > mx[1] ? y : mx[1]; mx[2] = z > mx[2] ? z : mx[2];
+    }
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            const F a = __shfl_xor(mn[d], m, 64), b = __shfl_xor(mx[d], m, 64);
+            mn[d] = a < mn[d] ? a : mn[d];
+            mx[d] = b > mx[d] ? b : mx[d];
+        }
+    }
+    if (NW > 1) {
+        if (lane == 0) {
+#pragma unroll
+            for (int d = 0; d < 3; ++d) { red[wave * 8 + d] = mn[d]; red[wave * 8 + 3 + d] = mx[d]; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                const F a = red[w * 8 + d], b = red[w * 8 + 3 + d];
+                mn[d] = a < mn[d] ? a : mn[d];
+                mx[d] = b > mx[d] ? b : mx[d];
+            }
+        }
+    }
+
+    // 2. cell edge: r * (1 + 2^-7), enlarged until the grid fits the cell table (uniform across the workgroup).
+    //    NaN / inf coordinates degrade to a single cell (every query then scans the whole patch).
+    const F ex = mx[0] - mn[0], ey = mx[1] - mn[1], ez = mx[2] - mn[2];
+    F h = r * (F)1.0078125;
+    int nx = 1, ny = 1, nz = 1;
+    const bool finite = (ex >= (F)0) && (ey >= (F)0) && (ez >= (F)0) && (ex + ey + ez < (F)1e30);
+    if (finite) {
+        for (int it = 0; it < 64; ++it) {
+            const F ih = (F)1 / h;
+            const F fx = ex * ih, fy = ey * ih, fz = ez * ih;
+            const F cells = (floor(fx) + (F)1) * (floor(fy) + (F)1) * (floor(fz) + (F)1);
+            if (cells <= (F)cell_cap) { nx = (int)fx + 1; ny = (int)fy + 1; nz = (int)fz + 1; break; }
+            if (it == 63) { h = (ex + ey + ez) * (F)2 + r; break; }  // gives a single cell
+            F f = cbrt(cells / (F)cell_cap);  // exact for a volume; a surface needs a few rounds
+            h *= f < (F)1.05 ? (F)1.05 : f;
+        }
+    }
+    g.minx = finite ? mn[0] : (F)0; g.miny = finite ? mn[1] : (F)0; g.minz = finite ? mn[2] : (F)0;
+    g.h = h; g.inv_h = (F)1 / h;
+    g.nx = nx; g.ny = ny; g.nz = nz;
+    const int ncell = nx * ny * nz;
+
+    // 3. histogram: E[c + 1] += 1 through 32-bit LDS atomics on the packed uint16 pairs
+    unsigned int *Ew = reinterpret_cast<unsigned int *>(E);
+    for (int i = tid; i < (ncell + 3) / 2; i += NT) Ew[i] = 0u;
+    __syncthreads();
+    for (int j = tid; j < nt; j += NT) {
+        const F x = (F)tg[3 * j] - (F)ox, y = (F)tg[3 * j + 1] - (F)oy, z = (F)tg[3 * j + 2] - (F)oz;
+        int cx, cy, cz;
+        grid_cell(g, x, y, z, cx, cy, cz);
+        cx = cx < 0 ? 0 : (cx >= nx ? nx - 1 : cx);
+        cy = cy < 0 ? 0 : (cy >= ny ? ny - 1 : cy);
+        cz = cz < 0 ? 0 : (cz >= nz ? nz - 1 : cz);
+        const int e = (cz * ny + cy) * nx + cx + 1;
+        atomicAdd(&Ew[e >> 1], (e & 1) ? 0x10000u : 1u);
+    }
+    __syncthreads();
+
+    // 4. exclusive prefix over the counts: E[c + 1] <- number of points in cells < c  (E[0] stays 0)
+    {
+        const int chunk = (ncell + NT - 1) / NT;
+        const int c0 = tid * chunk, c1 = (c0 + chunk < ncell) ? c0 + chunk : ncell;
+        int sum = 0;
+        for (int c = c0; c < c1; ++c) sum += (int)E[c + 1];
+        // inclusive scan of the per-thread sums inside the wave (Hillis-Steele on shuffles; once per patch)
+        int inc = sum;
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) {
+            const int v = __shfl_up(inc, m, 64);
+            if (lane >= m) inc += v;
+        }
+        int *wsum = reinterpret_cast<int *>(red);
+        if (NW > 1) {
+            __syncthreads();  // `red` was read above by every thread
+            if (lane == 63) wsum[wave] = inc;
+            __syncthreads();
+        }
+        int base = inc - sum;
+        if (NW > 1) {
+#pragma unroll
+            for (int w = 0; w < NW; ++w) base += (w < wave) ? wsum[w] : 0;
+        }
+        for (int c = c0; c < c1; ++c) {
+            const int cnt = (int)E[c + 1];
+            E[c + 1] = (unsigned short)base;
+            base += cnt;
+        }
+    }
+    __syncthreads();
+
+    // 5. scatter: the slot E[c + 1] is the running cursor of cell c; when all points are placed it equals the
+    //    start of cell c + 1, which is exactly the prefix table the queries read.
+    for (int j = tid; j < nt; j += NT) {
+        GridPt<F> q;
+        q.x = (F)tg[3 * j] - (F)ox; q.y = (F)tg[3 * j + 1] - (F)oy; q.z = (F)tg[3 * j + 2] - (F)oz;
+        q.id = j;
+        int cx, cy, cz;
+        grid_cell(g, q.x, q.y, q.z, cx, cy, cz);
+        cx = cx < 0 ? 0 : (cx >= nx ? nx - 1 : cx);
+        cy = cy < 0 ? 0 : (cy >= ny ? ny - 1 : cy);
+        cz = cz < 0 ? 0 : (cz >= nz ? nz - 1 : cz);
+        const int e = (cz * ny + cy) * nx + cx + 1;
+        const unsigned int old = atomicAdd(&Ew[e >> 1], (e & 1) ? 0x10000u : 1u);
+        const int pos = (int)((e & 1) ? (old >> 16) : (old & 0xffffu));
+        tl[pos] = q;
+    }
+    __syncthreads();
+}
+
+// ---- query ---------------------------------------------------------------------------------------------
+// Exact nearest target of (px, py, pz) among those with d2 < r2: every lane of the wave owns one query (lanes
+// with valid == false own none) and ALL lanes of the wave must make the call together.
+//
+// `best` comes in init(r2)'d, or holding a real candidate (e.g. last iteration's correspondence, re-measured):
+// its d2 is an upper bound of the answer and prunes the stencil BEFORE anything is scanned:
+//   * the x-range of every row is narrowed to the cells within sqrt(best) of the query,
+//   * rows (y, z) whose distance to the query exceeds the bound are dropped.
+// The surviving non-empty rows are written as packed {start, end} pairs to a per-lane list in LDS
+// (rl[k * NT + tid]: consecutive lanes -> consecutive banks) and then scanned by ONE flat, fully predicated
+// loop: a single backward branch on a wave-uniform condition, next candidate and next row descriptor fetched
+// one step ahead.  Both bounds are inclusive with slack for the rounding of the cell arithmetic, so exact
+// ties on d2 with a smaller index are still seen.
+constexpr int GRID_ROWS = 9;
+
+template <typename F> __device__ __forceinline__ F grid_sqrt(F v);
+template <> __device__ __forceinline__ float grid_sqrt<float>(float v) { return __builtin_amdgcn_sqrtf(v); }  // 1 ulp; the bound carries slack
+template <> __device__ __forceinline__ double grid_sqrt<double>(double v) { return __builtin_sqrt(v); }
+
+template <typename F, int NT>
+__device__ __forceinline__ void grid_nn(const PatchGrid<F> &g, const GridPt<F> *__restrict__ tl,
+                                        const unsigned short *__restrict__ E, unsigned int *__restrict__ rl, bool valid,
+                                        F px, F py, F pz, Best<F> &best, unsigned long long *prof = nullptr) {
+    const int tid = (int)threadIdx.x;
+    int cx, cy, cz;
+    grid_cell(g, px, py, pz, cx, cy, cz);
+    // bound on the distance of anything that can still win, with slack for the rounding of cell coordinates
+    const F slack = (F)1e-5 * g.h + (F)1e-6 * (fabs(px) + fabs(py) + fabs(pz) + fabs(g.minx) + fabs(g.miny) + fabs(g.minz));
+    const F b2 = best.d2();
+    const F bnd = grid_sqrt<F>(b2) * (F)1.00001 + slack;
+    int x0 = floor_to_int((px - bnd - g.minx) * g.inv_h), x1 = floor_to_int((px + bnd - g.minx) * g.inv_h);
+    x0 = x0 < cx - 1 ? cx - 1 : x0;  // never wider than the 3-cell stencil (bnd <= r < h)
+    x1 = x1 > cx + 1 ? cx + 1 : x1;
+    x0 = x0 < 0 ? 0 : x0;
+    x1 = x1 >= g.nx ? g.nx - 1 : x1;
+    const bool xok = valid && x0 <= x1;
+    const F fy = py - (g.miny + (F)cy * g.h), fz = pz - (g.minz + (F)cz * g.h);
+    const int nxny = g.nx * g.ny;
+    const int base0 = (cz * g.ny + cy) * g.nx;
+    const int span = x1 - x0 + 1;
+
+    // 1. row descriptors: both prefix entries of the 9 rows are fetched before any is used
+    unsigned int s_[GRID_ROWS], e_[GRID_ROWS];
+    bool keep[GRID_ROWS];
+#pragma unroll
+    for (int r = 0; r < GRID_ROWS; ++r) {
+        // centre row first, then the four face neighbours, then the corners
+        constexpr int DY[GRID_ROWS] = {0, -1, 1, 0, 0, -1, 1, -1, 1};
+        constexpr int DZ[GRID_ROWS] = {0, 0, 0, -1, 1, -1, -1, 1, 1};
+        const int y = cy + DY[r], z = cz + DZ[r];
+        bool k = xok && y >= 0 && y < g.ny && z >= 0 && z < g.nz;
+        F ddy = (DY[r] < 0 ? fy : (DY[r] > 0 ? g.h - fy : (F)0)) - slack;
+        F ddz = (DZ[r] < 0 ? fz : (DZ[r] > 0 ? g.h - fz : (F)0)) - slack;
+        ddy = ddy > (F)0 ? ddy : (F)0;
+        ddz = ddz > (F)0 ? ddz : (F)0;
+        if (DY[r] != 0 || DZ[r] != 0) k = k && !((ddy * ddy + ddz * ddz) * (F)0.99999 > b2);
+        const int a = k ? base0 + DY[r] * g.nx + DZ[r] * nxny + x0 : 0;
+        s_[r] = E[a];
+        e_[r] = E[k ? a + span : 0];
+        keep[r] = k;
+    }
+    // 2. compact the non-empty survivors into the per-lane list, sentinel {0, 0} behind them
+    int cnt = 0;
+#pragma unroll
+    for (int r = 0; r < GRID_ROWS; ++r) {
+        const bool k = keep[r] && s_[r] < e_[r];
+        if (k) rl[cnt * NT + tid] = s_[r] | (e_[r] << 16);
+        cnt += k ? 1 : 0;
+    }
+    rl[cnt * NT + tid] = 0u;
+#ifdef F4L_ICP_PROF
+    int n_steps = 0;
+#endif
+    // 3. flat scan
+    unsigned int cur = rl[tid];
+    int j = (int)(cur & 0xffffu), e = (int)(cur >> 16);
+    int k = cnt < 1 ? cnt : 1;
+    unsigned int nxt = rl[k * NT + tid];
+    GridPt<F> q = tl[j < e ? j : 0];
+    while (__any(j < e)) {
+        const bool act = j < e;
+        // next position first, so that its loads are in flight while the current candidate is evaluated
+        int jn = j + 1;
+        const bool roll = jn >= e;
+        jn = roll ? (int)(nxt & 0xffffu) : jn;
+        const int en = roll ? (int)(nxt >> 16) : e;
+        k = roll ? (k + 1 > cnt ? cnt : k + 1) : k;
+        const GridPt<F> qn = tl[jn < en ? jn : 0];
+        const unsigned int nn = rl[k * NT + tid];
+        // current candidate
+        const F d = grid_d2(px - q.x, py - q.y, pz - q.z);
+        best.offer_if(act, d, q.id, j);
+#ifdef F4L_ICP_PROF
+        n_steps += act ? 1 : 0;
+#endif
+        q = qn; j = jn; e = en;
+        nxt = roll ? nn : nxt;
+    }
+#ifdef F4L_ICP_PROF
+    if (prof) {
+        atomicAdd(&prof[6], (unsigned long long)n_steps);
+        atomicAdd(&prof[7], (unsigned long long)(xok ? 9 : 0));
+        atomicAdd(&prof[8], (unsigned long long)cnt);
+        atomicAdd(&prof[9], valid ? 1ULL : 0ULL);
+        int m = n_steps;
+#pragma unroll
+        for (int sh = 32; sh >= 1; sh >>= 1) { const int o = __shfl_xor(m, sh, 64); m = o > m ? o : m; }
+        if (lane_id() == 0) { atomicAdd(&prof[10], (unsigned long long)m); atomicAdd(&prof[11], 1ULL); }
+    }
+#endif
+}
+
+}  // namespace f4l
