@@ -61,6 +61,13 @@ __device__ __forceinline__ double dpp_mov(double v) {
     const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, ROW_MASK, 0xf, true);
     return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, true));
+}
+__device__ __forceinline__ float bcast_lane63(float v) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
 __device__ __forceinline__ double bcast_lane63(double v) {
     const long long b = __double_as_longlong(v);
     const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffLL), 63);
@@ -80,8 +87,8 @@ __device__ __forceinline__ double wave_sum_dpp(double v) {
 
 // The same for N independent values, stage by stage in groups of at most 6, so that the dependency chains of a
 // group interleave without keeping 2 N temporaries alive.
-template <int N, int LO, int HI>
-__device__ __forceinline__ void wave_sum_dpp_group(double (&v)[N]) {
+template <typename T, int N, int LO, int HI>
+__device__ __forceinline__ void wave_sum_dpp_group(T (&v)[N]) {
 #pragma unroll
     for (int i = LO; i < HI; ++i) v[i] += dpp_mov<0xB1, 0xf>(v[i]);
 #pragma unroll
@@ -97,11 +104,11 @@ __device__ __forceinline__ void wave_sum_dpp_group(double (&v)[N]) {
 #pragma unroll
     for (int i = LO; i < HI; ++i) v[i] = bcast_lane63(v[i]);
 }
-template <int N, int LO = 0>
-__device__ __forceinline__ void wave_sum_dpp_n(double (&v)[N]) {
+template <int N, int LO = 0, typename T>
+__device__ __forceinline__ void wave_sum_dpp_n(T (&v)[N]) {
     constexpr int HI = LO + 6 < N ? LO + 6 : N;
-    wave_sum_dpp_group<N, LO, HI>(v);
-    if constexpr (HI < N) wave_sum_dpp_n<N, HI>(v);
+    wave_sum_dpp_group<T, N, LO, HI>(v);
+    if constexpr (HI < N) wave_sum_dpp_n<N, HI, T>(v);
 }
 
 // Sum NV doubles across a workgroup of NW waves; every thread receives the totals in v[].

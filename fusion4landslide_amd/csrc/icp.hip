@@ -27,6 +27,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "f4l_device.h"
 #include "patch_grid.h"
 
@@ -49,7 +51,8 @@ struct IcpArgs {
     double rel_fitness, rel_rmse;
     int fixed_iters;
     int tgt_cap;   // target slots in LDS (patches with more targets take the brute-force global path)
-    int src_cap;   // source slots in LDS (0: sources are re-read from global memory each pass)
+    int cert_cap;  // source points per patch the certificate arrays (prev, mabs, queue) can hold
+    int src_cap;   // source points per patch staged in LDS (0: read from global memory every pass)
     int cell_cap;  // grid cells the prefix table can hold
     double *T_out, *fitness_out, *rmse_out;
     int32_t *iters_out, *corr_out;
@@ -122,21 +125,44 @@ __device__ __forceinline__ double uniform_f64(double v) {
     return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 
-// LDS layout (dynamic): [ scratch | state | targets tl | sources sl | prefix table E ]
-//   scratch : NW * 32 doubles (partial sums; doubles as the scratch of grid_build)
-//   state   : Rc[9], tc[3], done flag, fitness, rmse, iterations, V[9] of the last SVD (warm start)  (32 doubles)
+// LDS layout (dynamic):
+//   scratch : NW * 32 doubles (partial sums; doubles as the scratch of grid_build and of the prologue reductions)
+//   state   : 48 doubles: Rc[9] 0..8, tc[3] 9..11, done 12, fitness 13, rmse 14, iterations 15, V[9] of the last
+//             SVD 16..24 (warm start), source centroid 25..27, source radius 28, accumulated motion bound 29
+//   qcnt    : NW ints (length of each wave's segment of the search queue)
+//   tl      : tgt_cap grid points          mabs : cert_cap F        rl : (GRID_ROWS + 1) * NT uint
+//   E       : cell_cap + 8 uint16          prev : cert_cap uint16   queue : NW * seg uint16
+//
+// Nearest-neighbour certificates.  A search that scans everything within sqrt(b0) of the query knows, besides
+// the nearest target, a distance M that every OTHER target keeps: M^2 = min(runner-up d2, b0).  While the query
+// has moved less than M - d(query, nearest) since then, the nearest target is provably unchanged (triangle
+// inequality) and the search is skipped: only d(query, nearest) is re-measured.  Motion is bounded per pass for
+// the whole patch by |p_new - p_old| <= ||Ru - I||_F * radius + |(Ru - I) centroid + tu| and summed in state[29];
+// mabs[i] stores M + (that sum at search time).  Each pass therefore has two phases: a dense one that re-measures
+// and certifies (or queues) every source point, and a search phase over the queued points only, compacted
+// across the workgroup.  Results are exactly those of searching every point in every pass.
 template <int MODE, int NW, typename F>
 __global__ __launch_bounds__(NW * 64, 4) void icp_kernel(IcpArgs a) {
     constexpr int NV = (MODE == F4L_ICP_POINT2POINT) ? 17 : 29;
     constexpr int NT = NW * 64;
+    // Correspondence sums.  float32 search + point-to-point: per-lane partial sums and the in-wave reduction are
+    // float32 on coordinates CENTRED on the image of the source centroid (|values| <= patch radius, means ~ 0, so
+    // neither the products nor the covariance's mean correction cancel); everything after the wave totals is
+    // double.  float64 search (parity mode) and point-to-plane: double throughout, uncentred like the reference.
+    constexpr bool CENTRED = (MODE == F4L_ICP_POINT2POINT) && sizeof(F) == 4;
+    using A = typename std::conditional<CENTRED, float, double>::type;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     double *scratch = reinterpret_cast<double *>(smem_raw);
     double *state = scratch + NW * 32;
-    GridPt<F> *tl = reinterpret_cast<GridPt<F> *>(state + 32);
-    GridPt<F> *sl = tl + a.tgt_cap;
-    unsigned int *rl = reinterpret_cast<unsigned int *>(sl + a.src_cap);          // per-lane row lists of grid_nn
+    int *qcnt = reinterpret_cast<int *>(state + 48);
+    GridPt<F> *tl = reinterpret_cast<GridPt<F> *>(qcnt + 4);
+    F *mabs = reinterpret_cast<F *>(tl + a.tgt_cap);
+    F *sl = mabs + ((a.cert_cap + 3) & ~3);  // origin-relative source points, packed xyz
+    unsigned int *rl = reinterpret_cast<unsigned int *>(sl + 3 * ((a.src_cap + 3) & ~3));
     unsigned short *E = reinterpret_cast<unsigned short *>(rl + (GRID_ROWS + 1) * NT);
-    unsigned short *prev = E + a.cell_cap + 8;  // sorted position of each source point's last correspondence
+    unsigned short *prev = E + a.cell_cap + 8;
+    const int seg = ((a.cert_cap + NT - 1) / NT) * 64;  // queue entries one wave can produce
+    unsigned short *queue = prev + ((a.cert_cap + 7) & ~7);
 
     const int64_t p = blockIdx.x;
     if (p >= a.P) return;
@@ -147,6 +173,7 @@ __global__ __launch_bounds__(NW * 64, 4) void icp_kernel(IcpArgs a) {
     const float *__restrict__ tg = a.tgt + 3 * t0;
     const bool active = ns > 0 && a.r2 > 0.0;  // o3d returns the init untouched when max_corr_dist <= 0
     const bool tgt_in_lds = nt > 0 && nt <= a.tgt_cap;
+    const bool use_cert = tgt_in_lds && ns <= a.cert_cap && !(a.debug & 4);
     const bool src_in_lds = ns <= a.src_cap;
 
     // per-patch origin: first target point (else first source point, else 0)
@@ -157,24 +184,52 @@ __global__ __launch_bounds__(NW * 64, 4) void icp_kernel(IcpArgs a) {
 #ifdef F4L_ICP_PROF
     unsigned long long prof_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
+#ifdef F4L_ICP_PROF
+    const unsigned long long rt_start = __builtin_amdgcn_s_memrealtime();
+#endif
     PROF_T(pt_start);
+    // search radius: a little beyond the correspondence radius, so that "no target within r" can be certified too
+    const F rF = (F)a.r, r2 = (F)a.r2;
+    const F rs = rF * (F)1.0625, rs2 = rs * rs;
+    const F mu = rF * (F)0.125;  // margin of the certificates beyond the re-measured correspondence
     PatchGrid<F> g;
     g.minx = g.miny = g.minz = (F)0; g.h = (F)1; g.inv_h = (F)1; g.nx = g.ny = g.nz = 1;
+    double cs[3] = {0.0, 0.0, 0.0}, srad = 0.0;
     if (active) {  // uniform across the workgroup
-        if (tgt_in_lds) grid_build<F, NT>(tg, nt, ox, oy, oz, (F)a.r, a.cell_cap, tl, E, reinterpret_cast<F *>(scratch), g);
-        if (src_in_lds) {
+        if (tgt_in_lds) grid_build<F, NT>(tg, nt, ox, oy, oz, rs, a.cell_cap, tl, E, reinterpret_cast<F *>(scratch), g);
+        {
+            // centroid and radius of the source patch (origin-relative): the lever arm of the motion bound
+            double sum[3] = {0.0, 0.0, 0.0};
             for (int i = tid; i < ns; i += NT) {
-                GridPt<F> q;
-                q.x = (F)sg[3 * i] - (F)ox; q.y = (F)sg[3 * i + 1] - (F)oy; q.z = (F)sg[3 * i + 2] - (F)oz;
-                q.id = i;
-                sl[i] = q;
-                prev[i] = 0xffffu;
+                sum[0] += (double)((F)sg[3 * i] - (F)ox); sum[1] += (double)((F)sg[3 * i + 1] - (F)oy);
+                sum[2] += (double)((F)sg[3 * i + 2] - (F)oz);
+                if (use_cert) { prev[i] = 0xffffu; mabs[i] = (F)0; }
+                if (src_in_lds) { sl[3 * i] = (F)sg[3 * i] - (F)ox; sl[3 * i + 1] = (F)sg[3 * i + 1] - (F)oy; sl[3 * i + 2] = (F)sg[3 * i + 2] - (F)oz; }
             }
+            block_sum<3, NW>(sum, scratch);
+            cs[0] = sum[0] / (double)ns; cs[1] = sum[1] / (double)ns; cs[2] = sum[2] / (double)ns;
+            double mx2 = 0.0;
+            for (int i = tid; i < ns; i += NT) {
+                const double dx = (double)((F)sg[3 * i] - (F)ox) - cs[0], dy = (double)((F)sg[3 * i + 1] - (F)oy) - cs[1],
+                             dz = (double)((F)sg[3 * i + 2] - (F)oz) - cs[2];
+                const double d2 = dx * dx + dy * dy + dz * dz;
+                mx2 = d2 > mx2 ? d2 : mx2;
+            }
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) { const double o = __shfl_xor(mx2, m, 64); mx2 = o > mx2 ? o : mx2; }
+            if (NW > 1) {
+                __syncthreads();
+                if (lane == 0) scratch[wave] = mx2;
+                __syncthreads();
+#pragma unroll
+                for (int w = 0; w < NW; ++w) mx2 = scratch[w] > mx2 ? scratch[w] : mx2;
+            }
+            srad = sqrt(mx2) * (1.0 + 1e-6);
         }
     }
+    __syncthreads();  // scratch is free again
 
     // running transform in origin-relative coordinates, p' = Rc s' + tc, lives in LDS `state`
-    // (state[0..8] = Rc, [9..11] = tc, [12] = done flag, [13] = fitness, [14] = rmse, [15] = iterations)
     if (tid == 0) {
         if (a.init_T) {
             const double *T = a.init_T + 16 * p;
@@ -191,14 +246,19 @@ __global__ __launch_bounds__(NW * 64, 4) void icp_kernel(IcpArgs a) {
         state[12] = 0.0; state[13] = 0.0; state[14] = 0.0; state[15] = 0.0;
 #pragma unroll
         for (int i = 0; i < 9; ++i) state[16 + i] = (i % 4 == 0) ? 1.0 : 0.0;
+        state[25] = cs[0]; state[26] = cs[1]; state[27] = cs[2]; state[28] = srad; state[29] = 0.0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)  // image of the source centroid under the current transform
+            state[30 + i] = state[3 * i] * cs[0] + state[3 * i + 1] * cs[1] + state[3 * i + 2] * cs[2] + state[9 + i];
     }
     __syncthreads();
-
     PROF_T(pt_built);
     PROF_ADD(1, pt_built, pt_start);
-    const F r2 = (F)a.r2;
+
     const int n_pass = active ? a.max_iter + 1 : 0;
-    const bool use_prev = src_in_lds && !(a.debug & 4);
+    // the solving wave rotates with the patch index so that co-resident workgroups do not all solve on the same SIMD
+    const int solver = (a.debug & 16) ? 0 : (int)(blockIdx.x % NW);
+    const unsigned long long lt_mask = (1ULL << lane) - 1ULL;
 
     for (int pass = 0; pass < n_pass; ++pass) {
         // the transform is uniform: keep it in scalar registers
@@ -206,80 +266,149 @@ __global__ __launch_bounds__(NW * 64, 4) void icp_kernel(IcpArgs a) {
                 R3 = (F)uniform_f64(state[3]), R4 = (F)uniform_f64(state[4]), R5 = (F)uniform_f64(state[5]),
                 R6 = (F)uniform_f64(state[6]), R7 = (F)uniform_f64(state[7]), R8 = (F)uniform_f64(state[8]);
         const F t0f = (F)uniform_f64(state[9]), t1f = (F)uniform_f64(state[10]), t2f = (F)uniform_f64(state[11]);
-        double acc[NV];
+        const F dsum = (F)(uniform_f64(state[29]) * (1.0 + 1e-6));  // rounded up
+        const F cpx = CENTRED ? (F)uniform_f64(state[30]) : (F)0, cpy = CENTRED ? (F)uniform_f64(state[31]) : (F)0,
+                cpz = CENTRED ? (F)uniform_f64(state[32]) : (F)0;
+        A acc[NV];
 #pragma unroll
-        for (int i = 0; i < NV; ++i) acc[i] = 0.0;
+        for (int i = 0; i < NV; ++i) acc[i] = (A)0;
         PROF_T(pt_p0);
 
-        for (int base = 0; base < ns; base += NT) {
-            const int si = base + tid;
-            const bool valid = si < ns;
-            const int ii = valid ? si : ns - 1;  // idle lanes recompute the last point (keeps loads in bounds)
+        // one accepted correspondence (p: moved source point, q: target, d: squared distance, bj: target index)
+        auto accumulate = [&](F px, F py, F pz, F qx, F qy, F qz, F d, int bj) {
+            const A dpx = (A)(px - cpx), dpy = (A)(py - cpy), dpz = (A)(pz - cpz);
+            const A dqx = (A)(qx - cpx), dqy = (A)(qy - cpy), dqz = (A)(qz - cpz);
+            acc[0] += (A)1;
+            acc[1] += (A)d;
+            if (MODE == F4L_ICP_POINT2POINT) {
+                acc[2] += dpx; acc[3] += dpy; acc[4] += dpz;
+                acc[5] += dqx; acc[6] += dqy; acc[7] += dqz;
+                acc[8] += dqx * dpx; acc[9] += dqx * dpy; acc[10] += dqx * dpz;
+                acc[11] += dqy * dpx; acc[12] += dqy * dpy; acc[13] += dqy * dpz;
+                acc[14] += dqz * dpx; acc[15] += dqz * dpy; acc[16] += dqz * dpz;
+            } else {
+                const float *nn = a.tgt_normals + 3 * (t0 + bj);
+                const A nx = nn[0], ny = nn[1], nz = nn[2];
+                const A r = (dpx - dqx) * nx + (dpy - dqy) * ny + (dpz - dqz) * nz;
+                A J[6];
+                J[0] = dpy * nz - dpz * ny; J[1] = dpz * nx - dpx * nz; J[2] = dpx * ny - dpy * nx;
+                J[3] = nx; J[4] = ny; J[5] = nz;
+                int k = 2;
+#pragma unroll
+                for (int u = 0; u < 6; ++u)
+#pragma unroll
+                    for (int v = u; v < 6; ++v) acc[k++] += J[u] * J[v];  // 21 upper-triangular terms
+#pragma unroll
+                for (int u = 0; u < 6; ++u) acc[23 + u] += J[u] * r;
+            }
+        };
+
+        int n_search = ns;  // source points that need a search in this pass
+        if (use_cert) {
+            // ---- phase 1: re-measure last pass's correspondence of every source point; certify or queue
+            unsigned short *myq = queue + wave * seg;
+            int nq = 0;
+            for (int base = 0; base < ns; base += NT) {
+                const int i = base + tid;
+                const bool valid = i < ns;
+                const int ii = valid ? i : ns - 1;  // idle lanes recompute the last point (keeps loads in bounds)
+                F x, y, z;
+                if (src_in_lds) { x = sl[3 * ii]; y = sl[3 * ii + 1]; z = sl[3 * ii + 2]; }
+                else { x = (F)sg[3 * ii] - (F)ox; y = (F)sg[3 * ii + 1] - (F)oy; z = (F)sg[3 * ii + 2] - (F)oz; }
+                const F px = R0 * x + R1 * y + R2 * z + t0f;
+                const F py = R3 * x + R4 * y + R5 * z + t1f;
+                const F pz = R6 * x + R7 * y + R8 * z + t2f;
+                const int pv = (int)prev[ii];  // 0xffff: never searched, 0xfffe: nothing within the search radius
+                const F room = mabs[ii] - dsum;  // distance every OTHER target is still known to keep
+                const GridPt<F> q = tl[pv < 0xfffe ? pv : 0];
+                const F d = grid_d2(px - q.x, py - q.y, pz - q.z);
+                bool cert = pv < 0xfffe ? grid_sqrt<F>(d) * (F)1.000001 < room : (pv == 0xfffe && room > rF * (F)1.000001);
+                cert = cert && valid;
+                const bool hit = cert && pv < 0xfffe && d < r2;
+                if (hit) accumulate(px, py, pz, q.x, q.y, q.z, d, q.id);
+                if (a.corr_out && cert) a.corr_out[s0 + i] = hit ? q.id : -1;
+                const bool need = valid && !cert;
+                const unsigned long long m = __ballot(need);
+                if (need) myq[nq + __builtin_popcountll(m & lt_mask)] = (unsigned short)i;
+                nq += __builtin_popcountll(m);
+            }
+            if (lane == 0) qcnt[wave] = nq;
+            __syncthreads();
+            n_search = 0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) n_search += qcnt[w];
+        }
+        PROF_T(pt_p0b);
+        PROF_ADD(15, pt_p0b, pt_p0);
+
+        // ---- phase 2: search the queued points (all points without certificates), 64 per wave
+        for (int base = 0; base < n_search; base += NT) {
+            const int k = base + tid;
+            const bool valid = k < n_search;
+            int i = valid ? k : n_search - 1;
+            if (use_cert) {
+                int w = 0, loc = i;
+#pragma unroll
+                for (int u = 0; u < NW - 1; ++u) {
+                    const int c = qcnt[u];
+                    const bool beyond = (w == u) && loc >= c;
+                    loc = beyond ? loc - c : loc;
+                    w = beyond ? w + 1 : w;
+                }
+                i = (int)queue[w * seg + loc];
+            }
             F x, y, z;
-            if (src_in_lds) { const GridPt<F> s = sl[ii]; x = s.x; y = s.y; z = s.z; }
-            else { x = (F)sg[3 * ii] - (F)ox; y = (F)sg[3 * ii + 1] - (F)oy; z = (F)sg[3 * ii + 2] - (F)oz; }
+            if (src_in_lds) { x = sl[3 * i]; y = sl[3 * i + 1]; z = sl[3 * i + 2]; }
+            else { x = (F)sg[3 * i] - (F)ox; y = (F)sg[3 * i + 1] - (F)oy; z = (F)sg[3 * i + 2] - (F)oz; }
             const F px = R0 * x + R1 * y + R2 * z + t0f;
             const F py = R3 * x + R4 * y + R5 * z + t1f;
             const F pz = R6 * x + R7 * y + R8 * z + t2f;
             Best<F> best;
-            best.init(r2);
-            if (a.debug & 2) { if (nt > 0) best.offer((F)1e-4, 0, 0); }
-            else if (tgt_in_lds) {
-                // last pass's correspondence, re-measured, bounds the search from the start
-                const int pv = (use_prev && valid) ? (int)prev[ii] : 0xffff;
-                if (pv != 0xffff) {
-                    const GridPt<F> q = tl[pv];
-                    best.offer(grid_d2(px - q.x, py - q.y, pz - q.z), q.id, pv);
+            F b0 = rs2;
+            if (tgt_in_lds) {
+                if (use_cert) {
+                    // last pass's correspondence, re-measured, bounds the search from the start
+                    const int pv = (int)prev[i];
+                    if (pv < 0xfffe && !(a.debug & 8)) {
+                        const GridPt<F> q = tl[pv];
+                        const F bb = grid_sqrt<F>(grid_d2(px - q.x, py - q.y, pz - q.z)) * (F)1.000001 + mu;
+                        b0 = bb * bb < rs2 ? bb * bb : rs2;
+                    }
                 }
+                best.init(b0);
 #ifdef F4L_ICP_PROF
                 grid_nn<F, NT>(g, tl, E, rl, valid, px, py, pz, best, (a.debug & 64) ? a.prof : nullptr);
 #else
                 grid_nn<F, NT>(g, tl, E, rl, valid, px, py, pz, best);
 #endif
-                if (use_prev && valid) prev[ii] = (unsigned short)(best.pos >= 0 ? best.pos : 0xffff);
-            } else nn_global<F>(tg, nt, ox, oy, oz, px, py, pz, best);
+                if (use_cert && valid) {
+                    const F m2 = best.second < b0 ? best.second : b0;
+                    prev[i] = (unsigned short)(best.pos >= 0 ? best.pos : 0xfffe);
+                    mabs[i] = grid_sqrt<F>(m2) * (F)0.999999 + dsum;
+                }
+            } else {
+                best.init(r2);
+                nn_global<F>(tg, nt, ox, oy, oz, px, py, pz, best);
+            }
             const bool hit = valid && best.pos >= 0 && best.d2() < r2;  // SearchHybrid: d2 < r^2
             const int bj = best.id();  // index inside the target patch
-            if (a.corr_out && valid) a.corr_out[s0 + si] = hit ? bj : -1;
+            if (a.corr_out && valid) a.corr_out[s0 + i] = hit ? bj : -1;
             if (hit) {
                 F qx, qy, qz;
                 if (tgt_in_lds) { const GridPt<F> q = tl[best.pos]; qx = q.x; qy = q.y; qz = q.z; }
                 else { qx = (F)tg[3 * bj] - (F)ox; qy = (F)tg[3 * bj + 1] - (F)oy; qz = (F)tg[3 * bj + 2] - (F)oz; }
-                const double dpx = px, dpy = py, dpz = pz, dqx = qx, dqy = qy, dqz = qz;
-                acc[0] += 1.0;
-                acc[1] += (double)best.d2();
-                if (MODE == F4L_ICP_POINT2POINT) {
-                    acc[2] += dpx; acc[3] += dpy; acc[4] += dpz;
-                    acc[5] += dqx; acc[6] += dqy; acc[7] += dqz;
-                    acc[8] += dqx * dpx; acc[9] += dqx * dpy; acc[10] += dqx * dpz;
-                    acc[11] += dqy * dpx; acc[12] += dqy * dpy; acc[13] += dqy * dpz;
-                    acc[14] += dqz * dpx; acc[15] += dqz * dpy; acc[16] += dqz * dpz;
-                } else {
-                    const float *nn = a.tgt_normals + 3 * (t0 + bj);
-                    const double nx = nn[0], ny = nn[1], nz = nn[2];
-                    const double r = (dpx - dqx) * nx + (dpy - dqy) * ny + (dpz - dqz) * nz;
-                    double J[6];
-                    J[0] = dpy * nz - dpz * ny; J[1] = dpz * nx - dpx * nz; J[2] = dpx * ny - dpy * nx;
-                    J[3] = nx; J[4] = ny; J[5] = nz;
-                    int k = 2;
-#pragma unroll
-                    for (int u = 0; u < 6; ++u)
-#pragma unroll
-                        for (int v = u; v < 6; ++v) acc[k++] += J[u] * J[v];  // 21 upper-triangular terms
-#pragma unroll
-                    for (int u = 0; u < 6; ++u) acc[23 + u] += J[u] * r;
-                }
+                accumulate(px, py, pz, qx, qy, qz, best.d2(), bj);
             }
         }
 
         PROF_T(pt_p1);
-        PROF_ADD(2, pt_p1, pt_p0);
-        // DPP reduction inside the wave, then the NW partials through LDS; wave 0 solves
+        PROF_ADD(2, pt_p1, pt_p0b);
+        // DPP reduction inside the wave, then the NW partials (as double) through LDS; one wave solves
         wave_sum_dpp_n<NV>(acc);
         if (NW > 1) {
             if (lane == 0) {
 #pragma unroll
-                for (int i = 0; i < NV; ++i) scratch[wave * 32 + i] = acc[i];
+                for (int i = 0; i < NV; ++i) scratch[wave * 32 + i] = (double)acc[i];
             }
             PROF_T(pt_p1b);
             PROF_ADD(12, pt_p1b, pt_p1);
@@ -287,10 +416,11 @@ __global__ __launch_bounds__(NW * 64, 4) void icp_kernel(IcpArgs a) {
         }
         PROF_T(pt_p2);
         PROF_ADD(3, pt_p2, pt_p1);
-        if (wave == 0) {
+        if (wave == solver) {
             // The solve is one long dependent chain executed by a single wave while the rest of the workgroup
             // waits: let it win the issue arbitration against the other workgroups' waves on this SIMD.
             __builtin_amdgcn_s_setprio(3);
+            double tot[NV];
             if (NW > 1) {
                 // lane i sums the NW partials of value i (one LDS read per wave), then the totals go to scalar
                 // registers: keeps NW * NV partial sums from being live at once
@@ -302,8 +432,11 @@ __global__ __launch_bounds__(NW * 64, 4) void icp_kernel(IcpArgs a) {
 #pragma unroll
                 for (int i = 0; i < NV; ++i) {
                     const int lo = __builtin_amdgcn_readlane(tlo, i), hi = __builtin_amdgcn_readlane(thi, i);
-                    acc[i] = __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+                    tot[i] = __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
                 }
+            } else {
+#pragma unroll
+                for (int i = 0; i < NV; ++i) tot[i] = (double)acc[i];
             }
             double Rc[9], tc[3];
 #pragma unroll
@@ -311,9 +444,9 @@ __global__ __launch_bounds__(NW * 64, 4) void icp_kernel(IcpArgs a) {
             tc[0] = state[9]; tc[1] = state[10]; tc[2] = state[11];
             const double fitness = state[13], rmse = state[14];
             int iters = (int)state[15];
-            const double m = acc[0];
+            const double m = tot[0];
             const double fit_new = m > 0.0 ? m / (double)ns : 0.0;
-            const double rmse_new = m > 0.0 ? sqrt(acc[1] / m) : 0.0;
+            const double rmse_new = m > 0.0 ? sqrt(tot[1] / m) : 0.0;
             bool done = false;
             if (pass > 0) {
                 iters = pass;
@@ -321,18 +454,25 @@ __global__ __launch_bounds__(NW * 64, 4) void icp_kernel(IcpArgs a) {
                     done = true;
             }
             if (pass == a.max_iter) done = true;
+            double motion = 0.0;
             if (!done && m > 0.0 && !(a.debug & 1)) {
                 double Ru[9], tu[3];
                 bool have = true;
                 if (MODE == F4L_ICP_POINT2POINT) {
                     // Eigen::umeyama without scaling
                     const double im = 1.0 / m;
-                    const double mp0 = acc[2] * im, mp1 = acc[3] * im, mp2 = acc[4] * im;
-                    const double mq0 = acc[5] * im, mq1 = acc[6] * im, mq2 = acc[7] * im;
+                    // means about the centring point (zero when the sums are uncentred); the covariance is shift invariant
+                    const double cm0 = tot[2] * im, cm1 = tot[3] * im, cm2 = tot[4] * im;
+                    const double cq0 = tot[5] * im, cq1 = tot[6] * im, cq2 = tot[7] * im;
                     double sg9[9];
-                    sg9[0] = acc[8] * im - mq0 * mp0; sg9[1] = acc[9] * im - mq0 * mp1; sg9[2] = acc[10] * im - mq0 * mp2;
-                    sg9[3] = acc[11] * im - mq1 * mp0; sg9[4] = acc[12] * im - mq1 * mp1; sg9[5] = acc[13] * im - mq1 * mp2;
-                    sg9[6] = acc[14] * im - mq2 * mp0; sg9[7] = acc[15] * im - mq2 * mp1; sg9[8] = acc[16] * im - mq2 * mp2;
+                    sg9[0] = tot[8] * im - cq0 * cm0; sg9[1] = tot[9] * im - cq0 * cm1; sg9[2] = tot[10] * im - cq0 * cm2;
+                    sg9[3] = tot[11] * im - cq1 * cm0; sg9[4] = tot[12] * im - cq1 * cm1; sg9[5] = tot[13] * im - cq1 * cm2;
+                    sg9[6] = tot[14] * im - cq2 * cm0; sg9[7] = tot[15] * im - cq2 * cm1; sg9[8] = tot[16] * im - cq2 * cm2;
+                    // the shift the lanes applied: the float32 value of the centroid image
+                    const double sh0 = CENTRED ? (double)(F)state[30] : 0.0, sh1 = CENTRED ? (double)(F)state[31] : 0.0,
+                                 sh2 = CENTRED ? (double)(F)state[32] : 0.0;
+                    const double mp0 = cm0 + sh0, mp1 = cm1 + sh1, mp2 = cm2 + sh2;
+                    const double mq0 = cq0 + sh0, mq1 = cq1 + sh1, mq2 = cq2 + sh2;
                     double U[9], S[3], V[9], V0[9];
 #pragma unroll
                     for (int i = 0; i < 9; ++i) V0[i] = state[16 + i];
@@ -357,9 +497,9 @@ __global__ __launch_bounds__(NW * 64, 4) void icp_kernel(IcpArgs a) {
 #pragma unroll
                     for (int u = 0; u < 6; ++u)
 #pragma unroll
-                        for (int v = u; v < 6; ++v) { M[u][v] = acc[k]; M[v][u] = acc[k]; ++k; }
+                        for (int v = u; v < 6; ++v) { M[u][v] = tot[k]; M[v][u] = tot[k]; ++k; }
 #pragma unroll
-                    for (int u = 0; u < 6; ++u) M[u][6] = -acc[23 + u];
+                    for (int u = 0; u < 6; ++u) M[u][6] = -tot[23 + u];
                     have = solve6(M, x);
                     if (have) {
                         // o3d TransformVector6dToMatrix4d: Rz(x2) Ry(x1) Rx(x0), translation x[3:6]
@@ -381,6 +521,25 @@ __global__ __launch_bounds__(NW * 64, 4) void icp_kernel(IcpArgs a) {
                     }
                 }
                 if (have) {  // T <- update * T
+                    // bound on how far any source point moves with this update (see the kernel's header comment):
+                    // rotation about the patch centroid's image times the patch radius, plus the centroid's own step
+                    {
+                        const double c0 = state[25], c1 = state[26], c2 = state[27];
+                        const double cp0 = Rc[0] * c0 + Rc[1] * c1 + Rc[2] * c2 + tc[0];
+                        const double cp1 = Rc[3] * c0 + Rc[4] * c1 + Rc[5] * c2 + tc[1];
+                        const double cp2 = Rc[6] * c0 + Rc[7] * c1 + Rc[8] * c2 + tc[2];
+                        double fro = 0.0;
+#pragma unroll
+                        for (int i = 0; i < 9; ++i) { const double e = Ru[i] - ((i % 4 == 0) ? 1.0 : 0.0); fro += e * e; }
+                        const double m0 = (Ru[0] - 1.0) * cp0 + Ru[1] * cp1 + Ru[2] * cp2 + tu[0];
+                        const double m1 = Ru[3] * cp0 + (Ru[4] - 1.0) * cp1 + Ru[5] * cp2 + tu[1];
+                        const double m2 = Ru[6] * cp0 + Ru[7] * cp1 + (Ru[8] - 1.0) * cp2 + tu[2];
+                        const double cpn = sqrt(cp0 * cp0 + cp1 * cp1 + cp2 * cp2);
+                        // positions are evaluated in F from the rounded transform: a few ulps of their magnitude
+                        const double eps_pos = sizeof(F) == 4 ? 4e-6 : 1e-14;
+                        motion = sqrt(fro) * state[28] + sqrt(m0 * m0 + m1 * m1 + m2 * m2) + eps_pos * (state[28] + cpn);
+                        motion *= 1.0 + 1e-9;
+                    }
                     double Rn[9], tn[3];
                     mul3(Ru, Rc, Rn);
                     tn[0] = Ru[0] * tc[0] + Ru[1] * tc[1] + Ru[2] * tc[2] + tu[0];
@@ -397,6 +556,10 @@ __global__ __launch_bounds__(NW * 64, 4) void icp_kernel(IcpArgs a) {
                 state[9] = tc[0]; state[10] = tc[1]; state[11] = tc[2];
                 state[12] = done ? 1.0 : 0.0;
                 state[13] = fit_new; state[14] = rmse_new; state[15] = (double)iters;
+                state[29] += motion;
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+                    state[30 + i] = Rc[3 * i] * state[25] + Rc[3 * i + 1] * state[26] + Rc[3 * i + 2] * state[27] + tc[i];
             }
             __builtin_amdgcn_s_setprio(0);
         }
@@ -413,9 +576,12 @@ __global__ __launch_bounds__(NW * 64, 4) void icp_kernel(IcpArgs a) {
     PROF_T(pt_end);
     PROF_ADD(0, pt_end, pt_start);
 #ifdef F4L_ICP_PROF
+    const unsigned long long rt_end = __builtin_amdgcn_s_memrealtime();
+    prof_acc[14] += rt_end - rt_start;
+    if (a.prof && tid == 0) { a.prof[16 + 2 * p] = rt_start; a.prof[17 + 2 * p] = rt_end; }
     if (a.prof && tid == 0) {
-        const int slots[7] = {0, 1, 2, 3, 4, 5, 12};
-        for (int i = 0; i < 7; ++i) atomicAdd(&a.prof[slots[i]], prof_acc[slots[i]]);
+        const int slots[9] = {0, 1, 2, 3, 4, 5, 15, 12, 14};
+        for (int i = 0; i < 9; ++i) atomicAdd(&a.prof[slots[i]], prof_acc[slots[i]]);
     }
 #endif
     if (tid == 0) {
@@ -510,8 +676,8 @@ extern "C" int f4l_piecewise_icp(const float *src, const int64_t *src_off, const
     else if (P >= 4096 && max_src_patch_host <= 2048) nw = 2;
     { const char *e = getenv("F4L_ICP_WAVES"); if (e) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) nw = v; } }
 
-    // LDS plan: targets first (they make the grid possible), then the prefix table, then the sources
-    const size_t fixed = (size_t)(nw * 32 + 32) * sizeof(double) + (size_t)(GRID_ROWS + 1) * nw * 64 * sizeof(unsigned int);
+    // LDS plan: targets first (they make the grid possible), then the prefix table, then the certificate arrays
+    const size_t fixed = (size_t)(nw * 32 + 48) * sizeof(double) + 16 + (size_t)(GRID_ROWS + 1) * nw * 64 * sizeof(unsigned int);
     int tgt_cap = (int)(max_tgt_patch_host < ICP_TGT_MAX ? max_tgt_patch_host : ICP_TGT_MAX);
     if (tgt_cap < 1) tgt_cap = 1;
     int cell_cap = pow2_ceil(2 * (int64_t)tgt_cap);
@@ -520,25 +686,60 @@ extern "C" int f4l_piecewise_icp(const float *src, const int64_t *src_off, const
     while (fixed + (size_t)tgt_cap * pt + table_bytes(cell_cap) > (size_t)ICP_LDS_BUDGET && cell_cap > 512) cell_cap >>= 1;
     while (fixed + (size_t)tgt_cap * pt + table_bytes(cell_cap) > (size_t)ICP_LDS_BUDGET) tgt_cap -= 256;
     size_t lds = fixed + (size_t)tgt_cap * pt + table_bytes(cell_cap);
+    const int nt_threads = nw * 64;
+    auto cert_bytes = [&](int64_t cap) {
+        const size_t seg = (size_t)((cap + nt_threads - 1) / nt_threads) * 64;
+        return (size_t)((cap + 3) & ~(int64_t)3) * (f64 ? 8 : 4) + (size_t)((cap + 7) & ~(int64_t)7) * 2 + (size_t)nw * seg * 2 + 16;
+    };
+    int cert_cap = 0;
+    if (max_src_patch_host < 0xfff0 && lds + cert_bytes(max_src_patch_host) <= (size_t)ICP_LDS_BUDGET) cert_cap = (int)max_src_patch_host;
+    lds += cert_bytes(cert_cap);
+    // sources in LDS too when that keeps at least four workgroups on a CU (or when it all fits anyway for one)
     int src_cap = 0;
-    if (lds + (size_t)max_src_patch_host * (pt + 2) + 16 <= (size_t)ICP_LDS_BUDGET) src_cap = (int)max_src_patch_host;
-    lds += (size_t)src_cap * (pt + 2) + 16;
+    {
+        const size_t sb = (size_t)((max_src_patch_host + 3) & ~(int64_t)3) * 3 * (f64 ? 8 : 4);
+        if (lds + sb <= (size_t)ICP_LDS_BUDGET && (lds + sb <= 40 * 1024 || lds > 40 * 1024)) src_cap = (int)max_src_patch_host;
+        if (src_cap) lds += sb;
+    }
     lds = (lds + 15) & ~(size_t)15;
-    a.tgt_cap = tgt_cap; a.src_cap = src_cap; a.cell_cap = cell_cap;
+    a.tgt_cap = tgt_cap; a.cert_cap = cert_cap; a.cell_cap = cell_cap; a.src_cap = src_cap;
     a.prof = nullptr;
 #ifdef F4L_ICP_PROF
     if (getenv("F4L_ICP_PROF")) {
         unsigned long long *dp = nullptr, hp[16];
-        F4L_HIP_CHECK(hipMalloc(&dp, sizeof(hp)));
-        F4L_HIP_CHECK(hipMemset(dp, 0, sizeof(hp)));
+        const size_t prof_bytes = sizeof(hp) + (size_t)P * 16;
+        F4L_HIP_CHECK(hipMalloc(&dp, prof_bytes));
+        F4L_HIP_CHECK(hipMemset(dp, 0, prof_bytes));
         a.prof = dp;
         int rc = f64 ? launch_icp<double>(a, mode, nw, lds, (hipStream_t)stream) : launch_icp<float>(a, mode, nw, lds, (hipStream_t)stream);
         F4L_HIP_CHECK(hipDeviceSynchronize());
         F4L_HIP_CHECK(hipMemcpy(hp, dp, sizeof(hp), hipMemcpyDeviceToHost));
+        if (getenv("F4L_ICP_PROF_WG")) {  // per-workgroup start/end (100 MHz ticks) -> schedule statistics
+            unsigned long long *wg = (unsigned long long *)malloc((size_t)P * 16);
+            F4L_HIP_CHECK(hipMemcpy(wg, dp + 16, (size_t)P * 16, hipMemcpyDeviceToHost));
+            unsigned long long t0 = ~0ULL, t1 = 0, dmin = ~0ULL, dmax = 0;
+            double dsum = 0;
+            for (int64_t i = 0; i < P; ++i) {
+                const unsigned long long b = wg[2 * i], e = wg[2 * i + 1], d = e - b;
+                t0 = b < t0 ? b : t0; t1 = e > t1 ? e : t1; dmin = d < dmin ? d : dmin; dmax = d > dmax ? d : dmax; dsum += (double)d;
+            }
+            fprintf(stderr, "[icp prof wg] span %.1f us | per WG: min %.1f mean %.1f max %.1f us | mean concurrency %.0f WGs\n",
+                    (t1 - t0) * 0.01, dmin * 0.01, dsum / P * 0.01, dmax * 0.01, dsum / (double)(t1 - t0));
+            const int NB = 20;
+            for (int b = 0; b < NB; ++b) {  // running workgroups at 20 instants
+                const unsigned long long t = t0 + (t1 - t0) * (unsigned long long)(2 * b + 1) / (2 * NB);
+                int live = 0;
+                for (int64_t i = 0; i < P; ++i) live += (wg[2 * i] <= t && t < wg[2 * i + 1]) ? 1 : 0;
+                fprintf(stderr, "%d ", live);
+            }
+            fprintf(stderr, "\n");
+            if (FILE *f = fopen(getenv("F4L_ICP_PROF_WG"), "wb")) { fwrite(wg, 16, (size_t)P, f); fclose(f); }
+            free(wg);
+        }
         hipFree(dp);
-        fprintf(stderr, "[icp prof] P=%lld nw=%d lds=%zu tgt_cap=%d src_cap=%d cell_cap=%d | per-WG mean cycles: total %.0f build %.0f search %.0f reduce %.0f solve %.0f barrier %.0f dpp %.0f sweeps/solve %.2f | per query: steps %.2f rows %.2f rows_taken %.2f wave-steps/batch %.2f\n",
-                (long long)P, nw, lds, tgt_cap, src_cap, cell_cap, hp[0] / (double)P, hp[1] / (double)P, hp[2] / (double)P,
-                hp[3] / (double)P, hp[4] / (double)P, hp[5] / (double)P, hp[12] / (double)P, hp[13] / (double)(hp[14] ? hp[14] : 1), hp[6] / (double)(hp[9] ? hp[9] : 1),
+        fprintf(stderr, "[icp prof] P=%lld nw=%d lds=%zu tgt_cap=%d cert_cap=%d src_cap=%d cell_cap=%d | per-WG mean cycles: total %.0f build %.0f phase1 %.0f search %.0f reduce %.0f solve %.0f barrier %.0f dpp %.0f clock %.3f GHz | per query: steps %.2f rows %.2f rows_taken %.2f wave-steps/batch %.2f\n",
+                (long long)P, nw, lds, tgt_cap, cert_cap, src_cap, cell_cap, hp[0] / (double)P, hp[1] / (double)P, hp[15] / (double)P, hp[2] / (double)P,
+                hp[3] / (double)P, hp[4] / (double)P, hp[5] / (double)P, hp[12] / (double)P, hp[0] / (double)(hp[14] ? hp[14] : 1) * 0.1, hp[6] / (double)(hp[9] ? hp[9] : 1),
                 hp[7] / (double)(hp[9] ? hp[9] : 1), hp[8] / (double)(hp[9] ? hp[9] : 1), hp[10] / (double)(hp[11] ? hp[11] : 1));
         return rc;
     }

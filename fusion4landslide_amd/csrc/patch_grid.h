@@ -64,26 +64,28 @@ __device__ __forceinline__ double grid_d2(double dx, double dy, double dz) {
     return t;
 }
 
-// ---- best-candidate record: lexicographic (d2, original index) ------------------------------------------
+// ---- best-candidate record: lexicographic (d2, original index), plus the runner-up distance ---------------
+// `second` is the smallest d2 offered that did NOT end up as the best: a lower bound on the distance of every
+// other scanned target, which is what the nearest-neighbour certificates of icp.hip are made of.
 // float32: one 64-bit key {bits(d2) : id}; d2 >= 0, so the IEEE bit pattern orders like the value.
 template <typename F> struct Best;
 template <> struct Best<float> {
     unsigned long long key;
     int pos;
-    __device__ __forceinline__ void init(float r2) {
-        key = ((unsigned long long)__float_as_uint(r2) << 32) | 0xffffffffULL;
+    float second;
+    __device__ __forceinline__ void init(float bound2) {
+        key = ((unsigned long long)__float_as_uint(bound2) << 32) | 0xffffffffULL;
         pos = -1;
+        second = __builtin_inff();
     }
-    __device__ __forceinline__ void offer(float d, int id, int j) {
-        const unsigned long long k = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned int)id;
-        const bool better = k < key;
-        key = better ? k : key;
-        pos = better ? j : pos;
-    }
+    __device__ __forceinline__ void offer(float d, int id, int j) { offer_if(true, d, id, j); }
     // predicated form for the flat scan loop (no branch: every lane executes the same instructions)
     __device__ __forceinline__ void offer_if(bool act, float d, int id, int j) {
+        d = act ? d : __builtin_inff();
         const unsigned long long k = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned int)id;
-        const bool better = act && k < key;
+        const bool better = k < key;
+        const float loser = better ? d2() : d;
+        second = loser < second ? loser : second;
         key = better ? k : key;
         pos = better ? j : pos;
     }
@@ -91,14 +93,15 @@ template <> struct Best<float> {
     __device__ __forceinline__ int id() const { return (int)(unsigned int)(key & 0xffffffffULL); }
 };
 template <> struct Best<double> {
-    double d;
+    double d, second;
     int i, pos;
-    __device__ __forceinline__ void init(double r2) { d = r2; i = 0x7fffffff; pos = -1; }
-    __device__ __forceinline__ void offer(double dd, int id, int j) {
-        if (dd < d || (dd == d && id < i)) { d = dd; i = id; pos = j; }
-    }
+    __device__ __forceinline__ void init(double bound2) { d = bound2; i = 0x7fffffff; pos = -1; second = __builtin_inf(); }
+    __device__ __forceinline__ void offer(double dd, int id, int j) { offer_if(true, dd, id, j); }
     __device__ __forceinline__ void offer_if(bool act, double dd, int id, int j) {
-        const bool better = act && (dd < d || (dd == d && id < i));
+        dd = act ? dd : __builtin_inf();
+        const bool better = dd < d || (dd == d && id < i);
+        const double loser = better ? d : dd;
+        second = loser < second ? loser : second;
         d = better ? dd : d;
         i = better ? id : i;
         pos = better ? j : pos;
@@ -245,8 +248,9 @@ __device__ __forceinline__ void grid_build(const float *__restrict__ tg, int nt,
 // Exact nearest target of (px, py, pz) among those with d2 < r2: every lane of the wave owns one query (lanes
 // with valid == false own none) and ALL lanes of the wave must make the call together.
 //
-// `best` comes in init(r2)'d, or holding a real candidate (e.g. last iteration's correspondence, re-measured):
-// its d2 is an upper bound of the answer and prunes the stencil BEFORE anything is scanned:
+// `best` comes in init(b2)'d with an upper bound b2 <= (cell edge)^2 of the squared distance of interest (the
+// correspondence radius, or last iteration's correspondence re-measured plus a margin); everything with
+// d2 <= b2 is scanned, and the bound prunes the stencil BEFORE anything is scanned:
 //   * the x-range of every row is narrowed to the cells within sqrt(best) of the query,
 //   * rows (y, z) whose distance to the query exceeds the bound are dropped.
 // The surviving non-empty rows are written as packed {start, end} pairs to a per-lane list in LDS
