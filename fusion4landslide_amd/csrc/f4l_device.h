@@ -256,6 +256,84 @@ __device__ __forceinline__ void svd3(const double *A, double *U, double *S, doub
     svd3_finish(W, Vm, U, S, V);
 }
 
+// ---- double precision reciprocal / reciprocal square root without the IEEE fix-up sequences -----------------
+// v_rcp_f64 / v_rsq_f64 deliver ~1e-7 relative; two Newton steps bring them to a couple of ulps (not correctly
+// rounded, no denormal / inf handling): ~8 dependent instructions instead of ~25.  For normal, positive x.
+__device__ __forceinline__ double fast_rcp(double x) {
+    double y = __builtin_amdgcn_rcp(x);
+    y = y * __builtin_fma(-x, y, 2.0);
+    y = y * __builtin_fma(-x, y, 2.0);
+    return y;
+}
+__device__ __forceinline__ double fast_rsqrt(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    y = y * __builtin_fma(-0.5 * x * y, y, 1.5);
+    y = y * __builtin_fma(-0.5 * x * y, y, 1.5);
+    return y;
+}
+__device__ __forceinline__ double fast_sqrt(double x) { return x > 0.0 ? x * fast_rsqrt(x) : 0.0; }
+
+// svd3_finish for the ICP solve: same decisions, squared norms instead of norms (no square roots before the
+// sort), normalisation by fast_rsqrt; the singular values themselves are not needed there.
+__device__ __forceinline__ void svd3_finish_fast(double *W, double *Vm, double *U, double *V) {
+    double q0 = W[0] * W[0] + W[3] * W[3] + W[6] * W[6];
+    double q1 = W[1] * W[1] + W[4] * W[4] + W[7] * W[7];
+    double q2 = W[2] * W[2] + W[5] * W[5] + W[8] * W[8];
+#define F4L_SWAPCOL(a, b)                                                        \
+    {                                                                            \
+        _Pragma("unroll") for (int i = 0; i < 3; ++i) {                          \
+            double tw = W[3 * i + a]; W[3 * i + a] = W[3 * i + b]; W[3 * i + b] = tw; \
+            double tv = Vm[3 * i + a]; Vm[3 * i + a] = Vm[3 * i + b]; Vm[3 * i + b] = tv; \
+        }                                                                        \
+    }
+    if (q1 > q0) { double t = q0; q0 = q1; q1 = t; F4L_SWAPCOL(0, 1) }
+    if (q2 > q0) { double t = q0; q0 = q2; q2 = t; F4L_SWAPCOL(0, 2) }
+    if (q2 > q1) { double t = q1; q1 = q2; q2 = t; F4L_SWAPCOL(1, 2) }
+#undef F4L_SWAPCOL
+#pragma unroll
+    for (int i = 0; i < 9; ++i) V[i] = Vm[i];
+    double u0[3], u1[3], u2[3];
+    if (q0 > 1e-290) {
+        const double inv = fast_rsqrt(q0);
+        u0[0] = W[0] * inv; u0[1] = W[3] * inv; u0[2] = W[6] * inv;
+    } else {
+        u0[0] = Vm[0]; u0[1] = Vm[3]; u0[2] = Vm[6];
+    }
+    double pr = u0[0] * W[1] + u0[1] * W[4] + u0[2] * W[7];
+    u1[0] = W[1] - pr * u0[0]; u1[1] = W[4] - pr * u0[1]; u1[2] = W[7] - pr * u0[2];
+    double m1 = u1[0] * u1[0] + u1[1] * u1[1] + u1[2] * u1[2];
+    if (!(m1 > 1e-28 * q0 && m1 > 1e-290)) {  // second direction carries no signal: complete it from V
+        pr = u0[0] * Vm[1] + u0[1] * Vm[4] + u0[2] * Vm[7];
+        u1[0] = Vm[1] - pr * u0[0]; u1[1] = Vm[4] - pr * u0[1]; u1[2] = Vm[7] - pr * u0[2];
+        m1 = u1[0] * u1[0] + u1[1] * u1[1] + u1[2] * u1[2];
+        if (!(m1 > 1e-16)) {
+            const double ax = fabs(u0[0]), ay = fabs(u0[1]), az = fabs(u0[2]);
+            double e0 = 0.0, e1 = 0.0, e2 = 0.0;
+            if (ax <= ay) { if (ax <= az) e0 = 1.0; else e2 = 1.0; }
+            else { if (ay <= az) e1 = 1.0; else e2 = 1.0; }
+            u1[0] = u0[1] * e2 - u0[2] * e1;
+            u1[1] = u0[2] * e0 - u0[0] * e2;
+            u1[2] = u0[0] * e1 - u0[1] * e0;
+            m1 = u1[0] * u1[0] + u1[1] * u1[1] + u1[2] * u1[2];
+        }
+    }
+    {
+        const double inv = fast_rsqrt(m1);
+        u1[0] *= inv; u1[1] *= inv; u1[2] *= inv;
+    }
+    u2[0] = u0[1] * u1[2] - u0[2] * u1[1];
+    u2[1] = u0[2] * u1[0] - u0[0] * u1[2];
+    u2[2] = u0[0] * u1[1] - u0[1] * u1[0];
+    {
+        const bool sig = q2 > 1e-28 * q0 && q2 > 0.0;
+        const double r0 = sig ? W[2] : Vm[2], r1 = sig ? W[5] : Vm[5], r2 = sig ? W[8] : Vm[8];
+        if (u2[0] * r0 + u2[1] * r1 + u2[2] * r2 < 0.0) { u2[0] = -u2[0]; u2[1] = -u2[1]; u2[2] = -u2[2]; }
+    }
+    U[0] = u0[0]; U[1] = u1[0]; U[2] = u2[0];
+    U[3] = u0[1]; U[4] = u1[1]; U[5] = u2[1];
+    U[6] = u0[2]; U[7] = u1[2]; U[8] = u2[2];
+}
+
 // ---- the same SVD for the per-iteration solve of the ICP kernel, built for latency ------------------------
 // A rotation only has to (a) be orthogonal to working precision and (b) shrink the off-diagonal term; how
 // accurately its ANGLE is computed merely steers convergence.  So the angle uses the raw v_rcp_f64 /
@@ -263,8 +341,9 @@ __device__ __forceinline__ void svd3(const double *A, double *U, double *S, doub
 // only c = (1 + t^2)^(-1/2) is polished by two Newton steps to full double precision; s = c t then makes
 // c^2 + s^2 = 1 to rounding.  Columns count as orthogonal at |gamma| <= 8 eps sqrt(alpha beta): the exit
 // test of svd3 (eps / 4) sits below the rounding noise of gamma and usually burns all 60 sweeps.
+// Returns gamma^2 / (alpha beta) BEFORE the rotation (0 when the pair already counts as orthogonal).
 template <int P, int Q>
-__device__ __forceinline__ bool jacobi_rotate_fast(double *W, double *V) {
+__device__ __forceinline__ double jacobi_rotate_fast(double *W, double *V) {
     double alpha = 0.0, beta = 0.0, gamma = 0.0;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
@@ -273,7 +352,8 @@ __device__ __forceinline__ bool jacobi_rotate_fast(double *W, double *V) {
         gamma += W[3 * i + P] * W[3 * i + Q];
     }
     const double tol = 8.0 * 2.220446049250313e-16;
-    if (!(gamma * gamma > (tol * tol) * (alpha * beta))) return false;  // converged pair (also gamma == 0, NaN)
+    const double g2 = gamma * gamma, ab = alpha * beta;
+    if (!(g2 > (tol * tol) * ab)) return 0.0;  // converged pair (also gamma == 0, NaN)
     const double zeta = (beta - alpha) * 0.5 * __builtin_amdgcn_rcp(gamma);
     double t = __builtin_amdgcn_rcp(fabs(zeta) + __builtin_amdgcn_sqrt(__builtin_fma(zeta, zeta, 1.0)));
     t = zeta < 0.0 ? -t : t;
@@ -291,12 +371,12 @@ __device__ __forceinline__ bool jacobi_rotate_fast(double *W, double *V) {
         V[3 * i + P] = c * vp - sn * vq;
         V[3 * i + Q] = sn * vp + c * vq;
     }
-    return true;
+    return g2 * __builtin_amdgcn_rcp(ab);
 }
 
 // A = U diag(S) V^T with the sweeps WARM-STARTED from V0 (orthogonal; the V of the previous ICP iteration, or I):
 // W = A V0 already has nearly orthogonal columns when A moved little, so one or two sweeps finish it.
-__device__ __forceinline__ int svd3_warm(const double *A, const double *V0, double *U, double *S, double *V) {
+__device__ __forceinline__ int svd3_warm(const double *A, const double *V0, double *U, double *V) {
     double W[9], Vm[9];
 #pragma unroll
     for (int i = 0; i < 9; ++i) Vm[i] = V0[i];
@@ -307,14 +387,15 @@ __device__ __forceinline__ int svd3_warm(const double *A, const double *V0, doub
             W[3 * i + j] = A[3 * i] * V0[j] + A[3 * i + 1] * V0[3 + j] + A[3 * i + 2] * V0[6 + j];
     int sweeps = 0;
     for (; sweeps < 16; ++sweeps) {
-        bool any = false;
-        any |= jacobi_rotate_fast<0, 1>(W, Vm);
-        any |= jacobi_rotate_fast<0, 2>(W, Vm);
-        any |= jacobi_rotate_fast<1, 2>(W, Vm);
-        if (!any) break;
+        double worst = jacobi_rotate_fast<0, 1>(W, Vm);
+        worst = fmax(worst, jacobi_rotate_fast<0, 2>(W, Vm));
+        worst = fmax(worst, jacobi_rotate_fast<1, 2>(W, Vm));
+        // Jacobi converges quadratically: relative off-diagonals below 1e-8 before a sweep are below the
+        // threshold after it, so no verification sweep is needed (the angle's 1e-7 error leaves 1e-15 at most)
+        if (worst < 1e-16) break;
     }
-    svd3_finish(W, Vm, U, S, V);
-    return sweeps;  // rotating sweeps (the final, idle one not counted)
+    svd3_finish_fast(W, Vm, U, V);
+    return sweeps;
 }
 
 // R = A diag(1,1,d) B^T for row-major 3x3 A, B.

@@ -34,6 +34,9 @@
 
 namespace f4l {
 
+#ifndef ICP_WAVES_PER_EU
+#define ICP_WAVES_PER_EU 4
+#endif
 constexpr int ICP_LDS_BUDGET = 160 * 1024 - 512;  // dynamic LDS a single workgroup may ask for on gfx950
 constexpr int ICP_TGT_MAX = 8192;                 // target points kept in LDS at most
 constexpr int ICP_CELL_MAX = 16384;               // grid cells at most (uint16 prefix table)
@@ -78,7 +81,7 @@ __device__ __forceinline__ void nn_global(const float *__restrict__ tg, int nt, 
 #pragma unroll 4
     for (int j = 0; j < nt; ++j) {
         const F qx = (F)tg[3 * j] - (F)ox, qy = (F)tg[3 * j + 1] - (F)oy, qz = (F)tg[3 * j + 2] - (F)oz;
-        best.offer(grid_d2(px - qx, py - qy, pz - qz), j, j);
+        best.offer(grid_d2(px - qx, py - qy, pz - qz), (unsigned int)j);  // tag = plain index (no slot on this path)
     }
 }
 
@@ -142,7 +145,7 @@ __device__ __forceinline__ double uniform_f64(double v) {
 // and certifies (or queues) every source point, and a search phase over the queued points only, compacted
 // across the workgroup.  Results are exactly those of searching every point in every pass.
 template <int MODE, int NW, typename F>
-__global__ __launch_bounds__(NW * 64, 4) void icp_kernel(IcpArgs a) {
+__global__ __launch_bounds__(NW * 64, ICP_WAVES_PER_EU) void icp_kernel(IcpArgs a) {
     constexpr int NV = (MODE == F4L_ICP_POINT2POINT) ? 17 : 29;
     constexpr int NT = NW * 64;
     // Correspondence sums.  float32 search + point-to-point: per-lane partial sums and the in-wave reduction are
@@ -156,7 +159,7 @@ __global__ __launch_bounds__(NW * 64, 4) void icp_kernel(IcpArgs a) {
     double *state = scratch + NW * 32;
     int *qcnt = reinterpret_cast<int *>(state + 48);
     GridPt<F> *tl = reinterpret_cast<GridPt<F> *>(qcnt + 4);
-    F *mabs = reinterpret_cast<F *>(tl + a.tgt_cap);
+    F *mabs = reinterpret_cast<F *>(tl + a.tgt_cap + 1);  // tl[nt] is the dummy record of the grid
     F *sl = mabs + ((a.cert_cap + 3) & ~3);  // origin-relative source points, packed xyz
     unsigned int *rl = reinterpret_cast<unsigned int *>(sl + 3 * ((a.src_cap + 3) & ~3));
     unsigned short *E = reinterpret_cast<unsigned short *>(rl + (GRID_ROWS + 1) * NT);
@@ -325,8 +328,9 @@ __global__ __launch_bounds__(NW * 64, 4) void icp_kernel(IcpArgs a) {
                 bool cert = pv < 0xfffe ? grid_sqrt<F>(d) * (F)1.000001 < room : (pv == 0xfffe && room > rF * (F)1.000001);
                 cert = cert && valid;
                 const bool hit = cert && pv < 0xfffe && d < r2;
-                if (hit) accumulate(px, py, pz, q.x, q.y, q.z, d, q.id);
-                if (a.corr_out && cert) a.corr_out[s0 + i] = hit ? q.id : -1;
+                const int qid = (int)(q.tag >> 16);
+                if (hit) accumulate(px, py, pz, q.x, q.y, q.z, d, qid);
+                if (a.corr_out && cert) a.corr_out[s0 + i] = hit ? qid : -1;
                 const bool need = valid && !cert;
                 const unsigned long long m = __ballot(need);
                 if (need) myq[nq + __builtin_popcountll(m & lt_mask)] = (unsigned short)i;
@@ -342,8 +346,8 @@ __global__ __launch_bounds__(NW * 64, 4) void icp_kernel(IcpArgs a) {
         PROF_ADD(15, pt_p0b, pt_p0);
 
         // ---- phase 2: search the queued points (all points without certificates), 64 per wave
-        for (int base = 0; base < n_search; base += NT) {
-            const int k = base + tid;
+        for (int base = wave * 64; base < n_search; base += NT) {  // a wave without queued points skips the batch
+            const int k = base + lane;
             const bool valid = k < n_search;
             int i = valid ? k : n_search - 1;
             if (use_cert) {
@@ -377,25 +381,25 @@ __global__ __launch_bounds__(NW * 64, 4) void icp_kernel(IcpArgs a) {
                 }
                 best.init(b0);
 #ifdef F4L_ICP_PROF
-                grid_nn<F, NT>(g, tl, E, rl, valid, px, py, pz, best, (a.debug & 64) ? a.prof : nullptr);
+                grid_nn<F, NT>(g, tl, nt, E, rl, valid, px, py, pz, best, (a.debug & 64) ? a.prof : nullptr);
 #else
-                grid_nn<F, NT>(g, tl, E, rl, valid, px, py, pz, best);
+                grid_nn<F, NT>(g, tl, nt, E, rl, valid, px, py, pz, best);
 #endif
                 if (use_cert && valid) {
                     const F m2 = best.second < b0 ? best.second : b0;
-                    prev[i] = (unsigned short)(best.pos >= 0 ? best.pos : 0xfffe);
+                    prev[i] = (unsigned short)(best.found() ? best.slot() : 0xfffe);
                     mabs[i] = grid_sqrt<F>(m2) * (F)0.999999 + dsum;
                 }
             } else {
                 best.init(r2);
                 nn_global<F>(tg, nt, ox, oy, oz, px, py, pz, best);
             }
-            const bool hit = valid && best.pos >= 0 && best.d2() < r2;  // SearchHybrid: d2 < r^2
-            const int bj = best.id();  // index inside the target patch
+            const bool hit = valid && best.found() && best.d2() < r2;  // SearchHybrid: d2 < r^2
+            const int bj = tgt_in_lds ? best.id() : (int)best.tag();  // index inside the target patch
             if (a.corr_out && valid) a.corr_out[s0 + i] = hit ? bj : -1;
             if (hit) {
                 F qx, qy, qz;
-                if (tgt_in_lds) { const GridPt<F> q = tl[best.pos]; qx = q.x; qy = q.y; qz = q.z; }
+                if (tgt_in_lds) { const GridPt<F> q = tl[best.slot()]; qx = q.x; qy = q.y; qz = q.z; }
                 else { qx = (F)tg[3 * bj] - (F)ox; qy = (F)tg[3 * bj + 1] - (F)oy; qz = (F)tg[3 * bj + 2] - (F)oz; }
                 accumulate(px, py, pz, qx, qy, qz, best.d2(), bj);
             }
@@ -460,7 +464,7 @@ __global__ __launch_bounds__(NW * 64, 4) void icp_kernel(IcpArgs a) {
                 bool have = true;
                 if (MODE == F4L_ICP_POINT2POINT) {
                     // Eigen::umeyama without scaling
-                    const double im = 1.0 / m;
+                    const double im = fast_rcp(m);
                     // means about the centring point (zero when the sums are uncentred); the covariance is shift invariant
                     const double cm0 = tot[2] * im, cm1 = tot[3] * im, cm2 = tot[4] * im;
                     const double cq0 = tot[5] * im, cq1 = tot[6] * im, cq2 = tot[7] * im;
@@ -473,10 +477,10 @@ __global__ __launch_bounds__(NW * 64, 4) void icp_kernel(IcpArgs a) {
                                  sh2 = CENTRED ? (double)(F)state[32] : 0.0;
                     const double mp0 = cm0 + sh0, mp1 = cm1 + sh1, mp2 = cm2 + sh2;
                     const double mq0 = cq0 + sh0, mq1 = cq1 + sh1, mq2 = cq2 + sh2;
-                    double U[9], S[3], V[9], V0[9];
+                    double U[9], V[9], V0[9];
 #pragma unroll
                     for (int i = 0; i < 9; ++i) V0[i] = state[16 + i];
-                    const int n_sweeps = svd3_warm(sg9, V0, U, S, V);
+                    const int n_sweeps = svd3_warm(sg9, V0, U, V);
 #ifdef F4L_ICP_PROF
                     (void)n_sweeps;
 #else
@@ -534,10 +538,10 @@ __global__ __launch_bounds__(NW * 64, 4) void icp_kernel(IcpArgs a) {
                         const double m0 = (Ru[0] - 1.0) * cp0 + Ru[1] * cp1 + Ru[2] * cp2 + tu[0];
                         const double m1 = Ru[3] * cp0 + (Ru[4] - 1.0) * cp1 + Ru[5] * cp2 + tu[1];
                         const double m2 = Ru[6] * cp0 + Ru[7] * cp1 + (Ru[8] - 1.0) * cp2 + tu[2];
-                        const double cpn = sqrt(cp0 * cp0 + cp1 * cp1 + cp2 * cp2);
+                        const double cpn = fast_sqrt(cp0 * cp0 + cp1 * cp1 + cp2 * cp2);
                         // positions are evaluated in F from the rounded transform: a few ulps of their magnitude
                         const double eps_pos = sizeof(F) == 4 ? 4e-6 : 1e-14;
-                        motion = sqrt(fro) * state[28] + sqrt(m0 * m0 + m1 * m1 + m2 * m2) + eps_pos * (state[28] + cpn);
+                        motion = fast_sqrt(fro) * state[28] + fast_sqrt(m0 * m0 + m1 * m1 + m2 * m2) + eps_pos * (state[28] + cpn);
                         motion *= 1.0 + 1e-9;
                     }
                     double Rn[9], tn[3];
@@ -680,12 +684,12 @@ extern "C" int f4l_piecewise_icp(const float *src, const int64_t *src_off, const
     const size_t fixed = (size_t)(nw * 32 + 48) * sizeof(double) + 16 + (size_t)(GRID_ROWS + 1) * nw * 64 * sizeof(unsigned int);
     int tgt_cap = (int)(max_tgt_patch_host < ICP_TGT_MAX ? max_tgt_patch_host : ICP_TGT_MAX);
     if (tgt_cap < 1) tgt_cap = 1;
-    int cell_cap = pow2_ceil(2 * (int64_t)tgt_cap);
+    int cell_cap = (int)((2 * (int64_t)tgt_cap + 255) & ~(int64_t)255);  // ~2 cells per target point
     cell_cap = cell_cap < 512 ? 512 : (cell_cap > ICP_CELL_MAX ? ICP_CELL_MAX : cell_cap);
     auto table_bytes = [](int cells) { return ((size_t)cells + 8) * 2; };
-    while (fixed + (size_t)tgt_cap * pt + table_bytes(cell_cap) > (size_t)ICP_LDS_BUDGET && cell_cap > 512) cell_cap >>= 1;
-    while (fixed + (size_t)tgt_cap * pt + table_bytes(cell_cap) > (size_t)ICP_LDS_BUDGET) tgt_cap -= 256;
-    size_t lds = fixed + (size_t)tgt_cap * pt + table_bytes(cell_cap);
+    while (fixed + (size_t)(tgt_cap + 1) * pt + table_bytes(cell_cap) > (size_t)ICP_LDS_BUDGET && cell_cap > 512) cell_cap >>= 1;
+    while (fixed + (size_t)(tgt_cap + 1) * pt + table_bytes(cell_cap) > (size_t)ICP_LDS_BUDGET) tgt_cap -= 256;
+    size_t lds = fixed + (size_t)(tgt_cap + 1) * pt + table_bytes(cell_cap);
     const int nt_threads = nw * 64;
     auto cert_bytes = [&](int64_t cap) {
         const size_t seg = (size_t)((cap + nt_threads - 1) / nt_threads) * 64;
@@ -698,7 +702,7 @@ extern "C" int f4l_piecewise_icp(const float *src, const int64_t *src_off, const
     int src_cap = 0;
     {
         const size_t sb = (size_t)((max_src_patch_host + 3) & ~(int64_t)3) * 3 * (f64 ? 8 : 4);
-        if (lds + sb <= (size_t)ICP_LDS_BUDGET && (lds + sb <= 40 * 1024 || lds > 40 * 1024)) src_cap = (int)max_src_patch_host;
+        if (!getenv("F4L_ICP_NOSL") && lds + sb <= (size_t)ICP_LDS_BUDGET && (lds + sb <= 40 * 1024 || lds > 40 * 1024)) src_cap = (int)max_src_patch_host;
         if (src_cap) lds += sb;
     }
     lds = (lds + 15) & ~(size_t)15;
@@ -737,10 +741,10 @@ extern "C" int f4l_piecewise_icp(const float *src, const int64_t *src_off, const
             free(wg);
         }
         hipFree(dp);
-        fprintf(stderr, "[icp prof] P=%lld nw=%d lds=%zu tgt_cap=%d cert_cap=%d src_cap=%d cell_cap=%d | per-WG mean cycles: total %.0f build %.0f phase1 %.0f search %.0f reduce %.0f solve %.0f barrier %.0f dpp %.0f clock %.3f GHz | per query: steps %.2f rows %.2f rows_taken %.2f wave-steps/batch %.2f\n",
+        fprintf(stderr, "[icp prof] P=%lld nw=%d lds=%zu tgt_cap=%d cert_cap=%d src_cap=%d cell_cap=%d | per-WG mean cycles: total %.0f build %.0f phase1 %.0f search %.0f reduce %.0f solve %.0f barrier %.0f dpp %.0f clock %.3f GHz | per query: steps %.2f rows %.2f rows_taken %.2f wave-steps/batch %.2f | per WG-pass: searched %.1f of %.1f, wave-batches %.2f\n",
                 (long long)P, nw, lds, tgt_cap, cert_cap, src_cap, cell_cap, hp[0] / (double)P, hp[1] / (double)P, hp[15] / (double)P, hp[2] / (double)P,
                 hp[3] / (double)P, hp[4] / (double)P, hp[5] / (double)P, hp[12] / (double)P, hp[0] / (double)(hp[14] ? hp[14] : 1) * 0.1, hp[6] / (double)(hp[9] ? hp[9] : 1),
-                hp[7] / (double)(hp[9] ? hp[9] : 1), hp[8] / (double)(hp[9] ? hp[9] : 1), hp[10] / (double)(hp[11] ? hp[11] : 1));
+                hp[7] / (double)(hp[9] ? hp[9] : 1), hp[8] / (double)(hp[9] ? hp[9] : 1), hp[10] / (double)(hp[11] ? hp[11] : 1), hp[9] / (double)P / (max_iter + 1), (double)max_src_patch_host, hp[11] / (double)P / (max_iter + 1));
         return rc;
     }
 #endif

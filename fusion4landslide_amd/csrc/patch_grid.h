@@ -8,7 +8,8 @@
 // known, so the whole patch is counting-sorted ONCE into cubic cells of edge h >= r that live in LDS for all
 // ICP iterations:
 //
-//   tl[0..nt)      target points in cell order, {x, y, z, original index}  (coordinates relative to the patch origin)
+//   tl[0..nt)      target points in cell order, {x, y, z, tag = original index : slot}  (patch-relative coordinates);
+//   tl[nt]         a dummy point at infinity that idle lanes read
 //   E[0..ncell]    packed uint16 prefix table: points of cell c are tl[E[c] .. E[c+1])
 //
 // Cells are numbered x-fastest, so the three x-neighbours of a cell form ONE contiguous run ("row") of tl; a
@@ -28,8 +29,8 @@ namespace f4l {
 
 // ---- point records as staged in LDS ------------------------------------------------------------------
 template <typename F> struct GridPt;
-template <> struct __attribute__((aligned(16))) GridPt<float> { float x, y, z; int id; };              // 16 B
-template <> struct __attribute__((aligned(16))) GridPt<double> { double x, y, z; int id; int pad; };   // 32 B
+template <> struct __attribute__((aligned(16))) GridPt<float> { float x, y, z; unsigned int tag; };                // 16 B
+template <> struct __attribute__((aligned(16))) GridPt<double> { double x, y, z; unsigned int tag; int pad; };   // 32 B
 
 template <typename F> struct PatchGrid {
     F minx, miny, minz, h, inv_h;
@@ -65,56 +66,57 @@ __device__ __forceinline__ double grid_d2(double dx, double dy, double dz) {
 }
 
 // ---- best-candidate record: lexicographic (d2, original index), plus the runner-up distance ---------------
-// `second` is the smallest d2 offered that did NOT end up as the best: a lower bound on the distance of every
-// other scanned target, which is what the nearest-neighbour certificates of icp.hip are made of.
-// float32: one 64-bit key {bits(d2) : id}; d2 >= 0, so the IEEE bit pattern orders like the value.
+// A grid point carries one 32-bit tag {original index : 16 | slot in tl : 16}; comparing tags compares original
+// indices (the slot rides along for free and tells where the winner's coordinates are).  `second` is the
+// smallest d2 offered that did NOT end up as the best: a lower bound on the distance of every other scanned
+// target, which is what the nearest-neighbour certificates of icp.hip are made of (invariant: best <= second).
+// float32: one 64-bit key {bits(d2) : tag}; d2 >= 0, so the IEEE bit pattern orders like the value.
+constexpr unsigned int GRID_NO_TAG = 0xffffffffu;
+__device__ __forceinline__ unsigned int grid_tag(int id, int slot) { return ((unsigned int)id << 16) | (unsigned int)slot; }
+
 template <typename F> struct Best;
 template <> struct Best<float> {
     unsigned long long key;
-    int pos;
     float second;
     __device__ __forceinline__ void init(float bound2) {
-        key = ((unsigned long long)__float_as_uint(bound2) << 32) | 0xffffffffULL;
-        pos = -1;
+        key = ((unsigned long long)__float_as_uint(bound2) << 32) | GRID_NO_TAG;
         second = __builtin_inff();
     }
-    __device__ __forceinline__ void offer(float d, int id, int j) { offer_if(true, d, id, j); }
-    // predicated form for the flat scan loop (no branch: every lane executes the same instructions)
-    __device__ __forceinline__ void offer_if(bool act, float d, int id, int j) {
-        d = act ? d : __builtin_inff();
-        const unsigned long long k = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned int)id;
-        const bool better = k < key;
-        const float loser = better ? d2() : d;
-        second = loser < second ? loser : second;
-        key = better ? k : key;
-        pos = better ? j : pos;
+    // branch free; a candidate at d2 = +inf (the dummy slot idle lanes read) changes nothing
+    __device__ __forceinline__ void offer(float d, unsigned int tag) {
+        const unsigned long long k = ((unsigned long long)__float_as_uint(d) << 32) | tag;
+        second = __builtin_amdgcn_fmed3f(d, d2(), second);  // = min(second, max(d, best)) because best <= second
+        key = k < key ? k : key;
     }
     __device__ __forceinline__ float d2() const { return __uint_as_float((unsigned int)(key >> 32)); }
-    __device__ __forceinline__ int id() const { return (int)(unsigned int)(key & 0xffffffffULL); }
+    __device__ __forceinline__ unsigned int tag() const { return (unsigned int)(key & 0xffffffffULL); }
+    __device__ __forceinline__ bool found() const { return tag() != GRID_NO_TAG; }
+    __device__ __forceinline__ int id() const { return (int)(tag() >> 16); }
+    __device__ __forceinline__ int slot() const { return (int)(tag() & 0xffffu); }
 };
 template <> struct Best<double> {
     double d, second;
-    int i, pos;
-    __device__ __forceinline__ void init(double bound2) { d = bound2; i = 0x7fffffff; pos = -1; second = __builtin_inf(); }
-    __device__ __forceinline__ void offer(double dd, int id, int j) { offer_if(true, dd, id, j); }
-    __device__ __forceinline__ void offer_if(bool act, double dd, int id, int j) {
-        dd = act ? dd : __builtin_inf();
-        const bool better = dd < d || (dd == d && id < i);
+    unsigned int t;
+    __device__ __forceinline__ void init(double bound2) { d = bound2; t = GRID_NO_TAG; second = __builtin_inf(); }
+    __device__ __forceinline__ void offer(double dd, unsigned int tag) {
+        const bool better = dd < d || (dd == d && tag < t);
         const double loser = better ? d : dd;
         second = loser < second ? loser : second;
         d = better ? dd : d;
-        i = better ? id : i;
-        pos = better ? j : pos;
+        t = better ? tag : t;
     }
     __device__ __forceinline__ double d2() const { return d; }
-    __device__ __forceinline__ int id() const { return i; }
+    __device__ __forceinline__ unsigned int tag() const { return t; }
+    __device__ __forceinline__ bool found() const { return t != GRID_NO_TAG; }
+    __device__ __forceinline__ int id() const { return (int)(t >> 16); }
+    __device__ __forceinline__ int slot() const { return (int)(t & 0xffffu); }
 };
 
 // ---- build ---------------------------------------------------------------------------------------------
 // Called by all NT threads of the workgroup.  tg: packed float32 [nt][3] of the patch in global memory;
 // (ox, oy, oz): patch origin; r: search radius (> 0); cell_cap: capacity of E in cells (E holds cell_cap + 2
 // uint16, 4-byte aligned); red: NT/64 * 8 values of F scratch in LDS.  On return (after a barrier) tl and E
-// are complete and g describes the grid.  nt >= 1, nt <= 65535.
+// are complete and g describes the grid.  1 <= nt <= 65534; tl holds nt + 1 records.
 template <typename F, int NT>
 __device__ __forceinline__ void grid_build(const float *__restrict__ tg, int nt, float ox, float oy, float oz, F r,
                                            int cell_cap, GridPt<F> *__restrict__ tl, unsigned short *__restrict__ E,
@@ -230,7 +232,6 @@ __device__ __forceinline__ void grid_build(const float *__restrict__ tg, int nt,
     for (int j = tid; j < nt; j += NT) {
         GridPt<F> q;
         q.x = (F)tg[3 * j] - (F)ox; q.y = (F)tg[3 * j + 1] - (F)oy; q.z = (F)tg[3 * j + 2] - (F)oz;
-        q.id = j;
         int cx, cy, cz;
         grid_cell(g, q.x, q.y, q.z, cx, cy, cz);
         cx = cx < 0 ? 0 : (cx >= nx ? nx - 1 : cx);
@@ -239,7 +240,14 @@ __device__ __forceinline__ void grid_build(const float *__restrict__ tg, int nt,
         const int e = (cz * ny + cy) * nx + cx + 1;
         const unsigned int old = atomicAdd(&Ew[e >> 1], (e & 1) ? 0x10000u : 1u);
         const int pos = (int)((e & 1) ? (old >> 16) : (old & 0xffffu));
+        q.tag = grid_tag(j, pos);
         tl[pos] = q;
+    }
+    if (tid == 0) {  // the dummy: farther than anything, never a winner
+        GridPt<F> q;
+        q.x = q.y = q.z = (F)(sizeof(F) == 4 ? 1e30 : 1e300);
+        q.tag = GRID_NO_TAG;
+        tl[nt] = q;
     }
     __syncthreads();
 }
@@ -265,7 +273,7 @@ template <> __device__ __forceinline__ float grid_sqrt<float>(float v) { return 
 template <> __device__ __forceinline__ double grid_sqrt<double>(double v) { return __builtin_sqrt(v); }
 
 template <typename F, int NT>
-__device__ __forceinline__ void grid_nn(const PatchGrid<F> &g, const GridPt<F> *__restrict__ tl,
+__device__ __forceinline__ void grid_nn(const PatchGrid<F> &g, const GridPt<F> *__restrict__ tl, int dummy,
                                         const unsigned short *__restrict__ E, unsigned int *__restrict__ rl, bool valid,
                                         F px, F py, F pz, Best<F> &best, unsigned long long *prof = nullptr) {
     const int tid = (int)threadIdx.x;
@@ -281,64 +289,62 @@ __device__ __forceinline__ void grid_nn(const PatchGrid<F> &g, const GridPt<F> *
     x0 = x0 < 0 ? 0 : x0;
     x1 = x1 >= g.nx ? g.nx - 1 : x1;
     const bool xok = valid && x0 <= x1;
+    // per-axis: is the neighbour layer inside the grid, and how far away is it (squared, never overestimated)
     const F fy = py - (g.miny + (F)cy * g.h), fz = pz - (g.minz + (F)cz * g.h);
-    const int nxny = g.nx * g.ny;
-    const int base0 = (cz * g.ny + cy) * g.nx;
+    F ylo = fy - slack, yhi = g.h - fy - slack, zlo = fz - slack, zhi = g.h - fz - slack;
+    ylo = ylo > (F)0 ? ylo : (F)0; yhi = yhi > (F)0 ? yhi : (F)0;
+    zlo = zlo > (F)0 ? zlo : (F)0; zhi = zhi > (F)0 ? zhi : (F)0;
+    const F ysq[3] = {ylo * ylo, (F)0, yhi * yhi}, zsq[3] = {zlo * zlo, (F)0, zhi * zhi};
+    const bool yin[3] = {cy >= 1 && cy <= g.ny, cy >= 0 && cy < g.ny, cy >= -1 && cy < g.ny - 1};
+    const bool zin[3] = {cz >= 1 && cz <= g.nz, cz >= 0 && cz < g.nz, cz >= -1 && cz < g.nz - 1};
+    const F b2s = b2 * (F)1.00001;
+    const int nxny = __mul24(g.nx, g.ny);
+    const int base0 = __mul24(__mul24(cz, g.ny) + cy, g.nx) + x0;  // garbage when cy / cz are far outside: then no row is kept
     const int span = x1 - x0 + 1;
 
-    // 1. row descriptors: both prefix entries of the 9 rows are fetched before any is used
+    // 1. prefix entries of the 9 rows (centre row first, then the four face neighbours, then the corners), all
+    //    fetched before any is used; rows outside the grid or beyond the bound read entry 0 twice (empty)
     unsigned int s_[GRID_ROWS], e_[GRID_ROWS];
-    bool keep[GRID_ROWS];
 #pragma unroll
     for (int r = 0; r < GRID_ROWS; ++r) {
-        // centre row first, then the four face neighbours, then the corners
         constexpr int DY[GRID_ROWS] = {0, -1, 1, 0, 0, -1, 1, -1, 1};
         constexpr int DZ[GRID_ROWS] = {0, 0, 0, -1, 1, -1, -1, 1, 1};
-        const int y = cy + DY[r], z = cz + DZ[r];
-        bool k = xok && y >= 0 && y < g.ny && z >= 0 && z < g.nz;
-        F ddy = (DY[r] < 0 ? fy : (DY[r] > 0 ? g.h - fy : (F)0)) - slack;
-        F ddz = (DZ[r] < 0 ? fz : (DZ[r] > 0 ? g.h - fz : (F)0)) - slack;
-        ddy = ddy > (F)0 ? ddy : (F)0;
-        ddz = ddz > (F)0 ? ddz : (F)0;
-        if (DY[r] != 0 || DZ[r] != 0) k = k && !((ddy * ddy + ddz * ddz) * (F)0.99999 > b2);
-        const int a = k ? base0 + DY[r] * g.nx + DZ[r] * nxny + x0 : 0;
-        s_[r] = E[a];
+        const bool k = xok && yin[DY[r] + 1] && zin[DZ[r] + 1] && !(ysq[DY[r] + 1] + zsq[DZ[r] + 1] > b2s);
+        const int a = base0 + DY[r] * g.nx + DZ[r] * nxny;
+        s_[r] = E[k ? a : 0];
         e_[r] = E[k ? a + span : 0];
-        keep[r] = k;
     }
-    // 2. compact the non-empty survivors into the per-lane list, sentinel {0, 0} behind them
+    // 2. compact the non-empty rows into the per-lane list (branch free: every row is written at the cursor, the
+    //    cursor only moves past rows worth keeping), sentinel {0, 0} behind them
     int cnt = 0;
 #pragma unroll
     for (int r = 0; r < GRID_ROWS; ++r) {
-        const bool k = keep[r] && s_[r] < e_[r];
-        if (k) rl[cnt * NT + tid] = s_[r] | (e_[r] << 16);
-        cnt += k ? 1 : 0;
+        rl[cnt * NT + tid] = s_[r] | (e_[r] << 16);
+        cnt += s_[r] < e_[r] ? 1 : 0;
     }
     rl[cnt * NT + tid] = 0u;
 #ifdef F4L_ICP_PROF
     int n_steps = 0;
 #endif
-    // 3. flat scan
+    // 3. flat scan; idle lanes sit on the dummy slot
     unsigned int cur = rl[tid];
     int j = (int)(cur & 0xffffu), e = (int)(cur >> 16);
     int k = cnt < 1 ? cnt : 1;
     unsigned int nxt = rl[k * NT + tid];
-    GridPt<F> q = tl[j < e ? j : 0];
+    GridPt<F> q = tl[j < e ? j : dummy];
     while (__any(j < e)) {
-        const bool act = j < e;
         // next position first, so that its loads are in flight while the current candidate is evaluated
         int jn = j + 1;
         const bool roll = jn >= e;
         jn = roll ? (int)(nxt & 0xffffu) : jn;
         const int en = roll ? (int)(nxt >> 16) : e;
         k = roll ? (k + 1 > cnt ? cnt : k + 1) : k;
-        const GridPt<F> qn = tl[jn < en ? jn : 0];
+        const GridPt<F> qn = tl[jn < en ? jn : dummy];
         const unsigned int nn = rl[k * NT + tid];
         // current candidate
-        const F d = grid_d2(px - q.x, py - q.y, pz - q.z);
-        best.offer_if(act, d, q.id, j);
+        best.offer(grid_d2(px - q.x, py - q.y, pz - q.z), q.tag);
 #ifdef F4L_ICP_PROF
-        n_steps += act ? 1 : 0;
+        n_steps += j < e ? 1 : 0;
 #endif
         q = qn; j = jn; e = en;
         nxt = roll ? nn : nxt;
