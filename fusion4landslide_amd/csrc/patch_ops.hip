@@ -10,6 +10,7 @@
 // Both stage the patch once in LDS (coalesced dword loads of the packed [n][3] floats) and then only
 // broadcast-read it.
 #include "f4l_device.h"
+#include "patch_grid.h"
 #include "topk.h"
 
 namespace f4l {
@@ -202,29 +203,46 @@ __global__ __launch_bounds__(PN_NT) void patch_normals_kernel(const float *__res
     }
 }
 
-// refine_dvfs_with_threshold: one workgroup per patch; target patch in LDS as float4 relative to its first
-// point; every lane owns source points, brute-force nearest neighbour, validity d2 < thr^2.
-__global__ __launch_bounds__(PN_NT) void nn_refine_kernel(const float *__restrict__ src, const int64_t *__restrict__ src_off,
-                                                           const float *__restrict__ tgt, const int64_t *__restrict__ tgt_off,
-                                                           int64_t P, const double *__restrict__ T,
-                                                           const double *__restrict__ thr, int lds_cap,
-                                                           int32_t *__restrict__ nn_out, float *__restrict__ out6) {
-    extern __shared__ __attribute__((aligned(16))) float4 tl4[];
+// refine_dvfs_with_threshold: one workgroup per patch.  The target patch is counting-sorted into the LDS-resident
+// uniform grid of patch_grid.h (cell edge >= the patch's threshold), every lane owns source points and asks the
+// grid for the nearest target within the threshold: the minimiser of (d2, index), i.e. what a scan in index
+// order returns.  Patches beyond the LDS budget fall back to that scan over global memory.
+struct NnRefineArgs {
+    const float *src;
+    const int64_t *src_off;
+    const float *tgt;
+    const int64_t *tgt_off;
+    int64_t P;
+    const double *T;
+    const double *thr;
+    int tgt_cap, cell_cap;
+    int32_t *nn_out;
+    float *out6;
+};
+
+__global__ __launch_bounds__(PN_NT) void nn_refine_kernel(NnRefineArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char nr_smem[];
+    float *red = reinterpret_cast<float *>(nr_smem);  // PN_NW * 8 floats of build scratch
+    GridPt<float> *tl = reinterpret_cast<GridPt<float> *>(red + PN_NW * 8);
+    unsigned int *rl = reinterpret_cast<unsigned int *>(tl + a.tgt_cap + 1);
+    unsigned short *E = reinterpret_cast<unsigned short *>(rl + (GRID_ROWS + 1) * PN_NT);
     const int64_t p = blockIdx.x;
-    if (p >= P) return;
-    const int64_t s0 = src_off[p], t0 = tgt_off[p];
-    const int ns = (int)(src_off[p + 1] - s0), nt = (int)(tgt_off[p + 1] - t0);
-    const float *__restrict__ sg = src + 3 * s0;
-    const float *__restrict__ tg = tgt + 3 * t0;
+    if (p >= a.P) return;
+    const int64_t s0 = a.src_off[p], t0 = a.tgt_off[p];
+    const int ns = (int)(a.src_off[p + 1] - s0), nt = (int)(a.tgt_off[p + 1] - t0);
+    const float *__restrict__ sg = a.src + 3 * s0;
+    const float *__restrict__ tg = a.tgt + 3 * t0;
     const int tid = (int)threadIdx.x;
-    const bool in_lds = nt <= lds_cap;
+    const double th = a.thr[p];
+    const float th2 = (float)(th * th);
+    const bool searchable = nt > 0 && th > 0.0;
+    const bool in_lds = searchable && nt <= a.tgt_cap;
     float ox = 0.f, oy = 0.f, oz = 0.f;
     if (nt > 0) { ox = tg[0]; oy = tg[1]; oz = tg[2]; }
-    if (in_lds) {
-        for (int j = tid; j < nt; j += PN_NT) tl4[j] = make_float4(tg[3 * j] - ox, tg[3 * j + 1] - oy, tg[3 * j + 2] - oz, 0.f);
-        __syncthreads();
-    }
-    const double *Tp = T + 16 * p;
+    PatchGrid<float> g;
+    g.minx = g.miny = g.minz = 0.f; g.h = 1.f; g.inv_h = 1.f; g.nx = g.ny = g.nz = 1;
+    if (in_lds) grid_build<float, PN_NT>(tg, nt, ox, oy, oz, (float)th * 1.000001f, a.cell_cap, tl, E, red, g);
+    const double *Tp = a.T + 16 * p;
     // p' = R (s' + o) + t - o with s' = s - o
     float Rf[9], tf[3];
 #pragma unroll
@@ -233,37 +251,34 @@ __global__ __launch_bounds__(PN_NT) void nn_refine_kernel(const float *__restric
         const double o_i = i == 0 ? ox : (i == 1 ? oy : oz);
         tf[i] = (float)(Tp[4 * i] * (double)ox + Tp[4 * i + 1] * (double)oy + Tp[4 * i + 2] * (double)oz + Tp[4 * i + 3] - o_i);
     }
-    const double th = thr[p];
-    const float th2 = (float)(th * th);
-    for (int i = tid; i < ns; i += PN_NT) {
-        const float sx = sg[3 * i], sy = sg[3 * i + 1], sz = sg[3 * i + 2];
+    for (int base = 0; base < ns; base += PN_NT) {  // whole waves take part in every query (grid_nn is wave wide)
+        const int i = base + tid;
+        const bool valid = i < ns;
+        const int ii = valid ? i : ns - 1;
+        const float sx = sg[3 * ii], sy = sg[3 * ii + 1], sz = sg[3 * ii + 2];
         const float x = sx - ox, y = sy - oy, z = sz - oz;
         const float px = Rf[0] * x + Rf[1] * y + Rf[2] * z + tf[0];
         const float py = Rf[3] * x + Rf[4] * y + Rf[5] * z + tf[1];
         const float pz = Rf[6] * x + Rf[7] * y + Rf[8] * z + tf[2];
-        float best = __builtin_inff();
+        Best<float> best;
+        best.init(th2);
         int bj = -1;
         if (in_lds) {
-#pragma unroll 8
-            for (int j = 0; j < nt; ++j) {
-                const float4 q = tl4[j];
-                const float dx = px - q.x, dy = py - q.y, dz = pz - q.z;
-                const float d = dx * dx + dy * dy + dz * dz;
-                if (d < best) { best = d; bj = j; }
-            }
-        } else {
-            for (int j = 0; j < nt; ++j) {
-                const float dx = px - (tg[3 * j] - ox), dy = py - (tg[3 * j + 1] - oy), dz = pz - (tg[3 * j + 2] - oz);
-                const float d = dx * dx + dy * dy + dz * dz;
-                if (d < best) { best = d; bj = j; }
-            }
+            grid_nn<float, PN_NT>(g, tl, nt, E, rl, valid, px, py, pz, best);
+            if (best.found()) bj = best.id();
+        } else if (searchable) {
+            for (int j = 0; j < nt; ++j)
+                best.offer(grid_d2(px - (tg[3 * j] - ox), py - (tg[3 * j + 1] - oy), pz - (tg[3 * j + 2] - oz)), (unsigned int)j);
+            if (best.found()) bj = (int)best.tag();
         }
-        const bool hit = bj >= 0 && best < th2;  // :80 dists[0] < distance_threshold ** 2
-        if (nn_out) nn_out[s0 + i] = hit ? bj : -1;
-        if (out6) {
-            float *o6 = out6 + 6 * (s0 + i);
-            o6[0] = sx; o6[1] = sy; o6[2] = sz;
-            o6[3] = hit ? tg[3 * bj] : 0.f; o6[4] = hit ? tg[3 * bj + 1] : 0.f; o6[5] = hit ? tg[3 * bj + 2] : 0.f;
+        const bool hit = valid && bj >= 0 && best.d2() < th2;  // :80 dists[0] < distance_threshold ** 2
+        if (valid) {
+            if (a.nn_out) a.nn_out[s0 + i] = hit ? bj : -1;
+            if (a.out6) {
+                float *o6 = a.out6 + 6 * (s0 + i);
+                o6[0] = sx; o6[1] = sy; o6[2] = sz;
+                o6[3] = hit ? tg[3 * bj] : 0.f; o6[4] = hit ? tg[3 * bj + 1] : 0.f; o6[5] = hit ? tg[3 * bj + 2] : 0.f;
+            }
         }
     }
 }
@@ -294,12 +309,17 @@ extern "C" int f4l_nn_refine(const float *src, const int64_t *src_off, const flo
     if (P < 0 || !src_off || !tgt_off || !T || !thr || max_tgt_patch_host < 0) return F4L_EINVAL;
     if (P == 0) return F4L_OK;
     if (P > 0x7fffffffLL || max_tgt_patch_host > 0x3fffffffLL) return F4L_EUNSUPPORTED;
-    const int cap = (int)(max_tgt_patch_host < 8192 ? max_tgt_patch_host : 8192);
-    const size_t lds = (size_t)cap * 16;
+    int cap = (int)(max_tgt_patch_host < 8192 ? max_tgt_patch_host : 8192);
+    if (cap < 1) cap = 1;
+    int cells = (int)((2 * (int64_t)cap + 255) & ~(int64_t)255);
+    cells = cells < 512 ? 512 : (cells > 16384 ? 16384 : cells);
+    const size_t lds = (size_t)PN_NW * 8 * 4 + (size_t)(cap + 1) * 16 + (size_t)(GRID_ROWS + 1) * PN_NT * 4 + ((size_t)cells + 8) * 2;
     if (lds > 64 * 1024)
         F4L_HIP_CHECK(hipFuncSetAttribute((const void *)nn_refine_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(nn_refine_kernel, dim3((unsigned)P), dim3(PN_NT), lds, (hipStream_t)stream, src, src_off, tgt,
-                       tgt_off, P, T, thr, cap, nn_out, out6);
+    NnRefineArgs a;
+    a.src = src; a.src_off = src_off; a.tgt = tgt; a.tgt_off = tgt_off; a.P = P; a.T = T; a.thr = thr;
+    a.tgt_cap = cap; a.cell_cap = cells; a.nn_out = nn_out; a.out6 = out6;
+    hipLaunchKernelGGL(nn_refine_kernel, dim3((unsigned)P), dim3(PN_NT), lds, (hipStream_t)stream, a);
     F4L_LAUNCH_CHECK();
     return F4L_OK;
 }
