@@ -5,7 +5,7 @@ Contract (driver):  python bench.py --gpus N --steps K --warmup W   (N > 1 via t
 prints ONE JSON line on rank 0.
 
 A "step" is one pass of the hot path over one tile, inputs resident in HBM when the clock starts:
-    per-patch weighted Kabsch init (f4l_kabsch_batched on the 1-NN correspondences)
+    per-patch weighted Kabsch init (f4l_kabsch_transforms on the 1-NN correspondences)
  -> 20 fixed point-to-point ICP iterations per patch (f4l_piecewise_icp, max_corr_dist 0.1 m, no early exit)
  -> dense displacement rows [s, T s] for every source point (f4l_apply_transform)
  -> (N > 1) RCCL all-gather of the per-patch results (T, fitness, rmse, iters: 152 B per patch).
@@ -79,10 +79,7 @@ def main():
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
 
     def step(i_timed=None):
-        R, t = engine.kabsch_batched(cs, ct, coff, eps=1e-6)
-        T0 = eye.clone()
-        T0[:, :3, :3] = R
-        T0[:, :3, 3] = t
+        T0 = engine.kabsch_transforms(cs, ct, coff, eps=1e-6)  # weighted_procrustes(return_transform=True) per patch
         if i_timed is not None:
             ev[i_timed][0].record()
         out = engine.piecewise_icp(src, so, tgt, to, init_T=T0, max_corr_dist=MAX_CORR, max_iter=MAX_ITER,

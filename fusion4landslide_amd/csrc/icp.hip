@@ -442,10 +442,6 @@ __global__ __launch_bounds__(NW * 64, ICP_WAVES_PER_EU) void icp_kernel(IcpArgs 
 #pragma unroll
                 for (int i = 0; i < NV; ++i) tot[i] = (double)acc[i];
             }
-            double Rc[9], tc[3];
-#pragma unroll
-            for (int i = 0; i < 9; ++i) Rc[i] = state[i];
-            tc[0] = state[9]; tc[1] = state[10]; tc[2] = state[11];
             const double fitness = state[13], rmse = state[14];
             int iters = (int)state[15];
             const double m = tot[0];
@@ -458,40 +454,43 @@ __global__ __launch_bounds__(NW * 64, ICP_WAVES_PER_EU) void icp_kernel(IcpArgs 
                     done = true;
             }
             if (pass == a.max_iter) done = true;
-            double motion = 0.0;
+            // update [Ru | tu] of this iteration (origin-relative): p_new = Ru p_old + tu
+            double Ru[9], tu[3];
+            bool have = false;
             if (!done && m > 0.0 && !(a.debug & 1)) {
-                double Ru[9], tu[3];
-                bool have = true;
+                have = true;
                 if (MODE == F4L_ICP_POINT2POINT) {
-                    // Eigen::umeyama without scaling
+                    // Eigen::umeyama without scaling.  Means about the centring point (zero shift when the sums are
+                    // uncentred); the covariance is shift invariant.
                     const double im = fast_rcp(m);
-                    // means about the centring point (zero when the sums are uncentred); the covariance is shift invariant
-                    const double cm0 = tot[2] * im, cm1 = tot[3] * im, cm2 = tot[4] * im;
-                    const double cq0 = tot[5] * im, cq1 = tot[6] * im, cq2 = tot[7] * im;
                     double sg9[9];
-                    sg9[0] = tot[8] * im - cq0 * cm0; sg9[1] = tot[9] * im - cq0 * cm1; sg9[2] = tot[10] * im - cq0 * cm2;
-                    sg9[3] = tot[11] * im - cq1 * cm0; sg9[4] = tot[12] * im - cq1 * cm1; sg9[5] = tot[13] * im - cq1 * cm2;
-                    sg9[6] = tot[14] * im - cq2 * cm0; sg9[7] = tot[15] * im - cq2 * cm1; sg9[8] = tot[16] * im - cq2 * cm2;
+                    {
+                        const double cm0 = tot[2] * im, cm1 = tot[3] * im, cm2 = tot[4] * im;
+                        const double cq0 = tot[5] * im, cq1 = tot[6] * im, cq2 = tot[7] * im;
+                        sg9[0] = tot[8] * im - cq0 * cm0; sg9[1] = tot[9] * im - cq0 * cm1; sg9[2] = tot[10] * im - cq0 * cm2;
+                        sg9[3] = tot[11] * im - cq1 * cm0; sg9[4] = tot[12] * im - cq1 * cm1; sg9[5] = tot[13] * im - cq1 * cm2;
+                        sg9[6] = tot[14] * im - cq2 * cm0; sg9[7] = tot[15] * im - cq2 * cm1; sg9[8] = tot[16] * im - cq2 * cm2;
+                    }
+                    // nearly aligned clouds (every iteration but possibly the first): Newton on SO(3); otherwise,
+                    // and for rank-deficient sums, the warm-started Jacobi SVD (same optimum, U diag(1,1,det) V^T)
+                    if ((a.debug & 128) || !rot_newton(sg9, Ru)) {
+                        double U[9], V[9], V0[9];
+#pragma unroll
+                        for (int i = 0; i < 9; ++i) V0[i] = state[16 + i];
+                        svd3_warm(sg9, V0, U, V);
+                        if (lane == 0) {
+#pragma unroll
+                            for (int i = 0; i < 9; ++i) state[16 + i] = V[i];
+                        }
+                        const double sgn = (det3(U) * det3(V) < 0.0) ? -1.0 : 1.0;
+                        mul_diag_bt(U, sgn, V, Ru);
+                    }
+                    // (the means are recomputed rather than kept alive across the rotation solve)
                     // the shift the lanes applied: the float32 value of the centroid image
                     const double sh0 = CENTRED ? (double)(F)state[30] : 0.0, sh1 = CENTRED ? (double)(F)state[31] : 0.0,
                                  sh2 = CENTRED ? (double)(F)state[32] : 0.0;
-                    const double mp0 = cm0 + sh0, mp1 = cm1 + sh1, mp2 = cm2 + sh2;
-                    const double mq0 = cq0 + sh0, mq1 = cq1 + sh1, mq2 = cq2 + sh2;
-                    double U[9], V[9], V0[9];
-#pragma unroll
-                    for (int i = 0; i < 9; ++i) V0[i] = state[16 + i];
-                    const int n_sweeps = svd3_warm(sg9, V0, U, V);
-#ifdef F4L_ICP_PROF
-                    (void)n_sweeps;
-#else
-                    (void)n_sweeps;
-#endif
-                    if (lane == 0) {
-#pragma unroll
-                        for (int i = 0; i < 9; ++i) state[16 + i] = V[i];
-                    }
-                    const double sgn = (det3(U) * det3(V) < 0.0) ? -1.0 : 1.0;
-                    mul_diag_bt(U, sgn, V, Ru);
+                    const double mp0 = tot[2] * im + sh0, mp1 = tot[3] * im + sh1, mp2 = tot[4] * im + sh2;
+                    const double mq0 = tot[5] * im + sh0, mq1 = tot[6] * im + sh1, mq2 = tot[7] * im + sh2;
                     tu[0] = mq0 - (Ru[0] * mp0 + Ru[1] * mp1 + Ru[2] * mp2);
                     tu[1] = mq1 - (Ru[3] * mp0 + Ru[4] * mp1 + Ru[5] * mp2);
                     tu[2] = mq2 - (Ru[6] * mp0 + Ru[7] * mp1 + Ru[8] * mp2);
@@ -524,46 +523,42 @@ __global__ __launch_bounds__(NW * 64, ICP_WAVES_PER_EU) void icp_kernel(IcpArgs 
                         tu[2] = Ru[6] * o0 + Ru[7] * o1 + Ru[8] * o2 + tg2 - o2;
                     }
                 }
-                if (have) {  // T <- update * T
-                    // bound on how far any source point moves with this update (see the kernel's header comment):
-                    // rotation about the patch centroid's image times the patch radius, plus the centroid's own step
-                    {
-                        const double c0 = state[25], c1 = state[26], c2 = state[27];
-                        const double cp0 = Rc[0] * c0 + Rc[1] * c1 + Rc[2] * c2 + tc[0];
-                        const double cp1 = Rc[3] * c0 + Rc[4] * c1 + Rc[5] * c2 + tc[1];
-                        const double cp2 = Rc[6] * c0 + Rc[7] * c1 + Rc[8] * c2 + tc[2];
-                        double fro = 0.0;
-#pragma unroll
-                        for (int i = 0; i < 9; ++i) { const double e = Ru[i] - ((i % 4 == 0) ? 1.0 : 0.0); fro += e * e; }
-                        const double m0 = (Ru[0] - 1.0) * cp0 + Ru[1] * cp1 + Ru[2] * cp2 + tu[0];
-                        const double m1 = Ru[3] * cp0 + (Ru[4] - 1.0) * cp1 + Ru[5] * cp2 + tu[1];
-                        const double m2 = Ru[6] * cp0 + Ru[7] * cp1 + (Ru[8] - 1.0) * cp2 + tu[2];
-                        const double cpn = fast_sqrt(cp0 * cp0 + cp1 * cp1 + cp2 * cp2);
-                        // positions are evaluated in F from the rounded transform: a few ulps of their magnitude
-                        const double eps_pos = sizeof(F) == 4 ? 4e-6 : 1e-14;
-                        motion = fast_sqrt(fro) * state[28] + fast_sqrt(m0 * m0 + m1 * m1 + m2 * m2) + eps_pos * (state[28] + cpn);
-                        motion *= 1.0 + 1e-9;
-                    }
-                    double Rn[9], tn[3];
-                    mul3(Ru, Rc, Rn);
-                    tn[0] = Ru[0] * tc[0] + Ru[1] * tc[1] + Ru[2] * tc[2] + tu[0];
-                    tn[1] = Ru[3] * tc[0] + Ru[4] * tc[1] + Ru[5] * tc[2] + tu[1];
-                    tn[2] = Ru[6] * tc[0] + Ru[7] * tc[1] + Ru[8] * tc[2] + tu[2];
-#pragma unroll
-                    for (int i = 0; i < 9; ++i) Rc[i] = Rn[i];
-                    tc[0] = tn[0]; tc[1] = tn[1]; tc[2] = tn[2];
-                }
             }
             if (lane == 0) {
-#pragma unroll
-                for (int i = 0; i < 9; ++i) state[i] = Rc[i];
-                state[9] = tc[0]; state[10] = tc[1]; state[11] = tc[2];
                 state[12] = done ? 1.0 : 0.0;
                 state[13] = fit_new; state[14] = rmse_new; state[15] = (double)iters;
-                state[29] += motion;
+            }
+            if (have) {  // T <- update * T; the running transform is only now fetched from LDS
+                const double cp0 = state[30], cp1 = state[31], cp2 = state[32];  // centroid image under the old T
+                // bound on how far any source point moves with this update (see the kernel's header comment):
+                // rotation about the patch centroid's image times the patch radius, plus the centroid's own step
+                double fro = 0.0;
 #pragma unroll
-                for (int i = 0; i < 3; ++i)
-                    state[30 + i] = Rc[3 * i] * state[25] + Rc[3 * i + 1] * state[26] + Rc[3 * i + 2] * state[27] + tc[i];
+                for (int i = 0; i < 9; ++i) { const double e = Ru[i] - ((i % 4 == 0) ? 1.0 : 0.0); fro += e * e; }
+                const double n0 = Ru[0] * cp0 + Ru[1] * cp1 + Ru[2] * cp2 + tu[0];  // centroid image under the new T
+                const double n1 = Ru[3] * cp0 + Ru[4] * cp1 + Ru[5] * cp2 + tu[1];
+                const double n2 = Ru[6] * cp0 + Ru[7] * cp1 + Ru[8] * cp2 + tu[2];
+                const double m0 = n0 - cp0, m1 = n1 - cp1, m2 = n2 - cp2;
+                const double cpn = fast_sqrt(cp0 * cp0 + cp1 * cp1 + cp2 * cp2);
+                // positions are evaluated in F from the rounded transform: a few ulps of their magnitude
+                const double eps_pos = sizeof(F) == 4 ? 4e-6 : 1e-14;
+                double motion = fast_sqrt(fro) * state[28] + fast_sqrt(m0 * m0 + m1 * m1 + m2 * m2) + eps_pos * (state[28] + cpn);
+                motion *= 1.0 + 1e-9;
+                double Rc[9], tc[3], Rn[9];
+#pragma unroll
+                for (int i = 0; i < 9; ++i) Rc[i] = state[i];
+                tc[0] = state[9]; tc[1] = state[10]; tc[2] = state[11];
+                mul3(Ru, Rc, Rn);
+                const double tn0 = Ru[0] * tc[0] + Ru[1] * tc[1] + Ru[2] * tc[2] + tu[0];
+                const double tn1 = Ru[3] * tc[0] + Ru[4] * tc[1] + Ru[5] * tc[2] + tu[1];
+                const double tn2 = Ru[6] * tc[0] + Ru[7] * tc[1] + Ru[8] * tc[2] + tu[2];
+                if (lane == 0) {
+#pragma unroll
+                    for (int i = 0; i < 9; ++i) state[i] = Rn[i];
+                    state[9] = tn0; state[10] = tn1; state[11] = tn2;
+                    state[29] += motion;
+                    state[30] = n0; state[31] = n1; state[32] = n2;
+                }
             }
             __builtin_amdgcn_s_setprio(0);
         }

@@ -16,7 +16,8 @@ template <typename T, int NW>
 __global__ __launch_bounds__(NW * 64) void kabsch_kernel(const T *__restrict__ src, const T *__restrict__ ref,
                                                          const T *__restrict__ w, const int64_t *__restrict__ off,
                                                          int64_t P, double w_thresh, double eps,
-                                                         double *__restrict__ R_out, double *__restrict__ t_out) {
+                                                         double *__restrict__ R_out, double *__restrict__ t_out,
+                                                         double *__restrict__ T_out) {
     __shared__ double scratch[NW * 9];
     const int64_t p = blockIdx.x;
     if (p >= P) return;
@@ -60,20 +61,31 @@ __global__ __launch_bounds__(NW * 64) void kabsch_kernel(const T *__restrict__ s
     block_sum<9, NW>(h, scratch);
 
     if (tid == 0) {
-        double U[9], S[3], V[9], R[9];
+        double U[9], V[9], R[9];
         if (n == 0) {
             R[0] = 1; R[1] = 0; R[2] = 0; R[3] = 0; R[4] = 1; R[5] = 0; R[6] = 0; R[7] = 0; R[8] = 1;
         } else {
-            svd3(h, U, S, V);
+            const double I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+            svd3_warm(h, I3, U, V);  // the latency-trimmed Jacobi of f4l_device.h (cold start)
             const double d = det3(V) * det3(U);  // det(V U^T)
             const double sg = d > 0.0 ? 1.0 : (d < 0.0 ? -1.0 : 0.0);  // torch.sign (:111)
             mul_diag_bt(V, sg, U, R);
         }
+        const double t0 = ct0 - (R[0] * cs0 + R[1] * cs1 + R[2] * cs2);  // :113
+        const double t1 = ct1 - (R[3] * cs0 + R[4] * cs1 + R[5] * cs2);
+        const double t2 = ct2 - (R[6] * cs0 + R[7] * cs1 + R[8] * cs2);
+        if (R_out) {
 #pragma unroll
-        for (int i = 0; i < 9; ++i) R_out[9 * p + i] = R[i];
-        t_out[3 * p + 0] = ct0 - (R[0] * cs0 + R[1] * cs1 + R[2] * cs2);  // :113
-        t_out[3 * p + 1] = ct1 - (R[3] * cs0 + R[4] * cs1 + R[5] * cs2);
-        t_out[3 * p + 2] = ct2 - (R[6] * cs0 + R[7] * cs1 + R[8] * cs2);
+            for (int i = 0; i < 9; ++i) R_out[9 * p + i] = R[i];
+        }
+        if (t_out) { t_out[3 * p + 0] = t0; t_out[3 * p + 1] = t1; t_out[3 * p + 2] = t2; }
+        if (T_out) {  // return_transform=True: the 4x4 of scripts/weighted_svd.py:115-120
+            double *M = T_out + 16 * p;
+            M[0] = R[0]; M[1] = R[1]; M[2] = R[2]; M[3] = t0;
+            M[4] = R[3]; M[5] = R[4]; M[6] = R[5]; M[7] = t1;
+            M[8] = R[6]; M[9] = R[7]; M[10] = R[8]; M[11] = t2;
+            M[12] = 0.0; M[13] = 0.0; M[14] = 0.0; M[15] = 1.0;
+        }
     }
 }
 
@@ -101,17 +113,17 @@ __global__ void kabsch_residual_kernel(const float *__restrict__ src, const floa
 
 template <typename T>
 static int launch_kabsch(const T *src, const T *ref, const T *w, const int64_t *off, int64_t P, int64_t n_total,
-                         double w_thresh, double eps, double *R_out, double *t_out, hipStream_t st) {
-    if (P < 0 || n_total < 0 || !off || !R_out || !t_out || (n_total > 0 && (!src || !ref))) return F4L_EINVAL;
+                         double w_thresh, double eps, double *R_out, double *t_out, double *T_out, hipStream_t st) {
+    if (P < 0 || n_total < 0 || !off || (!T_out && (!R_out || !t_out)) || (n_total > 0 && (!src || !ref))) return F4L_EINVAL;
     if (P == 0) return F4L_OK;
     if (P > 0x7fffffffLL) return F4L_EUNSUPPORTED;
     // one wave per patch while patches are small (no LDS round, no barrier); four waves otherwise
     if (n_total / P <= 256)
         hipLaunchKernelGGL((kabsch_kernel<T, 1>), dim3((unsigned)P), dim3(64), 0, st, src, ref, w, off, P, w_thresh,
-                           eps, R_out, t_out);
+                           eps, R_out, t_out, T_out);
     else
         hipLaunchKernelGGL((kabsch_kernel<T, 4>), dim3((unsigned)P), dim3(256), 0, st, src, ref, w, off, P, w_thresh,
-                           eps, R_out, t_out);
+                           eps, R_out, t_out, T_out);
     F4L_LAUNCH_CHECK();
     return F4L_OK;
 }
@@ -121,13 +133,18 @@ static int launch_kabsch(const T *src, const T *ref, const T *w, const int64_t *
 extern "C" int f4l_kabsch_batched(const float *src, const float *ref, const float *w, const int64_t *off, int64_t P,
                                   int64_t n_total, double w_thresh, double eps, double *R_out, double *t_out,
                                   void *stream) {
-    return f4l::launch_kabsch<float>(src, ref, w, off, P, n_total, w_thresh, eps, R_out, t_out, (hipStream_t)stream);
+    return f4l::launch_kabsch<float>(src, ref, w, off, P, n_total, w_thresh, eps, R_out, t_out, nullptr, (hipStream_t)stream);
 }
 
 extern "C" int f4l_kabsch_batched_f64(const double *src, const double *ref, const double *w, const int64_t *off,
                                       int64_t P, int64_t n_total, double w_thresh, double eps, double *R_out,
                                       double *t_out, void *stream) {
-    return f4l::launch_kabsch<double>(src, ref, w, off, P, n_total, w_thresh, eps, R_out, t_out, (hipStream_t)stream);
+    return f4l::launch_kabsch<double>(src, ref, w, off, P, n_total, w_thresh, eps, R_out, t_out, nullptr, (hipStream_t)stream);
+}
+
+extern "C" int f4l_kabsch_transforms(const float *src, const float *ref, const float *w, const int64_t *off, int64_t P,
+                                     int64_t n_total, double w_thresh, double eps, double *T_out, void *stream) {
+    return f4l::launch_kabsch<float>(src, ref, w, off, P, n_total, w_thresh, eps, nullptr, nullptr, T_out, (hipStream_t)stream);
 }
 
 extern "C" int f4l_kabsch_residuals(const float *src, const float *ref, const int64_t *off, int64_t P,

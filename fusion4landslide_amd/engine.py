@@ -60,6 +60,23 @@ def kabsch_batched(src, ref, off, weights=None, weight_thresh=0.0, eps=1e-7):
     return R, t
 
 
+def kabsch_transforms(src, ref, off, weights=None, weight_thresh=0.0, eps=1e-7):
+    """`weighted_procrustes(..., return_transform=True)` per patch (scripts/weighted_svd.py:115-120): (P, 4, 4) float64,
+    ready to be the `init_T` of :func:`piecewise_icp` (src/coarse_to_fine_matching_base.py:3341-3360)."""
+    torch = require_gpu()
+    src = _dev(src, torch.float32, "src", (3,))
+    ref = _dev(ref, torch.float32, "ref", (3,))
+    off = _dev(off, torch.int64, "off")
+    w = None if weights is None else _dev(weights, torch.float32, "weights")
+    n, P = src.shape[0], off.shape[0] - 1
+    if ref.shape[0] != n or (w is not None and w.shape[0] != n):
+        raise ValueError("src, ref and weights must have the same number of rows")
+    T = torch.empty((P, 4, 4), dtype=torch.float64, device=src.device)
+    check(lib().f4l_kabsch_transforms(ptr(src), ptr(ref), ptr(w), ptr(off), P, n, float(weight_thresh), float(eps), ptr(T),
+                                      stream_ptr()), "f4l_kabsch_transforms")
+    return T
+
+
 def kabsch_residuals(src, ref, off, R, t):
     """|| R_p s_i + t_p - r_i || per row (scripts/weighted_svd.py:143-146) -> (n,) float64."""
     torch = require_gpu()

@@ -72,6 +72,12 @@ int f4l_kabsch_batched_f64(const double *src, const double *ref, const double *w
                            int64_t P, int64_t n_total, double w_thresh, double eps, double *R_out,
                            double *t_out, void *stream);
 
+/* The same solve with `return_transform=True` (scripts/weighted_svd.py:115-120): T_out double [P][16], row-major
+ * 4x4 [R t; 0 0 0 1] per patch -- the `init` of the ICP call that follows at
+ * src/coarse_to_fine_matching_base.py:3358, without any glue kernels in between. */
+int f4l_kabsch_transforms(const float *src, const float *ref, const float *w, const int64_t *off, int64_t P,
+                          int64_t n_total, double w_thresh, double eps, double *T_out, void *stream);
+
 /* Residual norms || R_p s_i + t_p - r_i || per row (scripts/weighted_svd.py:143-146), float64 [n_total].
  * The caller prunes rows (res < 1 m at :147, or 2.5 x median at src/rgb_guided.py:113-118). */
 int f4l_kabsch_residuals(const float *src, const float *ref, const int64_t *off, int64_t P, int64_t n_total,
