@@ -41,6 +41,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="C2_1M_2k")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline budget (0 disables)")
+    ap.add_argument("--extras", type=int, default=1, help="also time the float64 parity mode and the kNN-30 kernel (rank 0, N = 1)")
     args = ap.parse_args()
 
     import numpy as np
@@ -62,7 +63,8 @@ def main():
 
     cfg = synthetic.CONFIGS[args.config]
     n, cells, res = cfg["n"], cfg["cells"], cfg["resolution"]
-    d = synthetic.make_patches(n, cells, res, seed=10 * rank)  # every rank owns its own tile
+    raster = float(os.environ.get("F4L_BENCH_RASTER", "0")) or None  # experiment: scan-like point order inside patches
+    d = synthetic.make_patches(n, cells, res, seed=10 * rank, raster=raster)  # every rank owns its own tile
     P = d["P"]
     src, tgt = torch.from_numpy(d["src"]).to(dev), torch.from_numpy(d["tgt"]).to(dev)
     so, to = torch.from_numpy(d["src_off"]).to(dev), torch.from_numpy(d["tgt_off"]).to(dev)
@@ -78,12 +80,12 @@ def main():
     gathered = [torch.empty((P, 19), dtype=torch.float64, device=dev) for _ in range(world)] if world > 1 else None
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
 
-    def step(i_timed=None):
+    def step(i_timed=None, search="f32"):
         T0 = engine.kabsch_transforms(cs, ct, coff, eps=1e-6)  # weighted_procrustes(return_transform=True) per patch
         if i_timed is not None:
             ev[i_timed][0].record()
         out = engine.piecewise_icp(src, so, tgt, to, init_T=T0, max_corr_dist=MAX_CORR, max_iter=MAX_ITER,
-                                   fixed_iters=True, max_src_patch=d["max_src"], max_tgt_patch=d["max_tgt"])
+                                   fixed_iters=True, max_src_patch=d["max_src"], max_tgt_patch=d["max_tgt"], search=search)
         if i_timed is not None:
             ev[i_timed][1].record()
         rows = engine.apply_transform(src, so, out["T"])
@@ -128,11 +130,46 @@ def main():
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
                          "kernel_ms": round(icp_ms, 4), "algorithmic_bytes": alg_bytes},
         }
+        # HBM bytes per launch of icp_kernel from the PMC counters: cannot be collected from inside this process; they
+        # come from the committed rocprofv3 passes of this same command (profiles/README.md), when the workload matches
+        tr = os.path.join(ROOT, "profiles", "icp_kernel_traffic.json")
+        if os.path.exists(tr):
+            t = json.load(open(tr))
+            if t.get("workload") == args.config:
+                line["roofline"]["traffic"] = t["hbm_bytes_per_launch"]
+                line["roofline"]["traffic_source"] = t["source"]
+        if world == 1 and args.extras:
+            line["extras"] = extras(torch, engine, step, src, args)
         if args.cpu_seconds > 0:
             line["cpu_baseline"] = cpu_baseline(d, cs_h, ct_h, coff_h, args.cpu_seconds)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def extras(torch, engine, step, src, args):
+    """Secondary figures of SURVEY.md 8(d), outside the timed region of the headline metric."""
+    out = {}
+    n = src.shape[0]
+
+    def timed(fn, reps):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps
+
+    # the same step with the float64 search (parity mode: reproduces the CPU oracle to 1e-9 m, see tests)
+    s64 = timed(lambda: step(search="f64"), max(2, args.steps // 2))
+    out["parity_mode_f64"] = {"value": round(n / s64 / 1e6, 3), "unit": "Mpts/s", "ms_per_step": round(1e3 * s64, 4)}
+    # exact kNN-30 of the source epoch (supervoxel stage): 12 B read + 120 B written per point
+    sk = timed(lambda: engine.knn(src, 30), 3)
+    out["knn30"] = {"value": round(n / sk / 1e6, 3), "unit": "Mpts/s", "ms": round(1e3 * sk, 3),
+                    "achieved_GBs": round(132.0 * n / sk / 1e9, 2), "frac_of_hbm_peak": round(132.0 * n / sk / 1e9 / HBM_PEAK_GBS, 5),
+                    "note": "f4l_knn end to end (binning + sort + search), algorithmic 132 B/pt"}
+    return out
 
 
 def cpu_baseline(d, cs, ct, coff, budget_s):

@@ -669,10 +669,11 @@ extern "C" int f4l_piecewise_icp(const float *src, const int64_t *src_off, const
     { const char *dbg = getenv("F4L_ICP_DEBUG"); a.debug = dbg ? atoi(dbg) : 0; }
     a.T_out = T_out; a.fitness_out = fitness_out; a.rmse_out = rmse_out; a.iters_out = iters_out; a.corr_out = corr_out;
 
-    // waves per patch: enough waves to fill the 1024 SIMDs a few times over, as few barriers as possible
+    // waves per patch: four measured best from 2 k to 32 k patches of ~500 points (the LDS a patch needs limits a CU to
+    // ~4 patches, and a patch keeps 4 waves busier than 2); patches that fit one or two wavefronts get just those
     int nw = 4;
-    if (P >= 8192 && max_src_patch_host <= 1024) nw = 1;
-    else if (P >= 4096 && max_src_patch_host <= 2048) nw = 2;
+    if (max_src_patch_host <= 64) nw = 1;
+    else if (max_src_patch_host <= 128) nw = 2;
     { const char *e = getenv("F4L_ICP_WAVES"); if (e) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) nw = v; } }
 
     // LDS plan: targets first (they make the grid possible), then the prefix table, then the certificate arrays

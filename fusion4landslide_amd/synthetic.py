@@ -19,6 +19,8 @@ import numpy as np
 CONFIGS = {
     "C1_50k_64": dict(n=50_000, cells=8, resolution=1.386),
     "C2_1M_2k": dict(n=1_000_000, cells=45, resolution=1.386),
+    "C2x4_4M_8k": dict(n=4_000_000, cells=90, resolution=1.386),     # C2 density, four times the area (scaling runs)
+    "C2x16_16M_32k": dict(n=16_000_000, cells=180, resolution=1.386),
     "C3_10M_20k": dict(n=10_000_000, cells=141, resolution=0.1),
     "C4_50M_100k": dict(n=50_000_000, cells=316, resolution=1.386),
 }
@@ -92,13 +94,28 @@ def grid_partition(pts, cells, resolution, origin=(0.0, 0.0, 0.0)):
     return order, off
 
 
-def make_patches(n, cells, resolution, seed=0, noise=0.005, origin=(0.0, 0.0, 0.0), roughness=0.0):
+def _order_inside_patches(pts, order, off, cell):
+    """Re-order the points of every patch along a coarse (x, y) raster of `cell`-sized bins (stable)."""
+    p = pts[order].astype(np.float64)
+    pid = np.repeat(np.arange(len(off) - 1), np.diff(off))
+    bx = np.floor(p[:, 0] / cell).astype(np.int64)
+    by = np.floor(p[:, 1] / cell).astype(np.int64)
+    key = np.lexsort((bx, by, pid))
+    return order[key]
+
+
+def make_patches(n, cells, resolution, seed=0, noise=0.005, origin=(0.0, 0.0, 0.0), roughness=0.0, raster=None):
     """Two-epoch cloud already grouped into patch-contiguous CSR arrays.
 
+    raster: if set, points inside a patch are ordered along an (x, y) raster of that bin size (scan-like order);
+    default is the arbitrary order the sampling produced.
     Returns dict(src, src_off, tgt, tgt_off, P, max_src, max_tgt, meta)."""
     c = two_epoch_cloud(n, cells, resolution, noise=noise, seed=seed, origin=origin, roughness=roughness)
     so, soff = grid_partition(c["src"], cells, resolution, origin)
     to, toff = grid_partition(c["tgt"], cells, resolution, origin)
+    if raster:
+        so = _order_inside_patches(c["src"], so, soff, raster)
+        to = _order_inside_patches(c["tgt"], to, toff, raster)
     return dict(src=np.ascontiguousarray(c["src"][so]), src_off=soff, tgt=np.ascontiguousarray(c["tgt"][to]), tgt_off=toff,
                 P=cells * cells, max_src=int(np.diff(soff).max()), max_tgt=int(np.diff(toff).max()), meta=c)
 

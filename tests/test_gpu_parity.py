@@ -295,6 +295,49 @@ def test_icp_large_patch_global_path_matches_lds_path(eng):
         assert _max_disp(d, out["T"].cpu().numpy(), ref["T"]) <= tol, search
 
 
+@pytest.mark.parametrize("waves", ["1", "2", "4"])
+def test_icp_every_workgroup_shape_matches_oracle(eng, waves, monkeypatch):
+    """The host picks 1, 2 or 4 waves per patch from the patch count; force each shape on the same input (float64
+    search: must reproduce the oracle's trajectory whatever the shape) and on the fast path (same statistics)."""
+    monkeypatch.setenv("F4L_ICP_WAVES", waves)
+    d = _patches(n=20_000, cells=5, seed=9)
+    ref = O.piecewise_icp(d["src"], d["src_off"], d["tgt"], d["tgt_off"], max_corr_dist=0.1, max_iter=30)
+    out = eng.piecewise_icp(dev(d["src"]), dev(d["src_off"]), dev(d["tgt"]), dev(d["tgt_off"]), max_corr_dist=0.1,
+                            max_iter=30, search="f64")
+    assert _disp_per_patch(d, out["T"].cpu().numpy(), ref["T"]).max() <= 1e-9
+    assert np.array_equal(out["iters"].cpu().numpy(), ref["iters"])
+    out32 = eng.piecewise_icp(dev(d["src"]), dev(d["src_off"]), dev(d["tgt"]), dev(d["tgt_off"]), max_corr_dist=0.1,
+                              max_iter=30)
+    disp = _disp_per_patch(d, out32["T"].cpu().numpy(), ref["T"])
+    assert np.median(disp) <= 1e-5 and (disp <= 1e-4).mean() >= 0.85 and disp.max() <= 2e-3
+
+
+def test_icp_medium_patches_without_room_for_every_lds_array(eng):
+    """Patches of a few thousand points: the LDS plan drops the staged sources (and, beyond, the certificate arrays)
+    before it gives up the grid; results must not depend on which arrays made it into LDS."""
+    rng = np.random.default_rng(21)
+    P, n = 3, 6000
+    src_l, tgt_l = [], []
+    for p in range(P):
+        xy = rng.uniform(0, 4, (n, 2))
+        tgt_l.append(np.c_[xy, 0.3 * np.sin(1.7 * xy[:, 0]) * np.cos(2.3 * xy[:, 1]) + rng.normal(0, 0.003, n)])
+        xy2 = rng.uniform(0.3, 3.7, (n - 500 * p, 2))
+        s = np.c_[xy2, 0.3 * np.sin(1.7 * xy2[:, 0]) * np.cos(2.3 * xy2[:, 1])]
+        R0 = rot_from_axis_angle(rng.normal(size=3), 0.003)
+        src_l.append(s @ R0.T + rng.uniform(-0.02, 0.02, 3))
+    src, tgt = np.concatenate(src_l).astype(np.float32), np.concatenate(tgt_l).astype(np.float32)
+    soff, toff = ragged(rng, [len(a) for a in src_l]), ragged(rng, [len(a) for a in tgt_l])
+    ref = O.piecewise_icp(src, soff, tgt, toff, max_corr_dist=0.1, max_iter=30)
+    d = dict(src=src, src_off=soff, P=P)
+    out = eng.piecewise_icp(dev(src), dev(soff), dev(tgt), dev(toff), max_corr_dist=0.1, max_iter=30, search="f64",
+                            return_corr=True)
+    assert _disp_per_patch(d, out["T"].cpu().numpy(), ref["T"]).max() <= 1e-9
+    assert np.array_equal(out["iters"].cpu().numpy(), ref["iters"])
+    assert np.abs(out["fitness"].cpu().numpy() - ref["fitness"]).max() == 0.0
+    out32 = eng.piecewise_icp(dev(src), dev(soff), dev(tgt), dev(toff), max_corr_dist=0.1, max_iter=30)
+    assert _disp_per_patch(d, out32["T"].cpu().numpy(), ref["T"]).max() <= 1e-4
+
+
 def test_apply_transform_and_nn_refine(eng):
     d = _patches(n=12_000, cells=4, seed=6)
     rng = np.random.default_rng(1)

@@ -1,4 +1,5 @@
-python -m pytest tests -m gpu -q -x 2>&1 | tail -3
-b() { python bench.py --steps 5 --warmup 2 --cpu-seconds 0 2>&1 | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['roofline']['kernel_ms'], d['config']['mean_fitness'])"; }
-echo newton; b
-echo svd; F4L_ICP_DEBUG=128 b
+python -m pytest tests -m gpu -q 2>&1 | tail -3
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
+bash tools/gpu/profile_round.sh r1_c > gpurun_out/profile_r1_c.log 2>&1
+tail -1 gpurun_out/prof_r1_c/bench.json.log
+cat gpurun_out/prof_r1_c/traffic_raw.json
