@@ -179,7 +179,17 @@ __global__ __launch_bounds__(KNN_NW * 64) void knn_cells_kernel(KnnArgs a) {
                     }
                 }
                 const int nrow = rows - r0 < 64 ? rows - r0 : 64;
-                for (int rr = 0; rr < nrow; ++rr) {
+                for (int rq = 0; rq < nrow; ++rq) {
+                    int rr = rq;
+                    if (R == 1) {
+                        // nearest rows first (own row, the four face neighbours, the four corners): the list tightens
+                        // early, and a row that lies beyond the current k-th distance is not streamed at all
+                        rr = (int)((0x862075314ULL >> (4 * rq)) & 15ULL);
+                        const int dy = rr % 3 - 1, dz = rr / 3 - 1;
+                        const double ey = dy < 0 ? fy : (dy > 0 ? g.h - fy : 0.0), ez = dz < 0 ? fz : (dz > 0 ? g.h - fz : 0.0);
+                        const double ey0 = ey > 1e-6 * g.h ? ey - 1e-6 * g.h : 0.0, ez0 = ez > 1e-6 * g.h ? ez - 1e-6 * g.h : 0.0;
+                        if (ey0 * ey0 + ez0 * ez0 > best.kth(k)) continue;  // uniform (k-th entry is +inf until the list is full)
+                    }
                     const int s = __builtin_amdgcn_readlane(lo, rr), e = __builtin_amdgcn_readlane(hi, rr);
                     for (int b = s; b < e; b += 64) {
                         const int ci = b + lane;
