@@ -1,2 +1,1 @@
-python -m pytest tests -m gpu -q -x -k "knn or supervoxel or full_size" 2>&1 | tail -3
-python tools/gpu/time_knn.py 2>&1 | grep -v amdgpu
+python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 5 --warmup 2 --cpu-seconds 0 --extras 0 2>&1 | tail -2
