@@ -12,10 +12,14 @@
 
 namespace f4l {
 
-template <typename T, int NW>
+// V2 = false: scripts/weighted_svd.py:58-129 (weighted_procrustes).  V2 = true: src/functions.py:12-85
+// (kabsch_transformation_estimation, the F2S3 variant): weights normalised by (sum w + eps) first (when
+// normalize_w), thresholded AFTER that and only when the threshold is positive, means divided by (sum w' + eps)
+// again, covariance with the normalised weights, and the third column scaled by det(V U^T) itself, not its sign.
+template <typename T, int NW, bool V2>
 __global__ __launch_bounds__(NW * 64) void kabsch_kernel(const T *__restrict__ src, const T *__restrict__ ref,
                                                          const T *__restrict__ w, const int64_t *__restrict__ off,
-                                                         int64_t P, double w_thresh, double eps,
+                                                         int64_t P, double w_thresh, double eps, int normalize_w,
                                                          double *__restrict__ R_out, double *__restrict__ t_out,
                                                          double *__restrict__ T_out) {
     __shared__ double scratch[NW * 9];
@@ -27,11 +31,20 @@ __global__ __launch_bounds__(NW * 64) void kabsch_kernel(const T *__restrict__ s
     const T *ww = w ? w + o : nullptr;
     const int tid = (int)threadIdx.x, NT = NW * 64;
 
+    double pre = 1.0;  // V2: 1 / (sum w + eps) applied to every weight before anything else (functions.py:35-37)
+    if (V2 && normalize_w) {
+        double sw[1] = {0.0};
+        for (int i = tid; i < n; i += NT) sw[0] += ww ? (double)ww[i] : 1.0;
+        block_sum<1, NW>(sw, scratch);
+        pre = 1.0 / (sw[0] + eps);
+        __syncthreads();
+    }
     // pass 1: sum w, sum w s, sum w r   (weighted_svd.py:94-100)
     double a[7] = {0, 0, 0, 0, 0, 0, 0};
     for (int i = tid; i < n; i += NT) {
         double wi = ww ? (double)ww[i] : 1.0;
-        if (wi < w_thresh) wi = 0.0;
+        if (V2) { wi *= pre; if (w_thresh > 0.0 && wi < w_thresh) wi = 0.0; }
+        else if (wi < w_thresh) wi = 0.0;
         a[0] += wi;
         a[1] += wi * (double)s[3 * i];
         a[2] += wi * (double)s[3 * i + 1];
@@ -49,8 +62,8 @@ __global__ __launch_bounds__(NW * 64) void kabsch_kernel(const T *__restrict__ s
     double h[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     for (int i = tid; i < n; i += NT) {
         double wi = ww ? (double)ww[i] : 1.0;
-        if (wi < w_thresh) wi = 0.0;
-        wi *= inv;
+        if (V2) { wi *= pre; if (w_thresh > 0.0 && wi < w_thresh) wi = 0.0; }
+        else { if (wi < w_thresh) wi = 0.0; wi *= inv; }
         const double a0 = (double)s[3 * i] - cs0, a1 = (double)s[3 * i + 1] - cs1, a2 = (double)s[3 * i + 2] - cs2;
         const double b0 = wi * ((double)r[3 * i] - ct0), b1 = wi * ((double)r[3 * i + 1] - ct1),
                      b2 = wi * ((double)r[3 * i + 2] - ct2);
@@ -68,7 +81,7 @@ __global__ __launch_bounds__(NW * 64) void kabsch_kernel(const T *__restrict__ s
             const double I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
             svd3_warm(h, I3, U, V);  // the latency-trimmed Jacobi of f4l_device.h (cold start)
             const double d = det3(V) * det3(U);  // det(V U^T)
-            const double sg = d > 0.0 ? 1.0 : (d < 0.0 ? -1.0 : 0.0);  // torch.sign (:111)
+            const double sg = V2 ? d : (d > 0.0 ? 1.0 : (d < 0.0 ? -1.0 : 0.0));  // torch.sign (:111) / the determinant itself (functions.py:70-72)
             mul_diag_bt(V, sg, U, R);
         }
         const double t0 = ct0 - (R[0] * cs0 + R[1] * cs1 + R[2] * cs2);  // :113
@@ -111,19 +124,20 @@ __global__ void kabsch_residual_kernel(const float *__restrict__ src, const floa
     }
 }
 
-template <typename T>
+template <typename T, bool V2 = false>
 static int launch_kabsch(const T *src, const T *ref, const T *w, const int64_t *off, int64_t P, int64_t n_total,
-                         double w_thresh, double eps, double *R_out, double *t_out, double *T_out, hipStream_t st) {
+                         double w_thresh, double eps, double *R_out, double *t_out, double *T_out, hipStream_t st,
+                         int normalize_w = 0) {
     if (P < 0 || n_total < 0 || !off || (!T_out && (!R_out || !t_out)) || (n_total > 0 && (!src || !ref))) return F4L_EINVAL;
     if (P == 0) return F4L_OK;
     if (P > 0x7fffffffLL) return F4L_EUNSUPPORTED;
     // one wave per patch while patches are small (no LDS round, no barrier); four waves otherwise
     if (n_total / P <= 256)
-        hipLaunchKernelGGL((kabsch_kernel<T, 1>), dim3((unsigned)P), dim3(64), 0, st, src, ref, w, off, P, w_thresh,
-                           eps, R_out, t_out, T_out);
+        hipLaunchKernelGGL((kabsch_kernel<T, 1, V2>), dim3((unsigned)P), dim3(64), 0, st, src, ref, w, off, P, w_thresh,
+                           eps, normalize_w, R_out, t_out, T_out);
     else
-        hipLaunchKernelGGL((kabsch_kernel<T, 4>), dim3((unsigned)P), dim3(256), 0, st, src, ref, w, off, P, w_thresh,
-                           eps, R_out, t_out, T_out);
+        hipLaunchKernelGGL((kabsch_kernel<T, 4, V2>), dim3((unsigned)P), dim3(256), 0, st, src, ref, w, off, P, w_thresh,
+                           eps, normalize_w, R_out, t_out, T_out);
     F4L_LAUNCH_CHECK();
     return F4L_OK;
 }
@@ -145,6 +159,20 @@ extern "C" int f4l_kabsch_batched_f64(const double *src, const double *ref, cons
 extern "C" int f4l_kabsch_transforms(const float *src, const float *ref, const float *w, const int64_t *off, int64_t P,
                                      int64_t n_total, double w_thresh, double eps, double *T_out, void *stream) {
     return f4l::launch_kabsch<float>(src, ref, w, off, P, n_total, w_thresh, eps, nullptr, nullptr, T_out, (hipStream_t)stream);
+}
+
+extern "C" int f4l_kabsch2_batched(const float *src, const float *ref, const float *w, const int64_t *off, int64_t P,
+                                   int64_t n_total, int normalize_w, double w_thresh, double eps, double *R_out,
+                                   double *t_out, void *stream) {
+    return f4l::launch_kabsch<float, true>(src, ref, w, off, P, n_total, w_thresh, eps, R_out, t_out, nullptr,
+                                           (hipStream_t)stream, normalize_w);
+}
+
+extern "C" int f4l_kabsch2_batched_f64(const double *src, const double *ref, const double *w, const int64_t *off,
+                                       int64_t P, int64_t n_total, int normalize_w, double w_thresh, double eps,
+                                       double *R_out, double *t_out, void *stream) {
+    return f4l::launch_kabsch<double, true>(src, ref, w, off, P, n_total, w_thresh, eps, R_out, t_out, nullptr,
+                                            (hipStream_t)stream, normalize_w);
 }
 
 extern "C" int f4l_kabsch_residuals(const float *src, const float *ref, const int64_t *off, int64_t P,

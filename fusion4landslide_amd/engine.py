@@ -77,6 +77,43 @@ def kabsch_transforms(src, ref, off, weights=None, weight_thresh=0.0, eps=1e-7):
     return T
 
 
+def kabsch2_batched(src, ref, off, weights=None, normalize_w=True, w_threshold=0.0, eps=1e-7):
+    """Kabsch #2 (src/functions.py:12-85 `kabsch_transformation_estimation`) per ragged batch element.
+
+    src, ref: (n, 3) float32 or float64; off: (P+1,) int64; weights: (n,) or None.
+    Returns R (P, 3, 3) float64 (third column scaled by det(V U^T) like the reference), t (P, 3) float64."""
+    torch = require_gpu()
+    f64 = src.dtype == torch.float64
+    dt = torch.float64 if f64 else torch.float32
+    src = _dev(src, dt, "src", (3,))
+    ref = _dev(ref, dt, "ref", (3,))
+    off = _dev(off, torch.int64, "off")
+    w = None if weights is None else _dev(weights, dt, "weights")
+    n, P = src.shape[0], off.shape[0] - 1
+    if ref.shape[0] != n or (w is not None and w.shape[0] != n):
+        raise ValueError("src, ref and weights must have the same number of rows")
+    R = torch.empty((P, 3, 3), dtype=torch.float64, device=src.device)
+    t = torch.empty((P, 3), dtype=torch.float64, device=src.device)
+    fn = lib().f4l_kabsch2_batched_f64 if f64 else lib().f4l_kabsch2_batched
+    check(fn(ptr(src), ptr(ref), ptr(w), ptr(off), P, n, int(bool(normalize_w)), float(w_threshold), float(eps), ptr(R),
+             ptr(t), stream_ptr()), "f4l_kabsch2_batched")
+    return R, t
+
+
+def median_resolution(src, tgt=None):
+    """`_compute_median_resolution` (src/coarse_to_fine_matching_base.py:2716-2754): median distance of every point to
+    its nearest other point (exact 2-NN on the GPU, f4l_knn), the larger of the two clouds' medians when `tgt` is given.
+    Returns a Python float."""
+    torch = require_gpu()
+
+    def one(xyz):
+        _, d2 = knn(xyz, 2, return_d2=True)
+        return float(torch.quantile(torch.sqrt(d2[:, 1]), 0.5).item())  # numpy's median: mean of the middle pair
+
+    r = one(src)
+    return r if tgt is None else max(r, one(tgt))
+
+
 def kabsch_residuals(src, ref, off, R, t):
     """|| R_p s_i + t_p - r_i || per row (scripts/weighted_svd.py:143-146) -> (n,) float64."""
     torch = require_gpu()

@@ -78,6 +78,19 @@ int f4l_kabsch_batched_f64(const double *src, const double *ref, const double *w
 int f4l_kabsch_transforms(const float *src, const float *ref, const float *w, const int64_t *off, int64_t P,
                           int64_t n_total, double w_thresh, double eps, double *T_out, void *stream);
 
+/* Kabsch #2: src/functions.py:12-85 `kabsch_transformation_estimation` (the F2S3 / outlier-classifier variant;
+ * callers src/f2s3.py:340-366, src/models/outlier_classifier.py:65-106), batched over ragged correspondence lists:
+ *   w <- w / (sum w + eps) when normalize_w;  w[w < w_thresh] <- 0 when w_thresh > 0;
+ *   means divided by (sum w + eps) again;  H = sum (x1 - m1) w (x2 - m2)^T;  U S V^T = svd(H);
+ *   R = V diag(1, 1, det(V U^T)) U^T  (the determinant itself, as the reference);  t = m2 - R m1.
+ * `best_k` of the reference (which applies batch element 0's selection to every element) is not offered. */
+int f4l_kabsch2_batched(const float *src, const float *ref, const float *w, const int64_t *off, int64_t P,
+                        int64_t n_total, int normalize_w, double w_thresh, double eps, double *R_out, double *t_out,
+                        void *stream);
+int f4l_kabsch2_batched_f64(const double *src, const double *ref, const double *w, const int64_t *off, int64_t P,
+                            int64_t n_total, int normalize_w, double w_thresh, double eps, double *R_out,
+                            double *t_out, void *stream);
+
 /* Residual norms || R_p s_i + t_p - r_i || per row (scripts/weighted_svd.py:143-146), float64 [n_total].
  * The caller prunes rows (res < 1 m at :147, or 2.5 x median at src/rgb_guided.py:113-118). */
 int f4l_kabsch_residuals(const float *src, const float *ref, const int64_t *off, int64_t P, int64_t n_total,

@@ -130,3 +130,46 @@ def test_piecewise_icp_entry_writes_reference_files(tmp_path):
             assert 0.3 < still.mean() < 1.0
         else:
             assert np.median(dvfms[:, 3]) < 0.2
+
+
+def test_kabsch2_mirror_vs_golden_and_oracle(golden_dir):
+    """src/functions.py:12-85 on the GPU against vectors produced by the reference's own torch function."""
+    from fusion4landslide_amd import engine
+    from fusion4landslide_amd.src.functions import kabsch_transformation_estimation
+    g = np.load(os.path.join(golden_dir, "kabsch_golden.npz"))
+    for j in (0, 1):
+        x1, x2, w = (torch.from_numpy(g[f"k2_{j}_{k}"]).cuda() for k in ("x1", "x2", "w"))
+        R, t, res, flag = kabsch_transformation_estimation(x1, x2, w)
+        assert flag is False and R.shape == g[f"k2_{j}_R"].shape and t.shape == g[f"k2_{j}_t"].shape
+        assert np.abs(R.cpu().numpy() - g[f"k2_{j}_R"]).max() < 1e-9
+        assert np.abs(t.cpu().numpy() - g[f"k2_{j}_t"]).max() < 1e-9
+        assert np.abs(res.cpu().numpy() - g[f"k2_{j}_res"]).max() < 1e-9
+        R, t, _, _ = kabsch_transformation_estimation(x1, x2, None)
+        assert np.abs(R.cpu().numpy() - g[f"k2_{j}_R_now"]).max() < 1e-9
+        assert np.abs(t.cpu().numpy() - g[f"k2_{j}_t_now"]).max() < 1e-9
+    # float32 batch, threshold on the NORMALISED weights, against the numpy restatement
+    rng = np.random.default_rng(3)
+    x1 = rng.uniform(-1, 1, (7, 300, 3)).astype(np.float32)
+    x2 = (x1 @ np.array([[0.999, -0.04, 0.0], [0.04, 0.999, 0.0], [0.0, 0.0, 1.0]], np.float32) + 0.1).astype(np.float32)
+    w = rng.uniform(0, 1, (7, 300)).astype(np.float32)
+    for thr in (0, 1.0 / 300):
+        R, t, res, _ = kabsch_transformation_estimation(torch.from_numpy(x1).cuda(), torch.from_numpy(x2).cuda(),
+                                                        torch.from_numpy(w).cuda(), w_threshold=thr)
+        Rr, tr = O.kabsch_transformation_estimation(x1, x2, w, w_threshold=thr)
+        assert np.abs(R.cpu().numpy() - Rr).max() < 2e-5 and np.abs(t.cpu().numpy() - tr).max() < 2e-5
+    with pytest.raises(NotImplementedError):
+        kabsch_transformation_estimation(torch.from_numpy(x1).cuda(), torch.from_numpy(x2).cuda(), best_k=10)
+
+
+def test_median_resolution_vs_kdtree():
+    """_compute_median_resolution (src/coarse_to_fine_matching_base.py:2716-2754): sklearn kd-tree 2-NN there, scipy here."""
+    from scipy.spatial import cKDTree
+    from fusion4landslide_amd import engine, synthetic
+    c = synthetic.two_epoch_cloud(40_000, 9, 1.386, seed=5)
+    ref = []
+    for pts in (c["src"], c["tgt"][:30_001]):
+        d, _ = cKDTree(pts.astype(np.float64)).query(pts.astype(np.float64), k=2)
+        ref.append(np.median(d[:, 1]))
+    got = engine.median_resolution(torch.from_numpy(c["src"]).cuda(), torch.from_numpy(c["tgt"][:30_001]).cuda())
+    assert abs(got - max(ref)) <= 1e-12 * max(ref) + 1e-15
+    assert abs(engine.median_resolution(torch.from_numpy(c["src"]).cuda()) - ref[0]) <= 1e-12

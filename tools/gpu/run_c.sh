@@ -1,1 +1,1 @@
-python -m pytest tests -m gpu -q -x -k "workgroup_shape or medium_patches" 2>&1 | tail -15
+python -m pytest tests -m gpu -q -x -k "kabsch or median" 2>&1 | tail -15
