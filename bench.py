@@ -5,9 +5,11 @@ Contract (driver):  python bench.py --gpus N --steps K --warmup W   (N > 1 via t
 prints ONE JSON line on rank 0.
 
 A "step" is one pass of the hot path over one tile, inputs resident in HBM when the clock starts:
-    per-patch weighted Kabsch init (f4l_kabsch_transforms on the 1-NN correspondences)
- -> 20 fixed point-to-point ICP iterations per patch (f4l_piecewise_icp, max_corr_dist 0.1 m, no early exit)
- -> dense displacement rows [s, T s] for every source point (f4l_apply_transform)
+    per-patch weighted Kabsch init from the 1-NN correspondences
+ -> 20 fixed point-to-point ICP iterations per patch (max_corr_dist 0.1 m, no early exit)
+ -> dense displacement rows [s, T s] for every source point
+    (all three in ONE launch of f4l_patch_loop; f4l_kabsch_transforms / f4l_piecewise_icp / f4l_apply_transform are the
+    same stages as separate calls)
  -> (N > 1) RCCL all-gather of the per-patch results (T, fitness, rmse, iters: 152 B per patch).
 Workload at N = 1: BASELINE.json configs[1] ("C2_1M_2k": 1 M points per epoch, 45 x 45 = 2025 patches).
 Scaling is weak: tiles are the reference's independent units (<= 1 M points each, configs/landslide/*.yaml
@@ -84,14 +86,14 @@ def main():
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
 
     def step(i_timed=None, search="f32"):
-        T0 = engine.kabsch_transforms(cs, ct, coff, eps=1e-6)  # weighted_procrustes(return_transform=True) per patch
+        # the whole loop body in one launch (f4l_patch_loop): Kabsch init -> ICP -> rows
         if i_timed is not None:
             ev[i_timed][0].record()
-        out = engine.piecewise_icp(src, so, tgt, to, init_T=T0, max_corr_dist=MAX_CORR, max_iter=MAX_ITER,
-                                   fixed_iters=True, max_src_patch=d["max_src"], max_tgt_patch=d["max_tgt"], search=search)
+        out = engine.patch_loop(src, so, tgt, to, cs, ct, coff, None, 0.0, 1e-6, max_corr_dist=MAX_CORR, max_iter=MAX_ITER,
+                                fixed_iters=True, max_src_patch=d["max_src"], max_tgt_patch=d["max_tgt"], search=search)
         if i_timed is not None:
             ev[i_timed][1].record()
-        rows = engine.apply_transform(src, so, out["T"])
+        rows = out["rows"]
         if world > 1:
             slot = counter[0] % 2
             counter[0] += 1

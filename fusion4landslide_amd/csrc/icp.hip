@@ -48,6 +48,12 @@ struct IcpArgs {
     const int64_t *tgt_off;
     int64_t P;
     const double *init_T;
+    // fused loop body (f4l_patch_loop): Kabsch initialisation from correspondences in the prologue, displacement rows
+    // in the epilogue; all nullable
+    const float *corr_src, *corr_ref, *corr_w;
+    const int64_t *corr_off;
+    double kabsch_w_thresh, kabsch_eps;
+    float *rows_out;
     const float *tgt_normals;
     double r, r2;
     int max_iter;
@@ -232,10 +238,64 @@ __global__ __launch_bounds__(NW * 64, ICP_WAVES_PER_EU) void icp_kernel(IcpArgs 
     }
     __syncthreads();  // scratch is free again
 
+    // Fused initialisation: weighted Kabsch of this patch's correspondences (scripts/weighted_svd.py:58-129, the same
+    // arithmetic as kabsch_kernel<float, NW, false>): two streaming passes, block reductions, SVD on one thread.
+    double Tk[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};  // [R | t] rows
+    const bool fused_init = a.corr_off != nullptr;
+    if (fused_init) {
+        const int64_t c0 = a.corr_off[p];
+        const int nc = (int)(a.corr_off[p + 1] - c0);
+        const float *__restrict__ ks = a.corr_src + 3 * c0, *__restrict__ kr = a.corr_ref + 3 * c0;
+        const float *__restrict__ kw = a.corr_w ? a.corr_w + c0 : nullptr;
+        double s7[7] = {0, 0, 0, 0, 0, 0, 0};
+        for (int i = tid; i < nc; i += NT) {
+            double wi = kw ? (double)kw[i] : 1.0;
+            if (wi < a.kabsch_w_thresh) wi = 0.0;
+            s7[0] += wi;
+            s7[1] += wi * (double)ks[3 * i]; s7[2] += wi * (double)ks[3 * i + 1]; s7[3] += wi * (double)ks[3 * i + 2];
+            s7[4] += wi * (double)kr[3 * i]; s7[5] += wi * (double)kr[3 * i + 1]; s7[6] += wi * (double)kr[3 * i + 2];
+        }
+        block_sum<7, NW>(s7, scratch);
+        const double inv = 1.0 / (s7[0] + a.kabsch_eps);  // eps stays in the denominator (weighted_svd.py:96)
+        const double k0 = s7[1] * inv, k1 = s7[2] * inv, k2 = s7[3] * inv;
+        const double l0 = s7[4] * inv, l1 = s7[5] * inv, l2 = s7[6] * inv;
+        double h9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        for (int i = tid; i < nc; i += NT) {
+            double wi = kw ? (double)kw[i] : 1.0;
+            if (wi < a.kabsch_w_thresh) wi = 0.0;
+            wi *= inv;
+            const double a0 = (double)ks[3 * i] - k0, a1 = (double)ks[3 * i + 1] - k1, a2 = (double)ks[3 * i + 2] - k2;
+            const double b0 = wi * ((double)kr[3 * i] - l0), b1 = wi * ((double)kr[3 * i + 1] - l1),
+                         b2 = wi * ((double)kr[3 * i + 2] - l2);
+            h9[0] += a0 * b0; h9[1] += a0 * b1; h9[2] += a0 * b2;
+            h9[3] += a1 * b0; h9[4] += a1 * b1; h9[5] += a1 * b2;
+            h9[6] += a2 * b0; h9[7] += a2 * b1; h9[8] += a2 * b2;
+        }
+        __syncthreads();
+        block_sum<9, NW>(h9, scratch);
+        if (tid == 0 && nc > 0) {
+            double R[9];
+            const double Ht[9] = {h9[0], h9[3], h9[6], h9[1], h9[4], h9[7], h9[2], h9[5], h9[8]};
+            if (!rot_newton(Ht, R)) {  // R = V diag(1,1,sign det(V U^T)) U^T of H = U S V^T (weighted_svd.py:107-111)
+                double U[9], V[9];
+                const double I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+                svd3_warm(h9, I3, U, V);
+                const double dd = det3(V) * det3(U);
+                mul_diag_bt(V, dd > 0.0 ? 1.0 : (dd < 0.0 ? -1.0 : 0.0), U, R);
+            }
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { Tk[4 * i] = R[3 * i]; Tk[4 * i + 1] = R[3 * i + 1]; Tk[4 * i + 2] = R[3 * i + 2]; }
+            Tk[3] = l0 - (R[0] * k0 + R[1] * k1 + R[2] * k2);
+            Tk[7] = l1 - (R[3] * k0 + R[4] * k1 + R[5] * k2);
+            Tk[11] = l2 - (R[6] * k0 + R[7] * k1 + R[8] * k2);
+        }
+        __syncthreads();
+    }
+
     // running transform in origin-relative coordinates, p' = Rc s' + tc, lives in LDS `state`
     if (tid == 0) {
-        if (a.init_T) {
-            const double *T = a.init_T + 16 * p;
+        if (fused_init || a.init_T) {
+            const double *T = fused_init ? Tk : a.init_T + 16 * p;
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
                 state[3 * i] = T[4 * i]; state[3 * i + 1] = T[4 * i + 1]; state[3 * i + 2] = T[4 * i + 2];
@@ -607,6 +667,27 @@ __global__ __launch_bounds__(NW * 64, ICP_WAVES_PER_EU) void icp_kernel(IcpArgs 
     }
     if (!active && a.corr_out)
         for (int i = tid; i < ns; i += NT) a.corr_out[s0 + i] = -1;
+    if (a.rows_out) {
+        // fused displacement rows [s, T s] (src/coarse_to_fine_matching_base.py:3371-3374,3408): the arithmetic of
+        // apply_transform_kernel on the global 4x4 this thread rebuilds from the final LDS state
+        const double o0 = ox, o1 = oy, o2 = oz;
+        double r[9], tr[3];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) r[i] = state[i];
+        tr[0] = state[9] - (r[0] * o0 + r[1] * o1 + r[2] * o2) + o0;
+        tr[1] = state[10] - (r[3] * o0 + r[4] * o1 + r[5] * o2) + o1;
+        tr[2] = state[11] - (r[6] * o0 + r[7] * o1 + r[8] * o2) + o2;
+        float *__restrict__ out6 = a.rows_out + 6 * s0;
+        for (int i = tid; i < ns; i += NT) {
+            const float xf = sg[3 * i], yf = sg[3 * i + 1], zf = sg[3 * i + 2];
+            const double x = xf, y = yf, z = zf;
+            float *o6 = out6 + 6 * i;
+            o6[0] = xf; o6[1] = yf; o6[2] = zf;
+            o6[3] = (float)(r[0] * x + r[1] * y + r[2] * z + tr[0]);
+            o6[4] = (float)(r[3] * x + r[4] * y + r[5] * z + tr[1]);
+            o6[5] = (float)(r[6] * x + r[7] * y + r[8] * z + tr[2]);
+        }
+    }
 }
 
 }  // namespace f4l
@@ -642,12 +723,55 @@ static inline int pow2_ceil(int64_t v) {
 }
 }  // namespace f4l
 
+namespace f4l {
+struct IcpFusedExtra {
+    const float *corr_src = nullptr, *corr_ref = nullptr, *corr_w = nullptr;
+    const int64_t *corr_off = nullptr;
+    double w_thresh = 0.0, eps = 1e-7;
+    float *rows_out = nullptr;
+};
+static int icp_launch_host(const float *src, const int64_t *src_off, const float *tgt, const int64_t *tgt_off,
+                           int64_t P, const double *init_T, const float *tgt_normals, double max_corr_dist,
+                           int max_iter, double rel_fitness, double rel_rmse, int mode, int fixed_iters,
+                           int search_precision, int64_t max_src_patch_host, int64_t max_tgt_patch_host,
+                           double *T_out, double *fitness_out, double *rmse_out, int32_t *iters_out,
+                           int32_t *corr_out, const IcpFusedExtra &fx, void *stream);
+}  // namespace f4l
+
 extern "C" int f4l_piecewise_icp(const float *src, const int64_t *src_off, const float *tgt, const int64_t *tgt_off,
                                  int64_t P, const double *init_T, const float *tgt_normals, double max_corr_dist,
                                  int max_iter, double rel_fitness, double rel_rmse, int mode, int fixed_iters,
                                  int search_precision, int64_t max_src_patch_host, int64_t max_tgt_patch_host,
                                  double *T_out, double *fitness_out, double *rmse_out, int32_t *iters_out,
                                  int32_t *corr_out, void *stream) {
+    return f4l::icp_launch_host(src, src_off, tgt, tgt_off, P, init_T, tgt_normals, max_corr_dist, max_iter, rel_fitness,
+                                rel_rmse, mode, fixed_iters, search_precision, max_src_patch_host, max_tgt_patch_host,
+                                T_out, fitness_out, rmse_out, iters_out, corr_out, f4l::IcpFusedExtra(), stream);
+}
+
+extern "C" int f4l_patch_loop(const float *src, const int64_t *src_off, const float *tgt, const int64_t *tgt_off,
+                              int64_t P, const float *corr_src, const float *corr_ref, const float *corr_w,
+                              const int64_t *corr_off, double kabsch_w_thresh, double kabsch_eps,
+                              const float *tgt_normals, double max_corr_dist, int max_iter, double rel_fitness,
+                              double rel_rmse, int mode, int fixed_iters, int search_precision,
+                              int64_t max_src_patch_host, int64_t max_tgt_patch_host, double *T_out,
+                              double *fitness_out, double *rmse_out, int32_t *iters_out, int32_t *corr_out,
+                              float *rows_out, void *stream) {
+    if (!corr_off || ((!corr_src || !corr_ref) && P > 0)) return F4L_EINVAL;
+    f4l::IcpFusedExtra fx;
+    fx.corr_src = corr_src; fx.corr_ref = corr_ref; fx.corr_w = corr_w; fx.corr_off = corr_off;
+    fx.w_thresh = kabsch_w_thresh; fx.eps = kabsch_eps; fx.rows_out = rows_out;
+    return f4l::icp_launch_host(src, src_off, tgt, tgt_off, P, nullptr, tgt_normals, max_corr_dist, max_iter, rel_fitness,
+                                rel_rmse, mode, fixed_iters, search_precision, max_src_patch_host, max_tgt_patch_host,
+                                T_out, fitness_out, rmse_out, iters_out, corr_out, fx, stream);
+}
+
+static int f4l::icp_launch_host(const float *src, const int64_t *src_off, const float *tgt, const int64_t *tgt_off,
+                                int64_t P, const double *init_T, const float *tgt_normals, double max_corr_dist,
+                                int max_iter, double rel_fitness, double rel_rmse, int mode, int fixed_iters,
+                                int search_precision, int64_t max_src_patch_host, int64_t max_tgt_patch_host,
+                                double *T_out, double *fitness_out, double *rmse_out, int32_t *iters_out,
+                                int32_t *corr_out, const IcpFusedExtra &fx, void *stream) {
     using namespace f4l;
     if (P < 0 || !src_off || !tgt_off || !T_out || max_iter < 0 || max_src_patch_host < 0 || max_tgt_patch_host < 0)
         return F4L_EINVAL;
@@ -663,6 +787,8 @@ extern "C" int f4l_piecewise_icp(const float *src, const int64_t *src_off, const
     IcpArgs a;
     a.src = src; a.src_off = src_off; a.tgt = tgt; a.tgt_off = tgt_off; a.P = P;
     a.init_T = init_T; a.tgt_normals = tgt_normals;
+    a.corr_src = fx.corr_src; a.corr_ref = fx.corr_ref; a.corr_w = fx.corr_w; a.corr_off = fx.corr_off;
+    a.kabsch_w_thresh = fx.w_thresh; a.kabsch_eps = fx.eps; a.rows_out = fx.rows_out;
     a.r = max_corr_dist > 0.0 ? max_corr_dist : 0.0;
     a.r2 = a.r * a.r;
     a.max_iter = max_iter; a.rel_fitness = rel_fitness; a.rel_rmse = rel_rmse; a.fixed_iters = fixed_iters;

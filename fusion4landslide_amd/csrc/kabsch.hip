@@ -78,11 +78,17 @@ __global__ __launch_bounds__(NW * 64) void kabsch_kernel(const T *__restrict__ s
         if (n == 0) {
             R[0] = 1; R[1] = 0; R[2] = 0; R[3] = 0; R[4] = 1; R[5] = 0; R[6] = 0; R[7] = 0; R[8] = 1;
         } else {
-            const double I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-            svd3_warm(h, I3, U, V);  // the latency-trimmed Jacobi of f4l_device.h (cold start)
-            const double d = det3(V) * det3(U);  // det(V U^T)
-            const double sg = V2 ? d : (d > 0.0 ? 1.0 : (d < 0.0 ? -1.0 : 0.0));  // torch.sign (:111) / the determinant itself (functions.py:70-72)
-            mul_diag_bt(V, sg, U, R);
+            // Newton on SO(3) first (f4l_device.h: the maximiser of tr(R^T H^T), which is V diag(1,1,sign det) U^T whenever
+            // that is unique), the Jacobi SVD when the problem is rank deficient, near a reflection tie, or the
+            // rotation is large
+            const double Ht[9] = {h[0], h[3], h[6], h[1], h[4], h[7], h[2], h[5], h[8]};
+            if (!rot_newton(Ht, R)) {
+                const double I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+                svd3_warm(h, I3, U, V);  // the latency-trimmed Jacobi of f4l_device.h (cold start)
+                const double d = det3(V) * det3(U);  // det(V U^T)
+                const double sg = V2 ? d : (d > 0.0 ? 1.0 : (d < 0.0 ? -1.0 : 0.0));  // torch.sign (:111) / the determinant itself (functions.py:70-72)
+                mul_diag_bt(V, sg, U, R);
+            }
         }
         const double t0 = ct0 - (R[0] * cs0 + R[1] * cs1 + R[2] * cs2);  // :113
         const double t1 = ct1 - (R[3] * cs0 + R[4] * cs1 + R[5] * cs2);

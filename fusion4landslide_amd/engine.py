@@ -194,6 +194,60 @@ def piecewise_icp(src, src_off, tgt, tgt_off, init_T=None, max_corr_dist=0.1, ma
     return out
 
 
+def patch_loop(src, src_off, tgt, tgt_off, corr_src, corr_ref, corr_off, corr_weights=None, weight_thresh=0.0, eps=1e-6,
+               max_corr_dist=0.1, max_iter=30, rel_fitness=1e-6, rel_rmse=1e-6, icp_type="point2point", fixed_iters=False,
+               tgt_normals=None, return_corr=False, return_rows=True, max_src_patch=None, max_tgt_patch=None, search="f32"):
+    """The whole per-patch loop body of src/coarse_to_fine_matching_base.py:3254-3436 in one launch (f4l_patch_loop):
+    weighted Kabsch of each patch's correspondences -> ICP from that -> displacement rows [s, T s].
+
+    Equivalent to ``T0 = kabsch_transforms(...); out = piecewise_icp(..., init_T=T0); rows = apply_transform(src, src_off,
+    out["T"])``.  Returns the dict of :func:`piecewise_icp` plus ``rows`` (n_src, 6) float32 when ``return_rows``."""
+    torch = require_gpu()
+    if icp_type not in _ICP_MODES:
+        raise ValueError("ICP type not supported")  # utils/o3d_tools.py:43
+    mode = _ICP_MODES[icp_type]
+    src = _dev(src, torch.float32, "src", (3,))
+    tgt = _dev(tgt, torch.float32, "tgt", (3,))
+    src_off = _dev(src_off, torch.int64, "src_off")
+    tgt_off = _dev(tgt_off, torch.int64, "tgt_off")
+    corr_src = _dev(corr_src, torch.float32, "corr_src", (3,))
+    corr_ref = _dev(corr_ref, torch.float32, "corr_ref", (3,))
+    corr_off = _dev(corr_off, torch.int64, "corr_off")
+    cw = None if corr_weights is None else _dev(corr_weights, torch.float32, "corr_weights")
+    P = src_off.shape[0] - 1
+    if tgt_off.shape[0] - 1 != P or corr_off.shape[0] - 1 != P:
+        raise ValueError("src_off, tgt_off and corr_off must describe the same number of patches")
+    if corr_ref.shape[0] != corr_src.shape[0] or (cw is not None and cw.shape[0] != corr_src.shape[0]):
+        raise ValueError("corr_src, corr_ref and corr_weights must have the same number of rows")
+    if max_src_patch is None:
+        max_src_patch = _max_patch(src_off)
+    if max_tgt_patch is None:
+        max_tgt_patch = _max_patch(tgt_off)
+    tn = None
+    if mode == _lib.ICP_POINT2PLANE:
+        tn = patch_normals(tgt, tgt_off, 30, max_tgt_patch) if tgt_normals is None else _dev(
+            tgt_normals, torch.float32, "tgt_normals", (3,))
+    dev = src.device
+    T = torch.empty((P, 4, 4), dtype=torch.float64, device=dev)
+    fit = torch.empty((P,), dtype=torch.float64, device=dev)
+    rmse = torch.empty((P,), dtype=torch.float64, device=dev)
+    iters = torch.empty((P,), dtype=torch.int32, device=dev)
+    corr = torch.empty((src.shape[0],), dtype=torch.int32, device=dev) if return_corr else None
+    rows = torch.empty((src.shape[0], 6), dtype=torch.float32, device=dev) if return_rows else None
+    check(lib().f4l_patch_loop(ptr(src), ptr(src_off), ptr(tgt), ptr(tgt_off), P, ptr(corr_src), ptr(corr_ref), ptr(cw),
+                               ptr(corr_off), float(weight_thresh), float(eps), ptr(tn), float(max_corr_dist), int(max_iter),
+                               float(rel_fitness), float(rel_rmse), mode, int(bool(fixed_iters)),
+                               {"f32": _lib.SEARCH_F32, "f64": _lib.SEARCH_F64}[search], int(max_src_patch),
+                               int(max_tgt_patch), ptr(T), ptr(fit), ptr(rmse), ptr(iters), ptr(corr), ptr(rows),
+                               stream_ptr()), "f4l_patch_loop")
+    out = dict(T=T, fitness=fit, rmse=rmse, iters=iters)
+    if return_corr:
+        out["corr"] = corr
+    if return_rows:
+        out["rows"] = rows
+    return out
+
+
 def apply_transform(pts, off, T, inverse=False):
     """Rows [s, T_p s] (src/coarse_to_fine_matching_base.py:3371-3374,3408) -> (n, 6) float32."""
     torch = require_gpu()

@@ -120,6 +120,20 @@ int f4l_piecewise_icp(const float *src, const int64_t *src_off, const float *tgt
                       double *T_out, double *fitness_out, double *rmse_out, int32_t *iters_out,
                       int32_t *corr_out, void *stream);
 
+/* The whole loop body of src/coarse_to_fine_matching_base.py:3254-3436 for P patch matches in ONE launch:
+ *   weighted Kabsch of the patch's correspondences (:3341, scripts/weighted_svd.py:58-129; corr_src / corr_ref
+ *   float32 [n_corr][3], corr_w float32 [n_corr] or NULL, corr_off int64 [P+1]; a patch without correspondences
+ *   starts from the identity)  ->  ICP as f4l_piecewise_icp (:3353-3367)  ->  displacement rows [s, T s] of every
+ *   source point (:3371-3374, 3408; rows_out float32 [n_src][6], nullable).
+ * Same results as f4l_kabsch_transforms -> f4l_piecewise_icp -> f4l_apply_transform (T_out to rounding of the block
+ * reductions, rows_out bit-equal to f4l_apply_transform applied to T_out), without the two extra launches. */
+int f4l_patch_loop(const float *src, const int64_t *src_off, const float *tgt, const int64_t *tgt_off, int64_t P,
+                   const float *corr_src, const float *corr_ref, const float *corr_w, const int64_t *corr_off,
+                   double kabsch_w_thresh, double kabsch_eps, const float *tgt_normals, double max_corr_dist,
+                   int max_iter, double rel_fitness, double rel_rmse, int mode, int fixed_iters, int search_precision,
+                   int64_t max_src_patch_host, int64_t max_tgt_patch_host, double *T_out, double *fitness_out,
+                   double *rmse_out, int32_t *iters_out, int32_t *corr_out, float *rows_out, void *stream);
+
 /* Per-patch normal estimation as utils/o3d_tools.py:29-30 (`pcd.estimate_normals()` on the patch cloud:
  * kNN(knn=30) inside the patch, self included; smallest-eigenvector of the neighbourhood covariance;
  * (0,0,1) when degenerate; unoriented).  normals_out float32 [n][3]. */

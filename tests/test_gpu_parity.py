@@ -338,6 +338,38 @@ def test_icp_medium_patches_without_room_for_every_lds_array(eng):
     assert _disp_per_patch(d, out32["T"].cpu().numpy(), ref["T"]).max() <= 1e-4
 
 
+def test_patch_loop_equals_the_three_launches(eng):
+    """f4l_patch_loop = Kabsch init + ICP + displacement rows in one launch; same answers as the separate calls."""
+    from fusion4landslide_amd import synthetic
+    d = _patches(n=25_000, cells=5, seed=12)
+    src, so, tgt, to = dev(d["src"]), dev(d["src_off"]), dev(d["tgt"]), dev(d["tgt_off"])
+    P = d["P"]
+    eye = torch.eye(4, dtype=torch.float64, device="cuda").repeat(P, 1, 1)
+    nn, _ = eng.nn_refine(src, so, tgt, to, eye, torch.full((P,), 0.2, dtype=torch.float64, device="cuda"), return_rows=False)
+    cs, ct, coff = synthetic.correspondences_from_nn(d["src"], d["src_off"], d["tgt"], d["tgt_off"], nn.cpu().numpy())
+    coff[3] = coff[2]  # one patch without correspondences (its rows go to the next one): identity start there
+    w = np.random.default_rng(0).uniform(0.1, 1, len(cs)).astype(np.float32)
+    for search in ("f64", "f32"):
+        T0 = eng.kabsch_transforms(dev(cs), dev(ct), dev(coff), dev(w), 0.2, 1e-6)
+        ref = eng.piecewise_icp(src, so, tgt, to, init_T=T0, max_corr_dist=0.1, max_iter=30, search=search, return_corr=True)
+        rows_ref = eng.apply_transform(src, so, ref["T"])
+        out = eng.patch_loop(src, so, tgt, to, dev(cs), dev(ct), dev(coff), dev(w), 0.2, 1e-6, max_corr_dist=0.1, max_iter=30,
+                             search=search, return_corr=True)
+        assert np.allclose(T0.cpu().numpy()[2], np.eye(4))
+        disp = _disp_per_patch(d, out["T"].cpu().numpy(), ref["T"].cpu().numpy())
+        assert disp.max() <= (1e-9 if search == "f64" else 2e-3) and np.median(disp) <= 1e-9
+        if search == "f64":
+            assert torch.equal(out["iters"], ref["iters"]) and torch.equal(out["corr"], ref["corr"])
+        assert torch.equal(out["rows"], eng.apply_transform(src, so, out["T"]))  # the fused rows are apply_transform's
+        assert torch.equal(out["rows"][:, :3], src) and (out["rows"] - rows_ref).abs().max().item() <= 2e-3
+    Rr, tr = O.kabsch_batched(cs, ct, coff, w, 0.2, 1e-6)
+    ref_or = O.piecewise_icp(d["src"], d["src_off"], d["tgt"], d["tgt_off"],
+                             init_T=np.concatenate([np.concatenate([Rr, tr[:, :, None]], 2), np.tile([[[0, 0, 0, 1.0]]], (P, 1, 1))], 1),
+                             max_corr_dist=0.1, max_iter=30)
+    out = eng.patch_loop(src, so, tgt, to, dev(cs), dev(ct), dev(coff), dev(w), 0.2, 1e-6, max_corr_dist=0.1, max_iter=30, search="f64")
+    assert _disp_per_patch(d, out["T"].cpu().numpy(), ref_or["T"]).max() <= 1e-8
+
+
 def test_apply_transform_and_nn_refine(eng):
     d = _patches(n=12_000, cells=4, seed=6)
     rng = np.random.default_rng(1)

@@ -1,1 +1,2 @@
-python -m pytest tests -m gpu -q -x -k "kabsch or median" 2>&1 | tail -15
+python -m pytest tests -m gpu -q 2>&1 | tail -5
+python bench.py --steps 10 --warmup 3 --cpu-seconds 0 --extras 0 | tail -1 | cut -c1-330
