@@ -65,6 +65,8 @@ struct IcpArgs {
     int cell_cap;  // grid cells the prefix table can hold
     double *T_out, *fitness_out, *rmse_out;
     int32_t *iters_out, *corr_out;
+    int subdiv;     // cells per radius the grid may use (patch_grid.h: grid_build)
+    double mu_frac; // certificate margin as a fraction of the correspondence radius
     int debug;  // F4L_ICP_DEBUG env: 1 = skip the solve, 2 = skip the search, 4 = no row pruning (experiments)
     unsigned long long *prof;  // F4L_ICP_PROF builds only: per-phase shader-clock totals (see f4l_piecewise_icp)
 };
@@ -200,12 +202,11 @@ __global__ __launch_bounds__(NW * 64, ICP_WAVES_PER_EU) void icp_kernel(IcpArgs 
     // search radius: a little beyond the correspondence radius, so that "no target within r" can be certified too
     const F rF = (F)a.r, r2 = (F)a.r2;
     const F rs = rF * (F)1.0625, rs2 = rs * rs;
-    const F mu = rF * (F)0.125;  // margin of the certificates beyond the re-measured correspondence
     PatchGrid<F> g;
     g.minx = g.miny = g.minz = (F)0; g.h = (F)1; g.inv_h = (F)1; g.nx = g.ny = g.nz = 1;
     double cs[3] = {0.0, 0.0, 0.0}, srad = 0.0;
     if (active) {  // uniform across the workgroup
-        if (tgt_in_lds) grid_build<F, NT>(tg, nt, ox, oy, oz, rs, a.cell_cap, tl, E, reinterpret_cast<F *>(scratch), g);
+        if (tgt_in_lds) grid_build<F, NT>(tg, nt, ox, oy, oz, rs, a.cell_cap, tl, E, reinterpret_cast<F *>(scratch), g, a.subdiv);
         {
             // centroid and radius of the source patch (origin-relative): the lever arm of the motion bound
             double sum[3] = {0.0, 0.0, 0.0};
@@ -237,6 +238,9 @@ __global__ __launch_bounds__(NW * 64, ICP_WAVES_PER_EU) void icp_kernel(IcpArgs 
         }
     }
     __syncthreads();  // scratch is free again
+    // margin of the certificates beyond the re-measured correspondence: a fraction of the radius, less on grids
+    // finer than the radius (dense patches), where a wide margin would pull many points into every search
+    const F mu = rF * (F)a.mu_frac < g.h * (F)0.25 ? rF * (F)a.mu_frac : g.h * (F)0.25;
 
     // Fused initialisation: weighted Kabsch of this patch's correspondences (scripts/weighted_svd.py:58-129, the same
     // arithmetic as kabsch_kernel<float, NW, false>): two streaming passes, block reductions, SVD on one thread.
@@ -793,6 +797,9 @@ static int f4l::icp_launch_host(const float *src, const int64_t *src_off, const 
     a.r2 = a.r * a.r;
     a.max_iter = max_iter; a.rel_fitness = rel_fitness; a.rel_rmse = rel_rmse; a.fixed_iters = fixed_iters;
     { const char *dbg = getenv("F4L_ICP_DEBUG"); a.debug = dbg ? atoi(dbg) : 0; }
+    a.subdiv = 8; a.mu_frac = 0.125;
+    { const char *e = getenv("F4L_ICP_SUBDIV"); if (e && atoi(e) >= 1) a.subdiv = atoi(e); }
+    { const char *e = getenv("F4L_ICP_MU"); if (e && atof(e) > 0.0) a.mu_frac = atof(e); }
     a.T_out = T_out; a.fitness_out = fitness_out; a.rmse_out = rmse_out; a.iters_out = iters_out; a.corr_out = corr_out;
 
     // waves per patch: four measured best from 2 k to 32 k patches of ~500 points (the LDS a patch needs limits a CU to

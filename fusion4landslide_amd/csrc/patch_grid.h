@@ -19,7 +19,8 @@
 // point a brute-force scan in index order (and the oracle's KD-tree) returns, independent of the order in
 // which the counting sort happened to place points inside a cell.
 //
-// Exactness of the 3x3x3 stencil: cell coordinates are floor((x - min) / h) evaluated in floating point for
+// Exactness of the stencil (3x3x3 cells when h >= r, (2 w + 1)^3 with w = ceil(bound / h) otherwise): cell
+// coordinates are floor((x - min) / h) evaluated in floating point for
 // targets and queries alike (a monotone function of x); h = r * (1 + 2^-7) leaves 7e-3 cells of slack for its
 // rounding (float32 cell coordinates below 16384 are good to 3e-3), so |q - t| < r implies |cell(q) - cell(t)| <= 1 on every axis.
 #pragma once
@@ -35,7 +36,15 @@ template <> struct __attribute__((aligned(16))) GridPt<double> { double x, y, z;
 template <typename F> struct PatchGrid {
     F minx, miny, minz, h, inv_h;
     int nx, ny, nz;  // nx * ny * nz <= cell capacity
+    int wmax;        // cells per side of the stencil that covers the radius the grid was built for (>= 1)
 };
+
+__device__ __forceinline__ float grid_uniform(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+__device__ __forceinline__ double grid_uniform(double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readfirstlane((int)(b & 0xffffffffLL)), hi = __builtin_amdgcn_readfirstlane((int)(b >> 32));
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
 
 template <typename F> __device__ __forceinline__ F grid_inf();
 template <> __device__ __forceinline__ float grid_inf<float>() { return __builtin_inff(); }
@@ -120,7 +129,7 @@ template <> struct Best<double> {
 template <typename F, int NT>
 __device__ __forceinline__ void grid_build(const float *__restrict__ tg, int nt, float ox, float oy, float oz, F r,
                                            int cell_cap, GridPt<F> *__restrict__ tl, unsigned short *__restrict__ E,
-                                           F *__restrict__ red, PatchGrid<F> &g) {
+                                           F *__restrict__ red, PatchGrid<F> &g, int subdiv = 4) {
     constexpr int NW = NT / 64;
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
@@ -157,10 +166,21 @@ __device__ __forceinline__ void grid_build(const float *__restrict__ tg, int nt,
         }
     }
 
-    // 2. cell edge: r * (1 + 2^-7), enlarged until the grid fits the cell table (uniform across the workgroup).
-    //    NaN / inf coordinates degrade to a single cell (every query then scans the whole patch).
+    // 2. cell edge: r * (1 + 2^-7) / subdiv (patches that are dense relative to the radius get cells finer than the
+    //    radius; the stencil then spans wmax = ceil(r (1 + 2^-7) / h) cells per side), enlarged until the grid fits
+    //    the cell table (uniform across the workgroup).  NaN / inf coordinates degrade to a single cell (every
+    //    query then scans the whole patch).
     const F ex = mx[0] - mn[0], ey = mx[1] - mn[1], ez = mx[2] - mn[2];
-    F h = r * (F)1.0078125;
+    const F rpad = r * (F)1.0078125;
+    F h = rpad;
+    if (subdiv > 1) {
+        // subdivide only patches that are dense relative to the radius: aim at ~4 points per cell of the bounding
+        // box (a cube-root rule: conservative for surfaces, which leave most of the box empty)
+        const F n1 = (floor(ex / rpad) + (F)1) * (floor(ey / rpad) + (F)1) * (floor(ez / rpad) + (F)1);
+        const F sf = cbrt((F)nt / ((F)4 * n1));
+        const int sd = sf >= (F)subdiv ? subdiv : (sf < (F)1 ? 1 : (int)sf);
+        h = rpad / (F)sd;
+    }
     int nx = 1, ny = 1, nz = 1;
     const bool finite = (ex >= (F)0) && (ey >= (F)0) && (ez >= (F)0) && (ex + ey + ez < (F)1e30);
     if (finite) {
@@ -177,6 +197,15 @@ __device__ __forceinline__ void grid_build(const float *__restrict__ tg, int nt,
     g.minx = finite ? mn[0] : (F)0; g.miny = finite ? mn[1] : (F)0; g.minz = finite ? mn[2] : (F)0;
     g.h = h; g.inv_h = (F)1 / h;
     g.nx = nx; g.ny = ny; g.nz = nz;
+    {
+        const F wf = ceil(rpad / h - (F)1e-4);
+        g.wmax = wf < (F)1 ? 1 : (wf > (F)4096 ? 4096 : (int)wf);
+    }
+    // every thread computed the same grid: tell the compiler, so that it lives in scalar registers
+    g.minx = grid_uniform(g.minx); g.miny = grid_uniform(g.miny); g.minz = grid_uniform(g.minz);
+    g.h = grid_uniform(g.h); g.inv_h = grid_uniform(g.inv_h);
+    g.nx = __builtin_amdgcn_readfirstlane(g.nx); g.ny = __builtin_amdgcn_readfirstlane(g.ny);
+    g.nz = __builtin_amdgcn_readfirstlane(g.nz); g.wmax = __builtin_amdgcn_readfirstlane(g.wmax);
     const int ncell = nx * ny * nz;
 
     // 3. histogram: E[c + 1] += 1 through 32-bit LDS atomics on the packed uint16 pairs
@@ -272,61 +301,13 @@ template <typename F> __device__ __forceinline__ F grid_sqrt(F v);
 template <> __device__ __forceinline__ float grid_sqrt<float>(float v) { return __builtin_amdgcn_sqrtf(v); }  // 1 ulp; the bound carries slack
 template <> __device__ __forceinline__ double grid_sqrt<double>(double v) { return __builtin_sqrt(v); }
 
+// Flat scan of the first `cnt` entries of this lane's row list; idle lanes sit on the dummy slot.  Returns the number
+// of candidates this lane evaluated (profiling builds only use it).
 template <typename F, int NT>
-__device__ __forceinline__ void grid_nn(const PatchGrid<F> &g, const GridPt<F> *__restrict__ tl, int dummy,
-                                        const unsigned short *__restrict__ E, unsigned int *__restrict__ rl, bool valid,
-                                        F px, F py, F pz, Best<F> &best, unsigned long long *prof = nullptr) {
+__device__ __forceinline__ int grid_scan_rows(const GridPt<F> *__restrict__ tl, int dummy, const unsigned int *__restrict__ rl,
+                                              int cnt, F px, F py, F pz, Best<F> &best) {
     const int tid = (int)threadIdx.x;
-    int cx, cy, cz;
-    grid_cell(g, px, py, pz, cx, cy, cz);
-    // bound on the distance of anything that can still win, with slack for the rounding of cell coordinates
-    const F slack = (F)1e-5 * g.h + (F)1e-6 * (fabs(px) + fabs(py) + fabs(pz) + fabs(g.minx) + fabs(g.miny) + fabs(g.minz));
-    const F b2 = best.d2();
-    const F bnd = grid_sqrt<F>(b2) * (F)1.00001 + slack;
-    int x0 = floor_to_int((px - bnd - g.minx) * g.inv_h), x1 = floor_to_int((px + bnd - g.minx) * g.inv_h);
-    x0 = x0 < cx - 1 ? cx - 1 : x0;  // never wider than the 3-cell stencil (bnd <= r < h)
-    x1 = x1 > cx + 1 ? cx + 1 : x1;
-    x0 = x0 < 0 ? 0 : x0;
-    x1 = x1 >= g.nx ? g.nx - 1 : x1;
-    const bool xok = valid && x0 <= x1;
-    // per-axis: is the neighbour layer inside the grid, and how far away is it (squared, never overestimated)
-    const F fy = py - (g.miny + (F)cy * g.h), fz = pz - (g.minz + (F)cz * g.h);
-    F ylo = fy - slack, yhi = g.h - fy - slack, zlo = fz - slack, zhi = g.h - fz - slack;
-    ylo = ylo > (F)0 ? ylo : (F)0; yhi = yhi > (F)0 ? yhi : (F)0;
-    zlo = zlo > (F)0 ? zlo : (F)0; zhi = zhi > (F)0 ? zhi : (F)0;
-    const F ysq[3] = {ylo * ylo, (F)0, yhi * yhi}, zsq[3] = {zlo * zlo, (F)0, zhi * zhi};
-    const bool yin[3] = {cy >= 1 && cy <= g.ny, cy >= 0 && cy < g.ny, cy >= -1 && cy < g.ny - 1};
-    const bool zin[3] = {cz >= 1 && cz <= g.nz, cz >= 0 && cz < g.nz, cz >= -1 && cz < g.nz - 1};
-    const F b2s = b2 * (F)1.00001;
-    const int nxny = __mul24(g.nx, g.ny);
-    const int base0 = __mul24(__mul24(cz, g.ny) + cy, g.nx) + x0;  // garbage when cy / cz are far outside: then no row is kept
-    const int span = x1 - x0 + 1;
-
-    // 1. prefix entries of the 9 rows (centre row first, then the four face neighbours, then the corners), all
-    //    fetched before any is used; rows outside the grid or beyond the bound read entry 0 twice (empty)
-    unsigned int s_[GRID_ROWS], e_[GRID_ROWS];
-#pragma unroll
-    for (int r = 0; r < GRID_ROWS; ++r) {
-        constexpr int DY[GRID_ROWS] = {0, -1, 1, 0, 0, -1, 1, -1, 1};
-        constexpr int DZ[GRID_ROWS] = {0, 0, 0, -1, 1, -1, -1, 1, 1};
-        const bool k = xok && yin[DY[r] + 1] && zin[DZ[r] + 1] && !(ysq[DY[r] + 1] + zsq[DZ[r] + 1] > b2s);
-        const int a = base0 + DY[r] * g.nx + DZ[r] * nxny;
-        s_[r] = E[k ? a : 0];
-        e_[r] = E[k ? a + span : 0];
-    }
-    // 2. compact the non-empty rows into the per-lane list (branch free: every row is written at the cursor, the
-    //    cursor only moves past rows worth keeping), sentinel {0, 0} behind them
-    int cnt = 0;
-#pragma unroll
-    for (int r = 0; r < GRID_ROWS; ++r) {
-        rl[cnt * NT + tid] = s_[r] | (e_[r] << 16);
-        cnt += s_[r] < e_[r] ? 1 : 0;
-    }
-    rl[cnt * NT + tid] = 0u;
-#ifdef F4L_ICP_PROF
     int n_steps = 0;
-#endif
-    // 3. flat scan; idle lanes sit on the dummy slot
     unsigned int cur = rl[tid];
     int j = (int)(cur & 0xffffu), e = (int)(cur >> 16);
     int k = cnt < 1 ? cnt : 1;
@@ -349,11 +330,122 @@ __device__ __forceinline__ void grid_nn(const PatchGrid<F> &g, const GridPt<F> *
         q = qn; j = jn; e = en;
         nxt = roll ? nn : nxt;
     }
+    return n_steps;
+}
+
+// The rare wide search of grid_nn (points without a previous correspondence on a grid finer than the radius): the
+// (2 W + 1)^2 rows of the stencil, 9 at a time, every lane pruning with its own bound.  Deliberately NOT inlined and
+// written with rolled loops: it must not cost the common path registers or instruction-cache footprint.
+template <typename F, int NT>
+__device__ __forceinline__ Best<F> grid_nn_wide(const PatchGrid<F> &g, const GridPt<F> *__restrict__ tl, int dummy,
+                                                       const unsigned short *__restrict__ E, unsigned int *__restrict__ rl,
+                                                       int W, bool xok, int cy, int cz, int base0, int span, F fy, F fz,
+                                                       F slack, F b2s, F px, F py, F pz, Best<F> best) {
+    const int tid = (int)threadIdx.x;
+    const int nxny = __mul24(g.nx, g.ny);
+    int dy = -W, dz = -W;  // uniform
+    while (dz <= W) {
+        int cnt = 0;
+#pragma nounroll
+        for (int r = 0; r < 9 && dz <= W; ++r) {
+            const int ady = dy < 0 ? -dy : dy, adz = dz < 0 ? -dz : dz;
+            F ddy = dy == 0 ? (F)0 : (dy < 0 ? fy : g.h - fy) + (F)(ady - 1) * g.h - slack;
+            F ddz = dz == 0 ? (F)0 : (dz < 0 ? fz : g.h - fz) + (F)(adz - 1) * g.h - slack;
+            ddy = ddy > (F)0 ? ddy : (F)0;
+            ddz = ddz > (F)0 ? ddz : (F)0;
+            const int y = cy + dy, z = cz + dz;
+            const bool k = xok && y >= 0 && y < g.ny && z >= 0 && z < g.nz && !(ddy * ddy + ddz * ddz > b2s);
+            const int a = base0 + dy * g.nx + dz * nxny;
+            const unsigned int s1 = E[k ? a : 0], e1 = E[k ? a + span : 0];
+            rl[cnt * NT + tid] = s1 | (e1 << 16);
+            cnt += s1 < e1 ? 1 : 0;
+            if (++dy > W) { dy = -W; ++dz; }
+        }
+        rl[cnt * NT + tid] = 0u;
+        grid_scan_rows<F, NT>(tl, dummy, rl, cnt, px, py, pz, best);
+    }
+    return best;  // by value: a reference would pin the caller's record to memory on the common path too
+}
+
+template <typename F, int NT>
+__device__ __forceinline__ void grid_nn(const PatchGrid<F> &g, const GridPt<F> *__restrict__ tl, int dummy,
+                                        const unsigned short *__restrict__ E, unsigned int *__restrict__ rl, bool valid,
+                                        F px, F py, F pz, Best<F> &best, unsigned long long *prof = nullptr) {
+    const int tid = (int)threadIdx.x;
+    int cx, cy, cz;
+    grid_cell(g, px, py, pz, cx, cy, cz);
+    // bound on the distance of anything that can still win, with slack for the rounding of cell coordinates
+    const F slack = (F)1e-5 * g.h + (F)1e-6 * (fabs(px) + fabs(py) + fabs(pz) + fabs(g.minx) + fabs(g.miny) + fabs(g.minz));
+    const F b2 = best.d2();
+    const F bnd = grid_sqrt<F>(b2) * (F)1.00001 + slack;
+    int x0 = floor_to_int((px - bnd - g.minx) * g.inv_h), x1 = floor_to_int((px + bnd - g.minx) * g.inv_h);
+    x0 = x0 < cx - g.wmax ? cx - g.wmax : x0;  // never wider than the stencil the grid was built for
+    x1 = x1 > cx + g.wmax ? cx + g.wmax : x1;
+    x0 = x0 < 0 ? 0 : x0;
+    x1 = x1 >= g.nx ? g.nx - 1 : x1;
+    const bool xok = valid && x0 <= x1;
+    // layers of cells this lane's bound reaches on either side of its own cell (y and z; x is the run itself)
+    int W = 1;  // wave maximum (uniform); grids with cells no finer than the radius never need more than one layer
+#ifndef F4L_GRID_NOWIDE
+    if (g.wmax > 1) {
+        int wl = floor_to_int(bnd * g.inv_h) + 1;
+        wl = valid ? (wl > g.wmax ? g.wmax : wl) : 0;
+        W = __any(wl > 1) ? g.wmax : 1;  // (the rows of a wider stencil than a lane needs are pruned by its bound)
+    }
+#endif
+    const F fy = py - (g.miny + (F)cy * g.h), fz = pz - (g.minz + (F)cz * g.h);
+    const F b2s = b2 * (F)1.00001;
+    const int nxny = __mul24(g.nx, g.ny);
+    const int base0 = __mul24(__mul24(cz, g.ny) + cy, g.nx) + x0;  // garbage when cy / cz are far outside: then no row is kept
+    const int span = x1 - x0 + 1;
+#ifdef F4L_ICP_PROF
+    int n_steps = 0, cnt_total = 0;
+#endif
+
+    if (W <= 1) {
+        // ---- the common case: every bound of the wave fits the 3 x 3 layers around its cell
+        F ylo = fy - slack, yhi = g.h - fy - slack, zlo = fz - slack, zhi = g.h - fz - slack;
+        ylo = ylo > (F)0 ? ylo : (F)0; yhi = yhi > (F)0 ? yhi : (F)0;
+        zlo = zlo > (F)0 ? zlo : (F)0; zhi = zhi > (F)0 ? zhi : (F)0;
+        const F ysq[3] = {ylo * ylo, (F)0, yhi * yhi}, zsq[3] = {zlo * zlo, (F)0, zhi * zhi};
+        const bool yin[3] = {cy >= 1 && cy <= g.ny, cy >= 0 && cy < g.ny, cy >= -1 && cy < g.ny - 1};
+        const bool zin[3] = {cz >= 1 && cz <= g.nz, cz >= 0 && cz < g.nz, cz >= -1 && cz < g.nz - 1};
+        // prefix entries of the 9 rows (centre row first, then the four face neighbours, then the corners), all
+        // fetched before any is used; rows outside the grid or beyond the bound read entry 0 twice (empty)
+        unsigned int s_[GRID_ROWS], e_[GRID_ROWS];
+#pragma unroll
+        for (int r = 0; r < GRID_ROWS; ++r) {
+            constexpr int DY[GRID_ROWS] = {0, -1, 1, 0, 0, -1, 1, -1, 1};
+            constexpr int DZ[GRID_ROWS] = {0, 0, 0, -1, 1, -1, -1, 1, 1};
+            const bool k = xok && yin[DY[r] + 1] && zin[DZ[r] + 1] && !(ysq[DY[r] + 1] + zsq[DZ[r] + 1] > b2s);
+            const int a = base0 + DY[r] * g.nx + DZ[r] * nxny;
+            s_[r] = E[k ? a : 0];
+            e_[r] = E[k ? a + span : 0];
+        }
+        // compact the non-empty rows into the per-lane list (branch free: every row is written at the cursor, the
+        // cursor only moves past rows worth keeping), sentinel {0, 0} behind them
+        int cnt = 0;
+#pragma unroll
+        for (int r = 0; r < GRID_ROWS; ++r) {
+            rl[cnt * NT + tid] = s_[r] | (e_[r] << 16);
+            cnt += s_[r] < e_[r] ? 1 : 0;
+        }
+        rl[cnt * NT + tid] = 0u;
+#ifdef F4L_ICP_PROF
+        cnt_total += cnt;
+        n_steps +=
+#endif
+        grid_scan_rows<F, NT>(tl, dummy, rl, cnt, px, py, pz, best);
+    } else {
+#ifndef F4L_GRID_NOWIDE
+        best = grid_nn_wide<F, NT>(g, tl, dummy, E, rl, W, xok, cy, cz, base0, span, fy, fz, slack, b2s, px, py, pz, best);
+#endif
+    }
 #ifdef F4L_ICP_PROF
     if (prof) {
         atomicAdd(&prof[6], (unsigned long long)n_steps);
         atomicAdd(&prof[7], (unsigned long long)(xok ? 9 : 0));
-        atomicAdd(&prof[8], (unsigned long long)cnt);
+        atomicAdd(&prof[8], (unsigned long long)cnt_total);
         atomicAdd(&prof[9], valid ? 1ULL : 0ULL);
         int m = n_steps;
 #pragma unroll
