@@ -16,8 +16,9 @@ Scaling is weak: tiles are the reference's independent units (<= 1 M points each
 max_pts_per_tile), every rank owns one tile and only the per-patch results are exchanged.
 
 Extra objects on the JSON line:
-  roofline     dominant kernel = icp_kernel; achieved = algorithmic bytes per launch (20 iters x 24 B per source
-               point) / its mean duration measured with events on the launch stream; peak = 8 TB/s.
+  roofline     dominant kernel = icp_kernel (the fused loop body); achieved = algorithmic bytes per launch (20 iters x
+               24 B + 24 B Kabsch read + 24 B row written = 528 B per source point) / its mean duration
+               measured with events on the launch stream; peak = 8 TB/s.
   cpu_baseline the C oracle (oracle/f4l_oracle.c, 1 thread, "port") timed on a bounded sample of the same patches.
 """
 import argparse
@@ -32,6 +33,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is what a copy achieves
 ICP_BYTES_PER_PT_ITER = 24  # 12 B source point + 12 B share of the target patch
+FIXED_BYTES_PER_PT = 48      # ... + Kabsch init read (24 B/pt) + displacement row written (24 B/pt): the fused launch does all three
 MAX_ITER = 20
 MAX_CORR = 0.1
 
@@ -128,7 +130,7 @@ def main():
     if rank == 0:
         ms_per_step = 1e3 * elapsed / max(args.steps, 1)
         value = world * n / (ms_per_step * 1e-3) / 1e6
-        alg_bytes = ICP_BYTES_PER_PT_ITER * MAX_ITER * n
+        alg_bytes = (ICP_BYTES_PER_PT_ITER * MAX_ITER + FIXED_BYTES_PER_PT) * n  # 528 B per source point
         achieved = alg_bytes / (icp_ms * 1e-3) / 1e9
         line = {
             "metric": "M-points/sec piecewise ICP (20 iters, two-epoch cloud)",

@@ -9,9 +9,9 @@ cd /tmp && export TMPDIR=/tmp
 rm -rf $OUT; mkdir -p $OUT
 cd $R
 python3 bench.py --steps 10 --warmup 3 > $OUT/bench.json.log 2>$OUT/bench.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --steps 5 --warmup 2 --cpu-seconds 0 > $OUT/stats.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -- python3 bench.py --steps 3 --warmup 1 --cpu-seconds 0 > $OUT/fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -- python3 bench.py --steps 3 --warmup 1 --cpu-seconds 0 > $OUT/write.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --steps 5 --warmup 2 --cpu-seconds 0 --extras 0 > $OUT/stats.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -- python3 bench.py --steps 3 --warmup 1 --cpu-seconds 0 --extras 0 > $OUT/fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -- python3 bench.py --steps 3 --warmup 1 --cpu-seconds 0 --extras 0 > $OUT/write.log 2>&1
 python3 - "$OUT" <<'PY'
 import csv, glob, json, sys, collections
 out = sys.argv[1]

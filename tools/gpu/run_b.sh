@@ -1,1 +1,4 @@
-python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 5 --warmup 2 --cpu-seconds 0 --extras 0 2>&1 | tail -2
+bash tools/gpu/profile_round.sh r1_d > gpurun_out/profile_r1_d.log 2>&1
+tail -1 gpurun_out/prof_r1_d/bench.json.log
+cat gpurun_out/prof_r1_d/traffic_raw.json
+head -4 gpurun_out/prof_r1_d/stats/*/*_kernel_stats.csv | cut -c1-150
