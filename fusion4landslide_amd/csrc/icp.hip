@@ -67,7 +67,8 @@ struct IcpArgs {
     int32_t *iters_out, *corr_out;
     int subdiv;     // cells per radius the grid may use (patch_grid.h: grid_build)
     double mu_frac; // certificate margin as a fraction of the correspondence radius
-    int debug;  // F4L_ICP_DEBUG env: 1 = skip the solve, 2 = skip the search, 4 = no row pruning (experiments)
+    int debug;  // F4L_ICP_DEBUG env, bit switches for A/B measurements and tests: 4 = no certificates, 8 = no bound from
+                // the previous correspondence, 128 = always the Jacobi SVD (no Newton), 64 = search counters (profiling build)
     unsigned long long *prof;  // F4L_ICP_PROF builds only: per-phase shader-clock totals (see f4l_piecewise_icp)
 };
 
@@ -324,7 +325,7 @@ __global__ __launch_bounds__(NW * 64, ICP_WAVES_PER_EU) void icp_kernel(IcpArgs 
 
     const int n_pass = active ? a.max_iter + 1 : 0;
     // the solving wave rotates with the patch index so that co-resident workgroups do not all solve on the same SIMD
-    const int solver = (a.debug & 16) ? 0 : (int)(blockIdx.x % NW);
+    const int solver = (int)(blockIdx.x % NW);
     const unsigned long long lt_mask = (1ULL << lane) - 1ULL;
 
     for (int pass = 0; pass < n_pass; ++pass) {
@@ -521,7 +522,7 @@ __global__ __launch_bounds__(NW * 64, ICP_WAVES_PER_EU) void icp_kernel(IcpArgs 
             // update [Ru | tu] of this iteration (origin-relative): p_new = Ru p_old + tu
             double Ru[9], tu[3];
             bool have = false;
-            if (!done && m > 0.0 && !(a.debug & 1)) {
+            if (!done && m > 0.0) {
                 have = true;
                 if (MODE == F4L_ICP_POINT2POINT) {
                     // Eigen::umeyama without scaling.  Means about the centring point (zero shift when the sums are
@@ -831,7 +832,7 @@ static int f4l::icp_launch_host(const float *src, const int64_t *src_off, const 
     int src_cap = 0;
     {
         const size_t sb = (size_t)((max_src_patch_host + 3) & ~(int64_t)3) * 3 * (f64 ? 8 : 4);
-        if (!getenv("F4L_ICP_NOSL") && lds + sb <= (size_t)ICP_LDS_BUDGET && (lds + sb <= 40 * 1024 || lds > 40 * 1024)) src_cap = (int)max_src_patch_host;
+        if (lds + sb <= (size_t)ICP_LDS_BUDGET && (lds + sb <= 40 * 1024 || lds > 40 * 1024)) src_cap = (int)max_src_patch_host;
         if (src_cap) lds += sb;
     }
     lds = (lds + 15) & ~(size_t)15;

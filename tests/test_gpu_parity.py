@@ -312,6 +312,25 @@ def test_icp_every_workgroup_shape_matches_oracle(eng, waves, monkeypatch):
     assert np.median(disp) <= 1e-5 and (disp <= 1e-4).mean() >= 0.85 and disp.max() <= 2e-3
 
 
+@pytest.mark.parametrize("switch,what", [("4", "no certificates: every point searched in every pass"),
+                                         ("8", "no bound from the previous correspondence"),
+                                         ("128", "Jacobi SVD instead of Newton on SO(3)")])
+def test_icp_shortcuts_do_not_change_the_answer(eng, switch, what, monkeypatch):
+    """The certificates, the bounded search and the Newton solve are shortcuts, not approximations: switching each off
+    (F4L_ICP_DEBUG bits) must give the same transforms (float64 search: to 1e-9 m with equal iteration counts and
+    correspondences)."""
+    d = _patches(n=30_000, cells=6, seed=14)
+    args = (dev(d["src"]), dev(d["src_off"]), dev(d["tgt"]), dev(d["tgt_off"]))
+    kw = dict(max_corr_dist=0.1, max_iter=30, search="f64", return_corr=True)
+    base = eng.piecewise_icp(*args, **kw)
+    monkeypatch.setenv("F4L_ICP_DEBUG", switch)
+    alt = eng.piecewise_icp(*args, **kw)
+    monkeypatch.delenv("F4L_ICP_DEBUG")
+    assert _disp_per_patch(d, alt["T"].cpu().numpy(), base["T"].cpu().numpy()).max() <= 1e-9, what
+    assert torch.equal(alt["iters"], base["iters"]) and torch.equal(alt["corr"], base["corr"]), what
+    assert (alt["fitness"] - base["fitness"]).abs().max().item() == 0.0
+
+
 def test_icp_medium_patches_without_room_for_every_lds_array(eng):
     """Patches of a few thousand points: the LDS plan drops the staged sources (and, beyond, the certificate arrays)
     before it gives up the grid; results must not depend on which arrays made it into LDS."""

@@ -1,1 +1,1 @@
-python -m pytest tests -m gpu -q --durations=6 2>&1 | tail -12
+python -m pytest tests -m gpu -q 2>&1 | tail -4
