@@ -331,6 +331,22 @@ def test_icp_shortcuts_do_not_change_the_answer(eng, switch, what, monkeypatch):
     assert (alt["fitness"] - base["fitness"]).abs().max().item() == 0.0
 
 
+@pytest.mark.parametrize("search", ["f32", "f64"])
+def test_icp_is_bit_reproducible_run_to_run(eng, search):
+    """Counting sort with atomics, per-wave queues, rotating solver wave: none of it may leak scheduling order into the
+    results.  Same input, eight launches, bit-identical outputs (tools/gpu/determinism.py is the long version)."""
+    d = _patches(n=60_000, cells=8, seed=15)
+    args = (dev(d["src"]), dev(d["src_off"]), dev(d["tgt"]), dev(d["tgt_off"]))
+    first = None
+    for _ in range(8):
+        out = eng.piecewise_icp(*args, max_corr_dist=0.1, max_iter=20, fixed_iters=True, search=search, return_corr=True)
+        sig = (out["T"], out["fitness"], out["rmse"], out["iters"], out["corr"])
+        if first is None:
+            first = [t.clone() for t in sig]
+        else:
+            assert all(torch.equal(a, b) for a, b in zip(sig, first))
+
+
 def test_icp_medium_patches_without_room_for_every_lds_array(eng):
     """Patches of a few thousand points: the LDS plan drops the staged sources (and, beyond, the certificate arrays)
     before it gives up the grid; results must not depend on which arrays made it into LDS."""

@@ -1,1 +1,1 @@
-python -m pytest tests -m gpu -q 2>&1 | tail -4
+python tools/gpu/determinism.py 2>&1 | grep -v amdgpu | tail -12
