@@ -62,6 +62,7 @@ struct IcpArgs {
     int tgt_cap;   // target slots in LDS (patches with more targets take the brute-force global path)
     int cert_cap;  // source points per patch the certificate arrays (prev, mabs, queue) can hold
     int src_cap;   // source points per patch staged in LDS (0: read from global memory every pass)
+    int pp_cap;    // source points per patch whose position at their last search is kept (per-point certificates)
     int cell_cap;  // grid cells the prefix table can hold
     double *T_out, *fitness_out, *rmse_out;
     int32_t *iters_out, *corr_out;
@@ -170,7 +171,8 @@ __global__ __launch_bounds__(NW * 64, ICP_WAVES_PER_EU) void icp_kernel(IcpArgs 
     GridPt<F> *tl = reinterpret_cast<GridPt<F> *>(qcnt + 4);
     F *mabs = reinterpret_cast<F *>(tl + a.tgt_cap + 1);  // tl[nt] is the dummy record of the grid
     F *sl = mabs + ((a.cert_cap + 3) & ~3);  // origin-relative source points, packed xyz
-    unsigned int *rl = reinterpret_cast<unsigned int *>(sl + 3 * ((a.src_cap + 3) & ~3));
+    F *ps = sl + 3 * ((a.src_cap + 3) & ~3);  // position of every source point when it was last searched
+    unsigned int *rl = reinterpret_cast<unsigned int *>(ps + 3 * ((a.pp_cap + 3) & ~3));
     unsigned short *E = reinterpret_cast<unsigned short *>(rl + (GRID_ROWS + 1) * NT);
     unsigned short *prev = E + a.cell_cap + 8;
     const int seg = ((a.cert_cap + NT - 1) / NT) * 64;  // queue entries one wave can produce
@@ -187,6 +189,9 @@ __global__ __launch_bounds__(NW * 64, ICP_WAVES_PER_EU) void icp_kernel(IcpArgs 
     const bool tgt_in_lds = nt > 0 && nt <= a.tgt_cap;
     const bool use_cert = tgt_in_lds && ns <= a.cert_cap && !(a.debug & 4);
     const bool src_in_lds = ns <= a.src_cap;
+    // per-point certificates measure each point's own displacement since its last search; without room for that they
+    // fall back to the patch-wide motion bound accumulated in state[29]
+    const bool per_point = use_cert && ns <= a.pp_cap;
 
     // per-patch origin: first target point (else first source point, else 0)
     float ox = 0.f, oy = 0.f, oz = 0.f;
@@ -387,7 +392,11 @@ __global__ __launch_bounds__(NW * 64, ICP_WAVES_PER_EU) void icp_kernel(IcpArgs 
                 const F py = R3 * x + R4 * y + R5 * z + t1f;
                 const F pz = R6 * x + R7 * y + R8 * z + t2f;
                 const int pv = (int)prev[ii];  // 0xffff: never searched, 0xfffe: nothing within the search radius
-                const F room = mabs[ii] - dsum;  // distance every OTHER target is still known to keep
+                F room = mabs[ii] - dsum;  // distance every OTHER target is still known to keep
+                if (per_point) {
+                    const F mx = px - ps[3 * ii], my = py - ps[3 * ii + 1], mz = pz - ps[3 * ii + 2];
+                    room = mabs[ii] - grid_sqrt<F>(grid_d2(mx, my, mz)) * (F)1.000001;
+                }
                 const GridPt<F> q = tl[pv < 0xfffe ? pv : 0];
                 const F d = grid_d2(px - q.x, py - q.y, pz - q.z);
                 bool cert = pv < 0xfffe ? grid_sqrt<F>(d) * (F)1.000001 < room : (pv == 0xfffe && room > rF * (F)1.000001);
@@ -453,7 +462,10 @@ __global__ __launch_bounds__(NW * 64, ICP_WAVES_PER_EU) void icp_kernel(IcpArgs 
                 if (use_cert && valid) {
                     const F m2 = best.second < b0 ? best.second : b0;
                     prev[i] = (unsigned short)(best.found() ? best.slot() : 0xfffe);
-                    mabs[i] = grid_sqrt<F>(m2) * (F)0.999999 + dsum;
+                    if (per_point) {
+                        mabs[i] = grid_sqrt<F>(m2) * (F)0.999999;
+                        ps[3 * i] = px; ps[3 * i + 1] = py; ps[3 * i + 2] = pz;
+                    } else mabs[i] = grid_sqrt<F>(m2) * (F)0.999999 + dsum;
                 }
             } else {
                 best.init(r2);
@@ -828,15 +840,17 @@ static int f4l::icp_launch_host(const float *src, const int64_t *src_off, const 
     int cert_cap = 0;
     if (max_src_patch_host < 0xfff0 && lds + cert_bytes(max_src_patch_host) <= (size_t)ICP_LDS_BUDGET) cert_cap = (int)max_src_patch_host;
     lds += cert_bytes(cert_cap);
-    // sources in LDS too when that keeps at least four workgroups on a CU (or when it all fits anyway for one)
-    int src_cap = 0;
+    // then, while at least four workgroups still fit a CU (or nothing more than one fits anyway): the per-point
+    // certificate positions (worth ~10 % fewer searches than the patch-wide motion bound), then the staged sources
+    int src_cap = 0, pp_cap = 0;
     {
         const size_t sb = (size_t)((max_src_patch_host + 3) & ~(int64_t)3) * 3 * (f64 ? 8 : 4);
-        if (lds + sb <= (size_t)ICP_LDS_BUDGET && (lds + sb <= 40 * 1024 || lds > 40 * 1024)) src_cap = (int)max_src_patch_host;
-        if (src_cap) lds += sb;
+        auto fits = [&](size_t extra) { return lds + extra <= (size_t)ICP_LDS_BUDGET && (lds + extra <= 40 * 1024 || lds > 40 * 1024); };
+        if (cert_cap && !getenv("F4L_ICP_NOPP") && fits(sb)) { pp_cap = cert_cap; lds += sb; }
+        if (fits(sb)) { src_cap = (int)max_src_patch_host; lds += sb; }
     }
     lds = (lds + 15) & ~(size_t)15;
-    a.tgt_cap = tgt_cap; a.cert_cap = cert_cap; a.cell_cap = cell_cap; a.src_cap = src_cap;
+    a.tgt_cap = tgt_cap; a.cert_cap = cert_cap; a.cell_cap = cell_cap; a.src_cap = src_cap; a.pp_cap = pp_cap;
     a.prof = nullptr;
 #ifdef F4L_ICP_PROF
     if (getenv("F4L_ICP_PROF")) {
