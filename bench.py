@@ -87,7 +87,7 @@ def main():
     counter = [0]
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
 
-    def step(i_timed=None, search="f32"):
+    def step(i_timed=None, search="f64"):
         # the whole loop body in one launch (f4l_patch_loop): Kabsch init -> ICP -> rows
         if i_timed is not None:
             ev[i_timed][0].record()
@@ -136,9 +136,9 @@ def main():
             "metric": "M-points/sec piecewise ICP (20 iters, two-epoch cloud)",
             "value": round(value, 3), "unit": "Mpts/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f64", "data": "synthetic",
             "config": {"workload": args.config, "points_per_epoch_per_gpu": n, "patches_per_gpu": P,
-                       "icp": "point2point, 20 fixed iters, max_corr_dist 0.1 m", "parallelism": f"tiles x{world}",
+                       "icp": "point2point, 20 fixed iters, max_corr_dist 0.1 m, float64 search (parity mode)", "parallelism": f"tiles x{world}",
                        "mean_fitness": round(float(out["fitness"].mean().item()), 4)},
             "roofline": {"bound": "hbm", "kernel": "icp_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
@@ -175,9 +175,10 @@ def extras(torch, engine, step, src, args):
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / reps
 
-    # the same step with the float64 search (parity mode: reproduces the CPU oracle to 1e-9 m, see tests)
-    s64 = timed(lambda: step(search="f64"), max(2, args.steps // 2))
-    out["parity_mode_f64"] = {"value": round(n / s64 / 1e6, 3), "unit": "Mpts/s", "ms_per_step": round(1e3 * s64, 4)}
+    # the same step in the fast mode (float32 search and partial sums; not the headline: an ill-posed patch can end in
+    # a different local solution than the float64 arithmetic of the reference)
+    s32 = timed(lambda: step(search="f32"), max(2, args.steps // 2))
+    out["fast_mode_f32"] = {"value": round(n / s32 / 1e6, 3), "unit": "Mpts/s", "ms_per_step": round(1e3 * s32, 4)}
     # exact kNN-30 of the source epoch (supervoxel stage): 12 B read + 120 B written per point
     sk = timed(lambda: engine.knn(src, 30), 3)
     out["knn30"] = {"value": round(n / sk / 1e6, 3), "unit": "Mpts/s", "ms": round(1e3 * sk, 3),

@@ -169,10 +169,10 @@ __global__ __launch_bounds__(NW * 64, ICP_WAVES_PER_EU) void icp_kernel(IcpArgs 
     double *state = scratch + NW * 32;
     int *qcnt = reinterpret_cast<int *>(state + 48);
     GridPt<F> *tl = reinterpret_cast<GridPt<F> *>(qcnt + 4);
-    F *mabs = reinterpret_cast<F *>(tl + a.tgt_cap + 1);  // tl[nt] is the dummy record of the grid
-    F *sl = mabs + ((a.cert_cap + 3) & ~3);  // origin-relative source points, packed xyz
-    F *ps = sl + 3 * ((a.src_cap + 3) & ~3);  // position of every source point when it was last searched
-    unsigned int *rl = reinterpret_cast<unsigned int *>(ps + 3 * ((a.pp_cap + 3) & ~3));
+    float *mabs = reinterpret_cast<float *>(tl + a.tgt_cap + 1);  // tl[nt] is the dummy record of the grid
+    float *ps = mabs + ((a.cert_cap + 3) & ~3);  // position of every source point when it was last searched (float32)
+    F *sl = reinterpret_cast<F *>(ps + 3 * ((a.pp_cap + 3) & ~3));  // origin-relative source points, packed xyz
+    unsigned int *rl = reinterpret_cast<unsigned int *>(sl + 3 * ((a.src_cap + 3) & ~3));
     unsigned short *E = reinterpret_cast<unsigned short *>(rl + (GRID_ROWS + 1) * NT);
     unsigned short *prev = E + a.cell_cap + 8;
     const int seg = ((a.cert_cap + NT - 1) / NT) * 64;  // queue entries one wave can produce
@@ -219,7 +219,7 @@ __global__ __launch_bounds__(NW * 64, ICP_WAVES_PER_EU) void icp_kernel(IcpArgs 
             for (int i = tid; i < ns; i += NT) {
                 sum[0] += (double)((F)sg[3 * i] - (F)ox); sum[1] += (double)((F)sg[3 * i + 1] - (F)oy);
                 sum[2] += (double)((F)sg[3 * i + 2] - (F)oz);
-                if (use_cert) { prev[i] = 0xffffu; mabs[i] = (F)0; }
+                if (use_cert) { prev[i] = 0xffffu; mabs[i] = 0.f; }
                 if (src_in_lds) { sl[3 * i] = (F)sg[3 * i] - (F)ox; sl[3 * i + 1] = (F)sg[3 * i + 1] - (F)oy; sl[3 * i + 2] = (F)sg[3 * i + 2] - (F)oz; }
             }
             block_sum<3, NW>(sum, scratch);
@@ -392,18 +392,24 @@ __global__ __launch_bounds__(NW * 64, ICP_WAVES_PER_EU) void icp_kernel(IcpArgs 
                 const F py = R3 * x + R4 * y + R5 * z + t1f;
                 const F pz = R6 * x + R7 * y + R8 * z + t2f;
                 const int pv = (int)prev[ii];  // 0xffff: never searched, 0xfffe: nothing within the search radius
-                F room = mabs[ii] - dsum;  // distance every OTHER target is still known to keep
+                // distance every OTHER target is still known to keep.  The certificate arrays are float32 in both modes:
+                // bounds stored rounded down, positions with an allowance for their rounding.
+                F room = (F)mabs[ii] - dsum;
                 if (per_point) {
-                    const F mx = px - ps[3 * ii], my = py - ps[3 * ii + 1], mz = pz - ps[3 * ii + 2];
-                    room = mabs[ii] - grid_sqrt<F>(grid_d2(mx, my, mz)) * (F)1.000001;
+                    const F mx = px - (F)ps[3 * ii], my = py - (F)ps[3 * ii + 1], mz = pz - (F)ps[3 * ii + 2];
+                    F moved = grid_sqrt<F>(grid_d2(mx, my, mz)) * (F)1.000001;
+                    if (sizeof(F) == 8) moved += (F)2e-7 * (fabs(px) + fabs(py) + fabs(pz));
+                    room = (F)mabs[ii] - moved;
                 }
                 const GridPt<F> q = tl[pv < 0xfffe ? pv : 0];
-                const F d = grid_d2(px - q.x, py - q.y, pz - q.z);
+                F qx, qy, qz;
+                grid_rel(g, q, qx, qy, qz);
+                const F d = grid_d2(px - qx, py - qy, pz - qz);
                 bool cert = pv < 0xfffe ? grid_sqrt<F>(d) * (F)1.000001 < room : (pv == 0xfffe && room > rF * (F)1.000001);
                 cert = cert && valid;
                 const bool hit = cert && pv < 0xfffe && d < r2;
                 const int qid = (int)(q.tag >> 16);
-                if (hit) accumulate(px, py, pz, q.x, q.y, q.z, d, qid);
+                if (hit) accumulate(px, py, pz, qx, qy, qz, d, qid);
                 if (a.corr_out && cert) a.corr_out[s0 + i] = hit ? qid : -1;
                 const bool need = valid && !cert;
                 const unsigned long long m = __ballot(need);
@@ -449,7 +455,9 @@ __global__ __launch_bounds__(NW * 64, ICP_WAVES_PER_EU) void icp_kernel(IcpArgs 
                     const int pv = (int)prev[i];
                     if (pv < 0xfffe && !(a.debug & 8)) {
                         const GridPt<F> q = tl[pv];
-                        const F bb = grid_sqrt<F>(grid_d2(px - q.x, py - q.y, pz - q.z)) * (F)1.000001 + mu;
+                        F qx, qy, qz;
+                        grid_rel(g, q, qx, qy, qz);
+                        const F bb = grid_sqrt<F>(grid_d2(px - qx, py - qy, pz - qz)) * (F)1.000001 + mu;
                         b0 = bb * bb < rs2 ? bb * bb : rs2;
                     }
                 }
@@ -463,9 +471,9 @@ __global__ __launch_bounds__(NW * 64, ICP_WAVES_PER_EU) void icp_kernel(IcpArgs 
                     const F m2 = best.second < b0 ? best.second : b0;
                     prev[i] = (unsigned short)(best.found() ? best.slot() : 0xfffe);
                     if (per_point) {
-                        mabs[i] = grid_sqrt<F>(m2) * (F)0.999999;
-                        ps[3 * i] = px; ps[3 * i + 1] = py; ps[3 * i + 2] = pz;
-                    } else mabs[i] = grid_sqrt<F>(m2) * (F)0.999999 + dsum;
+                        mabs[i] = (float)(grid_sqrt<F>(m2) * (F)0.999999);
+                        ps[3 * i] = (float)px; ps[3 * i + 1] = (float)py; ps[3 * i + 2] = (float)pz;
+                    } else mabs[i] = (float)((grid_sqrt<F>(m2) * (F)0.999999 + dsum) * (F)0.9999998);
                 }
             } else {
                 best.init(r2);
@@ -476,7 +484,7 @@ __global__ __launch_bounds__(NW * 64, ICP_WAVES_PER_EU) void icp_kernel(IcpArgs 
             if (a.corr_out && valid) a.corr_out[s0 + i] = hit ? bj : -1;
             if (hit) {
                 F qx, qy, qz;
-                if (tgt_in_lds) { const GridPt<F> q = tl[best.slot()]; qx = q.x; qy = q.y; qz = q.z; }
+                if (tgt_in_lds) { const GridPt<F> q = tl[best.slot()]; grid_rel(g, q, qx, qy, qz); }
                 else { qx = (F)tg[3 * bj] - (F)ox; qy = (F)tg[3 * bj + 1] - (F)oy; qz = (F)tg[3 * bj + 2] - (F)oz; }
                 accumulate(px, py, pz, qx, qy, qz, best.d2(), bj);
             }
@@ -800,7 +808,8 @@ static int f4l::icp_launch_host(const float *src, const int64_t *src_off, const 
     if (P > 0x7fffffffLL || max_src_patch_host > 0x3fffffffLL || max_tgt_patch_host > 0x3fffffffLL)
         return F4L_EUNSUPPORTED;
     const bool f64 = search_precision == F4L_SEARCH_F64;
-    const size_t pt = f64 ? sizeof(GridPt<double>) : sizeof(GridPt<float>);
+    const size_t pt = sizeof(GridPt<float>);  // 16 B in both modes
+    static_assert(sizeof(GridPt<double>) == sizeof(GridPt<float>), "grid records are 16 B in both modes");
     IcpArgs a;
     a.src = src; a.src_off = src_off; a.tgt = tgt; a.tgt_off = tgt_off; a.P = P;
     a.init_T = init_T; a.tgt_normals = tgt_normals;
@@ -835,7 +844,7 @@ static int f4l::icp_launch_host(const float *src, const int64_t *src_off, const 
     const int nt_threads = nw * 64;
     auto cert_bytes = [&](int64_t cap) {
         const size_t seg = (size_t)((cap + nt_threads - 1) / nt_threads) * 64;
-        return (size_t)((cap + 3) & ~(int64_t)3) * (f64 ? 8 : 4) + (size_t)((cap + 7) & ~(int64_t)7) * 2 + (size_t)nw * seg * 2 + 16;
+        return (size_t)((cap + 3) & ~(int64_t)3) * 4 + (size_t)((cap + 7) & ~(int64_t)7) * 2 + (size_t)nw * seg * 2 + 16;
     };
     int cert_cap = 0;
     if (max_src_patch_host < 0xfff0 && lds + cert_bytes(max_src_patch_host) <= (size_t)ICP_LDS_BUDGET) cert_cap = (int)max_src_patch_host;
@@ -844,9 +853,10 @@ static int f4l::icp_launch_host(const float *src, const int64_t *src_off, const 
     // certificate positions (worth ~10 % fewer searches than the patch-wide motion bound), then the staged sources
     int src_cap = 0, pp_cap = 0;
     {
+        const size_t pb = (size_t)((max_src_patch_host + 3) & ~(int64_t)3) * 3 * 4;
         const size_t sb = (size_t)((max_src_patch_host + 3) & ~(int64_t)3) * 3 * (f64 ? 8 : 4);
         auto fits = [&](size_t extra) { return lds + extra <= (size_t)ICP_LDS_BUDGET && (lds + extra <= 40 * 1024 || lds > 40 * 1024); };
-        if (cert_cap && !getenv("F4L_ICP_NOPP") && fits(sb)) { pp_cap = cert_cap; lds += sb; }
+        if (cert_cap && !getenv("F4L_ICP_NOPP") && fits(pb)) { pp_cap = cert_cap; lds += pb; }
         if (fits(sb)) { src_cap = (int)max_src_patch_host; lds += sb; }
     }
     lds = (lds + 15) & ~(size_t)15;

@@ -31,13 +31,24 @@ namespace f4l {
 // ---- point records as staged in LDS ------------------------------------------------------------------
 template <typename F> struct GridPt;
 template <> struct __attribute__((aligned(16))) GridPt<float> { float x, y, z; unsigned int tag; };                // 16 B
-template <> struct __attribute__((aligned(16))) GridPt<double> { double x, y, z; unsigned int tag; int pad; };   // 32 B
+// float64 search: the ORIGINAL float32 coordinates; the patch-relative double is (double)x - origin, exact, formed on use
+// (16 B as well: the float64 mode keeps the LDS footprint, hence the occupancy, of the float32 mode)
+template <> struct __attribute__((aligned(16))) GridPt<double> { float x, y, z; unsigned int tag; };              // 16 B
 
 template <typename F> struct PatchGrid {
     F minx, miny, minz, h, inv_h;
     int nx, ny, nz;  // nx * ny * nz <= cell capacity
     int wmax;        // cells per side of the stencil that covers the radius the grid was built for (>= 1)
+    F ox, oy, oz;    // patch origin (only the float64 records need it: they hold absolute coordinates)
 };
+
+// patch-relative coordinates of a record
+__device__ __forceinline__ void grid_rel(const PatchGrid<float> &, const GridPt<float> &q, float &x, float &y, float &z) {
+    x = q.x; y = q.y; z = q.z;
+}
+__device__ __forceinline__ void grid_rel(const PatchGrid<double> &g, const GridPt<double> &q, double &x, double &y, double &z) {
+    x = (double)q.x - g.ox; y = (double)q.y - g.oy; z = (double)q.z - g.oz;
+}
 
 __device__ __forceinline__ float grid_uniform(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
 __device__ __forceinline__ double grid_uniform(double v) {
@@ -195,6 +206,7 @@ __device__ __forceinline__ void grid_build(const float *__restrict__ tg, int nt,
         }
     }
     g.minx = finite ? mn[0] : (F)0; g.miny = finite ? mn[1] : (F)0; g.minz = finite ? mn[2] : (F)0;
+    g.ox = (F)ox; g.oy = (F)oy; g.oz = (F)oz;
     g.h = h; g.inv_h = (F)1 / h;
     g.nx = nx; g.ny = ny; g.nz = nz;
     {
@@ -259,10 +271,12 @@ __device__ __forceinline__ void grid_build(const float *__restrict__ tg, int nt,
     // 5. scatter: the slot E[c + 1] is the running cursor of cell c; when all points are placed it equals the
     //    start of cell c + 1, which is exactly the prefix table the queries read.
     for (int j = tid; j < nt; j += NT) {
+        const F rx = (F)tg[3 * j] - (F)ox, ry = (F)tg[3 * j + 1] - (F)oy, rz = (F)tg[3 * j + 2] - (F)oz;
         GridPt<F> q;
-        q.x = (F)tg[3 * j] - (F)ox; q.y = (F)tg[3 * j + 1] - (F)oy; q.z = (F)tg[3 * j + 2] - (F)oz;
+        if (sizeof(F) == 4) { q.x = rx; q.y = ry; q.z = rz; }
+        else { q.x = tg[3 * j]; q.y = tg[3 * j + 1]; q.z = tg[3 * j + 2]; }
         int cx, cy, cz;
-        grid_cell(g, q.x, q.y, q.z, cx, cy, cz);
+        grid_cell(g, rx, ry, rz, cx, cy, cz);
         cx = cx < 0 ? 0 : (cx >= nx ? nx - 1 : cx);
         cy = cy < 0 ? 0 : (cy >= ny ? ny - 1 : cy);
         cz = cz < 0 ? 0 : (cz >= nz ? nz - 1 : cz);
@@ -274,7 +288,7 @@ __device__ __forceinline__ void grid_build(const float *__restrict__ tg, int nt,
     }
     if (tid == 0) {  // the dummy: farther than anything, never a winner
         GridPt<F> q;
-        q.x = q.y = q.z = (F)(sizeof(F) == 4 ? 1e30 : 1e300);
+        q.x = q.y = q.z = 1e30f;  // (squared: +inf in float32, 1e60 in float64 -- beyond any bound either way)
         q.tag = GRID_NO_TAG;
         tl[nt] = q;
     }
@@ -304,8 +318,8 @@ template <> __device__ __forceinline__ double grid_sqrt<double>(double v) { retu
 // Flat scan of the first `cnt` entries of this lane's row list; idle lanes sit on the dummy slot.  Returns the number
 // of candidates this lane evaluated (profiling builds only use it).
 template <typename F, int NT>
-__device__ __forceinline__ int grid_scan_rows(const GridPt<F> *__restrict__ tl, int dummy, const unsigned int *__restrict__ rl,
-                                              int cnt, F px, F py, F pz, Best<F> &best) {
+__device__ __forceinline__ int grid_scan_rows(const PatchGrid<F> &g, const GridPt<F> *__restrict__ tl, int dummy,
+                                              const unsigned int *__restrict__ rl, int cnt, F px, F py, F pz, Best<F> &best) {
     const int tid = (int)threadIdx.x;
     int n_steps = 0;
     unsigned int cur = rl[tid];
@@ -323,7 +337,9 @@ __device__ __forceinline__ int grid_scan_rows(const GridPt<F> *__restrict__ tl, 
         const GridPt<F> qn = tl[jn < en ? jn : dummy];
         const unsigned int nn = rl[k * NT + tid];
         // current candidate
-        best.offer(grid_d2(px - q.x, py - q.y, pz - q.z), q.tag);
+        F qx, qy, qz;
+        grid_rel(g, q, qx, qy, qz);
+        best.offer(grid_d2(px - qx, py - qy, pz - qz), q.tag);
 #ifdef F4L_ICP_PROF
         n_steps += j < e ? 1 : 0;
 #endif
@@ -362,7 +378,7 @@ __device__ __forceinline__ Best<F> grid_nn_wide(const PatchGrid<F> &g, const Gri
             if (++dy > W) { dy = -W; ++dz; }
         }
         rl[cnt * NT + tid] = 0u;
-        grid_scan_rows<F, NT>(tl, dummy, rl, cnt, px, py, pz, best);
+        grid_scan_rows<F, NT>(g, tl, dummy, rl, cnt, px, py, pz, best);
     }
     return best;  // by value: a reference would pin the caller's record to memory on the common path too
 }
@@ -435,7 +451,7 @@ __device__ __forceinline__ void grid_nn(const PatchGrid<F> &g, const GridPt<F> *
         cnt_total += cnt;
         n_steps +=
 #endif
-        grid_scan_rows<F, NT>(tl, dummy, rl, cnt, px, py, pz, best);
+        grid_scan_rows<F, NT>(g, tl, dummy, rl, cnt, px, py, pz, best);
     } else {
 #ifndef F4L_GRID_NOWIDE
         best = grid_nn_wide<F, NT>(g, tl, dummy, E, rl, W, xok, cy, cz, base0, span, fy, fz, slack, b2s, px, py, pz, best);

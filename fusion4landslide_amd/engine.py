@@ -145,13 +145,15 @@ def patch_normals(pts, off, knn=30, max_patch=None):
 
 def piecewise_icp(src, src_off, tgt, tgt_off, init_T=None, max_corr_dist=0.1, max_iter=30, rel_fitness=1e-6,
                   rel_rmse=1e-6, icp_type="point2point", fixed_iters=False, tgt_normals=None, return_corr=False,
-                  max_src_patch=None, max_tgt_patch=None, search="f32"):
+                  max_src_patch=None, max_tgt_patch=None, search="f64"):
     """Batched per-patch ICP (utils/o3d_tools.py:12-71 for P patch pairs in one launch).
 
     Returns dict(T (P,4,4) f64, fitness (P,) f64, rmse (P,) f64, iters (P,) i32[, corr (n_src,) i32]).
     ``fixed_iters=True`` is the benchmark mode (exactly ``max_iter`` updates, no early exit).
-    ``search="f64"`` evaluates the nearest-neighbour search in double like the reference's Open3D path (parity
-    mode, ~2x the time); ``"f32"`` searches in float32 on patch-relative coordinates.
+    ``search="f64"`` (default) evaluates positions, distances and sums in double like the reference's Open3D path
+    and reproduces the CPU oracle to 1e-9 m; ``"f32"`` is the fast mode (float32 search on patch-relative coordinates,
+    ~1.5x faster): same answer to ~1e-8 m on well-posed patches, but an ill-posed patch (displaced beyond the radius,
+    low fitness) can end in a different local solution.
     """
     torch = require_gpu()
     if icp_type not in _ICP_MODES:
@@ -196,7 +198,7 @@ def piecewise_icp(src, src_off, tgt, tgt_off, init_T=None, max_corr_dist=0.1, ma
 
 def patch_loop(src, src_off, tgt, tgt_off, corr_src, corr_ref, corr_off, corr_weights=None, weight_thresh=0.0, eps=1e-6,
                max_corr_dist=0.1, max_iter=30, rel_fitness=1e-6, rel_rmse=1e-6, icp_type="point2point", fixed_iters=False,
-               tgt_normals=None, return_corr=False, return_rows=True, max_src_patch=None, max_tgt_patch=None, search="f32"):
+               tgt_normals=None, return_corr=False, return_rows=True, max_src_patch=None, max_tgt_patch=None, search="f64"):
     """The whole per-patch loop body of src/coarse_to_fine_matching_base.py:3254-3436 in one launch (f4l_patch_loop):
     weighted Kabsch of each patch's correspondences -> ICP from that -> displacement rows [s, T s].
 

@@ -307,7 +307,7 @@ def test_icp_every_workgroup_shape_matches_oracle(eng, waves, monkeypatch):
     assert _disp_per_patch(d, out["T"].cpu().numpy(), ref["T"]).max() <= 1e-9
     assert np.array_equal(out["iters"].cpu().numpy(), ref["iters"])
     out32 = eng.piecewise_icp(dev(d["src"]), dev(d["src_off"]), dev(d["tgt"]), dev(d["tgt_off"]), max_corr_dist=0.1,
-                              max_iter=30)
+                              max_iter=30, search="f32")
     disp = _disp_per_patch(d, out32["T"].cpu().numpy(), ref["T"])
     assert np.median(disp) <= 1e-5 and (disp <= 1e-4).mean() >= 0.85 and disp.max() <= 2e-3
 
@@ -396,7 +396,7 @@ def test_icp_medium_patches_without_room_for_every_lds_array(eng):
     assert _disp_per_patch(d, out["T"].cpu().numpy(), ref["T"]).max() <= 1e-9
     assert np.array_equal(out["iters"].cpu().numpy(), ref["iters"])
     assert np.abs(out["fitness"].cpu().numpy() - ref["fitness"]).max() == 0.0
-    out32 = eng.piecewise_icp(dev(src), dev(soff), dev(tgt), dev(toff), max_corr_dist=0.1, max_iter=30)
+    out32 = eng.piecewise_icp(dev(src), dev(soff), dev(tgt), dev(toff), max_corr_dist=0.1, max_iter=30, search="f32")
     assert _disp_per_patch(d, out32["T"].cpu().numpy(), ref["T"]).max() <= 1e-4
 
 
@@ -541,7 +541,7 @@ def test_full_size_properties_1M(eng):
     from fusion4landslide_amd import synthetic
     d = synthetic.make_patches(1_000_000, 45, 1.386, seed=0)
     src, so, tgt, to = dev(d["src"]), dev(d["src_off"]), dev(d["tgt"]), dev(d["tgt_off"])
-    out = eng.piecewise_icp(src, so, tgt, to, max_corr_dist=0.1, max_iter=20, fixed_iters=True,
+    out = eng.piecewise_icp(src, so, tgt, to, max_corr_dist=0.1, max_iter=20, fixed_iters=True, search="f32",
                             max_src_patch=d["max_src"], max_tgt_patch=d["max_tgt"])
     T = out["T"].cpu().numpy()
     assert (out["iters"].cpu().numpy() == 20).all()

@@ -1,29 +1,3 @@
-python -m pytest tests -m gpu -q -x -k "certificates_are_exact" 2>&1 | tail -4
-python - <<'PY'
-# how sensitive is the one deviating patch of the full-size test?  float32 fast path with and without certificates
-import os, sys, numpy as np, torch
-sys.path.insert(0, os.getcwd())
-from fusion4landslide_amd import engine, synthetic
-d = synthetic.make_patches(1_000_000, 45, 1.386, seed=0)
-dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
-args = (dev(d["src"]), dev(d["src_off"]), dev(d["tgt"]), dev(d["tgt_off"]))
-kw = dict(max_corr_dist=0.1, max_iter=20, fixed_iters=True, max_src_patch=d["max_src"], max_tgt_patch=d["max_tgt"])
-outs = {}
-for name, env in (("pp", {}), ("global", {"F4L_ICP_NOPP": "1"}), ("nocert", {"F4L_ICP_DEBUG": "4"}), ("f64", {})):
-    for k in ("F4L_ICP_NOPP", "F4L_ICP_DEBUG"): os.environ.pop(k, None)
-    os.environ.update(env)
-    outs[name] = engine.piecewise_icp(*args, search="f64" if name == "f64" else "f32", **kw)
-def disp(a, b):
-    Ta, Tb = outs[a]["T"].cpu().numpy(), outs[b]["T"].cpu().numpy()
-    r = []
-    for p in range(d["P"]):
-        s = d["src"][d["src_off"][p]:d["src_off"][p + 1]].astype(np.float64)
-        r.append(np.abs((s @ Ta[p, :3, :3].T + Ta[p, :3, 3]) - (s @ Tb[p, :3, :3].T + Tb[p, :3, 3])).max())
-    return np.array(r)
-for a in ("pp", "global", "nocert"):
-    x = disp(a, "f64")
-    print(a, "vs f64: median %.2e  frac<=1e-4 %.4f  frac<=2e-3 %.4f  max %.2e" % (np.median(x), (x <= 1e-4).mean(), (x <= 2e-3).mean(), x.max()))
-x = disp("pp", "nocert"); print("pp vs nocert: median %.2e  frac<=1e-4 %.4f  max %.2e" % (np.median(x), (x <= 1e-4).mean(), x.max()))
-fit = outs["f64"]["fitness"].cpu().numpy(); bad = disp("pp", "f64") > 2e-3
-print("patches beyond 2 mm:", bad.sum(), "their fitness:", np.round(fit[bad], 3)[:10])
-PY
+python -m pytest tests -m gpu -q 2>&1 | tail -4
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+python bench.py --steps 10 --warmup 3 | tail -1
