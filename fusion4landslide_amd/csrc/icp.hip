@@ -404,7 +404,9 @@ __global__ __launch_bounds__(NW * 64, ICP_WAVES_PER_EU) void icp_kernel(IcpArgs 
                 const GridPt<F> q = tl[pv < 0xfffe ? pv : 0];
                 F qx, qy, qz;
                 grid_rel(g, q, qx, qy, qz);
-                const F d = grid_d2(px - qx, py - qy, pz - qz);
+                // (the same expression the search evaluates: certified and searched distances are the same bits)
+                const F d = grid_d2(grid_query(px, g.ox) - grid_coord(q.x, px), grid_query(py, g.oy) - grid_coord(q.y, py),
+                                    grid_query(pz, g.oz) - grid_coord(q.z, pz));
                 bool cert = pv < 0xfffe ? grid_sqrt<F>(d) * (F)1.000001 < room : (pv == 0xfffe && room > rF * (F)1.000001);
                 cert = cert && valid;
                 const bool hit = cert && pv < 0xfffe && d < r2;
@@ -455,9 +457,8 @@ __global__ __launch_bounds__(NW * 64, ICP_WAVES_PER_EU) void icp_kernel(IcpArgs 
                     const int pv = (int)prev[i];
                     if (pv < 0xfffe && !(a.debug & 8)) {
                         const GridPt<F> q = tl[pv];
-                        F qx, qy, qz;
-                        grid_rel(g, q, qx, qy, qz);
-                        const F bb = grid_sqrt<F>(grid_d2(px - qx, py - qy, pz - qz)) * (F)1.000001 + mu;
+                        const F bb = grid_sqrt<F>(grid_d2(grid_query(px, g.ox) - grid_coord(q.x, px), grid_query(py, g.oy) - grid_coord(q.y, py),
+                                                          grid_query(pz, g.oz) - grid_coord(q.z, pz))) * (F)1.000001 + mu;
                         b0 = bb * bb < rs2 ? bb * bb : rs2;
                     }
                 }

@@ -42,6 +42,15 @@ template <typename F> struct PatchGrid {
     F ox, oy, oz;    // patch origin (only the float64 records need it: they hold absolute coordinates)
 };
 
+// Distance arithmetic against a record.  float32: records are patch relative, subtract directly.  float64: records hold
+// the original (absolute) float32 coordinate; the query is shifted back by the origin ONCE (grid_query) and the
+// subtraction (query + origin) - (double)x is then what the reference's absolute-coordinate arithmetic evaluates,
+// rounded at ulp(|coordinate|) like there.
+__device__ __forceinline__ float grid_query(float p, float) { return p; }
+__device__ __forceinline__ double grid_query(double p, double o) { return p + o; }
+__device__ __forceinline__ float grid_coord(float v, float) { return v; }       // float32 record field -> as is
+__device__ __forceinline__ double grid_coord(float v, double) { return (double)v; }  // float64 mode: widen
+
 // patch-relative coordinates of a record
 __device__ __forceinline__ void grid_rel(const PatchGrid<float> &, const GridPt<float> &q, float &x, float &y, float &z) {
     x = q.x; y = q.y; z = q.z;
@@ -313,7 +322,9 @@ constexpr int GRID_ROWS = 9;
 
 template <typename F> __device__ __forceinline__ F grid_sqrt(F v);
 template <> __device__ __forceinline__ float grid_sqrt<float>(float v) { return __builtin_amdgcn_sqrtf(v); }  // 1 ulp; the bound carries slack
-template <> __device__ __forceinline__ double grid_sqrt<double>(double v) { return __builtin_sqrt(v); }
+// (float64 mode: every use is a bound that carries a 1e-6 relative allowance, so the float32 instruction -- good to
+//  ~2e-7 after the conversion -- replaces the ~25-instruction IEEE double sequence)
+template <> __device__ __forceinline__ double grid_sqrt<double>(double v) { return (double)__builtin_amdgcn_sqrtf((float)v); }
 
 // Flat scan of the first `cnt` entries of this lane's row list; idle lanes sit on the dummy slot.  Returns the number
 // of candidates this lane evaluated (profiling builds only use it).
@@ -327,6 +338,7 @@ __device__ __forceinline__ int grid_scan_rows(const PatchGrid<F> &g, const GridP
     int k = cnt < 1 ? cnt : 1;
     unsigned int nxt = rl[k * NT + tid];
     GridPt<F> q = tl[j < e ? j : dummy];
+    const F Qx = grid_query(px, g.ox), Qy = grid_query(py, g.oy), Qz = grid_query(pz, g.oz);
     while (__any(j < e)) {
         // next position first, so that its loads are in flight while the current candidate is evaluated
         int jn = j + 1;
@@ -337,9 +349,7 @@ __device__ __forceinline__ int grid_scan_rows(const PatchGrid<F> &g, const GridP
         const GridPt<F> qn = tl[jn < en ? jn : dummy];
         const unsigned int nn = rl[k * NT + tid];
         // current candidate
-        F qx, qy, qz;
-        grid_rel(g, q, qx, qy, qz);
-        best.offer(grid_d2(px - qx, py - qy, pz - qz), q.tag);
+        best.offer(grid_d2(Qx - grid_coord(q.x, Qx), Qy - grid_coord(q.y, Qy), Qz - grid_coord(q.z, Qz)), q.tag);
 #ifdef F4L_ICP_PROF
         n_steps += j < e ? 1 : 0;
 #endif

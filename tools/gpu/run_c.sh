@@ -1,3 +1,2 @@
-python -m pytest tests -m gpu -q 2>&1 | tail -4
-python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
-python bench.py --steps 10 --warmup 3 | tail -1
+python -m pytest tests -m gpu -q -x 2>&1 | tail -3
+python bench.py --steps 20 --warmup 5 --cpu-seconds 0 | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['roofline']['kernel_ms'], d['extras']['fast_mode_f32'])"
