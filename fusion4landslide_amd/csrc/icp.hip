@@ -37,6 +37,9 @@ namespace f4l {
 #ifndef ICP_WAVES_PER_EU
 #define ICP_WAVES_PER_EU 4
 #endif
+#ifndef ICP_WAVES_PER_EU_F64
+#define ICP_WAVES_PER_EU_F64 4
+#endif
 constexpr int ICP_LDS_BUDGET = 160 * 1024 - 512;  // dynamic LDS a single workgroup may ask for on gfx950
 constexpr int ICP_TGT_MAX = 8192;                 // target points kept in LDS at most
 constexpr int ICP_CELL_MAX = 16384;               // grid cells at most (uint16 prefix table)
@@ -155,7 +158,7 @@ __device__ __forceinline__ double uniform_f64(double v) {
 // and certifies (or queues) every source point, and a search phase over the queued points only, compacted
 // across the workgroup.  Results are exactly those of searching every point in every pass.
 template <int MODE, int NW, typename F>
-__global__ __launch_bounds__(NW * 64, ICP_WAVES_PER_EU) void icp_kernel(IcpArgs a) {
+__global__ __launch_bounds__(NW * 64, sizeof(F) == 8 ? ICP_WAVES_PER_EU_F64 : ICP_WAVES_PER_EU) void icp_kernel(IcpArgs a) {
     constexpr int NV = (MODE == F4L_ICP_POINT2POINT) ? 17 : 29;
     constexpr int NT = NW * 64;
     // Correspondence sums.  float32 search + point-to-point: per-lane partial sums and the in-wave reduction are

@@ -1,1 +1,2 @@
-F4L_ICP_PROF=1 python bench.py --steps 1 --warmup 1 --cpu-seconds 0 --extras 0 2>&1 | grep "icp prof\]" | tail -1
+python -m pytest tests -m gpu -q -x -k "knn or supervoxel or full_size or median" 2>&1 | tail -3
+python tools/gpu/time_knn.py 2>&1 | grep -v amdgpu
