@@ -161,6 +161,7 @@ __global__ __launch_bounds__(KNN_NW * 64) void knn_cells_kernel(KnnArgs a) {
         WaveTopK best;
         for (int R = 1;; ++R) {
             best.reset();
+            bool first = true;  // uniform
             const int side = 2 * R + 1, rows = side * side;
             for (int r0 = 0; r0 < rows; r0 += 64) {
                 int lo = 0, hi = 0;
@@ -200,7 +201,8 @@ __global__ __launch_bounds__(KNN_NW * 64) void knn_cells_kernel(KnnArgs a) {
                             cd = dist2_exact(cp.x, cp.y, cp.z, qp.x, qp.y, qp.z);
                             cid = __float_as_int(cp.w);
                         }
-                        best.offer(cd, cid, k);
+                        if (first) { best.fill_sorted(cd, cid); first = false; }
+                        else best.offer(cd, cid, k);
                     }
                 }
             }

@@ -165,7 +165,8 @@ __global__ __launch_bounds__(PN_NT) void patch_normals_kernel(const float *__res
                 cd = dist2_exact(base[3 * c], base[3 * c + 1], base[3 * c + 2], qx, qy, qz);
                 ci = c;
             }
-            best.offer(cd, ci, k);
+            if (c0 == 0) best.fill_sorted(cd, ci);  // first batch: sort in place instead of 64 insertions
+            else best.offer(cd, ci, k);
         }
         // cumulants of the k neighbours (self included), Open3D ComputeCovariance
         double cum[9];

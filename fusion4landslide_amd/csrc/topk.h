@@ -37,6 +37,28 @@ struct WaveTopK {
         d = __builtin_inf();
         i = 0x7fffffff;
     }
+    // First batch of a query: the list is empty, so instead of inserting the candidates one by one the 64 of them are
+    // loaded into the slots and sorted in place by a bitonic network across the lanes (21 compare-exchange stages).
+    // The list then holds up to 64 real entries, ascending; entries beyond the k-th are harmless.
+    __device__ __forceinline__ void fill_sorted(double cd, int ci) {
+        d = cd;
+        i = ci;
+        const int lane = lane_id();
+#pragma unroll
+        for (int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                const double od = __shfl_xor(d, j, 64);
+                const int oi = __shfl_xor(i, j, 64);
+                const bool up = (lane & k) == 0;     // this block sorts ascending (k == 64: every lane)
+                const bool lower = (lane & j) == 0;  // the lower lane of the pair
+                const bool mine_first = before(d, i, od, oi);
+                const bool keep_mine = (lower == up) ? mine_first : !mine_first;
+                d = keep_mine ? d : od;
+                i = keep_mine ? i : oi;
+            }
+        }
+    }
     // Offer one candidate per lane (cd = +inf for idle lanes).  k-1 must be wave-uniform.
     __device__ __forceinline__ void offer(double cd, int ci, int k) {
         double thr = readlane_f64(d, k - 1);

@@ -1,2 +1,2 @@
-python -m pytest tests -m gpu -q -x -k "knn or supervoxel or full_size or median" 2>&1 | tail -3
+python -m pytest tests -m gpu -q -x 2>&1 | tail -3
 python tools/gpu/time_knn.py 2>&1 | grep -v amdgpu
