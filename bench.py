@@ -156,6 +156,8 @@ def main():
             line["extras"] = extras(torch, engine, step, src, args)
         if world == 1 and args.cpu_seconds > 0:  # rank 0 at N = 1 only
             line["cpu_baseline"] = cpu_baseline(d, cs_h, ct_h, coff_h, args.cpu_seconds)
+            if args.extras:
+                line["cpu_baseline_supervoxel"] = cpu_baseline_supervoxel(torch, engine, d)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
@@ -185,6 +187,37 @@ def extras(torch, engine, step, src, args):
                     "achieved_GBs": round(132.0 * n / sk / 1e9, 2), "frac_of_hbm_peak": round(132.0 * n / sk / 1e9 / HBM_PEAK_GBS, 5),
                     "note": "f4l_knn end to end (binning + sort + search), algorithmic 132 B/pt"}
     return out
+
+
+def cpu_baseline_supervoxel(torch, engine, d, n=200_000, k=30):
+    """SURVEY.md 8(a) row a1 on a bounded sample (the first n points of the source epoch): `computeSupervoxel` without its
+    file I/O.  CPU side: the reference's OWN templates when oracle/_ref/libf4l_ref.so is there (kind "reference": the
+    header-only codelibrary driven by oracle/ref_harness.cpp), else the C restatement (kind "port"); one thread, like
+    the reference.  GPU side: f4l_supervoxel (kNN + normals on the device, the order-dependent segmentation on the
+    host), labels compared for identity."""
+    import numpy as np
+
+    from oracle import oracle as O
+
+    xyz = np.ascontiguousarray(d["meta"]["src"][:n])
+    res = 1.386
+    kind = "reference" if O.have_ref() else "port"
+    t = time.perf_counter()
+    ref = O.ref_supervoxel(xyz, k, res) if kind == "reference" else O.supervoxel(xyz, k, res)
+    cpu_s = time.perf_counter() - t
+    dev_xyz = torch.from_numpy(xyz).cuda()
+    engine.supervoxel(dev_xyz, k, res)  # warm-up
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    labels, K = engine.supervoxel(dev_xyz, k, res)
+    torch.cuda.synchronize()
+    gpu_s = time.perf_counter() - t
+    same = bool(np.array_equal(labels.cpu().numpy(), ref["labels"])) and K == ref["n_supervoxels"]
+    return {"value": round(len(xyz) / cpu_s / 1e6, 4), "unit": "Mpts/s", "cores": 1, "kind": kind,
+            "sample": f"first {len(xyz)} source points, k={k}, resolution {res} m, {cpu_s:.1f} s",
+            "this_repo": {"value": round(len(xyz) / gpu_s / 1e6, 4), "unit": "Mpts/s", "seconds": round(gpu_s, 3),
+                          "labels_identical": same, "n_supervoxels": int(K),
+                          "note": "kNN + normals on the GPU (milliseconds), segmentation replayed on one host core"}}
 
 
 def cpu_baseline(d, cs, ct, coff, budget_s):

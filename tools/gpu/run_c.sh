@@ -1,2 +1,1 @@
-python -m pytest tests -m gpu -q -x 2>&1 | tail -3
-python tools/gpu/time_knn.py 2>&1 | grep -v amdgpu
+python bench.py --steps 10 --warmup 3 | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['cpu_baseline'], d['cpu_baseline_supervoxel'])"
