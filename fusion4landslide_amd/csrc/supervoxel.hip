@@ -10,6 +10,9 @@
 //        result requires replaying that order.  It is written here as a flat, allocation-free host routine
 //        (pooled adjacency lists, SoA points) rather than the reference's Array<Array<int>> of heap vectors.
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cfloat>
 #include <cmath>
 #include <cstring>
@@ -102,6 +105,10 @@ static int segment_host(const float *xyz, const double *nrm, const int32_t *knn,
         adj_off[(size_t)i] = (int64_t)i * k;
     }
 
+    const bool timing = getenv("F4L_SV_TIMING") != nullptr;
+    auto tnow = [] { return std::chrono::steady_clock::now(); };
+    auto tsec = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+    const auto t_start = tnow();
     // starting lambda: median over points of the smallest metric to a neighbour (:105-113, median.h:27-30)
     for (int32_t i = 0; i < n; ++i) {
         double best = DBL_MAX;
@@ -118,6 +125,7 @@ static int segment_host(const float *xyz, const double *nrm, const int32_t *knn,
         lambda = std::max(DBL_EPSILON, tmp[(size_t)(n / 2)]);
     }
 
+    const auto t_lambda = tnow();
     // step 1 (:117-176): greedy fusion, lambda doubling until exactly n_target representatives remain
     int32_t n_reps = n, live = n;
     std::vector<int32_t> kept;
@@ -191,6 +199,7 @@ static int segment_host(const float *xyz, const double *nrm, const int32_t *knn,
         if (n_reps == n_target) break;
     }
 
+    const auto t_fuse = tnow();
     for (int32_t i = 0; i < n; ++i) labels[i] = find_root(parent.data(), i);  // :179-182
 
     // step 2 (:186-237): boundary exchange with a FIFO of points whose neighbourhood straddles two labels
@@ -236,6 +245,8 @@ static int segment_host(const float *xyz, const double *nrm, const int32_t *knn,
             }
     }
 
+    const auto t_refine = tnow();
+    if (timing) fprintf(stderr, "[sv timing] n=%d lambda0 %.3f s, fusion %.3f s, refine %.3f s\n", n, tsec(t_start, t_lambda), tsec(t_lambda, t_fuse), tsec(t_fuse, t_refine));
     // step 3 (:241-247): relabel 0..K-1 in representative order
     std::vector<int32_t> &map = queue;  // reuse
     for (int32_t s = 0; s < n_reps; ++s) map[(size_t)reps[(size_t)s]] = s;
