@@ -157,6 +157,63 @@ __device__ __forceinline__ double uniform_f64(double v) {
 // mabs[i] stores M + (that sum at search time).  Each pass therefore has two phases: a dense one that re-measures
 // and certifies (or queues) every source point, and a search phase over the queued points only, compacted
 // across the workgroup.  Results are exactly those of searching every point in every pass.
+// Grids finer than the radius (PatchGrid::wmax > 1): before the first pass, look for every point's neighbour inside the
+// 3 x 3 rows of its own cell only (bound just under one cell edge).  Points that find one enter pass 0 with a
+// correspondence and a certificate like in any later pass; only the others pay for the full (2 wmax + 1)^2 stencil,
+// and they do it in dense batches of their own (phase 2).  Runs once per patch, outside the pass loop, and is
+// deliberately not inlined: the loop's register allocation must not see it.
+template <typename F, int NT> struct PrepassArgs {
+    PatchGrid<F> g;
+    // byte offsets into the workgroup's dynamic LDS (pointers rebuilt inside, so that the accesses stay ds_* ops)
+    int tl, E, rl, sl /* -1: sources are read from global memory */, state, prev, mabs, ps /* -1: patch-wide bound */;
+    const float *sg;  // source points in global memory
+    float ox, oy, oz;
+    int ns, nt;
+    F rs;
+};
+
+template <typename F, int NT>
+__device__ __noinline__ void icp_prepass(const PrepassArgs<F, NT> &q) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int tid = (int)threadIdx.x;
+    const GridPt<F> *tl = reinterpret_cast<const GridPt<F> *>(smem_raw + q.tl);
+    const unsigned short *E = reinterpret_cast<const unsigned short *>(smem_raw + q.E);
+    unsigned int *rl = reinterpret_cast<unsigned int *>(smem_raw + q.rl);
+    const F *sl = reinterpret_cast<const F *>(smem_raw + (q.sl < 0 ? 0 : q.sl));
+    const double *state = reinterpret_cast<const double *>(smem_raw + q.state);
+    unsigned short *prev = reinterpret_cast<unsigned short *>(smem_raw + q.prev);
+    float *mabs = reinterpret_cast<float *>(smem_raw + q.mabs);
+    float *ps = reinterpret_cast<float *>(smem_raw + (q.ps < 0 ? 0 : q.ps));
+    const F R0 = (F)state[0], R1 = (F)state[1], R2 = (F)state[2], R3 = (F)state[3], R4 = (F)state[4],
+            R5 = (F)state[5], R6 = (F)state[6], R7 = (F)state[7], R8 = (F)state[8];
+    const F t0f = (F)state[9], t1f = (F)state[10], t2f = (F)state[11];
+    for (int base = 0; base < q.ns; base += NT) {
+        const int i = base + tid;
+        const int ii = i < q.ns ? i : q.ns - 1;
+        F x, y, z;
+        if (q.sl >= 0) { x = sl[3 * ii]; y = sl[3 * ii + 1]; z = sl[3 * ii + 2]; }
+        else { x = (F)q.sg[3 * ii] - (F)q.ox; y = (F)q.sg[3 * ii + 1] - (F)q.oy; z = (F)q.sg[3 * ii + 2] - (F)q.oz; }
+        const F px = R0 * x + R1 * y + R2 * z + t0f;
+        const F py = R3 * x + R4 * y + R5 * z + t1f;
+        const F pz = R6 * x + R7 * y + R8 * z + t2f;
+        F bt = grid_narrow_bound(q.g, px, py, pz);
+        bt = bt < q.rs ? bt : q.rs;
+        const bool valid = i < q.ns && bt > (F)0;
+        const F b0 = valid ? bt * bt : (F)0;
+        Best<F> best;
+        best.init(b0);
+        grid_nn<F, NT, false>(q.g, tl, q.nt, E, rl, valid, px, py, pz, best);
+        if (valid && best.found()) {
+            const F m2 = best.second < b0 ? best.second : b0;
+            prev[i] = (unsigned short)best.slot();
+            // (the patch-wide motion sum state[29] is still zero here)
+            mabs[i] = (float)(grid_sqrt<F>(m2) * (F)(q.ps >= 0 ? 0.999999 : 0.999999 * 0.9999998));
+            if (q.ps >= 0) { ps[3 * i] = (float)px; ps[3 * i + 1] = (float)py; ps[3 * i + 2] = (float)pz; }
+        }
+    }
+    // (every thread wrote its own points only, and phase 1 reads them with the same thread: no barrier)
+}
+
 template <int MODE, int NW, typename F>
 __global__ __launch_bounds__(NW * 64, sizeof(F) == 8 ? ICP_WAVES_PER_EU_F64 : ICP_WAVES_PER_EU) void icp_kernel(IcpArgs a) {
     constexpr int NV = (MODE == F4L_ICP_POINT2POINT) ? 17 : 29;
@@ -330,6 +387,15 @@ __global__ __launch_bounds__(NW * 64, sizeof(F) == 8 ? ICP_WAVES_PER_EU_F64 : IC
     __syncthreads();
     PROF_T(pt_built);
     PROF_ADD(1, pt_built, pt_start);
+
+    if (active && use_cert && g.wmax > 1 && !(a.debug & 16)) {
+        PrepassArgs<F, NT> q;
+        auto lds_off = [&](const void *ptr) { return (int)((const unsigned char *)ptr - smem_raw); };
+        q.g = g; q.tl = lds_off(tl); q.E = lds_off(E); q.rl = lds_off(rl); q.sl = src_in_lds ? lds_off(sl) : -1;
+        q.state = lds_off(state); q.prev = lds_off(prev); q.mabs = lds_off(mabs); q.ps = per_point ? lds_off(ps) : -1;
+        q.sg = sg; q.ox = ox; q.oy = oy; q.oz = oz; q.ns = ns; q.nt = nt; q.rs = rs;
+        icp_prepass<F, NT>(q);
+    }
 
     const int n_pass = active ? a.max_iter + 1 : 0;
     // the solving wave rotates with the patch index so that co-resident workgroups do not all solve on the same SIMD

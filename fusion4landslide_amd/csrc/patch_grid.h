@@ -393,7 +393,15 @@ __device__ __forceinline__ Best<F> grid_nn_wide(const PatchGrid<F> &g, const Gri
     return best;  // by value: a reference would pin the caller's record to memory on the common path too
 }
 
-template <typename F, int NT>
+// Largest search bound (a distance) that the 3 x 3 rows around a point's own cell are guaranteed to cover, slack of
+// grid_nn included; <= 0 when rounding slack eats the whole cell.
+template <typename F> __device__ __forceinline__ F grid_narrow_bound(const PatchGrid<F> &g, F px, F py, F pz) {
+    const F slack = (F)1e-5 * g.h + (F)1e-6 * (fabs(px) + fabs(py) + fabs(pz) + fabs(g.minx) + fabs(g.miny) + fabs(g.minz));
+    return (g.h - (F)2 * slack) * (F)0.9999;
+}
+
+// WIDE = false: the caller guarantees a bound below one cell edge (grid_narrow_bound), only the 3 x 3 path is emitted.
+template <typename F, int NT, bool WIDE = true>
 __device__ __forceinline__ void grid_nn(const PatchGrid<F> &g, const GridPt<F> *__restrict__ tl, int dummy,
                                         const unsigned short *__restrict__ E, unsigned int *__restrict__ rl, bool valid,
                                         F px, F py, F pz, Best<F> &best, unsigned long long *prof = nullptr) {
@@ -413,7 +421,7 @@ __device__ __forceinline__ void grid_nn(const PatchGrid<F> &g, const GridPt<F> *
     // layers of cells this lane's bound reaches on either side of its own cell (y and z; x is the run itself)
     int W = 1;  // wave maximum (uniform); grids with cells no finer than the radius never need more than one layer
 #ifndef F4L_GRID_NOWIDE
-    if (g.wmax > 1) {
+    if (WIDE && g.wmax > 1) {
         int wl = floor_to_int(bnd * g.inv_h) + 1;
         wl = valid ? (wl > g.wmax ? g.wmax : wl) : 0;
         W = __any(wl > 1) ? g.wmax : 1;  // (the rows of a wider stencil than a lane needs are pruned by its bound)
@@ -464,7 +472,7 @@ __device__ __forceinline__ void grid_nn(const PatchGrid<F> &g, const GridPt<F> *
         grid_scan_rows<F, NT>(g, tl, dummy, rl, cnt, px, py, pz, best);
     } else {
 #ifndef F4L_GRID_NOWIDE
-        best = grid_nn_wide<F, NT>(g, tl, dummy, E, rl, W, xok, cy, cz, base0, span, fy, fz, slack, b2s, px, py, pz, best);
+        if (WIDE) best = grid_nn_wide<F, NT>(g, tl, dummy, E, rl, W, xok, cy, cz, base0, span, fy, fz, slack, b2s, px, py, pz, best);
 #endif
     }
 #ifdef F4L_ICP_PROF

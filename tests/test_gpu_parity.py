@@ -400,6 +400,35 @@ def test_icp_medium_patches_without_room_for_every_lds_array(eng):
     assert _disp_per_patch(d, out32["T"].cpu().numpy(), ref["T"]).max() <= 1e-4
 
 
+@pytest.mark.parametrize("search", ["f64", "f32"])
+def test_icp_dense_patches_on_a_grid_finer_than_the_radius(eng, search, monkeypatch):
+    """Patches as wide as max_corr_dist itself with hundreds of points (BASELINE config C3's regime): the per-patch
+    grid is subdivided, searches go through the wide stencil, and pass 0 is preceded by the narrow look-up around each
+    point's own cell.  Same answers as the oracle, and the narrow look-up (F4L_ICP_DEBUG bit 16 switches it off) is a
+    shortcut, not an approximation."""
+    from fusion4landslide_amd import synthetic
+    d = synthetic.make_patches(40_000, 9, 0.1, seed=23)
+    assert d["max_tgt"] > 400
+    args = (dev(d["src"]), dev(d["src_off"]), dev(d["tgt"]), dev(d["tgt_off"]))
+    kw = dict(max_corr_dist=0.1, max_iter=30, search=search, return_corr=True)
+    out = eng.piecewise_icp(*args, **kw)
+    monkeypatch.setenv("F4L_ICP_DEBUG", "16")
+    alt = eng.piecewise_icp(*args, **kw)
+    monkeypatch.delenv("F4L_ICP_DEBUG")
+    assert torch.equal(alt["corr"], out["corr"]) and torch.equal(alt["iters"], out["iters"])
+    # (same correspondences, summed in another order: transforms agree to rounding, not to the bit)
+    same = _disp_per_patch(d, alt["T"].cpu().numpy(), out["T"].cpu().numpy())
+    assert same.max() <= (1e-9 if search == "f64" else 1e-4)
+    ref = O.piecewise_icp(d["src"], d["src_off"], d["tgt"], d["tgt_off"], max_corr_dist=0.1, max_iter=30)
+    disp = _disp_per_patch(d, out["T"].cpu().numpy(), ref["T"])
+    if search == "f64":
+        assert disp.max() <= 1e-9
+        assert np.array_equal(out["iters"].cpu().numpy(), ref["iters"])
+        assert np.abs(out["fitness"].cpu().numpy() - ref["fitness"]).max() == 0.0
+    else:
+        assert np.median(disp) <= 1e-5 and (disp <= 1e-4).mean() >= 0.85
+
+
 def test_patch_loop_equals_the_three_launches(eng):
     """f4l_patch_loop = Kabsch init + ICP + displacement rows in one launch; same answers as the separate calls."""
     from fusion4landslide_amd import synthetic

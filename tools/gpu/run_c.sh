@@ -1,1 +1,1 @@
-python bench.py --steps 10 --warmup 3 | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['cpu_baseline'], d['cpu_baseline_supervoxel'])"
+python -m pytest tests -m gpu -q -x -k "dense or shortcuts or full_size" 2>&1 | tail -15
