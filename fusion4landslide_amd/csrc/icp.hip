@@ -72,8 +72,11 @@ struct IcpArgs {
     int subdiv;     // cells per radius the grid may use (patch_grid.h: grid_build)
     double mu_frac; // certificate margin as a fraction of the correspondence radius
     int debug;  // F4L_ICP_DEBUG env, bit switches for A/B measurements and tests: 4 = no certificates, 8 = no bound from
-                // the previous correspondence, 128 = always the Jacobi SVD (no Newton), 64 = search counters (profiling build)
+                // the previous correspondence, 16 = no narrow look-up before pass 0 on fine grids, 128 = always the Jacobi
+                // SVD (no Newton), 64 = search counters (profiling build)
     unsigned long long *prof;  // F4L_ICP_PROF builds only: per-phase shader-clock totals (see f4l_piecewise_icp)
+    // size-class launches (icp_launch_host): workgroup b handles patch list[b] if b < *list_cnt, else nothing
+    const int *list, *list_cnt;
 };
 
 #ifdef F4L_ICP_PROF
@@ -238,7 +241,11 @@ __global__ __launch_bounds__(NW * 64, sizeof(F) == 8 ? ICP_WAVES_PER_EU_F64 : IC
     const int seg = ((a.cert_cap + NT - 1) / NT) * 64;  // queue entries one wave can produce
     unsigned short *queue = prev + ((a.cert_cap + 7) & ~7);
 
-    const int64_t p = blockIdx.x;
+    int64_t p = blockIdx.x;
+    if (a.list) {
+        if ((int)blockIdx.x >= *a.list_cnt) return;
+        p = a.list[blockIdx.x];
+    }
     if (p >= a.P) return;
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t s0 = a.src_off[p], t0 = a.tgt_off[p];
@@ -789,6 +796,21 @@ __global__ __launch_bounds__(NW * 64, sizeof(F) == 8 ? ICP_WAVES_PER_EU_F64 : IC
 
 namespace f4l {
 
+// Size classes: patch p goes to the first class whose bound holds max(sources, targets) of the patch.  The order inside
+// a class list depends on scheduling; nothing downstream does (every patch is solved on its own).
+constexpr int ICP_MAX_CLASSES = 4;
+struct ClassBounds { int n; int bound[ICP_MAX_CLASSES]; };
+__global__ void icp_bin_patches(const int64_t *__restrict__ src_off, const int64_t *__restrict__ tgt_off, int P,
+                                ClassBounds cb, int *__restrict__ cnt, int *__restrict__ list) {
+    const int p = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (p >= P) return;
+    const int64_t ns = src_off[p + 1] - src_off[p], nt = tgt_off[p + 1] - tgt_off[p];
+    const int64_t m = ns > nt ? ns : nt;
+    int k = 0;
+    while (k < cb.n - 1 && m > cb.bound[k]) ++k;
+    list[(size_t)k * P + atomicAdd(&cnt[k], 1)] = p;
+}
+
 template <int MODE, int NW, typename F>
 static int launch_icp_one(const IcpArgs &a, size_t lds, hipStream_t st) {
     if (lds > 64 * 1024)  // opt in to > 64 KiB of dynamic LDS
@@ -815,6 +837,54 @@ static inline int pow2_ceil(int64_t v) {
     int r = 1;
     while (r < v) r <<= 1;
     return r;
+}
+}  // namespace f4l
+
+namespace f4l {
+// Workgroup shape and LDS layout for patches of at most max_src sources and max_tgt targets.
+struct IcpPlan { int nw, tgt_cap, cell_cap, cert_cap, src_cap, pp_cap; size_t lds; };
+static IcpPlan icp_plan(int64_t max_src_patch_host, int64_t max_tgt_patch_host, bool f64) {
+    const size_t pt = sizeof(GridPt<float>);  // 16 B in both modes
+    // waves per patch: four measured best from 2 k to 32 k patches of ~500 points (the LDS a patch needs limits a CU to
+    // ~4 patches, and a patch keeps 4 waves busier than 2); patches that fit one or two wavefronts get just those
+    int nw = 4;
+    if (max_src_patch_host <= 64) nw = 1;
+    else if (max_src_patch_host <= 128) nw = 2;
+    { const char *e = getenv("F4L_ICP_WAVES"); if (e) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) nw = v; } }
+
+    // LDS plan: targets first (they make the grid possible), then the prefix table, then the certificate arrays
+    const size_t fixed = (size_t)(nw * 32 + 48) * sizeof(double) + 16 + (size_t)(GRID_ROWS + 1) * nw * 64 * sizeof(unsigned int);
+    int tgt_cap = (int)(max_tgt_patch_host < ICP_TGT_MAX ? max_tgt_patch_host : ICP_TGT_MAX);
+    if (tgt_cap < 1) tgt_cap = 1;
+    int cell_cap = (int)((2 * (int64_t)tgt_cap + 255) & ~(int64_t)255);  // ~2 cells per target point
+    cell_cap = cell_cap < 512 ? 512 : (cell_cap > ICP_CELL_MAX ? ICP_CELL_MAX : cell_cap);
+    auto table_bytes = [](int cells) { return ((size_t)cells + 8) * 2; };
+    while (fixed + (size_t)(tgt_cap + 1) * pt + table_bytes(cell_cap) > (size_t)ICP_LDS_BUDGET && cell_cap > 512) cell_cap >>= 1;
+    while (fixed + (size_t)(tgt_cap + 1) * pt + table_bytes(cell_cap) > (size_t)ICP_LDS_BUDGET) tgt_cap -= 256;
+    size_t lds = fixed + (size_t)(tgt_cap + 1) * pt + table_bytes(cell_cap);
+    const int nt_threads = nw * 64;
+    auto cert_bytes = [&](int64_t cap) {
+        const size_t seg = (size_t)((cap + nt_threads - 1) / nt_threads) * 64;
+        return (size_t)((cap + 3) & ~(int64_t)3) * 4 + (size_t)((cap + 7) & ~(int64_t)7) * 2 + (size_t)nw * seg * 2 + 16;
+    };
+    int cert_cap = 0;
+    if (max_src_patch_host < 0xfff0 && lds + cert_bytes(max_src_patch_host) <= (size_t)ICP_LDS_BUDGET) cert_cap = (int)max_src_patch_host;
+    lds += cert_bytes(cert_cap);
+    // then, while at least four workgroups still fit a CU (or nothing more than one fits anyway): the per-point
+    // certificate positions (worth ~10 % fewer searches than the patch-wide motion bound), then the staged sources
+    int src_cap = 0, pp_cap = 0;
+    {
+        const size_t pb = (size_t)((max_src_patch_host + 3) & ~(int64_t)3) * 3 * 4;
+        const size_t sb = (size_t)((max_src_patch_host + 3) & ~(int64_t)3) * 3 * (f64 ? 8 : 4);
+        auto fits = [&](size_t extra) { return lds + extra <= (size_t)ICP_LDS_BUDGET && (lds + extra <= 40 * 1024 || lds > 40 * 1024); };
+        if (cert_cap && !getenv("F4L_ICP_NOPP") && fits(pb)) { pp_cap = cert_cap; lds += pb; }
+        if (fits(sb)) { src_cap = (int)max_src_patch_host; lds += sb; }
+    }
+    lds = (lds + 15) & ~(size_t)15;
+    IcpPlan pl;
+    pl.nw = nw; pl.tgt_cap = tgt_cap; pl.cell_cap = cell_cap; pl.cert_cap = cert_cap; pl.src_cap = src_cap; pl.pp_cap = pp_cap;
+    pl.lds = lds;
+    return pl;
 }
 }  // namespace f4l
 
@@ -878,7 +948,6 @@ static int f4l::icp_launch_host(const float *src, const int64_t *src_off, const 
     if (P > 0x7fffffffLL || max_src_patch_host > 0x3fffffffLL || max_tgt_patch_host > 0x3fffffffLL)
         return F4L_EUNSUPPORTED;
     const bool f64 = search_precision == F4L_SEARCH_F64;
-    const size_t pt = sizeof(GridPt<float>);  // 16 B in both modes
     static_assert(sizeof(GridPt<double>) == sizeof(GridPt<float>), "grid records are 16 B in both modes");
     IcpArgs a;
     a.src = src; a.src_off = src_off; a.tgt = tgt; a.tgt_off = tgt_off; a.P = P;
@@ -894,43 +963,11 @@ static int f4l::icp_launch_host(const float *src, const int64_t *src_off, const 
     { const char *e = getenv("F4L_ICP_MU"); if (e && atof(e) > 0.0) a.mu_frac = atof(e); }
     a.T_out = T_out; a.fitness_out = fitness_out; a.rmse_out = rmse_out; a.iters_out = iters_out; a.corr_out = corr_out;
 
-    // waves per patch: four measured best from 2 k to 32 k patches of ~500 points (the LDS a patch needs limits a CU to
-    // ~4 patches, and a patch keeps 4 waves busier than 2); patches that fit one or two wavefronts get just those
-    int nw = 4;
-    if (max_src_patch_host <= 64) nw = 1;
-    else if (max_src_patch_host <= 128) nw = 2;
-    { const char *e = getenv("F4L_ICP_WAVES"); if (e) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) nw = v; } }
-
-    // LDS plan: targets first (they make the grid possible), then the prefix table, then the certificate arrays
-    const size_t fixed = (size_t)(nw * 32 + 48) * sizeof(double) + 16 + (size_t)(GRID_ROWS + 1) * nw * 64 * sizeof(unsigned int);
-    int tgt_cap = (int)(max_tgt_patch_host < ICP_TGT_MAX ? max_tgt_patch_host : ICP_TGT_MAX);
-    if (tgt_cap < 1) tgt_cap = 1;
-    int cell_cap = (int)((2 * (int64_t)tgt_cap + 255) & ~(int64_t)255);  // ~2 cells per target point
-    cell_cap = cell_cap < 512 ? 512 : (cell_cap > ICP_CELL_MAX ? ICP_CELL_MAX : cell_cap);
-    auto table_bytes = [](int cells) { return ((size_t)cells + 8) * 2; };
-    while (fixed + (size_t)(tgt_cap + 1) * pt + table_bytes(cell_cap) > (size_t)ICP_LDS_BUDGET && cell_cap > 512) cell_cap >>= 1;
-    while (fixed + (size_t)(tgt_cap + 1) * pt + table_bytes(cell_cap) > (size_t)ICP_LDS_BUDGET) tgt_cap -= 256;
-    size_t lds = fixed + (size_t)(tgt_cap + 1) * pt + table_bytes(cell_cap);
-    const int nt_threads = nw * 64;
-    auto cert_bytes = [&](int64_t cap) {
-        const size_t seg = (size_t)((cap + nt_threads - 1) / nt_threads) * 64;
-        return (size_t)((cap + 3) & ~(int64_t)3) * 4 + (size_t)((cap + 7) & ~(int64_t)7) * 2 + (size_t)nw * seg * 2 + 16;
-    };
-    int cert_cap = 0;
-    if (max_src_patch_host < 0xfff0 && lds + cert_bytes(max_src_patch_host) <= (size_t)ICP_LDS_BUDGET) cert_cap = (int)max_src_patch_host;
-    lds += cert_bytes(cert_cap);
-    // then, while at least four workgroups still fit a CU (or nothing more than one fits anyway): the per-point
-    // certificate positions (worth ~10 % fewer searches than the patch-wide motion bound), then the staged sources
-    int src_cap = 0, pp_cap = 0;
-    {
-        const size_t pb = (size_t)((max_src_patch_host + 3) & ~(int64_t)3) * 3 * 4;
-        const size_t sb = (size_t)((max_src_patch_host + 3) & ~(int64_t)3) * 3 * (f64 ? 8 : 4);
-        auto fits = [&](size_t extra) { return lds + extra <= (size_t)ICP_LDS_BUDGET && (lds + extra <= 40 * 1024 || lds > 40 * 1024); };
-        if (cert_cap && !getenv("F4L_ICP_NOPP") && fits(pb)) { pp_cap = cert_cap; lds += pb; }
-        if (fits(sb)) { src_cap = (int)max_src_patch_host; lds += sb; }
-    }
-    lds = (lds + 15) & ~(size_t)15;
-    a.tgt_cap = tgt_cap; a.cert_cap = cert_cap; a.cell_cap = cell_cap; a.src_cap = src_cap; a.pp_cap = pp_cap;
+    const IcpPlan pl = icp_plan(max_src_patch_host, max_tgt_patch_host, f64);
+    const int nw = pl.nw, tgt_cap = pl.tgt_cap, cell_cap = pl.cell_cap, cert_cap = pl.cert_cap, src_cap = pl.src_cap;
+    const size_t lds = pl.lds;
+    a.tgt_cap = tgt_cap; a.cert_cap = cert_cap; a.cell_cap = cell_cap; a.src_cap = src_cap; a.pp_cap = pl.pp_cap;
+    a.list = nullptr; a.list_cnt = nullptr;
     a.prof = nullptr;
 #ifdef F4L_ICP_PROF
     if (getenv("F4L_ICP_PROF")) {
@@ -972,6 +1009,36 @@ static int f4l::icp_launch_host(const float *src, const int64_t *src_off, const 
         return rc;
     }
 #endif
-    return f64 ? launch_icp<double>(a, mode, nw, lds, (hipStream_t)stream)
-               : launch_icp<float>(a, mode, nw, lds, (hipStream_t)stream);
+    // One LDS size per launch: when the largest patch would leave a CU with two workgroups or fewer, patches are
+    // binned by size on the device and every class is launched with its own plan, largest first.  The host does not
+    // know the class sizes (no synchronisation here): each launch has P workgroups, those past its class count return.
+    const int64_t big = max_src_patch_host > max_tgt_patch_host ? max_src_patch_host : max_tgt_patch_host;
+    ClassBounds cb;
+    cb.n = 0;
+    if (lds > 48 * 1024 && P >= 64 && !getenv("F4L_ICP_NOCLASSES"))
+        for (int b = 256; b <= 4096 && 2 * (int64_t)b <= big; b *= 4) cb.bound[cb.n++] = b;
+    if (cb.n == 0)
+        return f64 ? launch_icp<double>(a, mode, nw, lds, (hipStream_t)stream)
+                   : launch_icp<float>(a, mode, nw, lds, (hipStream_t)stream);
+    cb.bound[cb.n++] = (int)(big > 0x7fffffff ? 0x7fffffff : big);
+    hipStream_t st = (hipStream_t)stream;
+    int *buf = nullptr;
+    const size_t buf_bytes = ((size_t)cb.n * (size_t)P + (size_t)cb.n) * sizeof(int);
+    F4L_HIP_CHECK(hipMallocAsync((void **)&buf, buf_bytes, st));
+    int *cnt = buf + (size_t)cb.n * (size_t)P;
+    F4L_HIP_CHECK(hipMemsetAsync(cnt, 0, (size_t)cb.n * sizeof(int), st));
+    hipLaunchKernelGGL(icp_bin_patches, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st, src_off, tgt_off, (int)P, cb, cnt, buf);
+    F4L_LAUNCH_CHECK();
+    int rc = F4L_OK;
+    for (int k = cb.n - 1; k >= 0 && rc == F4L_OK; --k) {
+        const int64_t ms = max_src_patch_host < cb.bound[k] ? max_src_patch_host : cb.bound[k];
+        const int64_t mt = max_tgt_patch_host < cb.bound[k] ? max_tgt_patch_host : cb.bound[k];
+        const IcpPlan pk = icp_plan(ms, mt, f64);
+        IcpArgs ak = a;
+        ak.tgt_cap = pk.tgt_cap; ak.cert_cap = pk.cert_cap; ak.cell_cap = pk.cell_cap; ak.src_cap = pk.src_cap; ak.pp_cap = pk.pp_cap;
+        ak.list = buf + (size_t)k * (size_t)P; ak.list_cnt = cnt + k;
+        rc = f64 ? launch_icp<double>(ak, mode, pk.nw, pk.lds, st) : launch_icp<float>(ak, mode, pk.nw, pk.lds, st);
+    }
+    F4L_HIP_CHECK(hipFreeAsync(buf, st));
+    return rc;
 }

@@ -429,6 +429,42 @@ def test_icp_dense_patches_on_a_grid_finer_than_the_radius(eng, search, monkeypa
         assert np.median(disp) <= 1e-5 and (disp <= 1e-4).mean() >= 0.85
 
 
+def test_icp_size_classes_match_single_launch_and_oracle(eng, monkeypatch):
+    """A few patches of thousands of points among many small ones: the host bins patches by size on the device and
+    launches each class with its own LDS plan (F4L_ICP_NOCLASSES=1: one launch sized for the largest patch).  Same
+    correspondences and iteration counts either way, and the oracle's transforms."""
+    rng = np.random.default_rng(31)
+    sizes = [5000, 150, 0, 300, 2500] + [int(v) for v in rng.integers(40, 700, 75)]
+    src_l, tgt_l = [], []
+    for n in sizes:
+        side = max(0.2, np.sqrt(n / 400.0))  # ~400 points per square metre
+        xy = rng.uniform(0, side, (n, 2))
+        tgt_l.append(np.c_[xy, 0.3 * np.sin(1.7 * xy[:, 0]) * np.cos(2.3 * xy[:, 1]) + rng.normal(0, 0.003, n)])
+        m = max(0, n - int(rng.integers(0, 30)))
+        xy2 = rng.uniform(0.05 * side, 0.95 * side, (m, 2))
+        sp = np.c_[xy2, 0.3 * np.sin(1.7 * xy2[:, 0]) * np.cos(2.3 * xy2[:, 1])]
+        R0 = rot_from_axis_angle(rng.normal(size=3), 0.003)
+        src_l.append(sp @ R0.T + rng.uniform(-0.02, 0.02, 3))
+    src, tgt = np.concatenate(src_l).astype(np.float32), np.concatenate(tgt_l).astype(np.float32)
+    soff, toff = ragged(rng, [len(a) for a in src_l]), ragged(rng, [len(a) for a in tgt_l])
+    args = (dev(src), dev(soff), dev(tgt), dev(toff))
+    kw = dict(max_corr_dist=0.1, max_iter=30, search="f64", return_corr=True)
+    out = eng.piecewise_icp(*args, **kw)
+    monkeypatch.setenv("F4L_ICP_NOCLASSES", "1")
+    one = eng.piecewise_icp(*args, **kw)
+    monkeypatch.delenv("F4L_ICP_NOCLASSES")
+    assert torch.equal(one["corr"], out["corr"]) and torch.equal(one["iters"], out["iters"])
+    d = dict(src=src, src_off=soff, P=len(sizes))
+    assert _disp_per_patch(d, one["T"].cpu().numpy(), out["T"].cpu().numpy()).max() <= 1e-9
+    ref = O.piecewise_icp(src, soff, tgt, toff, max_corr_dist=0.1, max_iter=30)
+    assert _disp_per_patch(d, out["T"].cpu().numpy(), ref["T"]).max() <= 1e-9
+    assert np.array_equal(out["iters"].cpu().numpy(), ref["iters"])
+    assert np.abs(out["fitness"].cpu().numpy() - ref["fitness"]).max() == 0.0
+    out32 = eng.piecewise_icp(*args, max_corr_dist=0.1, max_iter=30, search="f32")
+    disp = _disp_per_patch(d, out32["T"].cpu().numpy(), ref["T"])
+    assert np.median(disp) <= 1e-5 and (disp <= 1e-4).mean() >= 0.85
+
+
 def test_patch_loop_equals_the_three_launches(eng):
     """f4l_patch_loop = Kabsch init + ICP + displacement rows in one launch; same answers as the separate calls."""
     from fusion4landslide_amd import synthetic
