@@ -70,6 +70,7 @@ struct IcpArgs {
     double *T_out, *fitness_out, *rmse_out;
     int32_t *iters_out, *corr_out;
     int subdiv;     // cells per radius the grid may use (patch_grid.h: grid_build)
+    float dens;     // points per bounding-box cell a subdivided grid keeps on average
     double mu_frac; // certificate margin as a fraction of the correspondence radius
     int debug;  // F4L_ICP_DEBUG env, bit switches for A/B measurements and tests: 4 = no certificates, 8 = no bound from
                 // the previous correspondence, 16 = no narrow look-up before pass 0 on fine grids, 128 = always the Jacobi
@@ -77,6 +78,7 @@ struct IcpArgs {
     unsigned long long *prof;  // F4L_ICP_PROF builds only: per-phase shader-clock totals (see f4l_piecewise_icp)
     // size-class launches (icp_launch_host): workgroup b handles patch list[b] if b < *list_cnt, else nothing
     const int *list, *list_cnt;
+    int prof_max_n;  // profiling builds: only patches up to this size are counted
 };
 
 #ifdef F4L_ICP_PROF
@@ -279,7 +281,7 @@ __global__ __launch_bounds__(NW * 64, sizeof(F) == 8 ? ICP_WAVES_PER_EU_F64 : IC
     g.minx = g.miny = g.minz = (F)0; g.h = (F)1; g.inv_h = (F)1; g.nx = g.ny = g.nz = 1;
     double cs[3] = {0.0, 0.0, 0.0}, srad = 0.0;
     if (active) {  // uniform across the workgroup
-        if (tgt_in_lds) grid_build<F, NT>(tg, nt, ox, oy, oz, rs, a.cell_cap, tl, E, reinterpret_cast<F *>(scratch), g, a.subdiv);
+        if (tgt_in_lds) grid_build<F, NT>(tg, nt, ox, oy, oz, rs, a.cell_cap, tl, E, reinterpret_cast<F *>(scratch), g, a.subdiv, (F)a.dens);
         {
             // centroid and radius of the source patch (origin-relative): the lever arm of the motion bound
             double sum[3] = {0.0, 0.0, 0.0};
@@ -540,7 +542,8 @@ __global__ __launch_bounds__(NW * 64, sizeof(F) == 8 ? ICP_WAVES_PER_EU_F64 : IC
                 }
                 best.init(b0);
 #ifdef F4L_ICP_PROF
-                grid_nn<F, NT>(g, tl, nt, E, rl, valid, px, py, pz, best, (a.debug & 64) ? a.prof : nullptr);
+                grid_nn<F, NT>(g, tl, nt, E, rl, valid, px, py, pz, best,
+                               ((a.debug & 64) && ns <= a.prof_max_n && nt <= a.prof_max_n) ? a.prof : nullptr);
 #else
                 grid_nn<F, NT>(g, tl, nt, E, rl, valid, px, py, pz, best);
 #endif
@@ -739,10 +742,11 @@ __global__ __launch_bounds__(NW * 64, sizeof(F) == 8 ? ICP_WAVES_PER_EU_F64 : IC
 #ifdef F4L_ICP_PROF
     const unsigned long long rt_end = __builtin_amdgcn_s_memrealtime();
     prof_acc[14] += rt_end - rt_start;
-    if (a.prof && tid == 0) { a.prof[16 + 2 * p] = rt_start; a.prof[17 + 2 * p] = rt_end; }
-    if (a.prof && tid == 0) {
+    if (a.prof && tid == 0) { a.prof[32 + 2 * p] = rt_start; a.prof[33 + 2 * p] = rt_end; }
+    if (a.prof && tid == 0 && ns <= a.prof_max_n && nt <= a.prof_max_n) {  // (F4L_ICP_PROF_MAXN: small patches only)
         const int slots[9] = {0, 1, 2, 3, 4, 5, 15, 12, 14};
         for (int i = 0; i < 9; ++i) atomicAdd(&a.prof[slots[i]], prof_acc[slots[i]]);
+        atomicAdd(&a.prof[26], 1ULL);
     }
 #endif
     if (tid == 0) {
@@ -798,17 +802,28 @@ namespace f4l {
 
 // Size classes: patch p goes to the first class whose bound holds max(sources, targets) of the patch.  The order inside
 // a class list depends on scheduling; nothing downstream does (every patch is solved on its own).
-constexpr int ICP_MAX_CLASSES = 4;
+constexpr int ICP_MAX_CLASSES = 12;
 struct ClassBounds { int n; int bound[ICP_MAX_CLASSES]; };
 __global__ void icp_bin_patches(const int64_t *__restrict__ src_off, const int64_t *__restrict__ tgt_off, int P,
                                 ClassBounds cb, int *__restrict__ cnt, int *__restrict__ list) {
     const int p = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-    if (p >= P) return;
-    const int64_t ns = src_off[p + 1] - src_off[p], nt = tgt_off[p + 1] - tgt_off[p];
-    const int64_t m = ns > nt ? ns : nt;
-    int k = 0;
-    while (k < cb.n - 1 && m > cb.bound[k]) ++k;
-    list[(size_t)k * P + atomicAdd(&cnt[k], 1)] = p;
+    const int lane = (int)(threadIdx.x & 63);
+    int k = -1;
+    if (p < P) {
+        const int64_t ns = src_off[p + 1] - src_off[p], nt = tgt_off[p + 1] - tgt_off[p];
+        const int64_t m = ns > nt ? ns : nt;
+        k = 0;
+        while (k < cb.n - 1 && m > cb.bound[k]) ++k;
+    }
+    for (int c = 0; c < cb.n; ++c) {  // one atomic per wave and class
+        const unsigned long long m = __ballot(k == c);
+        if (m == 0ULL) continue;
+        const int leader = __ffsll((long long)m) - 1;
+        int base = 0;
+        if (lane == leader) base = atomicAdd(&cnt[c], __builtin_popcountll(m));
+        base = __shfl(base, leader, 64);
+        if (k == c) list[(size_t)c * P + base + __builtin_popcountll(m & ((1ULL << lane) - 1ULL))] = p;
+    }
 }
 
 template <int MODE, int NW, typename F>
@@ -958,7 +973,8 @@ static int f4l::icp_launch_host(const float *src, const int64_t *src_off, const 
     a.r2 = a.r * a.r;
     a.max_iter = max_iter; a.rel_fitness = rel_fitness; a.rel_rmse = rel_rmse; a.fixed_iters = fixed_iters;
     { const char *dbg = getenv("F4L_ICP_DEBUG"); a.debug = dbg ? atoi(dbg) : 0; }
-    a.subdiv = 8; a.mu_frac = 0.125;
+    a.subdiv = 8; a.mu_frac = 0.125; a.dens = 2.f;
+    { const char *e = getenv("F4L_ICP_DENS"); if (e && atof(e) > 0.0) a.dens = (float)atof(e); }
     { const char *e = getenv("F4L_ICP_SUBDIV"); if (e && atoi(e) >= 1) a.subdiv = atoi(e); }
     { const char *e = getenv("F4L_ICP_MU"); if (e && atof(e) > 0.0) a.mu_frac = atof(e); }
     a.T_out = T_out; a.fitness_out = fitness_out; a.rmse_out = rmse_out; a.iters_out = iters_out; a.corr_out = corr_out;
@@ -971,17 +987,18 @@ static int f4l::icp_launch_host(const float *src, const int64_t *src_off, const 
     a.prof = nullptr;
 #ifdef F4L_ICP_PROF
     if (getenv("F4L_ICP_PROF")) {
-        unsigned long long *dp = nullptr, hp[16];
+        unsigned long long *dp = nullptr, hp[32];
         const size_t prof_bytes = sizeof(hp) + (size_t)P * 16;
         F4L_HIP_CHECK(hipMalloc(&dp, prof_bytes));
         F4L_HIP_CHECK(hipMemset(dp, 0, prof_bytes));
         a.prof = dp;
+        a.prof_max_n = getenv("F4L_ICP_PROF_MAXN") ? atoi(getenv("F4L_ICP_PROF_MAXN")) : 0x7fffffff;
         int rc = f64 ? launch_icp<double>(a, mode, nw, lds, (hipStream_t)stream) : launch_icp<float>(a, mode, nw, lds, (hipStream_t)stream);
         F4L_HIP_CHECK(hipDeviceSynchronize());
         F4L_HIP_CHECK(hipMemcpy(hp, dp, sizeof(hp), hipMemcpyDeviceToHost));
         if (getenv("F4L_ICP_PROF_WG")) {  // per-workgroup start/end (100 MHz ticks) -> schedule statistics
             unsigned long long *wg = (unsigned long long *)malloc((size_t)P * 16);
-            F4L_HIP_CHECK(hipMemcpy(wg, dp + 16, (size_t)P * 16, hipMemcpyDeviceToHost));
+            F4L_HIP_CHECK(hipMemcpy(wg, dp + 32, (size_t)P * 16, hipMemcpyDeviceToHost));
             unsigned long long t0 = ~0ULL, t1 = 0, dmin = ~0ULL, dmax = 0;
             double dsum = 0;
             for (int64_t i = 0; i < P; ++i) {
@@ -1002,10 +1019,17 @@ static int f4l::icp_launch_host(const float *src, const int64_t *src_off, const 
             free(wg);
         }
         hipFree(dp);
+        const double Pw = (double)(hp[26] ? hp[26] : 1);
         fprintf(stderr, "[icp prof] P=%lld nw=%d lds=%zu tgt_cap=%d cert_cap=%d src_cap=%d cell_cap=%d | per-WG mean cycles: total %.0f build %.0f phase1 %.0f search %.0f reduce %.0f solve %.0f barrier %.0f dpp %.0f clock %.3f GHz | per query: steps %.2f rows %.2f rows_taken %.2f wave-steps/batch %.2f | per WG-pass: searched %.1f of %.1f, wave-batches %.2f\n",
-                (long long)P, nw, lds, tgt_cap, cert_cap, src_cap, cell_cap, hp[0] / (double)P, hp[1] / (double)P, hp[15] / (double)P, hp[2] / (double)P,
-                hp[3] / (double)P, hp[4] / (double)P, hp[5] / (double)P, hp[12] / (double)P, hp[0] / (double)(hp[14] ? hp[14] : 1) * 0.1, hp[6] / (double)(hp[9] ? hp[9] : 1),
-                hp[7] / (double)(hp[9] ? hp[9] : 1), hp[8] / (double)(hp[9] ? hp[9] : 1), hp[10] / (double)(hp[11] ? hp[11] : 1), hp[9] / (double)P / (max_iter + 1), (double)max_src_patch_host, hp[11] / (double)P / (max_iter + 1));
+                (long long)Pw, nw, lds, tgt_cap, cert_cap, src_cap, cell_cap, hp[0] / (double)Pw, hp[1] / (double)Pw, hp[15] / (double)Pw, hp[2] / (double)Pw,
+                hp[3] / (double)Pw, hp[4] / (double)Pw, hp[5] / (double)Pw, hp[12] / (double)Pw, hp[0] / (double)(hp[14] ? hp[14] : 1) * 0.1, hp[6] / (double)(hp[9] ? hp[9] : 1),
+                hp[7] / (double)(hp[9] ? hp[9] : 1), hp[8] / (double)(hp[9] ? hp[9] : 1), hp[10] / (double)(hp[11] ? hp[11] : 1), hp[9] / (double)Pw / (max_iter + 1), (double)max_src_patch_host, hp[11] / (double)Pw / (max_iter + 1));
+        fprintf(stderr, "[icp prof wide] queries %llu wave-calls %llu mean W %.2f | scan rounds %llu, stencil rows per round %.2f, rows kept per lane-round %.2f, steps per lane-round %.2f\n",
+                hp[23], hp[24], hp[25] / (double)(hp[24] ? hp[24] : 1), hp[13], hp[22] / (double)(hp[13] ? hp[13] : 1),
+                hp[21] / (double)(hp[13] ? hp[13] : 1) / 64.0, hp[20] / (double)(hp[13] ? hp[13] : 1) / 64.0);
+        fprintf(stderr, "[icp prof grid_nn] cycles per wave-call: narrow %.0f (%llu calls), wide %.0f; wide stencil rows visited per call %.1f; calls with W >= 8: %llu\n",
+                hp[27] / (double)((hp[11] > hp[24] ? hp[11] - hp[24] : 1)), (unsigned long long)(hp[11] - hp[24]), hp[28] / (double)(hp[24] ? hp[24] : 1),
+                hp[29] / (double)(hp[24] ? hp[24] : 1), hp[30]);
         return rc;
     }
 #endif
@@ -1016,7 +1040,14 @@ static int f4l::icp_launch_host(const float *src, const int64_t *src_off, const 
     ClassBounds cb;
     cb.n = 0;
     if (lds > 48 * 1024 && P >= 64 && !getenv("F4L_ICP_NOCLASSES"))
-        for (int b = 256; b <= 4096 && 2 * (int64_t)b <= big; b *= 4) cb.bound[cb.n++] = b;
+    {
+        int step = 4;  // ratio between class bounds: 4 (256, 1024, 4096), 2, or 1 = sqrt(2)
+        if (const char *e = getenv("F4L_ICP_CLASS_STEP")) step = atoi(e);
+        for (int64_t b = 256; b <= 4096 && 3 * b <= 2 * big && cb.n < ICP_MAX_CLASSES - 1;) {
+            cb.bound[cb.n++] = (int)b;
+            b = step == 4 ? b * 4 : (step == 2 ? b * 2 : ((cb.n & 1) ? (b * 3) / 2 : (b * 4) / 3));
+        }
+    }
     if (cb.n == 0)
         return f64 ? launch_icp<double>(a, mode, nw, lds, (hipStream_t)stream)
                    : launch_icp<float>(a, mode, nw, lds, (hipStream_t)stream);

@@ -149,7 +149,7 @@ template <> struct Best<double> {
 template <typename F, int NT>
 __device__ __forceinline__ void grid_build(const float *__restrict__ tg, int nt, float ox, float oy, float oz, F r,
                                            int cell_cap, GridPt<F> *__restrict__ tl, unsigned short *__restrict__ E,
-                                           F *__restrict__ red, PatchGrid<F> &g, int subdiv = 4) {
+                                           F *__restrict__ red, PatchGrid<F> &g, int subdiv = 4, F dens = (F)4) {
     constexpr int NW = NT / 64;
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
@@ -194,11 +194,15 @@ __device__ __forceinline__ void grid_build(const float *__restrict__ tg, int nt,
     const F rpad = r * (F)1.0078125;
     F h = rpad;
     if (subdiv > 1) {
-        // subdivide only patches that are dense relative to the radius: aim at ~4 points per cell of the bounding
-        // box (a cube-root rule: conservative for surfaces, which leave most of the box empty)
-        const F n1 = (floor(ex / rpad) + (F)1) * (floor(ey / rpad) + (F)1) * (floor(ez / rpad) + (F)1);
-        const F sf = cbrt((F)nt / ((F)4 * n1));
-        const int sd = sf >= (F)subdiv ? subdiv : (sf < (F)1 ? 1 : (int)sf);
+        // subdivide only patches that are dense relative to the radius: the finest of r/1 .. r/subdiv that still leaves
+        // `dens` points per cell of the bounding box on average (surfaces leave most of the box empty, so occupied
+        // cells hold several times that)
+        int sd = 1;
+        for (int c = 2; c <= subdiv; ++c) {
+            const F ih = (F)c / rpad;
+            const F cells = (floor(ex * ih) + (F)1) * (floor(ey * ih) + (F)1) * (floor(ez * ih) + (F)1);
+            if (cells * dens <= (F)nt) sd = c;
+        }
         h = rpad / (F)sd;
     }
     int nx = 1, ny = 1, nz = 1;
@@ -360,35 +364,60 @@ __device__ __forceinline__ int grid_scan_rows(const PatchGrid<F> &g, const GridP
 }
 
 // The rare wide search of grid_nn (points without a previous correspondence on a grid finer than the radius): the
-// (2 W + 1)^2 rows of the stencil, 9 at a time, every lane pruning with its own bound.  Deliberately NOT inlined and
-// written with rolled loops: it must not cost the common path registers or instruction-cache footprint.
+// (2 W + 1)^2 rows of the stencil, 9 at a time, every lane pruning with its own bound.  Written with rolled loops and
+// a single scan site: it must not cost the common path registers or instruction-cache footprint.
 template <typename F, int NT>
 __device__ __forceinline__ Best<F> grid_nn_wide(const PatchGrid<F> &g, const GridPt<F> *__restrict__ tl, int dummy,
                                                        const unsigned short *__restrict__ E, unsigned int *__restrict__ rl,
                                                        int W, bool xok, int cy, int cz, int base0, int span, F fy, F fz,
-                                                       F slack, F b2s, F px, F py, F pz, Best<F> best) {
+                                                       F slack, F b2s, F px, F py, F pz, Best<F> best,
+                                                       unsigned long long *prof = nullptr) {
     const int tid = (int)threadIdx.x;
     const int nxny = __mul24(g.nx, g.ny);
-    int dy = -W, dz = -W;  // uniform
-    while (dz <= W) {
-        int cnt = 0;
-#pragma nounroll
-        for (int r = 0; r < 9 && dz <= W; ++r) {
-            const int ady = dy < 0 ? -dy : dy, adz = dz < 0 ? -dz : dz;
-            F ddy = dy == 0 ? (F)0 : (dy < 0 ? fy : g.h - fy) + (F)(ady - 1) * g.h - slack;
+    // (dy, dz) walks the stencil row by row; both are uniform.  Layers and rows that no lane of the wave can use
+    // (outside the grid -- surfaces leave most z layers empty -- or beyond every bound) cost one ballot, the others
+    // are collected nine at a time and scanned.
+    int dy = -W, dz = -W, r = 0, cnt = 0;
+    for (;;) {
+        if (dz <= W) {
+            const int adz = dz < 0 ? -dz : dz;
             F ddz = dz == 0 ? (F)0 : (dz < 0 ? fz : g.h - fz) + (F)(adz - 1) * g.h - slack;
-            ddy = ddy > (F)0 ? ddy : (F)0;
             ddz = ddz > (F)0 ? ddz : (F)0;
-            const int y = cy + dy, z = cz + dz;
-            const bool k = xok && y >= 0 && y < g.ny && z >= 0 && z < g.nz && !(ddy * ddy + ddz * ddz > b2s);
-            const int a = base0 + dy * g.nx + dz * nxny;
-            const unsigned int s1 = E[k ? a : 0], e1 = E[k ? a + span : 0];
-            rl[cnt * NT + tid] = s1 | (e1 << 16);
-            cnt += s1 < e1 ? 1 : 0;
+            const int z = cz + dz;
+            const bool zk = xok && z >= 0 && z < g.nz && !(ddz * ddz > b2s);
+            if (dy == -W && !__any(zk)) { ++dz; continue; }
+            const int ady = dy < 0 ? -dy : dy;
+            F ddy = dy == 0 ? (F)0 : (dy < 0 ? fy : g.h - fy) + (F)(ady - 1) * g.h - slack;
+            ddy = ddy > (F)0 ? ddy : (F)0;
+            const int y = cy + dy;
+            const bool k = zk && y >= 0 && y < g.ny && !(ddy * ddy + ddz * ddz > b2s);
+            if (__any(k)) {
+                const int a = base0 + dy * g.nx + dz * nxny;
+                const unsigned int s1 = E[k ? a : 0], e1 = E[k ? a + span : 0];
+                rl[cnt * NT + tid] = s1 | (e1 << 16);
+                cnt += s1 < e1 ? 1 : 0;
+                ++r;
+            }
             if (++dy > W) { dy = -W; ++dz; }
+            if (r < GRID_ROWS && dz <= W) continue;
         }
-        rl[cnt * NT + tid] = 0u;
-        grid_scan_rows<F, NT>(g, tl, dummy, rl, cnt, px, py, pz, best);
+        if (r > 0) {
+            rl[cnt * NT + tid] = 0u;
+#ifdef F4L_ICP_PROF
+            const int st =
+#endif
+            grid_scan_rows<F, NT>(g, tl, dummy, rl, cnt, px, py, pz, best);
+#ifdef F4L_ICP_PROF
+            if (prof) {  // slot 13: scan rounds of the wide path, slot 4 + 16: its steps, slot 5 + 16: rows kept
+                atomicAdd(&prof[20], (unsigned long long)st);
+                atomicAdd(&prof[21], (unsigned long long)cnt);
+                if (lane_id() == 0) { atomicAdd(&prof[13], 1ULL); atomicAdd(&prof[22], (unsigned long long)r); }
+            }
+#endif
+            r = 0;
+            cnt = 0;
+        }
+        if (dz > W) break;
     }
     return best;  // by value: a reference would pin the caller's record to memory on the common path too
 }
@@ -424,7 +453,10 @@ __device__ __forceinline__ void grid_nn(const PatchGrid<F> &g, const GridPt<F> *
     if (WIDE && g.wmax > 1) {
         int wl = floor_to_int(bnd * g.inv_h) + 1;
         wl = valid ? (wl > g.wmax ? g.wmax : wl) : 0;
-        W = __any(wl > 1) ? g.wmax : 1;  // (the rows of a wider stencil than a lane needs are pruned by its bound)
+        if (__any(wl > 1)) {  // the widest stencil any lane of the wave needs (rows beyond a lane's own bound are pruned)
+            W = g.wmax;
+            while (W > 2 && !__any(wl >= W)) --W;
+        }
     }
 #endif
     const F fy = py - (g.miny + (F)cy * g.h), fz = pz - (g.minz + (F)cz * g.h);
@@ -434,6 +466,7 @@ __device__ __forceinline__ void grid_nn(const PatchGrid<F> &g, const GridPt<F> *
     const int span = x1 - x0 + 1;
 #ifdef F4L_ICP_PROF
     int n_steps = 0, cnt_total = 0;
+    const unsigned long long pt0 = __builtin_readcyclecounter();
 #endif
 
     if (W <= 1) {
@@ -472,10 +505,21 @@ __device__ __forceinline__ void grid_nn(const PatchGrid<F> &g, const GridPt<F> *
         grid_scan_rows<F, NT>(g, tl, dummy, rl, cnt, px, py, pz, best);
     } else {
 #ifndef F4L_GRID_NOWIDE
+#ifdef F4L_ICP_PROF
+        if (prof) { atomicAdd(&prof[23], valid ? 1ULL : 0ULL); if (lane_id() == 0) { atomicAdd(&prof[24], 1ULL); atomicAdd(&prof[25], (unsigned long long)W); } }
+        if (WIDE) best = grid_nn_wide<F, NT>(g, tl, dummy, E, rl, W, xok, cy, cz, base0, span, fy, fz, slack, b2s, px, py, pz, best, prof);
+#else
         if (WIDE) best = grid_nn_wide<F, NT>(g, tl, dummy, E, rl, W, xok, cy, cz, base0, span, fy, fz, slack, b2s, px, py, pz, best);
+#endif
 #endif
     }
 #ifdef F4L_ICP_PROF
+    if (prof && lane_id() == 0) {
+        const unsigned long long dt = __builtin_readcyclecounter() - pt0;
+        atomicAdd(&prof[W <= 1 ? 27 : 28], dt);
+        if (W > 1) atomicAdd(&prof[29], (unsigned long long)((2 * W + 1) * (2 * W + 1)));
+        if (W >= 8) atomicAdd(&prof[30], 1ULL);
+    }
     if (prof) {
         atomicAdd(&prof[6], (unsigned long long)n_steps);
         atomicAdd(&prof[7], (unsigned long long)(xok ? 9 : 0));
