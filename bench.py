@@ -19,7 +19,8 @@ Extra objects on the JSON line:
   roofline     dominant kernel = icp_kernel (the fused loop body); achieved = algorithmic bytes per launch (20 iters x
                24 B + 24 B Kabsch read + 24 B row written = 528 B per source point) / its mean duration
                measured with events on the launch stream; peak = 8 TB/s.
-  cpu_baseline the C oracle (oracle/f4l_oracle.c, 1 thread, "port") timed on a bounded sample of the same patches.
+  cpu_baseline the C oracle (oracle/f4l_oracle.c, 1 thread, "port") timed on a bounded sample of the same patches;
+               cpu_baseline.all_cores: the same port with its patch loop on all host cores (OpenMP).
 """
 import argparse
 import json
@@ -152,6 +153,11 @@ def main():
             if t.get("workload") == args.config:
                 line["roofline"]["traffic"] = t["hbm_bytes_per_launch"]
                 line["roofline"]["traffic_source"] = t["source"]
+        if world == 1:
+            # the box's own device-to-device copy rate (SURVEY.md 8d asks for the fraction of nominal AND of measured)
+            copy_gbs = measured_copy_gbs(torch, dev)
+            line["roofline"]["peak_copy_measured"] = round(copy_gbs, 1)
+            line["roofline"]["frac_of_copy_measured"] = round(achieved / copy_gbs, 5)
         if world == 1 and args.extras:
             line["extras"] = extras(torch, engine, step, src, args)
         if world == 1 and args.cpu_seconds > 0:  # rank 0 at N = 1 only
@@ -161,6 +167,22 @@ def main():
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def measured_copy_gbs(torch, dev, gib=1.0, reps=10):
+    """Read + write bytes per second of a large device-to-device copy (the practical HBM peak of this box)."""
+    n = int(gib * (1 << 30)) // 4
+    a = torch.empty(n, dtype=torch.float32, device=dev).fill_(1.0)
+    b = torch.empty_like(a)
+    for _ in range(2):
+        b.copy_(a)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize()
+    return 2.0 * 4.0 * n * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
 
 def extras(torch, engine, step, src, args):
@@ -250,8 +272,42 @@ def cpu_baseline(d, cs, ct, coff, budget_s):
     rate = npts / dt
     want = int(min(P, max(probe, budget_s * rate / (d["src"].shape[0] / P))))
     dt, npts = run(0, want)
-    return {"value": round(npts / dt / 1e6, 5), "unit": "Mpts/s", "cores": 1, "kind": "port",
-            "sample": f"first {want} of {P} patches ({npts} source points), same Kabsch+ICP(20)+apply step, {dt:.1f} s"}
+    out = {"value": round(npts / dt / 1e6, 5), "unit": "Mpts/s", "cores": 1, "kind": "port",
+           "sample": f"first {want} of {P} patches ({npts} source points), same Kabsch+ICP(20)+apply step, {dt:.1f} s"}
+    # the same port with its patch loop on every core this process may use (OpenMP)
+    cores = host_cores()
+    if cores > 1:
+        used = O.set_threads(cores)
+        try:
+            want_all = int(min(P, max(probe, want * used * 0.5)))
+            run(0, min(want_all, 4 * used))  # thread start-up outside the clock
+            dt_all, npts_all, reps = 0.0, 0, 0
+            while dt_all < 0.3 * budget_s and reps < 20:
+                dt1, n1 = run(0, want_all)
+                dt_all, npts_all, reps = dt_all + dt1, npts_all + n1, reps + 1
+        finally:
+            O.set_threads(1)
+        out["all_cores"] = {"value": round(npts_all / dt_all / 1e6, 5), "unit": "Mpts/s", "cores": used,
+                            "sample": f"first {want_all} of {P} patches x{reps} ({npts_all} source points), {dt_all:.1f} s"}
+    return out
+
+
+def host_cores():
+    """CPUs this process can really use: the affinity mask, capped by the cgroup CPU quota when there is one."""
+    cores = len(os.sched_getaffinity(0))
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                quota, period = txt[0], float(txt[1])
+            else:
+                quota, period = txt[0], float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota not in ("max", "-1") and float(quota) > 0:
+                cores = max(1, min(cores, int(float(quota) / period + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return cores
 
 
 if __name__ == "__main__":

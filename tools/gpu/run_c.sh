@@ -1,8 +1,2 @@
-python -m pytest tests -m gpu -q -x 2>&1 | tail -3
-for rep in 1 2 3; do for v in old new; do
-  cp tools/gpu/ab/$v.so fusion4landslide_amd/lib/libf4l_hip.so
-  echo -n "$v: "; python bench.py --steps 20 --warmup 5 --cpu-seconds 0 --extras 0 2>&1 | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['roofline']['kernel_ms'])"
-done; done
-for c in C3_10M_20k C4_50M_100k; do
-echo -n "$c: "; python bench.py --config $c --steps 3 --warmup 1 --cpu-seconds 0 --extras 0 2>&1 | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['roofline']['kernel_ms'])"
-done
+nproc; cat /sys/fs/cgroup/cpu.max; python -c "import bench; print(bench.host_cores())"
+python bench.py --steps 10 --warmup 3 --extras 0 2>&1 | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['cpu_baseline'])"
