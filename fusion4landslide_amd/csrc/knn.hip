@@ -119,6 +119,12 @@ struct KnnArgs {
     const unsigned long long *cell_keys;  // [M] ascending
     const int32_t *cell_start;        // [M+1] first sorted index of each occupied cell
     int M;
+    // the queries, binned into the cells of the SAME grid (f4l_knn: the cloud itself; f4l_nn_query: another cloud,
+    // points outside the grid clamped into its border cells)
+    const float4 *q_sorted;
+    const unsigned long long *q_cell_keys;
+    const int32_t *q_cell_start;
+    int Mq;
     int64_t n;
     int k;
     GridSpec g;
@@ -129,13 +135,13 @@ struct KnnArgs {
 __global__ __launch_bounds__(KNN_NW * 64) void knn_cells_kernel(KnnArgs a) {
     const int lane = lane_id();
     const int c = (int)blockIdx.x * KNN_NW + (int)(threadIdx.x >> 6);
-    if (c >= a.M) return;  // whole wave exits together
+    if (c >= a.Mq) return;  // whole wave exits together
     const GridSpec g = a.g;
-    const unsigned long long key = a.cell_keys[c];
+    const unsigned long long key = a.q_cell_keys[c];
     const int cx = (int)(key % (unsigned long long)g.nx);
     const int cy = (int)((key / (unsigned long long)g.nx) % (unsigned long long)g.ny);
     const int cz = (int)(key / ((unsigned long long)g.nx * (unsigned long long)g.ny));
-    const int q_begin = a.cell_start[c], q_end = a.cell_start[c + 1];
+    const int q_begin = a.q_cell_start[c], q_end = a.q_cell_start[c + 1];
     const int k = a.k;
     const int max_dim = max(g.nx, max(g.ny, g.nz));
 
@@ -153,24 +159,27 @@ __global__ __launch_bounds__(KNN_NW * 64) void knn_cells_kernel(KnnArgs a) {
     }
 
     for (int q = q_begin; q < q_end; ++q) {
-        const float4 qp = a.sorted[q];
+        const float4 qp = a.q_sorted[q];
         const int qid = __float_as_int(qp.w);
         // distance from the query to the faces of its own cell, per axis (conservative by 1e-6 h)
         const double fx = ((double)qp.x - g.minx) - (double)cx * g.h, fy = ((double)qp.y - g.miny) - (double)cy * g.h,
                      fz = ((double)qp.z - g.minz) - (double)cz * g.h;
         WaveTopK best;
-        for (int R = 1;; ++R) {
+        for (int R = 1;;) {
             best.reset();
             bool first = true;  // uniform
-            const int side = 2 * R + 1, rows = side * side;
+            // rows of the block that lie inside the grid (R = 1: the fixed 3 x 3 of row_lo1 / row_hi1)
+            const int y0 = cy - R < 0 ? 0 : cy - R, y1 = cy + R >= g.ny ? g.ny - 1 : cy + R;
+            const int z0 = cz - R < 0 ? 0 : cz - R, z1 = cz + R >= g.nz ? g.nz - 1 : cz + R;
+            const int side = R == 1 ? 3 : y1 - y0 + 1, rows = R == 1 ? 9 : side * (z1 - z0 + 1);
             for (int r0 = 0; r0 < rows; r0 += 64) {
                 int lo = 0, hi = 0;
                 if (R == 1) { lo = row_lo1; hi = row_hi1; }
                 else {
                     const int r = r0 + lane;
                     if (r < rows) {
-                        const int yy = cy + (r % side) - R, zz = cz + (r / side) - R;
-                        if (yy >= 0 && yy < g.ny && zz >= 0 && zz < g.nz) {
+                        const int yy = y0 + (r % side), zz = z0 + (r / side);
+                        {
                             const int x0 = cx - R < 0 ? 0 : cx - R, x1 = cx + R >= g.nx ? g.nx - 1 : cx + R;
                             const int ca = lower_bound_u64(a.cell_keys, a.M, key_of(g, x0, yy, zz));
                             const int cb = lower_bound_u64(a.cell_keys, a.M, key_of(g, x1, yy, zz) + 1ULL);
@@ -180,9 +189,14 @@ __global__ __launch_bounds__(KNN_NW * 64) void knn_cells_kernel(KnnArgs a) {
                     }
                 }
                 const int nrow = rows - r0 < 64 ? rows - r0 : 64;
-                for (int rq = 0; rq < nrow; ++rq) {
+                // wider blocks (queries far from the cloud): most rows are empty, visit only the others
+                unsigned long long todo = R == 1 ? 0ULL : __ballot(hi > lo);
+                for (int rq = 0; R == 1 ? rq < nrow : todo != 0ULL; ++rq) {
                     int rr = rq;
-                    if (R == 1) {
+                    if (R != 1) {
+                        rr = __ffsll((long long)todo) - 1;
+                        todo &= todo - 1ULL;
+                    } else {
                         // nearest rows first (own row, the four face neighbours, the four corners): the list tightens
                         // early, and a row that lies beyond the current k-th distance is not streamed at all
                         rr = (int)((0x862075314ULL >> (4 * rq)) & 15ULL);
@@ -217,6 +231,8 @@ __global__ __launch_bounds__(KNN_NW * 64) void knn_cells_kernel(KnnArgs a) {
             if (cz + R < g.nz - 1) margin = fmin(margin, ((double)(R + 1)) * g.h - fz - eps);
             const double dk = best.kth(k);
             if (dk < margin * margin || R >= max_dim) break;  // uniform: dk, margin are wave-uniform
+            // fewer than k points in the whole block (queries far from the cloud): double it instead of one more layer
+            R = dk == __builtin_inf() ? (2 * R < max_dim ? 2 * R : max_dim) : R + 1;
         }
         if (lane < k) {
             a.idx_out[(int64_t)qid * k + lane] = best.i;
@@ -334,26 +350,17 @@ extern "C" size_t f4l_knn_workspace_bytes(int64_t n, int k) {
     return w.total;
 }
 
-// Synchronises `stream` (the bounding box and the occupied-cell count are read back to size the grid).
-extern "C" int f4l_knn(const float *xyz, int64_t n, int k, int32_t *idx_out, double *d2_out, void *workspace,
-                       size_t workspace_bytes, void *stream) {
-    using namespace f4l;
-    if (!xyz || n <= 0 || k < 1 || k > n || !idx_out || !workspace) return F4L_EINVAL;
-    if (k > F4L_MAX_K || n > 0x7fffffffLL) return F4L_EUNSUPPORTED;
-    hipStream_t st = (hipStream_t)stream;
-    KnnWs w;
-    int rc = knn_ws_layout(n, w, (unsigned char *)workspace);
-    if (rc != F4L_OK) return rc;
-    if (workspace_bytes < w.total) return F4L_EWORKSPACE;
-
-    // 1. bounding box
+namespace f4l {
+// Steps 1-4 of f4l_knn: bounding box, cell size for ~k/2 points per occupied cell, points sorted by cell, occupied-cell
+// table.  Synchronises `st`.
+static int bbox_to_host(const float *xyz, int64_t n, float *partial, hipStream_t st, double *mn, double *mx) {
     const unsigned bb_grid = grid_for(n, 256, 256);
-    hipLaunchKernelGGL(bbox_kernel, dim3(bb_grid), dim3(256), 0, st, xyz, n, w.bbox_partial);
+    hipLaunchKernelGGL(bbox_kernel, dim3(bb_grid), dim3(256), 0, st, xyz, n, partial);
     F4L_LAUNCH_CHECK();
     float hb[256 * 6];
-    F4L_HIP_CHECK(hipMemcpyAsync(hb, w.bbox_partial, (size_t)bb_grid * 6 * 4, hipMemcpyDeviceToHost, st));
+    F4L_HIP_CHECK(hipMemcpyAsync(hb, partial, (size_t)bb_grid * 6 * 4, hipMemcpyDeviceToHost, st));
     F4L_HIP_CHECK(hipStreamSynchronize(st));
-    double mn[3] = {1e300, 1e300, 1e300}, mx[3] = {-1e300, -1e300, -1e300};
+    for (int d = 0; d < 3; ++d) { mn[d] = 1e300; mx[d] = -1e300; }
     for (unsigned b = 0; b < bb_grid; ++b)
         for (int d = 0; d < 3; ++d) {
             if (hb[6 * b + d] < mn[d]) mn[d] = hb[6 * b + d];
@@ -361,6 +368,16 @@ extern "C" int f4l_knn(const float *xyz, int64_t n, int k, int32_t *idx_out, dou
         }
     for (int d = 0; d < 3; ++d)
         if (!(mx[d] >= mn[d]) || !std::isfinite(mn[d]) || !std::isfinite(mx[d])) return F4L_EINVAL;  // NaN / inf coordinates
+    return F4L_OK;
+}
+
+static int knn_build_grid(const float *xyz, int64_t n, int k, KnnWs &w, hipStream_t st, GridSpec &g, int &M) {
+    // 1. bounding box
+    double mn[3], mx[3];
+    {
+        const int rc = bbox_to_host(xyz, n, w.bbox_partial, st, mn, mx);
+        if (rc != F4L_OK) return rc;
+    }
 
     // 2. cell size: aim at ~k/2 points per occupied cell; start from a surface-density guess and correct with
     //    the measured occupancy (the result is exact for any h, only speed depends on it)
@@ -376,8 +393,7 @@ extern "C" int f4l_knn(const float *xyz, int64_t n, int k, int32_t *idx_out, dou
         h = std::sqrt(target * area / (double)n);
         if (!(h > 0.0)) h = diag;
     }
-    GridSpec g;
-    int M = 0;
+    M = 0;
     for (int iter = 0; iter < 5; ++iter) {
         // keep every axis below 2^20 cells so the linear key fits comfortably in 63 bits
         const double hmin = (e[2] > 0 ? e[2] : 1.0) / 1048000.0;
@@ -414,12 +430,186 @@ extern "C" int f4l_knn(const float *xyz, int64_t n, int k, int32_t *idx_out, dou
     // 4. sorted float4 layout
     hipLaunchKernelGGL(relayout_kernel, dim3(grid_for(n)), dim3(256), 0, st, xyz, w.ids_b, n, w.sorted);
     F4L_LAUNCH_CHECK();
+    return F4L_OK;
+}
+}  // namespace f4l
+
+// Synchronises `stream` (the bounding box and the occupied-cell count are read back to size the grid).
+extern "C" int f4l_knn(const float *xyz, int64_t n, int k, int32_t *idx_out, double *d2_out, void *workspace,
+                       size_t workspace_bytes, void *stream) {
+    using namespace f4l;
+    if (!xyz || n <= 0 || k < 1 || k > n || !idx_out || !workspace) return F4L_EINVAL;
+    if (k > F4L_MAX_K || n > 0x7fffffffLL) return F4L_EUNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    KnnWs w;
+    int rc = knn_ws_layout(n, w, (unsigned char *)workspace);
+    if (rc != F4L_OK) return rc;
+    if (workspace_bytes < w.total) return F4L_EWORKSPACE;
+    GridSpec g;
+    int M = 0;
+    rc = knn_build_grid(xyz, n, k, w, st, g, M);
+    if (rc != F4L_OK) return rc;
     // 5. one wave per occupied cell
     KnnArgs a;
     a.sorted = w.sorted; a.cell_keys = w.cell_keys; a.cell_start = w.cell_start; a.M = M; a.n = n; a.k = k; a.g = g;
+    a.q_sorted = w.sorted; a.q_cell_keys = w.cell_keys; a.q_cell_start = w.cell_start; a.Mq = M;
     a.idx_out = idx_out; a.d2_out = d2_out;
     hipLaunchKernelGGL(knn_cells_kernel, dim3((unsigned)((M + KNN_NW - 1) / KNN_NW)), dim3(KNN_NW * 64), 0, st, a);
     F4L_LAUNCH_CHECK();
+    return F4L_OK;
+}
+
+// ---- k nearest points of ANOTHER cloud --------------------------------------------------------------------------
+// (the cKDTree queries around the hot loop: src/coarse_to_fine_matching_base.py:1042-1046 `_voxel_subsampling`,
+//  :2716-2754 `_compute_median_resolution` is the self-query f4l_knn)
+extern "C" size_t f4l_nn_query_workspace_bytes(int64_t n, int64_t m, int k) {
+    (void)k;
+    if (n <= 0 || m <= 0) return 0;
+    f4l::KnnWs w, wq;
+    if (f4l::knn_ws_layout(n, w, nullptr) != F4L_OK || f4l::knn_ws_layout(m, wq, nullptr) != F4L_OK) return 0;
+    return w.total + wq.total;
+}
+
+// Synchronises `stream` (grid sizing reads the bounding box and the cell counts back).
+extern "C" int f4l_nn_query(const float *cloud, int64_t n, const float *queries, int64_t m, int k, int32_t *idx_out,
+                            double *d2_out, void *workspace, size_t workspace_bytes, void *stream) {
+    using namespace f4l;
+    if (m == 0) return F4L_OK;
+    if (!cloud || !queries || n <= 0 || m < 0 || k < 1 || k > n || !idx_out || !workspace) return F4L_EINVAL;
+    if (k > F4L_MAX_K || n > 0x7fffffffLL || m > 0x7fffffffLL) return F4L_EUNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    KnnWs w, wq;
+    int rc = knn_ws_layout(n, w, (unsigned char *)workspace);
+    if (rc != F4L_OK) return rc;
+    rc = knn_ws_layout(m, wq, (unsigned char *)workspace + w.total);
+    if (rc != F4L_OK) return rc;
+    if (workspace_bytes < w.total + wq.total) return F4L_EWORKSPACE;
+    GridSpec g;
+    int M = 0, Mq = 0;
+    rc = knn_build_grid(cloud, n, k, w, st, g, M);
+    if (rc != F4L_OK) return rc;
+    // the queries, binned into the cells of the cloud's grid (outside points land in its border cells; the search
+    // measures true distances, the cell only says where to start)
+    {
+        double mn[3], mx[3];
+        rc = bbox_to_host(queries, m, wq.bbox_partial, st, mn, mx);  // (rejects NaN / inf queries)
+        if (rc != F4L_OK) return rc;
+    }
+    hipLaunchKernelGGL(cell_key_kernel, dim3(grid_for(m)), dim3(256), 0, st, queries, m, g, wq.keys_a, wq.ids_a);
+    F4L_LAUNCH_CHECK();
+    const double ncell = (double)g.nx * (double)g.ny * (double)g.nz;
+    int end_bit = 1;
+    while (end_bit < 63 && (double)(1ULL << end_bit) < ncell) ++end_bit;
+    size_t tb = wq.prim_bytes;
+    F4L_HIP_CHECK(rocprim::radix_sort_pairs(wq.prim_temp, tb, wq.keys_a, wq.keys_b, wq.ids_a, wq.ids_b, (size_t)m, 0,
+                                            (unsigned)end_bit, st, false));
+    tb = wq.prim_bytes;
+    F4L_HIP_CHECK(rocprim::run_length_encode(wq.prim_temp, tb, wq.keys_b, (unsigned int)m, wq.cell_keys, wq.cell_counts,
+                                             wq.n_cells, st, false));
+    F4L_HIP_CHECK(hipMemcpyAsync(&Mq, wq.n_cells, 4, hipMemcpyDeviceToHost, st));
+    F4L_HIP_CHECK(hipStreamSynchronize(st));
+    if (Mq <= 0) return F4L_EHIP;
+    F4L_HIP_CHECK(hipMemsetAsync(wq.cell_counts + Mq, 0, 4, st));
+    tb = wq.prim_bytes;
+    F4L_HIP_CHECK(rocprim::exclusive_scan(wq.prim_temp, tb, wq.cell_counts, wq.cell_start, 0, (size_t)Mq + 1,
+                                          rocprim::plus<int32_t>(), st, false));
+    hipLaunchKernelGGL(relayout_kernel, dim3(grid_for(m)), dim3(256), 0, st, queries, wq.ids_b, m, wq.sorted);
+    F4L_LAUNCH_CHECK();
+    KnnArgs a;
+    a.sorted = w.sorted; a.cell_keys = w.cell_keys; a.cell_start = w.cell_start; a.M = M; a.n = n; a.k = k; a.g = g;
+    a.q_sorted = wq.sorted; a.q_cell_keys = wq.cell_keys; a.q_cell_start = wq.cell_start; a.Mq = Mq;
+    a.idx_out = idx_out; a.d2_out = d2_out;
+    hipLaunchKernelGGL(knn_cells_kernel, dim3((unsigned)((Mq + KNN_NW - 1) / KNN_NW)), dim3(KNN_NW * 64), 0, st, a);
+    F4L_LAUNCH_CHECK();
+    return F4L_OK;
+}
+
+// ---- voxel grid filter ---------------------------------------------------------------------------------------------
+// Open3D PointCloud::VoxelDownSample as called at src/coarse_to_fine_matching_base.py:1024-1025 [3P-knowledge]:
+// voxel index = floor((p - (min_bound - voxel/2)) / voxel) in double, one output point per occupied voxel = the mean of
+// its points.  Open3D emits voxels in hash-map order (unpinned); here: ascending (z, y, x) voxel index, and the mean
+// sums a voxel's points in ascending input index (deterministic).
+namespace f4l {
+__global__ void voxel_key_kernel(const float *__restrict__ xyz, int64_t n, double minx, double miny, double minz,
+                                 double voxel, unsigned long long nx, unsigned long long ny,
+                                 unsigned long long *__restrict__ keys, int32_t *__restrict__ ids) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const unsigned long long cx = (unsigned long long)floor(((double)xyz[3 * i] - minx) / voxel);
+        const unsigned long long cy = (unsigned long long)floor(((double)xyz[3 * i + 1] - miny) / voxel);
+        const unsigned long long cz = (unsigned long long)floor(((double)xyz[3 * i + 2] - minz) / voxel);
+        keys[i] = (cz * ny + cy) * nx + cx;
+        ids[i] = (int32_t)i;
+    }
+}
+#pragma clang fp contract(off)
+__global__ void voxel_mean_kernel(const float *__restrict__ xyz, const int32_t *__restrict__ ids,
+                                  const int32_t *__restrict__ start, int M, double *__restrict__ pts_out,
+                                  int32_t *__restrict__ count_out, int32_t *__restrict__ voxel_of_point) {
+    const int v = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (v >= M) return;
+    const int s = start[v], e = start[v + 1];
+    double sx = 0.0, sy = 0.0, sz = 0.0;
+    for (int j = s; j < e; ++j) {  // the radix sort is stable: ascending input index inside a voxel
+        const int64_t i = ids[j];
+        sx += (double)xyz[3 * i]; sy += (double)xyz[3 * i + 1]; sz += (double)xyz[3 * i + 2];
+        if (voxel_of_point) voxel_of_point[i] = v;
+    }
+    const double c = (double)(e - s);
+    pts_out[3 * (int64_t)v] = sx / c; pts_out[3 * (int64_t)v + 1] = sy / c; pts_out[3 * (int64_t)v + 2] = sz / c;
+    if (count_out) count_out[v] = e - s;
+}
+}  // namespace f4l
+
+extern "C" size_t f4l_voxel_downsample_workspace_bytes(int64_t n) { return f4l_knn_workspace_bytes(n, 1); }
+
+// pts_out: room for n points (3 doubles each); *m_out (host) receives the number of voxels.  Synchronises `stream`.
+extern "C" int f4l_voxel_downsample(const float *xyz, int64_t n, double voxel, double *pts_out, int32_t *count_out,
+                                    int32_t *voxel_of_point_out, int64_t *m_out, void *workspace, size_t workspace_bytes,
+                                    void *stream) {
+    using namespace f4l;
+    if (!m_out) return F4L_EINVAL;
+    *m_out = 0;
+    if (n == 0) return F4L_OK;
+    if (!xyz || n < 0 || !(voxel > 0.0) || !pts_out || !workspace) return F4L_EINVAL;
+    if (n > 0x7fffffffLL) return F4L_EUNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    KnnWs w;
+    int rc = knn_ws_layout(n, w, (unsigned char *)workspace);
+    if (rc != F4L_OK) return rc;
+    if (workspace_bytes < w.total) return F4L_EWORKSPACE;
+    double mn[3], mx[3];
+    rc = bbox_to_host(xyz, n, w.bbox_partial, st, mn, mx);
+    if (rc != F4L_OK) return rc;
+    double dims[3];
+    for (int d = 0; d < 3; ++d) {
+        mn[d] -= 0.5 * voxel;
+        dims[d] = std::floor((mx[d] - mn[d]) / voxel) + 1.0;
+        if (dims[d] > 2097151.0) return F4L_EUNSUPPORTED;  // 3 x 21 bits of key (Open3D: "voxel_size is too small")
+    }
+    hipLaunchKernelGGL(voxel_key_kernel, dim3(grid_for(n)), dim3(256), 0, st, xyz, n, mn[0], mn[1], mn[2], voxel,
+                       (unsigned long long)dims[0], (unsigned long long)dims[1], w.keys_a, w.ids_a);
+    F4L_LAUNCH_CHECK();
+    const double ncell = dims[0] * dims[1] * dims[2];
+    int end_bit = 1;
+    while (end_bit < 64 && std::ldexp(1.0, end_bit) < ncell) ++end_bit;
+    size_t tb = w.prim_bytes;
+    F4L_HIP_CHECK(rocprim::radix_sort_pairs(w.prim_temp, tb, w.keys_a, w.keys_b, w.ids_a, w.ids_b, (size_t)n, 0,
+                                            (unsigned)end_bit, st, false));
+    tb = w.prim_bytes;
+    F4L_HIP_CHECK(rocprim::run_length_encode(w.prim_temp, tb, w.keys_b, (unsigned int)n, w.cell_keys, w.cell_counts,
+                                             w.n_cells, st, false));
+    int M = 0;
+    F4L_HIP_CHECK(hipMemcpyAsync(&M, w.n_cells, 4, hipMemcpyDeviceToHost, st));
+    F4L_HIP_CHECK(hipStreamSynchronize(st));
+    if (M <= 0) return F4L_EHIP;
+    F4L_HIP_CHECK(hipMemsetAsync(w.cell_counts + M, 0, 4, st));
+    tb = w.prim_bytes;
+    F4L_HIP_CHECK(rocprim::exclusive_scan(w.prim_temp, tb, w.cell_counts, w.cell_start, 0, (size_t)M + 1,
+                                          rocprim::plus<int32_t>(), st, false));
+    hipLaunchKernelGGL(voxel_mean_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, xyz, w.ids_b, w.cell_start,
+                       M, pts_out, count_out, voxel_of_point_out);
+    F4L_LAUNCH_CHECK();
+    *m_out = M;
     return F4L_OK;
 }
 

@@ -297,6 +297,68 @@ def knn(xyz, k, return_d2=False):
     return (idx, d2) if return_d2 else idx
 
 
+def nn_query(cloud, queries, k=1, return_d2=False):
+    """The k nearest points of `cloud` for every query point -- `cKDTree(cloud).query(queries, k)` as used by
+    `_voxel_subsampling` (src/coarse_to_fine_matching_base.py:1042-1046) -> (m, k) int32[, (m, k) f64 squared]."""
+    torch = require_gpu()
+    cloud = _dev(cloud, torch.float32, "cloud", (3,))
+    queries = _dev(queries, torch.float32, "queries", (3,))
+    n, m = cloud.shape[0], queries.shape[0]
+    idx = torch.empty((m, k), dtype=torch.int32, device=cloud.device)
+    d2 = torch.empty((m, k), dtype=torch.float64, device=cloud.device) if return_d2 else None
+    nbytes = lib().f4l_nn_query_workspace_bytes(n, m, int(k))
+    ws = torch.empty((max(int(nbytes), 1),), dtype=torch.uint8, device=cloud.device)
+    check(lib().f4l_nn_query(ptr(cloud), n, ptr(queries), m, int(k), ptr(idx), ptr(d2), ptr(ws), C.c_size_t(nbytes),
+                             stream_ptr()), "f4l_nn_query")
+    return (idx, d2) if return_d2 else idx
+
+
+def voxel_downsample(xyz, voxel_size, return_map=False):
+    """Open3D `voxel_down_sample(voxel_size)` (src/coarse_to_fine_matching_base.py:1024-1025): the mean point of every
+    occupied voxel -> (M, 3) float64, voxels in ascending (z, y, x) index order[, points per voxel (M,) int32, voxel of
+    every input point (n,) int32]."""
+    torch = require_gpu()
+    xyz = _dev(xyz, torch.float32, "xyz", (3,))
+    n = xyz.shape[0]
+    pts = torch.empty((n, 3), dtype=torch.float64, device=xyz.device)
+    cnt = torch.empty((n,), dtype=torch.int32, device=xyz.device) if return_map else None
+    vop = torch.empty((n,), dtype=torch.int32, device=xyz.device) if return_map else None
+    m = C.c_int64(0)
+    nbytes = lib().f4l_voxel_downsample_workspace_bytes(n)
+    ws = torch.empty((max(int(nbytes), 1),), dtype=torch.uint8, device=xyz.device)
+    check(lib().f4l_voxel_downsample(ptr(xyz), n, float(voxel_size), ptr(pts), ptr(cnt), ptr(vop), C.byref(m), ptr(ws),
+                                     C.c_size_t(nbytes), stream_ptr()), "f4l_voxel_downsample")
+    M = int(m.value)
+    return (pts[:M], cnt[:M], vop) if return_map else pts[:M]
+
+
+def voxel_subsampling(src, tgt=None, voxel_size=None):
+    """`_voxel_subsampling` (src/coarse_to_fine_matching_base.py:1012-1057) for one cloud or both epochs: the adaptive
+    voxel size (`_compute_median_resolution`, :1022) unless given, the voxel-grid filter, the index of the original point
+    nearest to every voxel centre (`idx_voxel2pts`, :1042-1049) and its inverse (`idx_pts2voxel`, -1 for points that
+    represent no voxel, :1052-1059).  Returns a dict (per cloud: `pts_sub` float32 like pcd2tensor, `idx_voxel2pts`
+    int64, `idx_pts2voxel` int64) plus `voxel_size`."""
+    torch = require_gpu()
+    src = _dev(src, torch.float32, "src", (3,))
+    tgt = None if tgt is None else _dev(tgt, torch.float32, "tgt", (3,))
+    if voxel_size is None:
+        voxel_size = median_resolution(src, tgt)
+
+    def one(xyz):
+        sub = voxel_downsample(xyz, voxel_size).to(torch.float32)  # pcd2tensor casts to float32 (utils/o3d_tools.py:241-257)
+        v2p = nn_query(xyz, sub, 1)[:, 0].to(torch.int64)
+        p2v = torch.full((xyz.shape[0],), -1, dtype=torch.int64, device=xyz.device)
+        # (a point that is nearest to two voxel centres keeps the larger voxel index: what the reference's in-order
+        #  CPU assignment gives; its CUDA assignment leaves that case undefined)
+        p2v.scatter_reduce_(0, v2p, torch.arange(v2p.shape[0], dtype=torch.int64, device=xyz.device), "amax")
+        return dict(pts_sub=sub, idx_voxel2pts=v2p, idx_pts2voxel=p2v)
+
+    out = dict(voxel_size=float(voxel_size), src=one(src))
+    if tgt is not None:
+        out["tgt"] = one(tgt)
+    return out
+
+
 def normals(xyz, knn_idx):
     """PCA normals from neighbour lists (pca_estimate_normals.h:43-108) -> (n, 3) float64."""
     torch = require_gpu()

@@ -154,6 +154,25 @@ int f4l_nn_refine(const float *src, const int64_t *src_off, const float *tgt, co
                   const double *T, const double *thr, int64_t max_tgt_patch_host, int32_t *nn_out, float *out6,
                   void *stream);
 
+/* Tile preparation around the hot loop, `_voxel_subsampling` (src/coarse_to_fine_matching_base.py:1012-1057).
+ *
+ * f4l_voxel_downsample: Open3D `PointCloud.voxel_down_sample(voxel)` as called at :1024-1025 -- voxel index =
+ *   floor((p - (min_bound - voxel/2)) / voxel) in double, one output point per occupied voxel = the mean of its
+ *   points (summed in ascending input index).  Voxels come out in ascending (z, y, x) index order (Open3D's own
+ *   order is that of a hash map: unpinned).  pts_out double [n][3] (room for n, the first *m_out_host rows are
+ *   written); count_out int32 [n] (points per voxel) and voxel_of_point_out int32 [n] (voxel of every input
+ *   point) nullable; m_out_host is a HOST int64.  Synchronises `stream`.
+ * f4l_nn_query: the k nearest points of `cloud` for every query point (the cKDTree(...).query(sub, k=1) of
+ *   :1042-1046), squared Euclidean distance in double, ascending, exact-distance ties ordered by cloud index.
+ *   idx_out int32 [m][k]; d2_out double [m][k] or NULL.  1 <= k <= 64, k <= n.  Synchronises `stream`. */
+size_t f4l_voxel_downsample_workspace_bytes(int64_t n);
+int f4l_voxel_downsample(const float *xyz, int64_t n, double voxel, double *pts_out, int32_t *count_out,
+                         int32_t *voxel_of_point_out, int64_t *m_out_host, void *workspace, size_t workspace_bytes,
+                         void *stream);
+size_t f4l_nn_query_workspace_bytes(int64_t n, int64_t m, int k);
+int f4l_nn_query(const float *cloud, int64_t n, const float *queries, int64_t m, int k, int32_t *idx_out,
+                 double *d2_out, void *workspace, size_t workspace_bytes, void *stream);
+
 /* ------------------------------------------------------------------------------------------------
  * B1  supervoxel partition.  Replaces the SWIG export
  *   std::vector<int> computeSupervoxel(std::string input_file, int k_neighbors, double resolution,

@@ -173,3 +173,68 @@ def test_median_resolution_vs_kdtree():
     got = engine.median_resolution(torch.from_numpy(c["src"]).cuda(), torch.from_numpy(c["tgt"][:30_001]).cuda())
     assert abs(got - max(ref)) <= 1e-12 * max(ref) + 1e-15
     assert abs(engine.median_resolution(torch.from_numpy(c["src"]).cuda()) - ref[0]) <= 1e-12
+
+
+def test_nn_query_vs_kdtree():
+    """f4l_nn_query (the cKDTree(...).query of src/coarse_to_fine_matching_base.py:1042-1046): exact k nearest cloud
+    points of queries that lie inside, at the border of and far outside the cloud's bounding box."""
+    from scipy.spatial import cKDTree
+    from fusion4landslide_amd import engine, synthetic
+    rng = np.random.default_rng(41)
+    c = synthetic.two_epoch_cloud(60_000, 9, 1.386, seed=6)
+    cloud = c["src"]
+    q = np.concatenate([c["tgt"][:20_000],                                         # another epoch of the same surface
+                        cloud[:500],                                               # exact members of the cloud (d = 0)
+                        rng.uniform(-30, 40, (300, 3)).astype(np.float32),         # anywhere, mostly outside the box
+                        cloud[:200] + np.float32([0, 0, 25.0])])                   # far above
+    tree = cKDTree(cloud.astype(np.float64))
+    for k in (1, 4):
+        idx, d2 = engine.nn_query(torch.from_numpy(cloud).cuda(), torch.from_numpy(q).cuda(), k, return_d2=True)
+        idx, d2 = idx.cpu().numpy(), d2.cpu().numpy()
+        dref, iref = tree.query(q.astype(np.float64), k=k)
+        dref, iref = dref.reshape(len(q), k), iref.reshape(len(q), k)
+        assert np.abs(np.sqrt(d2) - dref).max() <= 1e-12 * max(1.0, dref.max())
+        same = idx == iref
+        # index mismatches only inside exact-distance tie groups
+        assert (np.abs(np.sqrt(d2) - dref)[~same] <= 1e-12).all()
+        assert same.mean() > 0.999
+        # distances really are those of the returned indices
+        got = ((cloud[idx.reshape(-1)].astype(np.float64) - np.repeat(q.astype(np.float64), k, axis=0)) ** 2).sum(1)
+        assert np.abs(got - d2.reshape(-1)).max() <= 1e-12 * max(1.0, d2.max())
+    # a single query, a single-point cloud, no queries
+    one = engine.nn_query(torch.from_numpy(cloud[:1]).cuda(), torch.from_numpy(q[:7]).cuda(), 1)
+    assert (one.cpu().numpy() == 0).all()
+    assert engine.nn_query(torch.from_numpy(cloud).cuda(), torch.zeros((0, 3)).cuda(), 1).shape == (0, 1)
+
+
+def test_voxel_downsample_and_subsampling_vs_oracle():
+    """f4l_voxel_downsample against the numpy restatement of Open3D's voxel grid filter, and the whole
+    `_voxel_subsampling` bookkeeping (src/coarse_to_fine_matching_base.py:1012-1057) against numpy + a KD-tree."""
+    from scipy.spatial import cKDTree
+    from fusion4landslide_amd import engine, synthetic
+    from oracle import oracle as O
+    c = synthetic.two_epoch_cloud(50_000, 9, 1.386, seed=7, origin=(2647.0, 1177.0, 1500.0))
+    for voxel in (0.35, 0.05, 40.0):
+        xyz = c["src"]
+        pts, cnt, vop = engine.voxel_downsample(torch.from_numpy(xyz).cuda(), voxel, return_map=True)
+        rp, rc, rv = O.voxel_downsample(xyz, voxel)
+        assert pts.shape[0] == len(rp) and np.array_equal(cnt.cpu().numpy(), rc) and np.array_equal(vop.cpu().numpy(), rv)
+        assert np.abs(pts.cpu().numpy() - rp).max() <= 1e-9
+    out = engine.voxel_subsampling(torch.from_numpy(c["src"]).cuda(), torch.from_numpy(c["tgt"]).cuda())
+    ref_res = max(np.median(cKDTree(p.astype(np.float64)).query(p.astype(np.float64), k=2)[0][:, 1]) for p in (c["src"], c["tgt"]))
+    assert abs(out["voxel_size"] - ref_res) <= 1e-12
+    for name in ("src", "tgt"):
+        xyz, o = c[name], out[name]
+        rp, _, _ = O.voxel_downsample(xyz, out["voxel_size"])
+        sub = o["pts_sub"].cpu().numpy()
+        assert sub.dtype == np.float32 and np.array_equal(sub, rp.astype(np.float32))
+        d, i = cKDTree(xyz.astype(np.float64)).query(sub.astype(np.float64), k=1)
+        v2p = o["idx_voxel2pts"].cpu().numpy()
+        dd = np.sqrt(((xyz[v2p].astype(np.float64) - sub.astype(np.float64)) ** 2).sum(1))
+        # (the centre of a two-point voxel is equidistant from both: index ties are common, distances must agree)
+        assert np.abs(dd - d).max() <= 1e-12 and (v2p == i).mean() > 0.95
+        p2v = o["idx_pts2voxel"].cpu().numpy()
+        assert p2v.shape == (len(xyz),) and (p2v >= -1).all()
+        hit = p2v >= 0
+        assert np.array_equal(np.sort(np.unique(v2p)), np.nonzero(hit)[0])
+        assert (v2p[p2v[hit]] == np.nonzero(hit)[0]).all()
