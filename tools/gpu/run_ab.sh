@@ -1,10 +1,4 @@
-# A/B of two builds of the library inside one box: tools/gpu/ab/{old,new}.so
 for rep in 1 2 3; do for v in old new; do
   cp tools/gpu/ab/$v.so fusion4landslide_amd/lib/libf4l_hip.so
   echo -n "$v: "; python bench.py --steps 20 --warmup 5 --cpu-seconds 0 --extras 0 2>&1 | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['roofline']['kernel_ms'])"
 done; done
-for v in old new; do
-  cp tools/gpu/ab/$v.so fusion4landslide_amd/lib/libf4l_hip.so
-  echo -n "C3 $v: "; python bench.py --config C3_10M_20k --steps 3 --warmup 1 --cpu-seconds 0 --extras 0 2>&1 | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['roofline']['kernel_ms'])"
-done
-python -m pytest tests -m gpu -q -x 2>&1 | tail -5
