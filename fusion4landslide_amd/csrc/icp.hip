@@ -914,7 +914,7 @@ static int icp_launch_host(const float *src, const int64_t *src_off, const float
                            int64_t P, const double *init_T, const float *tgt_normals, double max_corr_dist,
                            int max_iter, double rel_fitness, double rel_rmse, int mode, int fixed_iters,
                            int search_precision, int64_t max_src_patch_host, int64_t max_tgt_patch_host,
-                           double *T_out, double *fitness_out, double *rmse_out, int32_t *iters_out,
+                           int64_t n_src_host, double *T_out, double *fitness_out, double *rmse_out, int32_t *iters_out,
                            int32_t *corr_out, const IcpFusedExtra &fx, void *stream);
 }  // namespace f4l
 
@@ -922,11 +922,11 @@ extern "C" int f4l_piecewise_icp(const float *src, const int64_t *src_off, const
                                  int64_t P, const double *init_T, const float *tgt_normals, double max_corr_dist,
                                  int max_iter, double rel_fitness, double rel_rmse, int mode, int fixed_iters,
                                  int search_precision, int64_t max_src_patch_host, int64_t max_tgt_patch_host,
-                                 double *T_out, double *fitness_out, double *rmse_out, int32_t *iters_out,
-                                 int32_t *corr_out, void *stream) {
+                                 int64_t n_src_host, double *T_out, double *fitness_out, double *rmse_out,
+                                 int32_t *iters_out, int32_t *corr_out, void *stream) {
     return f4l::icp_launch_host(src, src_off, tgt, tgt_off, P, init_T, tgt_normals, max_corr_dist, max_iter, rel_fitness,
                                 rel_rmse, mode, fixed_iters, search_precision, max_src_patch_host, max_tgt_patch_host,
-                                T_out, fitness_out, rmse_out, iters_out, corr_out, f4l::IcpFusedExtra(), stream);
+                                n_src_host, T_out, fitness_out, rmse_out, iters_out, corr_out, f4l::IcpFusedExtra(), stream);
 }
 
 extern "C" int f4l_patch_loop(const float *src, const int64_t *src_off, const float *tgt, const int64_t *tgt_off,
@@ -934,26 +934,27 @@ extern "C" int f4l_patch_loop(const float *src, const int64_t *src_off, const fl
                               const int64_t *corr_off, double kabsch_w_thresh, double kabsch_eps,
                               const float *tgt_normals, double max_corr_dist, int max_iter, double rel_fitness,
                               double rel_rmse, int mode, int fixed_iters, int search_precision,
-                              int64_t max_src_patch_host, int64_t max_tgt_patch_host, double *T_out,
-                              double *fitness_out, double *rmse_out, int32_t *iters_out, int32_t *corr_out,
-                              float *rows_out, void *stream) {
+                              int64_t max_src_patch_host, int64_t max_tgt_patch_host, int64_t n_src_host,
+                              double *T_out, double *fitness_out, double *rmse_out, int32_t *iters_out,
+                              int32_t *corr_out, float *rows_out, void *stream) {
     if (!corr_off || ((!corr_src || !corr_ref) && P > 0)) return F4L_EINVAL;
     f4l::IcpFusedExtra fx;
     fx.corr_src = corr_src; fx.corr_ref = corr_ref; fx.corr_w = corr_w; fx.corr_off = corr_off;
     fx.w_thresh = kabsch_w_thresh; fx.eps = kabsch_eps; fx.rows_out = rows_out;
     return f4l::icp_launch_host(src, src_off, tgt, tgt_off, P, nullptr, tgt_normals, max_corr_dist, max_iter, rel_fitness,
                                 rel_rmse, mode, fixed_iters, search_precision, max_src_patch_host, max_tgt_patch_host,
-                                T_out, fitness_out, rmse_out, iters_out, corr_out, fx, stream);
+                                n_src_host, T_out, fitness_out, rmse_out, iters_out, corr_out, fx, stream);
 }
 
 static int f4l::icp_launch_host(const float *src, const int64_t *src_off, const float *tgt, const int64_t *tgt_off,
                                 int64_t P, const double *init_T, const float *tgt_normals, double max_corr_dist,
                                 int max_iter, double rel_fitness, double rel_rmse, int mode, int fixed_iters,
                                 int search_precision, int64_t max_src_patch_host, int64_t max_tgt_patch_host,
-                                double *T_out, double *fitness_out, double *rmse_out, int32_t *iters_out,
-                                int32_t *corr_out, const IcpFusedExtra &fx, void *stream) {
+                                int64_t n_src_host, double *T_out, double *fitness_out, double *rmse_out,
+                                int32_t *iters_out, int32_t *corr_out, const IcpFusedExtra &fx, void *stream) {
     using namespace f4l;
-    if (P < 0 || !src_off || !tgt_off || !T_out || max_iter < 0 || max_src_patch_host < 0 || max_tgt_patch_host < 0)
+    if (P < 0 || !src_off || !tgt_off || !T_out || max_iter < 0 || max_src_patch_host < 0 || max_tgt_patch_host < 0 ||
+        n_src_host < 0)
         return F4L_EINVAL;
     if (mode != F4L_ICP_POINT2POINT && mode != F4L_ICP_POINT2PLANE) return F4L_EINVAL;
     if (search_precision != F4L_SEARCH_F32 && search_precision != F4L_SEARCH_F64) return F4L_EINVAL;
@@ -1039,11 +1040,19 @@ static int f4l::icp_launch_host(const float *src, const int64_t *src_off, const 
     const int64_t big = max_src_patch_host > max_tgt_patch_host ? max_src_patch_host : max_tgt_patch_host;
     ClassBounds cb;
     cb.n = 0;
-    if (lds > 48 * 1024 && P >= 64 && !getenv("F4L_ICP_NOCLASSES"))
+    const bool lds_classes = lds > 48 * 1024;
+    // ... and when the patches are of uneven size (mean below 3/4 of the largest, known only if the caller passed the
+    // point count) patches of one or two wavefronts get workgroups of just those: 1.75x on a supervoxel partition
+    // (median 58 points, largest 153).  Evenly sized patches (C2: mean 494, largest 574) stay one launch.
+    const bool wave_classes = nw > 1 && P >= 512 &&
+                              (getenv("F4L_ICP_SMALLCLASSES") || (n_src_host > 0 && 4 * n_src_host <= 3 * P * max_src_patch_host));
+    if ((lds_classes || wave_classes) && P >= 64 && !getenv("F4L_ICP_NOCLASSES"))
     {
         int step = 4;  // ratio between class bounds: 4 (256, 1024, 4096), 2, or 1 = sqrt(2)
         if (const char *e = getenv("F4L_ICP_CLASS_STEP")) step = atoi(e);
-        for (int64_t b = 256; b <= 4096 && 3 * b <= 2 * big && cb.n < ICP_MAX_CLASSES - 1;) {
+        if (wave_classes)  // patches that fit one or two wavefronts get workgroups of just those
+            for (int64_t b = 64; b <= 128 && 3 * b <= 2 * big; b *= 2) cb.bound[cb.n++] = (int)b;
+        for (int64_t b = 256; lds_classes && b <= 4096 && 3 * b <= 2 * big && cb.n < ICP_MAX_CLASSES - 1;) {
             cb.bound[cb.n++] = (int)b;
             b = step == 4 ? b * 4 : (step == 2 ? b * 2 : ((cb.n & 1) ? (b * 3) / 2 : (b * 4) / 3));
         }

@@ -188,7 +188,7 @@ def piecewise_icp(src, src_off, tgt, tgt_off, init_T=None, max_corr_dist=0.1, ma
     check(lib().f4l_piecewise_icp(ptr(src), ptr(src_off), ptr(tgt), ptr(tgt_off), P, ptr(T0), ptr(tn),
                                   float(max_corr_dist), int(max_iter), float(rel_fitness), float(rel_rmse), mode,
                                   int(bool(fixed_iters)), {"f32": _lib.SEARCH_F32, "f64": _lib.SEARCH_F64}[search],
-                                  int(max_src_patch), int(max_tgt_patch), ptr(T), ptr(fit),
+                                  int(max_src_patch), int(max_tgt_patch), int(src.shape[0]), ptr(T), ptr(fit),
                                   ptr(rmse), ptr(iters), ptr(corr), stream_ptr()), "f4l_piecewise_icp")
     out = dict(T=T, fitness=fit, rmse=rmse, iters=iters)
     if return_corr:
@@ -240,7 +240,7 @@ def patch_loop(src, src_off, tgt, tgt_off, corr_src, corr_ref, corr_off, corr_we
                                ptr(corr_off), float(weight_thresh), float(eps), ptr(tn), float(max_corr_dist), int(max_iter),
                                float(rel_fitness), float(rel_rmse), mode, int(bool(fixed_iters)),
                                {"f32": _lib.SEARCH_F32, "f64": _lib.SEARCH_F64}[search], int(max_src_patch),
-                               int(max_tgt_patch), ptr(T), ptr(fit), ptr(rmse), ptr(iters), ptr(corr), ptr(rows),
+                               int(max_tgt_patch), int(src.shape[0]), ptr(T), ptr(fit), ptr(rmse), ptr(iters), ptr(corr), ptr(rows),
                                stream_ptr()), "f4l_patch_loop")
     out = dict(T=T, fitness=fit, rmse=rmse, iters=iters)
     if return_corr:

@@ -108,6 +108,9 @@ int f4l_kabsch_residuals(const float *src, const float *ref, const int64_t *off,
  *   search_precision : F4L_SEARCH_F32 | F4L_SEARCH_F64.  The transform, all sums and the solves are double in
  *                 both; F64 also evaluates point positions and squared distances in double, like Open3D.
  *   max_src_patch_host / max_tgt_patch_host : largest patch sizes (host-known; size LDS and pick the path)
+ *   n_src_host  : src_off[P] if the host knows it, else 0.  With it the launcher sees whether patch sizes are uneven
+ *                 (mean well below the largest) and then bins the patches by size on the device, so that patches
+ *                 of one or two wavefronts get workgroups of just those; results do not depend on it.
  * Outputs (any may be NULL except T_out):
  *   T_out double [P][16]; fitness_out, rmse_out double [P]; iters_out int32 [P];
  *   corr_out int32 [n_src]: index INSIDE the target patch of each source point's final correspondence,
@@ -117,7 +120,7 @@ int f4l_piecewise_icp(const float *src, const int64_t *src_off, const float *tgt
                       int64_t P, const double *init_T, const float *tgt_normals, double max_corr_dist,
                       int max_iter, double rel_fitness, double rel_rmse, int mode, int fixed_iters,
                       int search_precision, int64_t max_src_patch_host, int64_t max_tgt_patch_host,
-                      double *T_out, double *fitness_out, double *rmse_out, int32_t *iters_out,
+                      int64_t n_src_host, double *T_out, double *fitness_out, double *rmse_out, int32_t *iters_out,
                       int32_t *corr_out, void *stream);
 
 /* The whole loop body of src/coarse_to_fine_matching_base.py:3254-3436 for P patch matches in ONE launch:
@@ -131,8 +134,9 @@ int f4l_patch_loop(const float *src, const int64_t *src_off, const float *tgt, c
                    const float *corr_src, const float *corr_ref, const float *corr_w, const int64_t *corr_off,
                    double kabsch_w_thresh, double kabsch_eps, const float *tgt_normals, double max_corr_dist,
                    int max_iter, double rel_fitness, double rel_rmse, int mode, int fixed_iters, int search_precision,
-                   int64_t max_src_patch_host, int64_t max_tgt_patch_host, double *T_out, double *fitness_out,
-                   double *rmse_out, int32_t *iters_out, int32_t *corr_out, float *rows_out, void *stream);
+                   int64_t max_src_patch_host, int64_t max_tgt_patch_host, int64_t n_src_host, double *T_out,
+                   double *fitness_out, double *rmse_out, int32_t *iters_out, int32_t *corr_out, float *rows_out,
+                   void *stream);
 
 /* Per-patch normal estimation as utils/o3d_tools.py:29-30 (`pcd.estimate_normals()` on the patch cloud:
  * kNN(knn=30) inside the patch, self included; smallest-eigenvector of the neighbourhood covariance;

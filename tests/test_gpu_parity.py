@@ -429,12 +429,16 @@ def test_icp_dense_patches_on_a_grid_finer_than_the_radius(eng, search, monkeypa
         assert np.median(disp) <= 1e-5 and (disp <= 1e-4).mean() >= 0.85
 
 
-def test_icp_size_classes_match_single_launch_and_oracle(eng, monkeypatch):
-    """A few patches of thousands of points among many small ones: the host bins patches by size on the device and
-    launches each class with its own LDS plan (F4L_ICP_NOCLASSES=1: one launch sized for the largest patch).  Same
-    correspondences and iteration counts either way, and the oracle's transforms."""
+@pytest.mark.parametrize("mix", ["few huge patches among small ones", "many patches of one or two wavefronts"])
+def test_icp_size_classes_match_single_launch_and_oracle(eng, mix, monkeypatch):
+    """Patches of very different sizes: the host bins them by size on the device and launches each class with its own
+    LDS plan and workgroup shape (F4L_ICP_NOCLASSES=1: one launch sized for the largest patch).  Same correspondences
+    and iteration counts either way, and the oracle's transforms."""
     rng = np.random.default_rng(31)
-    sizes = [5000, 150, 0, 300, 2500] + [int(v) for v in rng.integers(40, 700, 75)]
+    if mix.startswith("few"):
+        sizes = [5000, 150, 0, 300, 2500] + [int(v) for v in rng.integers(40, 700, 75)]
+    else:  # >= 512 patches, mean well below the largest: classes of 64, 128 and the rest
+        sizes = [0, 1, 2, 3] + [int(v) for v in rng.integers(5, 110, 560)] + [int(v) for v in rng.integers(110, 400, 40)]
     src_l, tgt_l = [], []
     for n in sizes:
         side = max(0.2, np.sqrt(n / 400.0))  # ~400 points per square metre
