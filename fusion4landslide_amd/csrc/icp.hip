@@ -225,13 +225,17 @@ __global__ __launch_bounds__(NW * 64, sizeof(F) == 8 ? ICP_WAVES_PER_EU_F64 : IC
     constexpr int NT = NW * 64;
     // Correspondence sums.  float32 search + point-to-point: per-lane partial sums and the in-wave reduction are
     // float32 on coordinates CENTRED on the image of the source centroid (|values| <= patch radius, means ~ 0, so
-    // neither the products nor the covariance's mean correction cancel); everything after the wave totals is
-    // double.  float64 search (parity mode) and point-to-plane: double throughout, uncentred like the reference.
+    // neither the products nor the covariance's mean correction cancel); everything after the sums of the 16-lane
+    // rows is double.  float64 search (parity mode) and point-to-plane: double throughout, uncentred like the reference.
     constexpr bool CENTRED = (MODE == F4L_ICP_POINT2POINT) && sizeof(F) == 4;
     using A = typename std::conditional<CENTRED, float, double>::type;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    // partial sums: one row of NV doubles per 16-lane row of every wave (row_sums_transposed); icp_plan() sizes the
+    // region the same way
+    constexpr int SUM_ROWS = 4 * NW;
+    constexpr int SCRATCH = (SUM_ROWS * NV + 1) & ~1;
     double *scratch = reinterpret_cast<double *>(smem_raw);
-    double *state = scratch + NW * 32;
+    double *state = scratch + SCRATCH;
     int *qcnt = reinterpret_cast<int *>(state + 48);
     GridPt<F> *tl = reinterpret_cast<GridPt<F> *>(qcnt + 4);
     float *mabs = reinterpret_cast<float *>(tl + a.tgt_cap + 1);  // tl[nt] is the dummy record of the grid
@@ -573,16 +577,22 @@ __global__ __launch_bounds__(NW * 64, sizeof(F) == 8 ? ICP_WAVES_PER_EU_F64 : IC
         PROF_T(pt_p1);
         PROF_ADD(2, pt_p1, pt_p0b);
         // DPP reduction inside the wave, then the NW partials (as double) through LDS; one wave solves
-        wave_sum_dpp_n<NV>(acc);
-        if (NW > 1) {
-            if (lane == 0) {
+        {
+            A xs[NV / 4], ys[NV % 4 > 0 ? NV % 4 : 1];
+            row_sums_transposed<NV, A>(acc, xs, ys);
+            if ((lane & 12) == 0) {  // the first quad of every row writes the row's sums (as double)
+                double *row = scratch + (wave * 4 + (lane >> 4)) * NV;
 #pragma unroll
-                for (int i = 0; i < NV; ++i) scratch[wave * 32 + i] = (double)acc[i];
+                for (int m = 0; m < NV / 4; ++m) row[4 * m + (lane & 3)] = (double)xs[m];
+                if ((lane & 3) == 0) {
+#pragma unroll
+                    for (int j = 0; j < NV % 4; ++j) row[4 * (NV / 4) + j] = (double)ys[j];
+                }
             }
-            PROF_T(pt_p1b);
-            PROF_ADD(12, pt_p1b, pt_p1);
-            __syncthreads();
         }
+        PROF_T(pt_p1b);
+        PROF_ADD(12, pt_p1b, pt_p1);
+        __syncthreads();
         PROF_T(pt_p2);
         PROF_ADD(3, pt_p2, pt_p1);
         if (wave == solver) {
@@ -590,12 +600,13 @@ __global__ __launch_bounds__(NW * 64, sizeof(F) == 8 ? ICP_WAVES_PER_EU_F64 : IC
             // waits: let it win the issue arbitration against the other workgroups' waves on this SIMD.
             __builtin_amdgcn_s_setprio(3);
             double tot[NV];
-            if (NW > 1) {
-                // lane i sums the NW partials of value i (one LDS read per wave), then the totals go to scalar
-                // registers: keeps NW * NV partial sums from being live at once
-                double t = scratch[lane & 31];
+            {
+                // lane i sums the partial rows of value i (one LDS read per row), then the totals go to scalar
+                // registers: keeps SUM_ROWS * NV partial sums from being live at once
+                const int vi = lane < NV ? lane : NV - 1;
+                double t = scratch[vi];
 #pragma unroll
-                for (int w = 1; w < NW; ++w) t += scratch[w * 32 + (lane & 31)];
+                for (int w = 1; w < SUM_ROWS; ++w) t += scratch[w * NV + vi];
                 const long long tb = __double_as_longlong(t);
                 const int tlo = (int)(tb & 0xffffffffLL), thi = (int)(tb >> 32);
 #pragma unroll
@@ -603,9 +614,6 @@ __global__ __launch_bounds__(NW * 64, sizeof(F) == 8 ? ICP_WAVES_PER_EU_F64 : IC
                     const int lo = __builtin_amdgcn_readlane(tlo, i), hi = __builtin_amdgcn_readlane(thi, i);
                     tot[i] = __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
                 }
-            } else {
-#pragma unroll
-                for (int i = 0; i < NV; ++i) tot[i] = (double)acc[i];
             }
             const double fitness = state[13], rmse = state[14];
             int iters = (int)state[15];
@@ -858,7 +866,7 @@ static inline int pow2_ceil(int64_t v) {
 namespace f4l {
 // Workgroup shape and LDS layout for patches of at most max_src sources and max_tgt targets.
 struct IcpPlan { int nw, tgt_cap, cell_cap, cert_cap, src_cap, pp_cap; size_t lds; };
-static IcpPlan icp_plan(int64_t max_src_patch_host, int64_t max_tgt_patch_host, bool f64) {
+static IcpPlan icp_plan(int64_t max_src_patch_host, int64_t max_tgt_patch_host, bool f64, int mode) {
     const size_t pt = sizeof(GridPt<float>);  // 16 B in both modes
     // waves per patch: four measured best from 2 k to 32 k patches of ~500 points (the LDS a patch needs limits a CU to
     // ~4 patches, and a patch keeps 4 waves busier than 2); patches that fit one or two wavefronts get just those
@@ -868,7 +876,10 @@ static IcpPlan icp_plan(int64_t max_src_patch_host, int64_t max_tgt_patch_host, 
     { const char *e = getenv("F4L_ICP_WAVES"); if (e) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) nw = v; } }
 
     // LDS plan: targets first (they make the grid possible), then the prefix table, then the certificate arrays
-    const size_t fixed = (size_t)(nw * 32 + 48) * sizeof(double) + 16 + (size_t)(GRID_ROWS + 1) * nw * 64 * sizeof(unsigned int);
+    // (partial-sum region: as SCRATCH in icp_kernel)
+    const int nv = mode == F4L_ICP_POINT2POINT ? 17 : 29;
+    const int sum_doubles = (4 * nw * nv + 1) & ~1;
+    const size_t fixed = (size_t)(sum_doubles + 48) * sizeof(double) + 16 + (size_t)(GRID_ROWS + 1) * nw * 64 * sizeof(unsigned int);
     int tgt_cap = (int)(max_tgt_patch_host < ICP_TGT_MAX ? max_tgt_patch_host : ICP_TGT_MAX);
     if (tgt_cap < 1) tgt_cap = 1;
     int cell_cap = (int)((2 * (int64_t)tgt_cap + 255) & ~(int64_t)255);  // ~2 cells per target point
@@ -980,7 +991,7 @@ static int f4l::icp_launch_host(const float *src, const int64_t *src_off, const 
     { const char *e = getenv("F4L_ICP_MU"); if (e && atof(e) > 0.0) a.mu_frac = atof(e); }
     a.T_out = T_out; a.fitness_out = fitness_out; a.rmse_out = rmse_out; a.iters_out = iters_out; a.corr_out = corr_out;
 
-    const IcpPlan pl = icp_plan(max_src_patch_host, max_tgt_patch_host, f64);
+    const IcpPlan pl = icp_plan(max_src_patch_host, max_tgt_patch_host, f64, mode);
     const int nw = pl.nw, tgt_cap = pl.tgt_cap, cell_cap = pl.cell_cap, cert_cap = pl.cert_cap, src_cap = pl.src_cap;
     const size_t lds = pl.lds;
     a.tgt_cap = tgt_cap; a.cert_cap = cert_cap; a.cell_cap = cell_cap; a.src_cap = src_cap; a.pp_cap = pl.pp_cap;
@@ -1073,7 +1084,7 @@ static int f4l::icp_launch_host(const float *src, const int64_t *src_off, const 
     for (int k = cb.n - 1; k >= 0 && rc == F4L_OK; --k) {
         const int64_t ms = max_src_patch_host < cb.bound[k] ? max_src_patch_host : cb.bound[k];
         const int64_t mt = max_tgt_patch_host < cb.bound[k] ? max_tgt_patch_host : cb.bound[k];
-        const IcpPlan pk = icp_plan(ms, mt, f64);
+        const IcpPlan pk = icp_plan(ms, mt, f64, mode);
         IcpArgs ak = a;
         ak.tgt_cap = pk.tgt_cap; ak.cert_cap = pk.cert_cap; ak.cell_cap = pk.cell_cap; ak.src_cap = pk.src_cap; ak.pp_cap = pk.pp_cap;
         ak.list = buf + (size_t)k * (size_t)P; ak.list_cnt = cnt + k;

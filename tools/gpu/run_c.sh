@@ -1,1 +1,5 @@
-python -m pytest tests -m gpu -q -x -k "size_classes" 2>&1 | tail -8
+python -m pytest tests -m gpu -q -x 2>&1 | tail -5
+for rep in 1 2; do for v in old new; do
+  cp tools/gpu/ab/$v.so fusion4landslide_amd/lib/libf4l_hip.so
+  echo -n "$v: "; python bench.py --steps 20 --warmup 5 --cpu-seconds 0 2>&1 | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['roofline']['kernel_ms'], d['extras']['fast_mode_f32'])"
+done; done
