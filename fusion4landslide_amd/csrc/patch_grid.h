@@ -129,9 +129,8 @@ template <> struct Best<double> {
     __device__ __forceinline__ void init(double bound2) { d = bound2; t = GRID_NO_TAG; second = __builtin_inf(); }
     __device__ __forceinline__ void offer(double dd, unsigned int tag) {
         const bool better = dd < d || (dd == d && tag < t);
-        const double loser = better ? d : dd;
-        second = loser < second ? loser : second;
-        d = better ? dd : d;
+        second = fmin(second, fmax(dd, d));  // the loser of the two is the larger distance (or an equal one)
+        d = fmin(dd, d);
         t = better ? tag : t;
     }
     __device__ __forceinline__ double d2() const { return d; }

@@ -1,5 +1,4 @@
-python -m pytest tests -m gpu -q -x 2>&1 | tail -5
-for rep in 1 2; do for v in old new; do
-  cp tools/gpu/ab/$v.so fusion4landslide_amd/lib/libf4l_hip.so
-  echo -n "$v: "; python bench.py --steps 20 --warmup 5 --cpu-seconds 0 2>&1 | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['roofline']['kernel_ms'], d['extras']['fast_mode_f32'])"
-done; done
+bash tools/gpu/profile_round.sh r1_f > gpurun_out/profile_r1_f.log 2>&1
+tail -1 gpurun_out/prof_r1_f/bench.json.log | cut -c1-600
+cat gpurun_out/prof_r1_f/traffic_raw.json
+head -6 gpurun_out/prof_r1_f/stats/*/*_kernel_stats.csv | cut -c1-160
