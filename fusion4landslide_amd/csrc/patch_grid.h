@@ -128,9 +128,15 @@ template <> struct Best<double> {
     unsigned int t;
     __device__ __forceinline__ void init(double bound2) { d = bound2; t = GRID_NO_TAG; second = __builtin_inf(); }
     __device__ __forceinline__ void offer(double dd, unsigned int tag) {
-        const bool better = dd < d || (dd == d && tag < t);
-        second = fmin(second, fmax(dd, d));  // the loser of the two is the larger distance (or an equal one)
-        d = fmin(dd, d);
+        // branch free on purpose (the compiler turns the short-circuit form into two nested divergent branches per
+        // candidate), and raw v_min / v_max: fmin / fmax would canonicalise both operands first
+        const bool better = (dd < d) | ((dd == d) & (tag < t));
+        double hi, lo, s2;
+        asm("v_max_f64 %0, %1, %2" : "=v"(hi) : "v"(dd), "v"(d));  // the loser of the two is the larger distance (or an equal one)
+        asm("v_min_f64 %0, %1, %2" : "=v"(lo) : "v"(dd), "v"(d));
+        asm("v_min_f64 %0, %1, %2" : "=v"(s2) : "v"(second), "v"(hi));
+        second = s2;
+        d = lo;
         t = better ? tag : t;
     }
     __device__ __forceinline__ double d2() const { return d; }

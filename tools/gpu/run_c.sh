@@ -1,4 +1,5 @@
-bash tools/gpu/profile_round.sh r1_f > gpurun_out/profile_r1_f.log 2>&1
-tail -1 gpurun_out/prof_r1_f/bench.json.log | cut -c1-600
-cat gpurun_out/prof_r1_f/traffic_raw.json
-head -6 gpurun_out/prof_r1_f/stats/*/*_kernel_stats.csv | cut -c1-160
+python -m pytest tests -m gpu -q -x -k "icp or nn_refine or patch" 2>&1 | tail -3
+for rep in 1 2 3; do for v in old new new2; do
+  cp tools/gpu/ab/$v.so fusion4landslide_amd/lib/libf4l_hip.so
+  echo -n "$v: "; python bench.py --steps 20 --warmup 5 --cpu-seconds 0 --extras 0 2>&1 | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['roofline']['kernel_ms'])"
+done; done
