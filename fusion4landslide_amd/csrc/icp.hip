@@ -413,8 +413,12 @@ __global__ __launch_bounds__(NW * 64, sizeof(F) == 8 ? ICP_WAVES_PER_EU_F64 : IC
     const int n_pass = active ? a.max_iter + 1 : 0;
     // the solving wave rotates with the patch index so that co-resident workgroups do not all solve on the same SIMD
     const int solver = (int)(blockIdx.x % NW);
-    const unsigned long long lt_mask = (1ULL << lane) - 1ULL;
 
+    float nfx = 0.f, nfy = 0.f, nfz = 0.f;  // phase 1's next batch of source points (see there)
+    if (active && use_cert && !src_in_lds) {
+        const int in = tid < ns ? tid : ns - 1;
+        nfx = sg[3 * in]; nfy = sg[3 * in + 1]; nfz = sg[3 * in + 2];
+    }
     for (int pass = 0; pass < n_pass; ++pass) {
         // the transform is uniform: keep it in scalar registers
         const F R0 = (F)uniform_f64(state[0]), R1 = (F)uniform_f64(state[1]), R2 = (F)uniform_f64(state[2]),
@@ -469,7 +473,15 @@ __global__ __launch_bounds__(NW * 64, sizeof(F) == 8 ? ICP_WAVES_PER_EU_F64 : IC
                 const int ii = valid ? i : ns - 1;  // idle lanes recompute the last point (keeps loads in bounds)
                 F x, y, z;
                 if (src_in_lds) { x = sl[3 * ii]; y = sl[3 * ii + 1]; z = sl[3 * ii + 2]; }
-                else { x = (F)sg[3 * ii] - (F)ox; y = (F)sg[3 * ii + 1] - (F)oy; z = (F)sg[3 * ii + 2] - (F)oz; }
+                else {
+                    // sources that are not staged in LDS come from global memory one batch ahead: (nfx, nfy, nfz) was
+                    // requested while the previous batch (or, for the first batch, the previous pass) was at work
+                    const float cx_ = nfx, cy_ = nfy, cz_ = nfz;
+                    int in = base + NT + tid;  // this thread's point in the next batch; past the end: the first batch again
+                    in = base + NT < ns ? (in < ns ? in : ns - 1) : (tid < ns ? tid : ns - 1);
+                    nfx = sg[3 * in]; nfy = sg[3 * in + 1]; nfz = sg[3 * in + 2];
+                    x = (F)cx_ - (F)ox; y = (F)cy_ - (F)oy; z = (F)cz_ - (F)oz;
+                }
                 const F px = R0 * x + R1 * y + R2 * z + t0f;
                 const F py = R3 * x + R4 * y + R5 * z + t1f;
                 const F pz = R6 * x + R7 * y + R8 * z + t2f;
@@ -497,7 +509,9 @@ __global__ __launch_bounds__(NW * 64, sizeof(F) == 8 ? ICP_WAVES_PER_EU_F64 : IC
                 if (a.corr_out && cert) a.corr_out[s0 + i] = hit ? qid : -1;
                 const bool need = valid && !cert;
                 const unsigned long long m = __ballot(need);
-                if (need) myq[nq + __builtin_popcountll(m & lt_mask)] = (unsigned short)i;
+                if (need)  // position among the wave's queued lanes: set bits of m below this lane
+                    myq[nq + (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u))] =
+                        (unsigned short)i;
                 nq += __builtin_popcountll(m);
             }
             if (lane == 0) qcnt[wave] = nq;
