@@ -147,6 +147,21 @@ static int segment_host(const float *xyz, const double *nrm, const int32_t *knn,
         }
         for (int32_t s = 0; s < n_reps; ++s) {
             const int32_t i = reps[(size_t)s];
+            // the visiting order is known in advance and jumps through memory: request what the coming
+            // representatives will touch first (their list header, then the list itself and their own record)
+            if (s + 16 < n_reps) {
+                const int32_t f = reps[(size_t)s + 16];
+                __builtin_prefetch(&adj_off[(size_t)f]);
+                __builtin_prefetch(&adj_len[(size_t)f]);
+                __builtin_prefetch(&xyz[3 * (size_t)f]);
+                __builtin_prefetch(&nrm[3 * (size_t)f]);
+            }
+            if (s + 8 < n_reps) {
+                const int32_t f = reps[(size_t)s + 8];
+                __builtin_prefetch(adj_ptr(f));
+                __builtin_prefetch(adj_ptr(f) + 16);
+                __builtin_prefetch(&sizes[(size_t)f]);
+            }
             if (adj_len[(size_t)i] == 0) continue;
             visited[(size_t)i] = 1;
             int32_t front = 0, back = 1;

@@ -2,7 +2,7 @@
 dependence on scheduling), in both search modes and for every workgroup shape."""
 import os, sys
 import numpy as np, torch
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from fusion4landslide_amd import engine, synthetic
 d = synthetic.make_patches(300_000, 25, 1.386, seed=3)
 dev = torch.device("cuda")

@@ -3,7 +3,7 @@ epoch-2 points assigned to the patch of their nearest epoch-1 point, then the pe
 the nearest-neighbour refinement.  Stage timings on one GPU (synthetic C2-density cloud)."""
 import os, sys, time
 import numpy as np, torch
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from fusion4landslide_amd import engine, synthetic
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000

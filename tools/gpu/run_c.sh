@@ -1,5 +1,5 @@
-python -m pytest tests -m gpu -q -x -k "icp or patch" 2>&1 | tail -3
-for rep in 1 2 3; do for v in old new; do
-  cp tools/gpu/ab/$v.so fusion4landslide_amd/lib/libf4l_hip.so
-  echo -n "$v: "; python bench.py --steps 20 --warmup 5 --cpu-seconds 0 2>&1 | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['roofline']['kernel_ms'], d['extras']['fast_mode_f32']['value'])"
-done; done
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_knn -- python3 $GRAFT_REPO_ROOT/tools/gpu/time_knn.py > $GRAFT_REPO_ROOT/gpurun_out/prof_knn.log 2>&1
+cd $GRAFT_REPO_ROOT
+tail -3 gpurun_out/prof_knn.log
+head -14 gpurun_out/prof_knn/*/*_kernel_stats.csv | cut -c1-150

@@ -1,7 +1,7 @@
 """Kernel time of f4l_piecewise_icp versus the number of patches launched (first K patches of the C2 tile)."""
 import os, sys, time
 import numpy as np, torch
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from fusion4landslide_amd import engine, synthetic
 d = synthetic.make_patches(1_000_000, 45, 1.386, seed=0)
 dev = torch.device("cuda")

@@ -1,6 +1,6 @@
 import os, sys, time
 import numpy as np, torch
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from fusion4landslide_amd import engine, synthetic
 c = synthetic.two_epoch_cloud(1_000_000, 45, 1.386, seed=0)
 xyz = torch.from_numpy(c["src"]).cuda()
