@@ -541,6 +541,18 @@ __global__ void voxel_key_kernel(const float *__restrict__ xyz, int64_t n, doubl
         ids[i] = (int32_t)i;
     }
 }
+// pcl::VoxelGrid's cell of a point: floor(p * inverse_leaf) - min_b, all in float32, min_b = floor(min_p * inverse_leaf)
+__global__ void voxel_key_pcl_kernel(const float *__restrict__ xyz, int64_t n, float inv_leaf, int bx, int by, int bz,
+                                     unsigned long long nx, unsigned long long ny, unsigned long long *__restrict__ keys,
+                                     int32_t *__restrict__ ids) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const unsigned long long cx = (unsigned long long)((int)floorf(xyz[3 * i] * inv_leaf) - bx);
+        const unsigned long long cy = (unsigned long long)((int)floorf(xyz[3 * i + 1] * inv_leaf) - by);
+        const unsigned long long cz = (unsigned long long)((int)floorf(xyz[3 * i + 2] * inv_leaf) - bz);
+        keys[i] = (cz * ny + cy) * nx + cx;
+        ids[i] = (int32_t)i;
+    }
+}
 #pragma clang fp contract(off)
 __global__ void voxel_mean_kernel(const float *__restrict__ xyz, const int32_t *__restrict__ ids,
                                   const int32_t *__restrict__ start, int M, double *__restrict__ pts_out,
@@ -563,11 +575,11 @@ __global__ void voxel_mean_kernel(const float *__restrict__ xyz, const int32_t *
 extern "C" size_t f4l_voxel_downsample_workspace_bytes(int64_t n) { return f4l_knn_workspace_bytes(n, 1); }
 
 // pts_out: room for n points (3 doubles each); *m_out (host) receives the number of voxels.  Synchronises `stream`.
-extern "C" int f4l_voxel_downsample(const float *xyz, int64_t n, double voxel, double *pts_out, int32_t *count_out,
-                                    int32_t *voxel_of_point_out, int64_t *m_out, void *workspace, size_t workspace_bytes,
-                                    void *stream) {
+extern "C" int f4l_voxel_downsample(const float *xyz, int64_t n, double voxel, int layout, double *pts_out,
+                                    int32_t *count_out, int32_t *voxel_of_point_out, int64_t *m_out, void *workspace,
+                                    size_t workspace_bytes, void *stream) {
     using namespace f4l;
-    if (!m_out) return F4L_EINVAL;
+    if (!m_out || (layout != F4L_VOXEL_OPEN3D && layout != F4L_VOXEL_PCL)) return F4L_EINVAL;
     *m_out = 0;
     if (n == 0) return F4L_OK;
     if (!xyz || n < 0 || !(voxel > 0.0) || !pts_out || !workspace) return F4L_EINVAL;
@@ -581,13 +593,26 @@ extern "C" int f4l_voxel_downsample(const float *xyz, int64_t n, double voxel, d
     rc = bbox_to_host(xyz, n, w.bbox_partial, st, mn, mx);
     if (rc != F4L_OK) return rc;
     double dims[3];
-    for (int d = 0; d < 3; ++d) {
-        mn[d] -= 0.5 * voxel;
-        dims[d] = std::floor((mx[d] - mn[d]) / voxel) + 1.0;
-        if (dims[d] > 2097151.0) return F4L_EUNSUPPORTED;  // 3 x 21 bits of key (Open3D: "voxel_size is too small")
+    if (layout == F4L_VOXEL_OPEN3D) {
+        for (int d = 0; d < 3; ++d) {
+            mn[d] -= 0.5 * voxel;
+            dims[d] = std::floor((mx[d] - mn[d]) / voxel) + 1.0;
+            if (dims[d] > 2097151.0) return F4L_EUNSUPPORTED;  // 3 x 21 bits of key (Open3D: "voxel_size is too small")
+        }
+        hipLaunchKernelGGL(voxel_key_kernel, dim3(grid_for(n)), dim3(256), 0, st, xyz, n, mn[0], mn[1], mn[2], voxel,
+                           (unsigned long long)dims[0], (unsigned long long)dims[1], w.keys_a, w.ids_a);
+    } else {
+        // pcl::VoxelGrid::applyFilter [3P-knowledge]: float32 leaf and inverse leaf, cells counted from floor(min * inv)
+        const float inv_leaf = 1.0f / (float)voxel;
+        int b[3];
+        for (int d = 0; d < 3; ++d) {
+            b[d] = (int)std::floor((float)mn[d] * inv_leaf);
+            dims[d] = (double)((int)std::floor((float)mx[d] * inv_leaf) - b[d] + 1);
+            if (dims[d] > 2097151.0) return F4L_EUNSUPPORTED;  // (PCL: "Leaf size is too small for the input dataset")
+        }
+        hipLaunchKernelGGL(voxel_key_pcl_kernel, dim3(grid_for(n)), dim3(256), 0, st, xyz, n, inv_leaf, b[0], b[1], b[2],
+                           (unsigned long long)dims[0], (unsigned long long)dims[1], w.keys_a, w.ids_a);
     }
-    hipLaunchKernelGGL(voxel_key_kernel, dim3(grid_for(n)), dim3(256), 0, st, xyz, n, mn[0], mn[1], mn[2], voxel,
-                       (unsigned long long)dims[0], (unsigned long long)dims[1], w.keys_a, w.ids_a);
     F4L_LAUNCH_CHECK();
     const double ncell = dims[0] * dims[1] * dims[2];
     int end_bit = 1;

@@ -313,10 +313,11 @@ def nn_query(cloud, queries, k=1, return_d2=False):
     return (idx, d2) if return_d2 else idx
 
 
-def voxel_downsample(xyz, voxel_size, return_map=False):
-    """Open3D `voxel_down_sample(voxel_size)` (src/coarse_to_fine_matching_base.py:1024-1025): the mean point of every
-    occupied voxel -> (M, 3) float64, voxels in ascending (z, y, x) index order[, points per voxel (M,) int32, voxel of
-    every input point (n,) int32]."""
+def voxel_downsample(xyz, voxel_size, return_map=False, layout="open3d"):
+    """Open3D `voxel_down_sample(voxel_size)` (src/coarse_to_fine_matching_base.py:1024-1025), or with layout="pcl" the
+    `pcl::VoxelGrid` of cpp_core/pcd_tiling/pcd_tiling.cpp:118-227: the mean point of every occupied voxel -> (M, 3)
+    float64, voxels in ascending (z, y, x) index order[, points per voxel (M,) int32, voxel of every input point (n,)
+    int32]."""
     torch = require_gpu()
     xyz = _dev(xyz, torch.float32, "xyz", (3,))
     n = xyz.shape[0]
@@ -326,7 +327,8 @@ def voxel_downsample(xyz, voxel_size, return_map=False):
     m = C.c_int64(0)
     nbytes = lib().f4l_voxel_downsample_workspace_bytes(n)
     ws = torch.empty((max(int(nbytes), 1),), dtype=torch.uint8, device=xyz.device)
-    check(lib().f4l_voxel_downsample(ptr(xyz), n, float(voxel_size), ptr(pts), ptr(cnt), ptr(vop), C.byref(m), ptr(ws),
+    check(lib().f4l_voxel_downsample(ptr(xyz), n, float(voxel_size), {"open3d": 0, "pcl": 1}[layout], ptr(pts), ptr(cnt),
+                                     ptr(vop), C.byref(m), ptr(ws),
                                      C.c_size_t(nbytes), stream_ptr()), "f4l_voxel_downsample")
     M = int(m.value)
     return (pts[:M], cnt[:M], vop) if return_map else pts[:M]

@@ -169,8 +169,11 @@ int f4l_nn_refine(const float *src, const int64_t *src_off, const float *tgt, co
  * f4l_nn_query: the k nearest points of `cloud` for every query point (the cKDTree(...).query(sub, k=1) of
  *   :1042-1046), squared Euclidean distance in double, ascending, exact-distance ties ordered by cloud index.
  *   idx_out int32 [m][k]; d2_out double [m][k] or NULL.  1 <= k <= 64, k <= n.  Synchronises `stream`. */
+#define F4L_VOXEL_OPEN3D 0 /* cells anchored at min_bound - voxel/2, index by division in double (Open3D) */
+#define F4L_VOXEL_PCL 1    /* cells floor(p * (1/leaf)) in float32, counted from floor(min * (1/leaf)) (pcl::VoxelGrid, the
+                              filter of cpp_core/pcd_tiling/pcd_tiling.cpp:118-227); same output order, centroids in double */
 size_t f4l_voxel_downsample_workspace_bytes(int64_t n);
-int f4l_voxel_downsample(const float *xyz, int64_t n, double voxel, double *pts_out, int32_t *count_out,
+int f4l_voxel_downsample(const float *xyz, int64_t n, double voxel, int layout, double *pts_out, int32_t *count_out,
                          int32_t *voxel_of_point_out, int64_t *m_out_host, void *workspace, size_t workspace_bytes,
                          void *stream);
 size_t f4l_nn_query_workspace_bytes(int64_t n, int64_t m, int k);

@@ -86,7 +86,10 @@ def test_reference_module_layout_is_importable():
     import importlib
     for mod in ["fusion4landslide_amd.cpp_core.supervoxel_segmentation.build.supervoxel",
                 "fusion4landslide_amd.utils.o3d_tools", "fusion4landslide_amd.scripts.weighted_svd",
-                "fusion4landslide_amd.src.piecewise_icp", "fusion4landslide_amd.main_piecewise_icp"]:
+                "fusion4landslide_amd.src.piecewise_icp", "fusion4landslide_amd.main_piecewise_icp",
+                "fusion4landslide_amd.src.functions", "fusion4landslide_amd.cpp_core.pcd_tiling.build.pcd_tiling"]:
         importlib.import_module(mod)
+    pt = importlib.import_module("fusion4landslide_amd.cpp_core.pcd_tiling.build.pcd_tiling")
+    assert callable(pt.tile_point_clouds) and callable(pt.resave_point_cloud)
     sv = importlib.import_module("fusion4landslide_amd.cpp_core.supervoxel_segmentation.build.supervoxel")
     assert callable(sv.computeSupervoxel) and callable(sv.WritePoints)
