@@ -1,1 +1,1 @@
-python -m pytest tests -m gpu -q -x -k "voxel or tiling" 2>&1 | tail -8
+python -m pytest tests -m gpu -q -x -k "robust_rigid or kabsch2" 2>&1 | tail -12
