@@ -80,8 +80,18 @@ int32_t occupied_cells(const float *xyz, int32_t n, double resolution) {
 }  // namespace
 
 // supervoxel_segmentation.h:65-265.  Returns the number of supervoxels, or a negative F4L_E* code.
+// The two embarrassingly parallel sweeps of the segmentation can be computed elsewhere (f4l_supervoxel: on the GPU,
+// bit-identically) and handed in: dis0[i] = smallest metric from point i to a neighbour (:105-113), and, once the
+// fusion has produced the labels, flag[i] = "some neighbour of i carries another label" together with
+// dis[i] = metric(i, its representative) (:186-200).  Null members: computed here on the host.
+struct SegmentAssist {
+    const double *dis0 = nullptr;
+    void (*boundary)(const int32_t *labels, uint8_t *flag, double *dis, void *ctx) = nullptr;
+    void *ctx = nullptr;
+};
+
 static int segment_host(const float *xyz, const double *nrm, const int32_t *knn, int64_t n64, int k, double resolution,
-                        int32_t *labels) {
+                        int32_t *labels, const SegmentAssist &assist = SegmentAssist()) {
     if (n64 <= 0 || n64 > 0x7fffffffLL || k < 1 || !(resolution > 0.0)) return F4L_EINVAL;
     const int32_t n = (int32_t)n64;
     Segmenter sg{xyz, nrm, knn, n, k, resolution};
@@ -110,14 +120,16 @@ static int segment_host(const float *xyz, const double *nrm, const int32_t *knn,
     auto tsec = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
     const auto t_start = tnow();
     // starting lambda: median over points of the smallest metric to a neighbour (:105-113, median.h:27-30)
-    for (int32_t i = 0; i < n; ++i) {
-        double best = DBL_MAX;
-        for (int j = 0; j < k; ++j) {
-            const int32_t q = knn[(size_t)i * k + j];
-            if (q != i) best = std::min(best, sg.metric(i, q));
+    if (assist.dis0) std::memcpy(dis.data(), assist.dis0, (size_t)n * sizeof(double));
+    else
+        for (int32_t i = 0; i < n; ++i) {
+            double best = DBL_MAX;
+            for (int j = 0; j < k; ++j) {
+                const int32_t q = knn[(size_t)i * k + j];
+                if (q != i) best = std::min(best, sg.metric(i, q));
+            }
+            dis[(size_t)i] = best;
         }
-        dis[(size_t)i] = best;
-    }
     double lambda;
     {
         std::vector<double> tmp(dis);
@@ -218,7 +230,12 @@ static int segment_host(const float *xyz, const double *nrm, const int32_t *knn,
     for (int32_t i = 0; i < n; ++i) labels[i] = find_root(parent.data(), i);  // :179-182
 
     // step 2 (:186-237): boundary exchange with a FIFO of points whose neighbourhood straddles two labels
-    for (int32_t i = 0; i < n; ++i) dis[(size_t)i] = sg.metric(i, labels[i]);
+    std::vector<uint8_t> flag;  // (assisted) points with a neighbour of another label: only they start pushes below
+    if (assist.boundary) {
+        flag.resize((size_t)n);
+        assist.boundary(labels, flag.data(), dis.data(), assist.ctx);
+    } else
+        for (int32_t i = 0; i < n; ++i) dis[(size_t)i] = sg.metric(i, labels[i]);
     std::vector<int32_t> fifo((size_t)n);
     std::vector<uint8_t> in_q((size_t)n, 0);
     int64_t head = 0, tail = 0, count = 0;
@@ -228,7 +245,8 @@ static int segment_host(const float *xyz, const double *nrm, const int32_t *knn,
         ++count;
         in_q[(size_t)v] = 1;
     };
-    for (int32_t i = 0; i < n; ++i)
+    for (int32_t i = 0; i < n; ++i) {
+        if (!flag.empty() && !flag[(size_t)i]) continue;  // no neighbour of another label: the scan below pushes nothing
         for (int j = 0; j < k; ++j) {
             const int32_t q = knn[(size_t)i * k + j];
             if (labels[i] != labels[q]) {
@@ -236,6 +254,7 @@ static int segment_host(const float *xyz, const double *nrm, const int32_t *knn,
                 if (!in_q[(size_t)q]) push(q);
             }
         }
+    }
     while (count > 0) {
         const int32_t i = fifo[(size_t)head];
         head = head + 1 == n ? 0 : head + 1;
@@ -286,12 +305,80 @@ extern "C" int f4l_supervoxel_segment_host(const float *xyz_host, const double *
     return F4L_OK;
 }
 
+namespace f4l {
+// The VCCS metric on the device, the same operations in the same order as Segmenter::metric (no contraction; the
+// double sqrt and division of the device library are correctly rounded): bit-identical values.
+#pragma clang fp contract(off)
+__device__ __forceinline__ double sv_metric(const float *__restrict__ xyz, const double *__restrict__ nrm, int64_t a,
+                                            int64_t b, double resolution) {
+    const double dot = nrm[3 * a] * nrm[3 * b] + nrm[3 * a + 1] * nrm[3 * b + 1] + nrm[3 * a + 2] * nrm[3 * b + 2];
+    const double t1 = (double)xyz[3 * a] - xyz[3 * b], t2 = (double)xyz[3 * a + 1] - xyz[3 * b + 1],
+                 t3 = (double)xyz[3 * a + 2] - xyz[3 * b + 2];
+    return 1.0 - fabs(dot) + sqrt(t1 * t1 + t2 * t2 + t3 * t3) / resolution * 0.4;
+}
+__global__ void sv_min_metric_kernel(const float *__restrict__ xyz, const double *__restrict__ nrm,
+                                     const int32_t *__restrict__ knn, int64_t n, int k, double resolution,
+                                     double *__restrict__ dis0) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double best = DBL_MAX;
+    for (int j = 0; j < k; ++j) {
+        const int64_t q = knn[i * k + j];
+        if (q != i) {
+            const double m = sv_metric(xyz, nrm, i, q, resolution);
+            best = m < best ? m : best;  // std::min(best, m)
+        }
+    }
+    dis0[i] = best;
+}
+__global__ void sv_boundary_kernel(const float *__restrict__ xyz, const double *__restrict__ nrm,
+                                   const int32_t *__restrict__ knn, const int32_t *__restrict__ labels, int64_t n, int k,
+                                   double resolution, uint8_t *__restrict__ flag, double *__restrict__ dis) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int32_t l = labels[i];
+    bool f = false;
+    for (int j = 0; j < k; ++j) f = f || labels[knn[i * k + j]] != l;
+    flag[i] = f ? 1 : 0;
+    dis[i] = sv_metric(xyz, nrm, i, (int64_t)l, resolution);
+}
+
+struct BoundaryCtx {
+    const float *xyz;
+    const double *nrm;
+    const int32_t *knn;
+    int32_t *d_labels;
+    uint8_t *d_flag;
+    double *d_dis;
+    int64_t n;
+    int k;
+    double resolution;
+    hipStream_t st;
+    int rc;
+};
+static void boundary_on_device(const int32_t *labels, uint8_t *flag, double *dis, void *vctx) {
+    BoundaryCtx &c = *(BoundaryCtx *)vctx;
+    const unsigned grid = (unsigned)((c.n + 255) / 256);
+    c.rc = F4L_EHIP;
+    if (hipMemcpyAsync(c.d_labels, labels, (size_t)c.n * 4, hipMemcpyHostToDevice, c.st) != hipSuccess) return;
+    hipLaunchKernelGGL(sv_boundary_kernel, dim3(grid), dim3(256), 0, c.st, c.xyz, c.nrm, c.knn, c.d_labels, c.n, c.k,
+                       c.resolution, c.d_flag, c.d_dis);
+    if (hipGetLastError() != hipSuccess) return;
+    if (hipMemcpyAsync(flag, c.d_flag, (size_t)c.n, hipMemcpyDeviceToHost, c.st) != hipSuccess) return;
+    if (hipMemcpyAsync(dis, c.d_dis, (size_t)c.n * 8, hipMemcpyDeviceToHost, c.st) != hipSuccess) return;
+    if (hipStreamSynchronize(c.st) != hipSuccess) return;
+    c.rc = F4L_OK;
+}
+}  // namespace f4l
+
 extern "C" size_t f4l_supervoxel_workspace_bytes(int64_t n, int k) {
     if (n <= 0 || k < 1) return 0;
-    // kNN workspace + (when the caller does not want the intermediates) room for idx and normals
+    // kNN workspace + (when the caller does not want the intermediates) room for idx and normals + the two sweeps of
+    // the segmentation that run on the device (8 n of metric values, n of flags)
     const size_t a = f4l_knn_workspace_bytes(n, k);
     const size_t idx = ((size_t)n * k * 4 + 255) / 256 * 256, nrm = ((size_t)n * 24 + 255) / 256 * 256;
-    return a + idx + nrm;
+    const size_t dis = ((size_t)n * 8 + 255) / 256 * 256, flag = ((size_t)n + 255) / 256 * 256;
+    return a + idx + nrm + dis + flag;
 }
 
 // SYNCHRONISES `stream`: kNN and normals run on the device, the order-dependent segmentation on the host.
@@ -304,19 +391,27 @@ extern "C" int f4l_supervoxel(const float *xyz, int64_t n, int k, double resolut
     hipStream_t st = (hipStream_t)stream;
     const size_t knn_ws = f4l_knn_workspace_bytes(n, k);
     unsigned char *base = (unsigned char *)workspace;
-    const size_t idx_b = ((size_t)n * k * 4 + 255) / 256 * 256;
+    const size_t idx_b = ((size_t)n * k * 4 + 255) / 256 * 256, nrm_b = ((size_t)n * 24 + 255) / 256 * 256,
+                 dis_b = ((size_t)n * 8 + 255) / 256 * 256;
     int32_t *idx = knn_out ? knn_out : (int32_t *)(base + knn_ws);
     double *nrm = normals_out ? normals_out : (double *)(base + knn_ws + idx_b);
+    double *d_dis = (double *)(base + knn_ws + idx_b + nrm_b);
+    uint8_t *d_flag = (uint8_t *)(base + knn_ws + idx_b + nrm_b + dis_b);
     int rc = f4l_knn(xyz, n, k, idx, nullptr, workspace, knn_ws, stream);
     if (rc != F4L_OK) return rc;
     rc = f4l_normals(xyz, n, idx, k, nrm, stream);
     if (rc != F4L_OK) return rc;
+    // the starting lambda's sweep (smallest metric to a neighbour, per point) on the device
+    hipLaunchKernelGGL(f4l::sv_min_metric_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, xyz, nrm, idx, n, k,
+                       resolution, d_dis);
+    F4L_LAUNCH_CHECK();
     std::vector<float> h_xyz;
-    std::vector<double> h_nrm;
+    std::vector<double> h_nrm, h_dis0;
     std::vector<int32_t> h_idx, h_lab;
     try {
         h_xyz.resize((size_t)n * 3);
         h_nrm.resize((size_t)n * 3);
+        h_dis0.resize((size_t)n);
         h_idx.resize((size_t)n * k);
         h_lab.resize((size_t)n);
     } catch (const std::bad_alloc &) {
@@ -325,10 +420,24 @@ extern "C" int f4l_supervoxel(const float *xyz, int64_t n, int k, double resolut
     F4L_HIP_CHECK(hipMemcpyAsync(h_xyz.data(), xyz, (size_t)n * 12, hipMemcpyDeviceToHost, st));
     F4L_HIP_CHECK(hipMemcpyAsync(h_nrm.data(), nrm, (size_t)n * 24, hipMemcpyDeviceToHost, st));
     F4L_HIP_CHECK(hipMemcpyAsync(h_idx.data(), idx, (size_t)n * k * 4, hipMemcpyDeviceToHost, st));
+    F4L_HIP_CHECK(hipMemcpyAsync(h_dis0.data(), d_dis, (size_t)n * 8, hipMemcpyDeviceToHost, st));
     F4L_HIP_CHECK(hipStreamSynchronize(st));
     int32_t nsv = 0;
-    rc = f4l_supervoxel_segment_host(h_xyz.data(), h_nrm.data(), h_idx.data(), n, k, resolution, h_lab.data(), &nsv);
-    if (rc != F4L_OK) return rc;
+    f4l::BoundaryCtx bctx{xyz, nrm, idx, labels_out, d_flag, d_dis, n, k, resolution, st, F4L_OK};
+    f4l::SegmentAssist assist;
+    if (!getenv("F4L_SV_HOST_ONLY")) {  // (switch for A/B timing and for the test that both ways give the same labels)
+        assist.dis0 = h_dis0.data();
+        assist.boundary = f4l::boundary_on_device;
+        assist.ctx = &bctx;
+    }
+    try {
+        rc = f4l::segment_host(h_xyz.data(), h_nrm.data(), h_idx.data(), n, k, resolution, h_lab.data(), assist);
+    } catch (const std::bad_alloc &) {
+        return F4L_ENOMEM;
+    }
+    if (bctx.rc != F4L_OK) return bctx.rc;
+    if (rc < 0) return rc;
+    nsv = rc;
     F4L_HIP_CHECK(hipMemcpyAsync(labels_out, h_lab.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
     F4L_HIP_CHECK(hipStreamSynchronize(st));
     if (n_supervoxels_host) *n_supervoxels_host = nsv;

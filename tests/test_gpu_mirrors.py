@@ -276,3 +276,18 @@ def test_robust_rigid_fit_vs_per_set_restatement():
                 R, t = O.kabsch_transformation_estimation(c[None, :, :3], c[None, :, 3:], inl[None].astype(np.float64))
             assert np.abs(out["rot_est"][p].cpu().numpy() - R[0]).max() <= 1e-9, p
             assert np.abs(out["trans_est"][p].cpu().numpy() - t[0]).max() <= 1e-9, p
+
+
+def test_supervoxel_device_assisted_sweeps_give_the_same_labels(monkeypatch):
+    """f4l_supervoxel computes two sweeps of the segmentation on the GPU (starting lambda's per-point minimum metric,
+    boundary flags + distance to the representative after the fusion); F4L_SV_HOST_ONLY=1 keeps them on the host.  The
+    metric must be bit-identical on both sides: same labels, same count, on a cloud large enough to hit every branch."""
+    from fusion4landslide_amd import engine, synthetic
+    c = synthetic.two_epoch_cloud(250_000, 22, 1.386, seed=11, origin=(2647.0, 1177.0, 1500.0))
+    xyz = torch.from_numpy(c["src"]).cuda()
+    for res in (1.386, 0.4):
+        lab, K = engine.supervoxel(xyz, 30, res)
+        monkeypatch.setenv("F4L_SV_HOST_ONLY", "1")
+        lab_h, K_h = engine.supervoxel(xyz, 30, res)
+        monkeypatch.delenv("F4L_SV_HOST_ONLY")
+        assert K == K_h and torch.equal(lab, lab_h)
