@@ -1,6 +1,6 @@
-for rep in 1 2 3; do for v in old new; do
-  cp tools/gpu/ab/$v.so fusion4landslide_amd/lib/libf4l_hip.so
-  echo -n "$v: "; python bench.py --steps 20 --warmup 5 --cpu-seconds 0 2>&1 | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['roofline']['kernel_ms'], d['extras']['fast_mode_f32']['value'])"
-done; done
-cp tools/gpu/ab/new.so fusion4landslide_amd/lib/libf4l_hip.so
-python -m pytest tests -m gpu -q -x -k "icp or patch or nn_refine" 2>&1 | tail -3
+bash tools/gpu/profile_round.sh r1_g > gpurun_out/profile_r1_g.log 2>&1
+tail -1 gpurun_out/prof_r1_g/bench.json.log | cut -c1-300
+cat gpurun_out/prof_r1_g/traffic_raw.json
+head -4 gpurun_out/prof_r1_g/stats/*/*_kernel_stats.csv | cut -c1-160
+python tools/gpu/realistic_tile.py > gpurun_out/realistic_tile.log 2>&1; tail -22 gpurun_out/realistic_tile.log
+python tools/gpu/scale_p.py > gpurun_out/scale_p.log 2>&1; tail -8 gpurun_out/scale_p.log
