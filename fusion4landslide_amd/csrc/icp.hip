@@ -29,6 +29,8 @@
 
 #include <type_traits>
 
+#include <mutex>
+
 #include "f4l_device.h"
 #include "patch_grid.h"
 
@@ -878,6 +880,20 @@ static inline int pow2_ceil(int64_t v) {
 }  // namespace f4l
 
 namespace f4l {
+// Streams of the library's own for size classes that run beside the caller's stream; created once per device, never
+// destroyed (a process keeps its device for life).  Non-blocking: they synchronise with the caller's stream through
+// events only.
+static hipStream_t class_stream(int which) {
+    constexpr int MAX_DEV = 16;
+    static std::mutex mu;
+    static hipStream_t pool[MAX_DEV][ICP_MAX_CLASSES] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV || which < 0 || which >= ICP_MAX_CLASSES) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!pool[dev][which] && hipStreamCreateWithFlags(&pool[dev][which], hipStreamNonBlocking) != hipSuccess) return nullptr;
+    return pool[dev][which];
+}
+
 // Workgroup shape and LDS layout for patches of at most max_src sources and max_tgt targets.
 struct IcpPlan { int nw, tgt_cap, cell_cap, cert_cap, src_cap, pp_cap; size_t lds; };
 static IcpPlan icp_plan(int64_t max_src_patch_host, int64_t max_tgt_patch_host, bool f64, int mode) {
@@ -1094,6 +1110,15 @@ static int f4l::icp_launch_host(const float *src, const int64_t *src_off, const 
     F4L_HIP_CHECK(hipMemsetAsync(cnt, 0, (size_t)cb.n * sizeof(int), st));
     hipLaunchKernelGGL(icp_bin_patches, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st, src_off, tgt_off, (int)P, cb, cnt, buf);
     F4L_LAUNCH_CHECK();
+    // The classes are independent and none of them fills the machine to its end (a class of a few large patches is one
+    // long chain on a few CUs): they run side by side, the largest on the caller's stream, the others on streams of
+    // this library's own that fork from it after the binning and join it again (events; no host synchronisation).
+    const bool side = !getenv("F4L_ICP_SERIAL_CLASSES");
+    hipEvent_t forked = nullptr, joined[ICP_MAX_CLASSES] = {};
+    if (side) {
+        F4L_HIP_CHECK(hipEventCreateWithFlags(&forked, hipEventDisableTiming));
+        F4L_HIP_CHECK(hipEventRecord(forked, st));
+    }
     int rc = F4L_OK;
     for (int k = cb.n - 1; k >= 0 && rc == F4L_OK; --k) {
         const int64_t ms = max_src_patch_host < cb.bound[k] ? max_src_patch_host : cb.bound[k];
@@ -1102,8 +1127,23 @@ static int f4l::icp_launch_host(const float *src, const int64_t *src_off, const 
         IcpArgs ak = a;
         ak.tgt_cap = pk.tgt_cap; ak.cert_cap = pk.cert_cap; ak.cell_cap = pk.cell_cap; ak.src_cap = pk.src_cap; ak.pp_cap = pk.pp_cap;
         ak.list = buf + (size_t)k * (size_t)P; ak.list_cnt = cnt + k;
-        rc = f64 ? launch_icp<double>(ak, mode, pk.nw, pk.lds, st) : launch_icp<float>(ak, mode, pk.nw, pk.lds, st);
+        hipStream_t sk = st;
+        if (side && k != cb.n - 1) {
+            sk = class_stream(cb.n - 2 - k);
+            if (!sk) { rc = F4L_EHIP; break; }
+            F4L_HIP_CHECK(hipStreamWaitEvent(sk, forked, 0));
+        }
+        rc = f64 ? launch_icp<double>(ak, mode, pk.nw, pk.lds, sk) : launch_icp<float>(ak, mode, pk.nw, pk.lds, sk);
+        if (rc == F4L_OK && sk != st) {
+            F4L_HIP_CHECK(hipEventCreateWithFlags(&joined[k], hipEventDisableTiming));
+            F4L_HIP_CHECK(hipEventRecord(joined[k], sk));
+            F4L_HIP_CHECK(hipStreamWaitEvent(st, joined[k], 0));
+        }
     }
+    // (destroying an event whose work is still in flight only defers the release)
+    if (forked) (void)hipEventDestroy(forked);
+    for (int k = 0; k < ICP_MAX_CLASSES; ++k)
+        if (joined[k]) (void)hipEventDestroy(joined[k]);
     F4L_HIP_CHECK(hipFreeAsync(buf, st));
     return rc;
 }

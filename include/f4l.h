@@ -16,7 +16,9 @@
  *  - Transforms are row-major double [4][4]; rotations row-major double [3][3]  (Open3D returns
  *    float64 4x4, utils/o3d_tools.py:66).
  *  - `stream` is a hipStream_t (NULL = default stream).  Work is enqueued asynchronously on it; no
- *    call synchronises the device unless documented.  No global state; re-entrant.
+ *    call synchronises the device unless documented.  Re-entrant; the only state kept between calls is
+ *    a per-device set of helper streams (f4l_piecewise_icp / f4l_patch_loop run the size classes of an uneven
+ *    batch side by side on them; they fork from and join `stream` through events, so the caller sees one stream).
  *  - Return value: F4L_OK (0) or a negative F4L_E* code; nothing throws.
  *  - Functions taking `workspace` need a caller-provided scratch buffer of at least the byte count the
  *    matching *_workspace_bytes() query returns (so that nothing allocates inside a launch and the

@@ -1,6 +1,4 @@
-bash tools/gpu/profile_round.sh r1_g > gpurun_out/profile_r1_g.log 2>&1
-tail -1 gpurun_out/prof_r1_g/bench.json.log | cut -c1-300
-cat gpurun_out/prof_r1_g/traffic_raw.json
-head -4 gpurun_out/prof_r1_g/stats/*/*_kernel_stats.csv | cut -c1-160
-python tools/gpu/realistic_tile.py > gpurun_out/realistic_tile.log 2>&1; tail -22 gpurun_out/realistic_tile.log
-python tools/gpu/scale_p.py > gpurun_out/scale_p.log 2>&1; tail -8 gpurun_out/scale_p.log
+python -m pytest tests -m gpu -q -x -k "icp" 2>&1 | tail -3
+python tools/gpu/realistic_tile.py 2>&1 | grep "fixed iters" | tail -5
+F4L_ICP_SERIAL_CLASSES=1 python tools/gpu/realistic_tile.py 2>&1 | grep "fixed iters" | tail -5
+for e in 0 1; do echo -n "C3 serial=$e: "; env $( [ $e = 1 ] && echo F4L_ICP_SERIAL_CLASSES=1 ) python bench.py --config C3_10M_20k --steps 5 --warmup 2 --cpu-seconds 0 --extras 0 2>&1 | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'])"; done

@@ -1,2 +1,3 @@
-python -m pytest tests -m gpu -q 2>&1 | tail -5
-python bench.py --steps 10 --warmup 3 --cpu-seconds 0 2>&1 | tail -1
+python -m pytest tests -m gpu -q 2>&1 | tail -4
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+python bench.py --steps 10 --warmup 3 2>&1 | tail -1 | cut -c1-250
