@@ -19,6 +19,7 @@ Extra objects on the JSON line:
   roofline     dominant kernel = icp_kernel (the fused loop body); achieved = algorithmic bytes per launch (20 iters x
                24 B + 24 B Kabsch read + 24 B row written = 528 B per source point) / its mean duration
                measured with events on the launch stream; peak = 8 TB/s.
+  extras       the same step in float32 mode, with two tiles in flight on alternating streams, and exact kNN-30.
   cpu_baseline the C oracle (oracle/f4l_oracle.c, 1 thread, "port") timed on a bounded sample of the same patches;
                cpu_baseline.all_cores: the same port with its patch loop on all host cores (OpenMP).
 """
@@ -203,6 +204,24 @@ def extras(torch, engine, step, src, args):
     # a different local solution than the float64 arithmetic of the reference)
     s32 = timed(lambda: step(search="f32"), max(2, args.steps // 2))
     out["fast_mode_f32"] = {"value": round(n / s32 / 1e6, 3), "unit": "Mpts/s", "ms_per_step": round(1e3 * s32, 4)}
+    # consecutive tiles are independent: issued on two alternating streams, the draining tail of one launch (a tile is
+    # only two rounds of workgroups) overlaps the head of the next.  Same step, same work per tile; not the headline,
+    # because the per-launch roofline above is defined on an undisturbed launch.
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    reps = max(4, 2 * args.steps)
+
+    def alternate():
+        for i in range(reps):
+            with torch.cuda.stream(streams[i % 2]):
+                step()
+    alternate()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    alternate()
+    torch.cuda.synchronize()
+    s2 = (time.perf_counter() - t0) / reps
+    out["two_tiles_in_flight"] = {"value": round(n / s2 / 1e6, 3), "unit": "Mpts/s", "ms_per_tile": round(1e3 * s2, 4),
+                                  "note": "float64 mode, tiles issued on two alternating HIP streams"}
     # exact kNN-30 of the source epoch (supervoxel stage): 12 B read + 120 B written per point
     sk = timed(lambda: engine.knn(src, 30), 3)
     out["knn30"] = {"value": round(n / sk / 1e6, 3), "unit": "Mpts/s", "ms": round(1e3 * sk, 3),
