@@ -1,5 +1,5 @@
 import numpy as np, sys, os
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from fusion4landslide_amd import synthetic
 wg = np.fromfile("gpurun_out/wg.bin", dtype=np.uint64).reshape(-1, 2).astype(np.int64)
 d = synthetic.make_patches(1_000_000, 45, 1.386, seed=0)
