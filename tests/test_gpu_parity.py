@@ -676,3 +676,38 @@ def test_full_size_properties_1M(eng):
     assert bool((d2[:, 1:] >= d2[:, :-1]).all()) and bool((d2[:, 0] == 0).all())
     assert float((idx[:, 0] == torch.arange(1_000_000, device="cuda")).float().mean()) > 0.9999
     assert conv.any()
+
+
+def test_icp_launch_is_capturable_into_a_hip_graph(eng):
+    """The C ABI only enqueues on the caller's stream (the size classes fork to helper streams and join again through
+    events, temporaries come from the stream-ordered allocator): a launch can be captured once and replayed.  Checked for
+    the single-launch path and for an uneven batch that takes the size-class path."""
+    rng = np.random.default_rng(41)
+    cases = [_patches(n=20_000, cells=5, seed=19)]
+    sizes = rng.integers(10, 300, 700)
+    src_l, tgt_l = [], []
+    for m in sizes:
+        side = max(0.2, np.sqrt(m / 400.0))
+        xy = rng.uniform(0, side, (int(m), 2))
+        t = np.c_[xy, 0.3 * np.sin(1.7 * xy[:, 0]) * np.cos(2.3 * xy[:, 1])]
+        tgt_l.append(t)
+        src_l.append(t + rng.uniform(-0.02, 0.02, 3) + rng.normal(0, 0.002, t.shape))
+    off = ragged(rng, [int(m) for m in sizes])
+    cases.append(dict(src=np.concatenate(src_l).astype(np.float32), tgt=np.concatenate(tgt_l).astype(np.float32),
+                      src_off=off, tgt_off=off.copy(), max_src=int(sizes.max()), max_tgt=int(sizes.max())))
+    for d in cases:
+        args = (dev(d["src"]), dev(d["src_off"]), dev(d["tgt"]), dev(d["tgt_off"]))
+        kw = dict(max_corr_dist=0.1, max_iter=20, fixed_iters=True, max_src_patch=d["max_src"], max_tgt_patch=d["max_tgt"])
+        ref = eng.piecewise_icp(*args, **kw)
+        torch.cuda.synchronize()
+        g, s = torch.cuda.CUDAGraph(), torch.cuda.Stream()
+        with torch.cuda.stream(s):
+            eng.piecewise_icp(*args, **kw)
+            torch.cuda.synchronize()
+            with torch.cuda.graph(g, stream=s):
+                out = eng.piecewise_icp(*args, **kw)
+        for _ in range(3):
+            out["T"].zero_()
+            g.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(out["T"], ref["T"]) and torch.equal(out["iters"], ref["iters"])
