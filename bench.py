@@ -84,9 +84,8 @@ def main():
     cs, ct, coff = torch.from_numpy(cs_h).to(dev), torch.from_numpy(ct_h).to(dev), torch.from_numpy(coff_h).to(dev)
 
     # two sets of receive buffers: the all-gather of step i overlaps the compute of step i + 1 (tiles are independent)
-    gathered = [[torch.empty((P, 19), dtype=torch.float64, device=dev) for _ in range(world)] for _ in range(2)] if world > 1 else None
-    inflight = [None, None]  # (work handle, packed tensor kept alive) per buffer set
-    counter = [0]
+    from fusion4landslide_amd.sharding import TileResultGather
+    gather = TileResultGather(dist, torch, world, P, dev) if world > 1 else None
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
 
     def step(i_timed=None, search="f64"):
@@ -98,14 +97,8 @@ def main():
         if i_timed is not None:
             ev[i_timed][1].record()
         rows = out["rows"]
-        if world > 1:
-            slot = counter[0] % 2
-            counter[0] += 1
-            if inflight[slot] is not None:
-                inflight[slot][0].wait()  # stream-ordered: the buffer set is free again
-            packed = torch.cat([out["T"].reshape(P, 16), out["fitness"][:, None], out["rmse"][:, None],
-                                out["iters"].to(torch.float64)[:, None]], dim=1)
-            inflight[slot] = (dist.all_gather(gathered[slot], packed, async_op=True), packed)
+        if gather is not None:
+            gather.submit(out)
         return out, rows
 
     for _ in range(args.warmup):
@@ -116,9 +109,8 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         out, rows = step(i)
-    for w in inflight:
-        if w is not None:
-            w[0].wait()  # every all-gather of the timed steps has completed before the clock stops
+    if gather is not None:
+        gather.drain()  # every all-gather of the timed steps has completed before the clock stops
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

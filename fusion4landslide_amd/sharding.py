@@ -97,3 +97,40 @@ def piecewise_icp_sharded(src, src_off, tgt, tgt_off, init_T=None, rank=0, world
         local = dict(T=torch.zeros((0, 4, 4), dtype=torch.float64), fitness=torch.zeros(0), rmse=torch.zeros(0),
                      iters=torch.zeros(0, dtype=torch.int32))
     return gather_patch_results(local, ids_per_rank, rank, world, P, device), ids_per_rank
+
+
+class TileResultGather:
+    """Weak-scaling exchange of `bench.py --gpus N`: every rank owns whole tiles and all-gathers the per-patch results
+    (4x4 transform, fitness, rmse, iterations = 19 doubles per patch) of the tile it just finished.  Two sets of receive
+    buffers, so that the collective of step i runs while step i + 1 computes; `submit` blocks only when the set it is
+    about to reuse is still in flight, `drain` waits for everything.  Backend-agnostic (RCCL on the GPUs, gloo in the
+    CPU test)."""
+
+    def __init__(self, dist, torch, world, n_patches, device):
+        self.dist, self.torch, self.world, self.P = dist, torch, world, n_patches
+        self.sets = [[torch.empty((n_patches, 19), dtype=torch.float64, device=device) for _ in range(world)] for _ in range(2)]
+        self.inflight = [None, None]  # (work handle, packed tensor kept alive) per buffer set
+        self.count = 0
+
+    def pack(self, out):
+        torch = self.torch
+        return torch.cat([out["T"].reshape(self.P, 16), out["fitness"][:, None].to(torch.float64),
+                          out["rmse"][:, None].to(torch.float64), out["iters"].to(torch.float64)[:, None]], dim=1)
+
+    def submit(self, out):
+        slot = self.count % 2
+        self.count += 1
+        if self.inflight[slot] is not None:
+            self.inflight[slot][0].wait()  # the buffer set is free again
+        packed = self.pack(out)
+        self.inflight[slot] = (self.dist.all_gather(self.sets[slot], packed, async_op=True), packed)
+        return slot
+
+    def drain(self):
+        for w in self.inflight:
+            if w is not None:
+                w[0].wait()
+
+    def latest(self):
+        """The gathered results of the most recent submit (list over ranks of (P, 19) tensors); call after drain()."""
+        return self.sets[(self.count - 1) % 2]
