@@ -7,23 +7,30 @@
 // the 4x4 back (two device crossings per patch).
 //
 // Mapping to CDNA4
-//   * one workgroup of NW waves (1, 2 or 4; chosen by the host from the patch count and size) per patch pair;
-//   * the target patch is counting-sorted ONCE into an LDS-resident uniform grid with cell edge >= the
-//     correspondence radius (patch_grid.h) and stays there for every iteration; the source patch is staged in
-//     LDS as well, so after the prologue an iteration touches no global memory at all;
-//   * each lane owns one source point at a time and walks the <= 9 grid rows around it (float4 LDS reads),
-//     instead of the whole patch: ~25 candidates per query instead of ~500;
-//   * per pass the correspondence sums (17 doubles for Umeyama, 29 for the 6x6 point-to-plane system) are
-//     reduced with DPP row operations (no LDS traffic), then across the waves through LDS; wave 0 solves the 3x3
-//     Jacobi SVD / 6x6 system in double and broadcasts the new transform through LDS;
-//   * convergence test, iteration count, fitness and rmse are evaluated on the device.
-// HBM traffic per patch is one read of both clouds (plus two re-reads of the target from L2 while the grid
-// is built); the ALGORITHMIC traffic the roofline is priced with stays the reference's dataflow, 24 B per
-// source point per iteration.
+//   * one workgroup of NW waves (1, 2 or 4) per patch pair, every iteration inside the kernel.  The host sizes the LDS
+//     for the largest patch of a launch; batches of uneven sizes are binned on the device and launched per size class,
+//     side by side on helper streams (icp_launch_host);
+//   * the target patch is counting-sorted ONCE into an LDS-resident uniform grid (patch_grid.h: cells of the search
+//     radius, finer for patches that are dense relative to it) and stays there for every iteration;
+//   * a pass has two phases.  Phase 1 re-measures every source point's previous correspondence and certifies it
+//     (triangle inequality against the runner-up distance of its last search and the point's own motion since) or
+//     queues the point; phase 2 searches the queued points only, 64 per wave, each lane walking the <= 9 grid runs
+//     its bound reaches in one flat predicated loop.  ~87 % of the point-iterations are certified;
+//   * the correspondence sums of a pass (17 for Umeyama, 29 for the 6x6 point-to-plane system) are reduced by
+//     row_sums_transposed (f4l_device.h: the DPP quad stages transpose while they add), row partials go through LDS,
+//     one wave -- rotating with the patch index -- adds them, solves (Newton on SO(3), warm-started Jacobi SVD as
+//     fallback; elimination for the 6x6) and publishes the new transform through LDS;
+//   * convergence test, iteration count, fitness and rmse on the device; optional Kabsch initialisation from
+//     correspondences in the prologue and displacement rows in the epilogue (f4l_patch_loop).
+// The kernel is bound by the latency of that per-patch chain, not by HBM: per patch both clouds are read
+// about once; the ALGORITHMIC traffic the roofline is priced with stays the reference's dataflow, 24 B per source
+// point per iteration.
 //
-// Numerics: coordinates are taken relative to a per-patch origin (first target point) so that float32
-// distance arithmetic works at ~1 m magnitudes even for georeferenced clouds; the running transform and all
-// sums are double.  The grid search returns exactly the brute-force answer: the minimiser of (d2, index).
+// Numerics: coordinates are taken relative to a per-patch origin (first target point); the running transform, the
+// sums from the 16-lane rows on and the solves are double.  F = double (F4L_SEARCH_F64, the default) evaluates positions
+// and squared distances in double on the original float32 coordinates, like Open3D: same trajectory as the oracle to
+// 1e-9 m.  F = float searches in float32 on patch-relative coordinates.  Either way the search returns exactly the
+// brute-force answer of its arithmetic: the minimiser of (d2, index).
 #include <stdio.h>
 #include <stdlib.h>
 
