@@ -16,6 +16,10 @@
 // Distances are double with separately rounded mul/add, so d2 and the neighbour order equal the reference's
 // except inside groups of exactly equal d2, which are ordered by point id here.
 //
+// The same kernel answers queries from ANOTHER cloud (f4l_nn_query: the queries are binned into the cloud's grid, outside
+// points clamped into its border cells, blocks clipped to the grid and doubled while they hold fewer than k points),
+// and the binning machinery doubles as the voxel-grid filter (f4l_voxel_downsample: Open3D's and PCL's cell layouts).
+//
 // Roofline: algorithmic traffic is 12 B read + 4k B written per point (132 B/pt at k = 30).
 // The kernel is bounded by VALU/issue (top-k maintenance), not HBM; bench.py reports the achieved GB/s.
 #include <algorithm>

@@ -19,6 +19,11 @@
 // point a brute-force scan in index order (and the oracle's KD-tree) returns, independent of the order in
 // which the counting sort happened to place points inside a cell.
 //
+// Patches that are dense relative to the radius get cells finer than it (grid_build: r/2 .. r/8 while the bounding box
+// still holds >= `dens` points per cell); a query whose bound exceeds one cell then walks the (2 W + 1)^2 runs of a
+// wider stencil (grid_nn_wide).  Callers usually know a bound well below the radius (the previous correspondence,
+// re-measured), which narrows every run to the cells the bound reaches and drops runs beyond it.
+//
 // Exactness of the stencil (3x3x3 cells when h >= r, (2 w + 1)^3 with w = ceil(bound / h) otherwise): cell
 // coordinates are floor((x - min) / h) evaluated in floating point for
 // targets and queries alike (a monotone function of x); h = r * (1 + 2^-7) leaves 7e-3 cells of slack for its
