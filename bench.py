@@ -43,8 +43,8 @@ MAX_CORR = 0.1
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", default="C2_1M_2k")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline budget (0 disables)")
     ap.add_argument("--extras", type=int, default=1, help="also time the float64 parity mode and the kNN-30 kernel (rank 0, N = 1)")
