@@ -1,31 +1,42 @@
 #!/usr/bin/env python3
-"""bench.py -- M source-points/s through 20-iteration piecewise ICP on a synthetic two-epoch cloud.
+"""bench.py -- M source-points/s through 20-iteration piecewise ICP on ONE synthetic two-epoch cloud.
 
-Contract (driver):  python bench.py --gpus N --steps K --warmup W   (N > 1 via torch.distributed.run, one rank per GPU)
-prints ONE JSON line on rank 0.
+Contract (driver):  python bench.py --gpus N --steps K --warmup W   prints ONE JSON line on rank 0.
+  N > 1: either launched by the driver through torch.distributed.run (WORLD_SIZE = N in the environment), or -- when
+  WORLD_SIZE is unset -- this script starts N ranks itself (a `python -m torch.distributed.run` child process, before
+  anything in this process touches the GPU) and relays rank 0's line.  WORLD_SIZE != N is an error (exit code 2).
 
-A "step" is one pass of the hot path over one tile, inputs resident in HBM when the clock starts:
+Workload at every N: BASELINE.json's metric config "C4_50M_100k" (50 M points per epoch, 316 x 316 = 99 856 patches), which
+fits one MI355X (2.4 GB of inputs and outputs out of 288 GB).  The cloud is generated ON THE DEVICE by every rank
+(fusion4landslide_amd.synthetic.make_patches_device: counter-based, identical on every rank, < 1 s), its patches are
+assigned to the ranks by LPT on |src| x |tgt| (fusion4landslide_amd.sharding) and every rank keeps only its own share in
+HBM: total work is fixed as N grows ("scaling": "strong"), `value` = the cloud's 50 M source points / max-over-ranks time.
+
+A "step" is one pass of the hot path over the rank's share, inputs resident in HBM when the clock starts:
     per-patch weighted Kabsch init from the 1-NN correspondences
- -> 20 fixed point-to-point ICP iterations per patch (max_corr_dist 0.1 m, no early exit)
- -> dense displacement rows [s, T s] for every source point
-    (all three in ONE launch of f4l_patch_loop; f4l_kabsch_transforms / f4l_piecewise_icp / f4l_apply_transform are the
-    same stages as separate calls)
- -> (N > 1) RCCL all-gather of the per-patch results (T, fitness, rmse, iters: 152 B per patch).
-Workload at N = 1: BASELINE.json configs[1] ("C2_1M_2k": 1 M points per epoch, 45 x 45 = 2025 patches).
-Scaling is weak: tiles are the reference's independent units (<= 1 M points each, configs/landslide/*.yaml
-max_pts_per_tile), every rank owns one tile and only the per-patch results are exchanged.
+ -> 20 fixed point-to-point ICP iterations per patch (max_corr_dist 0.1 m, no early exit, float64 = Open3D's arithmetic)
+ -> dense displacement rows [s, T s] for every source point          (all three in ONE launch of f4l_patch_loop)
+ -> all-gather of the per-patch results (T, fitness, rmse, iters: 152 B per patch) over RCCL; the only exchange step.
 
 Extra objects on the JSON line:
-  roofline     dominant kernel = icp_kernel (the fused loop body); achieved = algorithmic bytes per launch (20 iters x
-               24 B + 24 B Kabsch read + 24 B row written = 528 B per source point) / its mean duration
-               measured with events on the launch stream; peak = 8 TB/s.
-  extras       the same step in float32 mode, with two tiles in flight on alternating streams, and exact kNN-30.
-  cpu_baseline the C oracle (oracle/f4l_oracle.c, 1 thread, "port") timed on a bounded sample of the same patches;
-               cpu_baseline.all_cores: the same port with its patch loop on all host cores (OpenMP).
+  roofline       dominant kernel = icp_kernel (the fused loop body) on rank 0: achieved = algorithmic bytes per launch
+                 (20 iters x 24 B + 24 B Kabsch read + 24 B row written = 528 B per source point) / its mean
+                 duration measured with events on the launch stream; peak = 8 TB/s; traffic = HBM bytes per launch from
+                 the committed rocprofv3 --pmc passes of this command (null when the kernel source changed since).
+  roofline_knn   the same for the exact kNN-30 kernel of the supervoxel stage (132 B per point), the kernel north_star
+                 asks HBM numbers for (N = 1 only).
+  extras         the other single-GPU BASELINE configs (C2 1 M, C3 10 M dense) and the float32 fast mode (N = 1 only).
+  cpu_baseline   the C oracle (oracle/f4l_oracle.c, "port") timed on a bounded prefix of the same patches, 1 thread, and
+                 with its patch loop on all host cores (rank 0, N = 1 only).
+
+--dry-run: orchestration check without a GPU (gloo, CPU tensors, a stub instead of the kernel launch; `value` is null).
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -33,133 +44,238 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is what a copy achieves
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
 ICP_BYTES_PER_PT_ITER = 24  # 12 B source point + 12 B share of the target patch
 FIXED_BYTES_PER_PT = 48      # ... + Kabsch init read (24 B/pt) + displacement row written (24 B/pt): the fused launch does all three
+KNN_BYTES_PER_PT = 132       # 12 B read + 30 x 4 B neighbour indices written
 MAX_ITER = 20
 MAX_CORR = 0.1
+KERNEL_SOURCES = ("icp.hip", "patch_grid.h", "f4l_device.h")
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--config", default="C2_1M_2k")
+    ap.add_argument("--config", default="C4_50M_100k")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline budget (0 disables)")
-    ap.add_argument("--extras", type=int, default=1, help="also time the float64 parity mode and the kNN-30 kernel (rank 0, N = 1)")
-    args = ap.parse_args()
+    ap.add_argument("--extras", type=int, default=1, help="also time C2, C3, the float32 mode and the kNN-30 kernel (N = 1)")
+    ap.add_argument("--dry-run", action="store_true", help="orchestration only: gloo + CPU tensors + a stub launch")
+    return ap.parse_args(argv)
 
+
+def launch_ranks(args):
+    """`--gpus N` without a launcher around us: start the N ranks as a child torch.distributed.run (this process has not
+    touched the GPU and never will) and relay what they print."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+def main():
+    args = parse_args()
+    world_env = os.environ.get("WORLD_SIZE")
+    if world_env is None and args.gpus > 1:
+        raise SystemExit(launch_ranks(args))
+    world = int(world_env or "1")
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; start one rank per GPU "
+              f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...)", file=sys.stderr)
+        raise SystemExit(2)
+    run_rank(args, world)
+
+
+def run_rank(args, world):
     import numpy as np
     import torch
     import torch.distributed as dist
 
-    from fusion4landslide_amd import engine, synthetic
+    from fusion4landslide_amd import sharding, synthetic
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an AMD GPU (no CPU fallback exists for the product path)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dry = args.dry_run
+    if dry:
+        dev = torch.device("cpu")
+        engine = None
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an AMD GPU (no CPU fallback exists for the product path; --dry-run checks the orchestration)")
+        from fusion4landslide_amd import engine
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if dry:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    def sync():
+        if not dry:
+            torch.cuda.synchronize()
 
     cfg = synthetic.CONFIGS[args.config]
     n, cells, res = cfg["n"], cfg["cells"], cfg["resolution"]
-    raster = float(os.environ.get("F4L_BENCH_RASTER", "0")) or None  # experiment: scan-like point order inside patches
-    d = synthetic.make_patches(n, cells, res, seed=10 * rank, raster=raster)  # every rank owns its own tile
-    P = d["P"]
-    src, tgt = torch.from_numpy(d["src"]).to(dev), torch.from_numpy(d["tgt"]).to(dev)
-    so, to = torch.from_numpy(d["src_off"]).to(dev), torch.from_numpy(d["tgt_off"]).to(dev)
-    eye = torch.eye(4, dtype=torch.float64, device=dev).repeat(P, 1, 1)
+    t_setup = time.perf_counter()
+    cloud = synthetic.make_patches_device(n, cells, res, dev, seed=0)  # the same cloud on every rank
+    P_total = cloud["P"]
+    d, ids_per_rank = sharding.shard_cloud(cloud, rank, world)          # ... of which this rank keeps its LPT share
+    del cloud
+    if not dry:
+        torch.cuda.empty_cache()
+    P, n_mine = d["P"], d["n_src"]
+    mine = torch.from_numpy(ids_per_rank[rank]).to(dev)
+    prob = Problem(torch, engine, synthetic, d, dev, dry, mine)
+    gather = sharding.PatchResultGather(dist, torch, ids_per_rank, rank, dev)
+    sync()
+    t_setup = time.perf_counter() - t_setup
 
-    # Kabsch-init correspondences (inputs of the path, produced upstream by matching in the reference):
-    # 1-NN of each source point inside its target patch within 2 x max_corr_dist.  Untimed setup.
-    nn, _ = engine.nn_refine(src, so, tgt, to, eye, torch.full((P,), 2 * MAX_CORR, dtype=torch.float64, device=dev),
-                             max_tgt_patch=d["max_tgt"], return_rows=False)
-    cs_h, ct_h, coff_h = synthetic.correspondences_from_nn(d["src"], d["src_off"], d["tgt"], d["tgt_off"], nn.cpu().numpy())
-    cs, ct, coff = torch.from_numpy(cs_h).to(dev), torch.from_numpy(ct_h).to(dev), torch.from_numpy(coff_h).to(dev)
+    ev = [] if dry else [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
 
-    # two sets of receive buffers: the all-gather of step i overlaps the compute of step i + 1 (tiles are independent)
-    from fusion4landslide_amd.sharding import TileResultGather
-    gather = TileResultGather(dist, torch, world, P, dev) if world > 1 else None
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-
-    def step(i_timed=None, search="f64"):
-        # the whole loop body in one launch (f4l_patch_loop): Kabsch init -> ICP -> rows
-        if i_timed is not None:
+    def step(i_timed=None):
+        if i_timed is not None and ev:
             ev[i_timed][0].record()
-        out = engine.patch_loop(src, so, tgt, to, cs, ct, coff, None, 0.0, 1e-6, max_corr_dist=MAX_CORR, max_iter=MAX_ITER,
-                                fixed_iters=True, max_src_patch=d["max_src"], max_tgt_patch=d["max_tgt"], search=search)
-        if i_timed is not None:
+        out = prob.step()
+        if i_timed is not None and ev:
             ev[i_timed][1].record()
-        rows = out["rows"]
-        if gather is not None:
-            gather.submit(out)
-        return out, rows
+        gather.submit(out)  # async all-gather; overlaps the next step's launch
+        return out
 
     for _ in range(args.warmup):
         step()
+    gather.drain()
+    sync()
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        out, rows = step(i)
-    if gather is not None:
-        gather.drain()  # every all-gather of the timed steps has completed before the clock stops
-    torch.cuda.synchronize()
+        out = step(i)
+    gather.drain()  # every all-gather of the timed steps has completed before the clock stops
+    sync()
     if world > 1:
         dist.barrier()
+    sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-    icp_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if args.steps > 0 else float("nan")
+    full = gather.latest() if args.steps + args.warmup > 0 else None
 
     if rank == 0:
         ms_per_step = 1e3 * elapsed / max(args.steps, 1)
-        value = world * n / (ms_per_step * 1e-3) / 1e6
-        alg_bytes = (ICP_BYTES_PER_PT_ITER * MAX_ITER + FIXED_BYTES_PER_PT) * n  # 528 B per source point
-        achieved = alg_bytes / (icp_ms * 1e-3) / 1e9
         line = {
             "metric": "M-points/sec piecewise ICP (20 iters, two-epoch cloud)",
-            "value": round(value, 3), "unit": "Mpts/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
-            "config": {"workload": args.config, "points_per_epoch_per_gpu": n, "patches_per_gpu": P,
-                       "icp": "point2point, 20 fixed iters, max_corr_dist 0.1 m, float64 search (parity mode)", "parallelism": f"tiles x{world}",
-                       "mean_fitness": round(float(out["fitness"].mean().item()), 4)},
-            "roofline": {"bound": "hbm", "kernel": "icp_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-                         "kernel_ms": round(icp_ms, 4), "algorithmic_bytes": alg_bytes},
+            "value": None if dry else round(n / (ms_per_step * 1e-3) / 1e6, 3), "unit": "Mpts/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": args.config, "points_per_epoch": n, "patches": P_total,
+                       "points_on_rank0": n_mine, "patches_on_rank0": P,
+                       "icp": "point2point, 20 fixed iters, max_corr_dist 0.1 m, float64 search (parity mode)",
+                       "parallelism": f"one cloud, patches LPT-sharded x{world}, all-gather of per-patch results",
+                       "setup_seconds": round(t_setup, 2)},
         }
-        # HBM bytes per launch of icp_kernel from the PMC counters: cannot be collected from inside this process; they
-        # come from the committed rocprofv3 passes of this same command (profiles/README.md), when the workload matches
-        tr = os.path.join(ROOT, "profiles", "icp_kernel_traffic.json")
-        if os.path.exists(tr):
-            t = json.load(open(tr))
-            if t.get("workload") == args.config:
-                line["roofline"]["traffic"] = t["hbm_bytes_per_launch"]
-                line["roofline"]["traffic_source"] = t["source"]
-        if world == 1:
-            # the box's own device-to-device copy rate (SURVEY.md 8d asks for the fraction of nominal AND of measured)
-            copy_gbs = measured_copy_gbs(torch, dev)
-            line["roofline"]["peak_copy_measured"] = round(copy_gbs, 1)
-            line["roofline"]["frac_of_copy_measured"] = round(achieved / copy_gbs, 5)
-        if world == 1 and args.extras:
-            line["extras"] = extras(torch, engine, step, src, args)
-        if world == 1 and args.cpu_seconds > 0:  # rank 0 at N = 1 only
-            line["cpu_baseline"] = cpu_baseline(d, cs_h, ct_h, coff_h, args.cpu_seconds)
-            if args.extras:
-                line["cpu_baseline_supervoxel"] = cpu_baseline_supervoxel(torch, engine, d)
+        if dry:
+            line["dry_run"] = True
+            line["dry_run_gather_ok"] = bool(full is not None and torch.equal(
+                full["fitness"], torch.arange(P_total, dtype=torch.float64)) and full["T"].shape == (P_total, 4, 4))
+        else:
+            line["config"]["mean_fitness"] = round(float(full["fitness"].mean().item()), 4)
+            icp_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if args.steps > 0 else float("nan")
+            alg_bytes = (ICP_BYTES_PER_PT_ITER * MAX_ITER + FIXED_BYTES_PER_PT) * n_mine  # 528 B per source point of the launch
+            achieved = alg_bytes / (icp_ms * 1e-3) / 1e9
+            line["roofline"] = {"bound": "hbm", "kernel": "icp_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                                "kernel_ms": round(icp_ms, 4), "algorithmic_bytes": alg_bytes,
+                                "note": "achieved = algorithmic bytes / kernel time (contract); the patch pair is LDS resident, "
+                                        "so the kernel is bound by VALU issue and its per-iteration dependency chain, not by HBM"}
+            attach_traffic(line["roofline"], "icp_kernel_traffic.json", args.config if world == 1 else None, icp_ms)
+            if world == 1:
+                copy_gbs = measured_copy_gbs(torch, dev)
+                line["roofline"]["peak_copy_measured"] = round(copy_gbs, 1)
+                line["roofline"]["frac_of_copy_measured"] = round(achieved / copy_gbs, 5)
+                if args.extras:
+                    line["roofline_knn"] = knn_roofline(torch, engine, d["src"][:10_000_000])
+                    line["extras"] = extras(torch, engine, synthetic, prob, dev, args)
+                if args.cpu_seconds > 0:  # rank 0 at N = 1 only
+                    line["cpu_baseline"] = cpu_baseline(prob, args.cpu_seconds)
+                    if args.extras:
+                        line["cpu_baseline_supervoxel"] = cpu_baseline_supervoxel(torch, engine, d["src"])
         print(json.dumps(line), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
+
+
+class Problem:
+    """One rank's share of a cloud, resident on the device, with the Kabsch-init correspondences of the path (inputs
+    produced upstream by matching in the reference; here the 1-NN of each source point inside its target patch within
+    2 x max_corr_dist -- untimed set-up)."""
+
+    def __init__(self, torch, engine, synthetic, d, dev, dry=False, ids=None):
+        self.torch, self.engine, self.d, self.dry, self.ids = torch, engine, d, dry, ids
+        P = d["P"]
+        if dry:
+            self.cs = self.ct = torch.zeros((0, 3), dtype=torch.float32)
+            self.coff = torch.zeros(P + 1, dtype=torch.int64)
+            return
+        eye = torch.eye(4, dtype=torch.float64, device=dev).repeat(P, 1, 1)
+        nn, _ = engine.nn_refine(d["src"], d["src_off"], d["tgt"], d["tgt_off"], eye,
+                                 torch.full((P,), 2 * MAX_CORR, dtype=torch.float64, device=dev),
+                                 max_tgt_patch=d["max_tgt"], return_rows=False)
+        self.cs, self.ct, self.coff = synthetic.correspondences_from_nn_device(d["src"], d["src_off"], d["tgt"], d["tgt_off"], nn)
+
+    def step(self, search="f64"):
+        d, torch = self.d, self.torch
+        if self.dry:  # stub launch: identity transforms, fitness = GLOBAL patch id (checked after the gather)
+            P = d["P"]
+            return dict(T=torch.eye(4, dtype=torch.float64).repeat(P, 1, 1), fitness=self.ids.to(torch.float64),
+                        rmse=torch.zeros(P, dtype=torch.float64), iters=torch.full((P,), MAX_ITER, dtype=torch.int32))
+        # the whole loop body in one launch (f4l_patch_loop): Kabsch init -> ICP -> rows
+        return self.engine.patch_loop(d["src"], d["src_off"], d["tgt"], d["tgt_off"], self.cs, self.ct, self.coff, None, 0.0, 1e-6,
+                                      max_corr_dist=MAX_CORR, max_iter=MAX_ITER, fixed_iters=True, max_src_patch=d["max_src"],
+                                      max_tgt_patch=d["max_tgt"], search=search)
+
+    def host_prefix(self, p_hi):
+        """The first p_hi patches as host numpy arrays (for the CPU baseline: the same bits the GPU worked on)."""
+        d = self.d
+        s1, t1, c1 = int(d["src_off"][p_hi]), int(d["tgt_off"][p_hi]), int(self.coff[p_hi])
+        h = lambda t: t.cpu().numpy()  # noqa: E731
+        return dict(src=h(d["src"][:s1]), src_off=h(d["src_off"][:p_hi + 1]), tgt=h(d["tgt"][:t1]), tgt_off=h(d["tgt_off"][:p_hi + 1]),
+                    cs=h(self.cs[:c1]), ct=h(self.ct[:c1]), coff=h(self.coff[:p_hi + 1]))
+
+
+def kernel_source_hash():
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCES:
+        h.update(open(os.path.join(ROOT, "fusion4landslide_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def attach_traffic(roof, fname, workload, kernel_ms):
+    """HBM bytes per launch from the PMC counters cannot be collected from inside this process; they come from the committed
+    rocprofv3 --pmc passes of this same command (profiles/README.md).  Used only when the workload AND the kernel sources
+    are the ones the passes were taken on -- otherwise `traffic` stays null rather than going stale."""
+    path = os.path.join(ROOT, "profiles", fname)
+    if workload is None or not os.path.exists(path):
+        return
+    t = json.load(open(path))
+    if t.get("workload") != workload:
+        return
+    if t.get("kernel_source_sha256_16") != kernel_source_hash():
+        roof["traffic_note"] = "profiles/%s was taken on other kernel sources; not reported" % fname
+        return
+    roof["traffic"] = t["hbm_bytes_per_launch"]
+    roof["traffic_source"] = t["source"]
+    roof["achieved_measured_traffic"] = round(t["hbm_bytes_per_launch"] / (kernel_ms * 1e-3) / 1e9, 2)
 
 
 def measured_copy_gbs(torch, dev, gib=1.0, reps=10):
@@ -178,65 +294,69 @@ def measured_copy_gbs(torch, dev, gib=1.0, reps=10):
     return 2.0 * 4.0 * n * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
 
-def extras(torch, engine, step, src, args):
-    """Secondary figures of SURVEY.md 8(d), outside the timed region of the headline metric."""
-    out = {}
-    n = src.shape[0]
-
-    def timed(fn, reps):
+def _timed(torch, fn, reps):
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
         fn()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            fn()
-        torch.cuda.synchronize()
-        return (time.perf_counter() - t0) / reps
-
-    # the same step in the fast mode (float32 search and partial sums; not the headline: an ill-posed patch can end in
-    # a different local solution than the float64 arithmetic of the reference, see DESIGN.md section 4)
-    s32 = timed(lambda: step(search="f32"), max(2, args.steps // 2))
-    out["fast_mode_f32"] = {"value": round(n / s32 / 1e6, 3), "unit": "Mpts/s", "ms_per_step": round(1e3 * s32, 4)}
-    # consecutive tiles are independent: issued on two alternating streams, the draining tail of one launch (a tile is
-    # only two rounds of workgroups) overlaps the head of the next.  Same step, same work per tile; not the headline,
-    # because the per-launch roofline above is defined on an undisturbed launch.
-    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
-    reps = max(4, 2 * args.steps)
-
-    def alternate():
-        for i in range(reps):
-            with torch.cuda.stream(streams[i % 2]):
-                step()
-    alternate()
+    e1.record()
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    alternate()
-    torch.cuda.synchronize()
-    s2 = (time.perf_counter() - t0) / reps
-    out["two_tiles_in_flight"] = {"value": round(n / s2 / 1e6, 3), "unit": "Mpts/s", "ms_per_tile": round(1e3 * s2, 4),
-                                  "note": "float64 mode, tiles issued on two alternating HIP streams"}
-    # exact kNN-30 of the source epoch (supervoxel stage): 12 B read + 120 B written per point
-    sk = timed(lambda: engine.knn(src, 30), 3)
-    out["knn30"] = {"value": round(n / sk / 1e6, 3), "unit": "Mpts/s", "ms": round(1e3 * sk, 3),
-                    "achieved_GBs": round(132.0 * n / sk / 1e9, 2), "frac_of_hbm_peak": round(132.0 * n / sk / 1e9 / HBM_PEAK_GBS, 5),
-                    "note": "f4l_knn end to end (binning + sort + search), algorithmic 132 B/pt"}
+    return e0.elapsed_time(e1) * 1e-3 / reps
+
+
+def knn_roofline(torch, engine, xyz, k=30):
+    """Exact kNN-30 of (up to 10 M points of) the source epoch, the search stage of `computeSupervoxel`: f4l_knn end to end
+    (binning + sort + search kernel) timed with events on the launch stream; 12 B read + 120 B written per point."""
+    n = xyz.shape[0]
+    s = _timed(torch, lambda: engine.knn(xyz, k), 5)
+    ach = KNN_BYTES_PER_PT * n / s / 1e9
+    roof = {"bound": "hbm", "kernel": "knn_cells_kernel (f4l_knn end to end)", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None, "kernel_ms": round(1e3 * s, 4),
+            "algorithmic_bytes": KNN_BYTES_PER_PT * n, "points": n, "k": k, "Mpts_per_s": round(n / s / 1e6, 2)}
+    return roof
+
+
+def extras(torch, engine, synthetic, prob, dev, args):
+    """Secondary figures of SURVEY.md 8(d), outside the timed region of the headline metric: the same step on the other
+    single-GPU configs of BASELINE.json, and in the float32 fast mode."""
+    out = {}
+    n = prob.d["n_src"]
+    # the fast mode (float32 search and partial sums; not the headline: an ill-posed patch can end in a different local
+    # solution than the float64 arithmetic of the reference, see DESIGN.md section 4)
+    s32 = _timed(torch, lambda: prob.step(search="f32"), max(2, args.steps // 5))
+    out["fast_mode_f32"] = {"workload": args.config, "value": round(n / s32 / 1e6, 3), "unit": "Mpts/s", "ms_per_step": round(1e3 * s32, 4)}
+    for name in ("C2_1M_2k", "C3_10M_20k"):
+        if name == args.config:
+            continue
+        c = synthetic.CONFIGS[name]
+        d = synthetic.make_patches_device(c["n"], c["cells"], c["resolution"], dev, seed=0)
+        d["n_src"] = c["n"]
+        p = Problem(torch, engine, synthetic, d, dev)
+        s = _timed(torch, p.step, 10)
+        out[name] = {"value": round(c["n"] / s / 1e6, 3), "unit": "Mpts/s", "ms_per_step": round(1e3 * s, 4), "patches": d["P"],
+                     "largest_patch": max(d["max_src"], d["max_tgt"]),
+                     "algorithmic_GBs": round(528.0 * c["n"] / s / 1e9, 1), "frac_of_hbm_peak": round(528.0 * c["n"] / s / 1e9 / HBM_PEAK_GBS, 5)}
+        del p, d
+        torch.cuda.empty_cache()
     return out
 
 
-def cpu_baseline_supervoxel(torch, engine, d, n=200_000, k=30):
-    """SURVEY.md 8(a) row a1 on a bounded sample (the first n points of the source epoch): `computeSupervoxel` without its
-    file I/O.  CPU side: the reference's OWN templates when oracle/_ref/libf4l_ref.so is there (kind "reference": the
-    header-only codelibrary driven by oracle/ref_harness.cpp), else the C restatement (kind "port"); one thread, like
-    the reference.  GPU side: f4l_supervoxel (kNN + normals on the device, the order-dependent segmentation on the
-    host), labels compared for identity."""
+def cpu_baseline_supervoxel(torch, engine, src, n=200_000, k=30):
+    """SURVEY.md 8(a) row a1 on a bounded sample (the first n points of the source epoch: patch-contiguous, i.e. a compact
+    strip of the cloud): `computeSupervoxel` without its file I/O.  CPU side: the C restatement (oracle/f4l_oracle.c,
+    label-identical to the reference's templates on the golden clouds; kind "port"), one thread like the reference.
+    The reference's own templates are timed in the build container only: nothing built from
+    /root/reference runs on the GPU box."""
     import numpy as np
 
     from oracle import oracle as O
 
-    xyz = np.ascontiguousarray(d["meta"]["src"][:n])
+    xyz = np.ascontiguousarray(src[:n].cpu().numpy())
     res = 1.386
-    kind = "reference" if O.have_ref() else "port"
     t = time.perf_counter()
-    ref = O.ref_supervoxel(xyz, k, res) if kind == "reference" else O.supervoxel(xyz, k, res)
+    ref = O.supervoxel(xyz, k, res)
     cpu_s = time.perf_counter() - t
     dev_xyz = torch.from_numpy(xyz).cuda()
     engine.supervoxel(dev_xyz, k, res)  # warm-up
@@ -246,43 +366,43 @@ def cpu_baseline_supervoxel(torch, engine, d, n=200_000, k=30):
     torch.cuda.synchronize()
     gpu_s = time.perf_counter() - t
     same = bool(np.array_equal(labels.cpu().numpy(), ref["labels"])) and K == ref["n_supervoxels"]
-    return {"value": round(len(xyz) / cpu_s / 1e6, 4), "unit": "Mpts/s", "cores": 1, "kind": kind,
+    return {"value": round(len(xyz) / cpu_s / 1e6, 4), "unit": "Mpts/s", "cores": 1, "kind": "port",
             "sample": f"first {len(xyz)} source points, k={k}, resolution {res} m, {cpu_s:.1f} s",
             "this_repo": {"value": round(len(xyz) / gpu_s / 1e6, 4), "unit": "Mpts/s", "seconds": round(gpu_s, 3),
-                          "labels_identical": same, "n_supervoxels": int(K),
-                          "note": "kNN + normals on the GPU (milliseconds), segmentation replayed on one host core"}}
+                          "labels_identical": same, "n_supervoxels": int(K)}}
 
 
-def cpu_baseline(d, cs, ct, coff, budget_s):
-    """The oracle (single-thread C port of the same step) on a bounded prefix of the tile's patches."""
+def cpu_baseline(prob, budget_s):
+    """The oracle (single-thread C port of the same step) on a bounded prefix of the rank's patches."""
     import numpy as np
 
     from oracle import oracle as O
 
-    P = d["P"]
-    # calibrate on a few patches, then size the sample to the budget
-    def run(p_lo, p_hi):
-        s0, s1, t0, t1 = d["src_off"][p_lo], d["src_off"][p_hi], d["tgt_off"][p_lo], d["tgt_off"][p_hi]
-        so, to = d["src_off"][p_lo:p_hi + 1] - s0, d["tgt_off"][p_lo:p_hi + 1] - t0
-        co = coff[p_lo:p_hi + 1] - coff[p_lo]
-        c0, c1 = coff[p_lo], coff[p_hi]
+    P = prob.d["P"]
+    pts_per_patch = prob.d["n_src"] / max(P, 1)
+
+    def run(h, p_hi):
         t = time.perf_counter()
-        R, tt = O.kabsch_batched(cs[c0:c1], ct[c0:c1], co, eps=1e-6)
-        T0 = np.tile(np.eye(4), (p_hi - p_lo, 1, 1))
+        R, tt = O.kabsch_batched(h["cs"], h["ct"], h["coff"], eps=1e-6)
+        T0 = np.tile(np.eye(4), (p_hi, 1, 1))
         T0[:, :3, :3] = R
         T0[:, :3, 3] = tt
-        res = O.piecewise_icp(d["src"][s0:s1], so, d["tgt"][t0:t1], to, init_T=T0, max_corr_dist=MAX_CORR,
+        res = O.piecewise_icp(h["src"], h["src_off"], h["tgt"], h["tgt_off"], init_T=T0, max_corr_dist=MAX_CORR,
                               max_iter=MAX_ITER, fixed_iters=True)
-        s = d["src"][s0:s1].astype(np.float64)
-        pid = np.repeat(np.arange(p_hi - p_lo), np.diff(so))
+        s = h["src"].astype(np.float64)
+        pid = np.repeat(np.arange(p_hi), np.diff(h["src_off"]))
         _ = np.einsum("nij,nj->ni", res["T"][pid, :3, :3], s) + res["T"][pid, :3, 3]
-        return time.perf_counter() - t, int(s1 - s0)
+        return time.perf_counter() - t, int(h["src"].shape[0])
 
     probe = min(P, 16)
-    dt, npts = run(0, probe)
+    dt, npts = run(prob.host_prefix(probe), probe)
+    for _ in range(2):  # calibrate twice: the first patches of a cloud are border patches and not typical
+        rate = npts / dt
+        probe = int(min(P, max(probe, 0.05 * budget_s * rate / pts_per_patch)))
+        dt, npts = run(prob.host_prefix(probe), probe)
     rate = npts / dt
-    want = int(min(P, max(probe, budget_s * rate / (d["src"].shape[0] / P))))
-    dt, npts = run(0, want)
+    want = int(min(P, max(probe, 0.7 * budget_s * rate / pts_per_patch)))
+    dt, npts = run(prob.host_prefix(want), want)
     out = {"value": round(npts / dt / 1e6, 5), "unit": "Mpts/s", "cores": 1, "kind": "port",
            "sample": f"first {want} of {P} patches ({npts} source points), same Kabsch+ICP(20)+apply step, {dt:.1f} s"}
     # the same port with its patch loop on every core this process may use (OpenMP; SURVEY.md 8d (ii))
@@ -291,10 +411,11 @@ def cpu_baseline(d, cs, ct, coff, budget_s):
         used = O.set_threads(cores)
         try:
             want_all = int(min(P, max(probe, want * used * 0.5)))
-            run(0, min(want_all, 4 * used))  # thread start-up outside the clock
+            h = prob.host_prefix(want_all)
+            run(prob.host_prefix(min(want_all, 4 * used)), min(want_all, 4 * used))  # thread start-up outside the clock
             dt_all, npts_all, reps = 0.0, 0, 0
             while dt_all < 0.3 * budget_s and reps < 20:
-                dt1, n1 = run(0, want_all)
+                dt1, n1 = run(h, want_all)
                 dt_all, npts_all, reps = dt_all + dt1, npts_all + n1, reps + 1
         finally:
             O.set_threads(1)

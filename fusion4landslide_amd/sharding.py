@@ -13,28 +13,36 @@ def lpt_assign(sizes, world):
     """Longest-processing-time-first: patches sorted by cost, each to the currently lightest rank.
     sizes: (P,) cost per patch (points x points for brute-force search).  Returns list of int64 arrays (patch ids per
     rank, ascending)."""
+    import heapq
     sizes = np.asarray(sizes, dtype=np.float64)
     order = np.argsort(-sizes, kind="stable")
-    load = np.zeros(world)
     owner = np.empty(len(sizes), dtype=np.int64)
-    for p in order:
-        r = int(np.argmin(load))
+    heap = [(0.0, r) for r in range(world)]  # (load, rank): ties go to the lowest rank, like argmin
+    for p, c in zip(order.tolist(), sizes[order].tolist()):
+        load, r = heap[0]
         owner[p] = r
-        load[r] += sizes[p]
+        heapq.heapreplace(heap, (load + c, r))
     return [np.nonzero(owner == r)[0] for r in range(world)]
 
 
 def take_patches(pts, off, ids):
-    """CSR sub-selection on host arrays: points of the patches `ids`, re-packed contiguously."""
-    off = np.asarray(off)
+    """CSR sub-selection: the points of the patches `ids`, re-packed contiguously, and their new offsets.  Works on host
+    numpy arrays and on torch tensors of any device alike (no per-patch loop: one repeat + one gather)."""
+    if isinstance(pts, np.ndarray):
+        off, ids = np.asarray(off), np.asarray(ids, dtype=np.int64)
+        cnt = off[ids + 1] - off[ids]
+        new_off = np.zeros(len(ids) + 1, dtype=np.int64)
+        np.cumsum(cnt, out=new_off[1:])
+        idx = np.repeat(off[ids] - new_off[:-1], cnt) + np.arange(new_off[-1], dtype=np.int64)
+        return np.ascontiguousarray(pts[idx]), new_off
+    import torch
+    ids = torch.as_tensor(ids, dtype=torch.int64, device=pts.device)
     cnt = off[ids + 1] - off[ids]
-    new_off = np.zeros(len(ids) + 1, dtype=np.int64)
-    np.cumsum(cnt, out=new_off[1:])
-    if len(ids):
-        idx = np.concatenate([np.arange(off[i], off[i + 1]) for i in ids]) if cnt.sum() else np.zeros(0, np.int64)
-    else:
-        idx = np.zeros(0, np.int64)
-    return np.ascontiguousarray(pts[idx]), new_off
+    new_off = torch.zeros(ids.shape[0] + 1, dtype=torch.int64, device=pts.device)
+    new_off[1:] = torch.cumsum(cnt, 0)
+    total = int(new_off[-1].item())
+    idx = torch.repeat_interleave(off[ids] - new_off[:-1], cnt, output_size=total) + torch.arange(total, dtype=torch.int64, device=pts.device)
+    return pts[idx].contiguous(), new_off
 
 
 def gather_patch_results(local, ids_per_rank, rank, world, P, device):
@@ -99,38 +107,73 @@ def piecewise_icp_sharded(src, src_off, tgt, tgt_off, init_T=None, rank=0, world
     return gather_patch_results(local, ids_per_rank, rank, world, P, device), ids_per_rank
 
 
-class TileResultGather:
-    """Weak-scaling exchange of `bench.py --gpus N`: every rank owns whole tiles and all-gathers the per-patch results
-    (4x4 transform, fitness, rmse, iterations = 19 doubles per patch) of the tile it just finished.  Two sets of receive
-    buffers, so that the collective of step i runs while step i + 1 computes; `submit` blocks only when the set it is
-    about to reuse is still in flight, `drain` waits for everything.  Backend-agnostic (RCCL on the GPUs, gloo in the
-    CPU test)."""
+def patch_costs(src_off, tgt_off):
+    """Cost model of one patch for the assignment: source points x target points (what a search without any pruning
+    would touch); host float64 array from host or device offsets."""
+    so = src_off.cpu().numpy() if hasattr(src_off, "cpu") else np.asarray(src_off)
+    to = tgt_off.cpu().numpy() if hasattr(tgt_off, "cpu") else np.asarray(tgt_off)
+    return np.diff(so).astype(np.float64) * np.maximum(np.diff(to), 1)
 
-    def __init__(self, dist, torch, world, n_patches, device):
-        self.dist, self.torch, self.world, self.P = dist, torch, world, n_patches
-        self.sets = [[torch.empty((n_patches, 19), dtype=torch.float64, device=device) for _ in range(world)] for _ in range(2)]
-        self.inflight = [None, None]  # (work handle, packed tensor kept alive) per buffer set
+
+def shard_cloud(d, rank, world):
+    """This rank's share of ONE two-epoch cloud `d` (dict src, src_off, tgt, tgt_off; numpy or torch on any device; the
+    same on every rank): LPT assignment of its patches, then the points of the rank's own patches re-packed.  Returns
+    (share dict with the same keys + P, max_src, max_tgt, n_src; ids_per_rank)."""
+    ids_per_rank = lpt_assign(patch_costs(d["src_off"], d["tgt_off"]), world)
+    mine = ids_per_rank[rank]
+    s, so = take_patches(d["src"], d["src_off"], mine)
+    t, to = take_patches(d["tgt"], d["tgt_off"], mine)
+    mx = lambda o: int((o[1:] - o[:-1]).max()) if len(mine) else 0  # noqa: E731
+    return dict(src=s, src_off=so, tgt=t, tgt_off=to, P=len(mine), max_src=mx(so), max_tgt=mx(to), n_src=int(so[-1])), ids_per_rank
+
+
+class PatchResultGather:
+    """The exchange step of the sharded path (`bench.py --gpus N`): every rank all-gathers the per-patch
+    results of its share (4x4 transform, fitness, rmse, iterations = 19 doubles = 152 B per patch; shares padded to the
+    largest one so that a plain fixed-size all-gather serves) and reads them back in GLOBAL patch order through one
+    precomputed gather.  Two sets of receive buffers: the collective of step i runs while step i + 1 computes; `submit`
+    blocks only when the set it is about to reuse is still in flight, `drain` waits for everything.  Backend-agnostic
+    (RCCL on the GPUs, gloo in the CPU tests)."""
+
+    def __init__(self, dist, torch, ids_per_rank, rank, device):
+        self.dist, self.torch, self.rank, self.world = dist, torch, rank, len(ids_per_rank)
+        self.p = len(ids_per_rank[rank])
+        self.pmax = max(1, max(len(i) for i in ids_per_rank))
+        self.P = sum(len(i) for i in ids_per_rank)
+        self.bufs = [torch.zeros((self.world * self.pmax, 19), dtype=torch.float64, device=device) for _ in range(2)]
+        self.packed = [torch.zeros((self.pmax, 19), dtype=torch.float64, device=device) for _ in range(2)]
+        pos = np.empty(self.P, dtype=np.int64)  # row of global patch g inside a receive buffer
+        for r, ids in enumerate(ids_per_rank):
+            pos[ids] = r * self.pmax + np.arange(len(ids))
+        self.pos = torch.from_numpy(pos).to(device)
+        self.inflight = [None, None]
         self.count = 0
 
-    def pack(self, out):
-        torch = self.torch
-        return torch.cat([out["T"].reshape(self.P, 16), out["fitness"][:, None].to(torch.float64),
-                          out["rmse"][:, None].to(torch.float64), out["iters"].to(torch.float64)[:, None]], dim=1)
-
     def submit(self, out):
+        torch = self.torch
         slot = self.count % 2
         self.count += 1
         if self.inflight[slot] is not None:
-            self.inflight[slot][0].wait()  # the buffer set is free again
-        packed = self.pack(out)
-        self.inflight[slot] = (self.dist.all_gather(self.sets[slot], packed, async_op=True), packed)
+            self.inflight[slot].wait()  # the buffer set is free again
+        pk, p = self.packed[slot], self.p
+        if p:
+            pk[:p, :16] = out["T"].reshape(p, 16)
+            pk[:p, 16], pk[:p, 17], pk[:p, 18] = out["fitness"], out["rmse"], out["iters"].to(torch.float64)
+        if self.world > 1:
+            views = list(self.bufs[slot].view(self.world, self.pmax, 19).unbind(0))
+            self.inflight[slot] = self.dist.all_gather(views, pk, async_op=True)
+        else:
+            self.bufs[slot][:self.pmax].copy_(pk)
         return slot
 
     def drain(self):
         for w in self.inflight:
             if w is not None:
-                w[0].wait()
+                w.wait()
+        self.inflight = [None, None]
 
     def latest(self):
-        """The gathered results of the most recent submit (list over ranks of (P, 19) tensors); call after drain()."""
-        return self.sets[(self.count - 1) % 2]
+        """Results of the most recent submit for ALL patches in global order; call after drain()."""
+        torch = self.torch
+        full = self.bufs[(self.count - 1) % 2][self.pos]
+        return dict(T=full[:, :16].reshape(self.P, 4, 4), fitness=full[:, 16], rmse=full[:, 17], iters=full[:, 18].to(torch.int32))

@@ -132,3 +132,115 @@ def correspondences_from_nn(src, src_off, tgt, tgt_off, nn):
     off = np.zeros(P + 1, dtype=np.int64)
     np.cumsum(counts, out=off[1:])
     return np.ascontiguousarray(cs), np.ascontiguousarray(ct), off
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# The same cloud model generated with torch ops ON THE DEVICE (bench.py and the full-size tests: 50 M points per epoch
+# take ~150 s in numpy on one host core, < 1 s here, and every rank of a multi-GPU run can build the SAME cloud on its
+# own GPU without replicating gigabytes on the host).  Point coordinates and noise come from a counter-based generator
+# (splitmix64 of seed / stream / point index, integer arithmetic: identical on every rank and every device), the surface
+# phases and the block motion field from the same PCG64 streams as `two_epoch_cloud`.  Same distribution, not the same
+# sample, as the numpy generator (which stays the generator of the small oracle-checked test clouds).
+_M64 = (1 << 64)
+_GAMMA = 0x9E3779B97F4A7C15 - _M64
+_MIX1 = 0xBF58476D1CE4E5B9 - _M64
+_MIX2 = 0x94D049BB133111EB - _M64
+
+
+def _lsr(x, s):
+    return (x >> s) & ((1 << (64 - s)) - 1)
+
+
+def _uniform01(torch, seed, stream, idx):
+    """Uniform double in [0, 1) for every int64 counter in `idx` (splitmix64 finaliser; wrapping int64 arithmetic)."""
+    x = idx * _GAMMA + ((int(seed) * 1000003 + int(stream)) * 0x632BE59BD9B4E019 % _M64 - (_M64 >> 1))
+    x = (x ^ _lsr(x, 30)) * _MIX1
+    x = (x ^ _lsr(x, 27)) * _MIX2
+    x = x ^ _lsr(x, 31)
+    return _lsr(x, 11).to(torch.float64) * (1.0 / 9007199254740992.0)
+
+
+def _normal(torch, seed, stream, idx):
+    u1 = 1.0 - _uniform01(torch, seed, 2 * stream, idx)  # (0, 1]
+    u2 = _uniform01(torch, seed, 2 * stream + 1, idx)
+    return torch.sqrt(-2.0 * torch.log(u1)) * torch.cos(2.0 * np.pi * u2)
+
+
+def _surface_t(torch, x, y, phases):
+    z = torch.zeros_like(x)
+    for j in range(1, 5):
+        a, f = 2.0 / 2 ** j, 2 ** j / 100.0
+        z += a * torch.sin(2 * np.pi * f * x + float(phases[j - 1, 0])) * torch.sin(2 * np.pi * f * y + float(phases[j - 1, 1]))
+    return z
+
+
+def make_patches_device(n, cells, resolution, device, seed=0, noise=0.005, chunk=8_000_000):
+    """`make_patches` on the device: dict(src, src_off, tgt, tgt_off (torch tensors on `device`), P, max_src, max_tgt, L).
+    src/tgt are float32 (n, 3) patch-contiguous, offsets int64; patch = (x, y) grid cell at `resolution`, points inside a
+    patch in ascending generation index."""
+    import torch
+
+    L = cells * resolution
+    phases = np.random.Generator(np.random.PCG64(seed)).uniform(0, 2 * np.pi, (4, 2))
+    r2 = np.random.Generator(np.random.PCG64(seed + 2))
+    nb = int(np.ceil(cells / 4.0))
+    B = nb * nb
+    ang = np.deg2rad(r2.uniform(0, 0.5, B))
+    Rb = _rodrigues(r2.normal(size=(B, 3)), ang)
+    stable = r2.uniform(size=B) < 0.7
+    t_small = r2.uniform(-0.05, 0.05, (B, 3))
+    t_big = r2.uniform(0.2, 0.5, (B, 3)) * np.where(r2.uniform(size=(B, 3)) < 0.5, -1.0, 1.0)
+    tb = np.where(stable[:, None], t_small, t_big)
+    Rb_d = torch.from_numpy(Rb.reshape(B, 9)).to(device)
+    tb_d = torch.from_numpy(tb).to(device)
+    bs = 4.0 * resolution
+    src = torch.empty((n, 3), dtype=torch.float32, device=device)
+    tgt = torch.empty((n, 3), dtype=torch.float32, device=device)
+    for lo in range(0, n, chunk):
+        hi = min(n, lo + chunk)
+        idx = torch.arange(lo, hi, dtype=torch.int64, device=device)
+        x, y = L * _uniform01(torch, seed, 0, idx), L * _uniform01(torch, seed, 1, idx)
+        src[lo:hi, 0], src[lo:hi, 1] = x.to(torch.float32), y.to(torch.float32)
+        src[lo:hi, 2] = (_surface_t(torch, x, y, phases) + noise * _normal(torch, seed, 1, idx)).to(torch.float32)
+        x, y = L * _uniform01(torch, seed, 6, idx), L * _uniform01(torch, seed, 7, idx)
+        z = _surface_t(torch, x, y, phases)
+        bx = torch.clamp((x / bs).to(torch.int64), max=nb - 1)
+        by = torch.clamp((y / bs).to(torch.int64), max=nb - 1)
+        bid = by * nb + bx
+        px, py, pz = x - (bx.to(torch.float64) + 0.5) * bs, y - (by.to(torch.float64) + 0.5) * bs, z
+        R = Rb_d[bid]
+        t = tb_d[bid]
+        qx = R[:, 0] * px + R[:, 1] * py + R[:, 2] * pz + (bx.to(torch.float64) + 0.5) * bs + t[:, 0]
+        qy = R[:, 3] * px + R[:, 4] * py + R[:, 5] * pz + (by.to(torch.float64) + 0.5) * bs + t[:, 1]
+        qz = R[:, 6] * px + R[:, 7] * py + R[:, 8] * pz + t[:, 2] + noise * _normal(torch, seed, 4, idx)
+        tgt[lo:hi, 0], tgt[lo:hi, 1], tgt[lo:hi, 2] = qx.to(torch.float32), qy.to(torch.float32), qz.to(torch.float32)
+        del idx, x, y, z, bx, by, bid, px, py, pz, R, t, qx, qy, qz
+
+    def partition(p):
+        cx = torch.clamp((p[:, 0].to(torch.float64) / resolution).to(torch.int64), 0, cells - 1)
+        cy = torch.clamp((p[:, 1].to(torch.float64) / resolution).to(torch.int64), 0, cells - 1)
+        cid = cy * cells + cx
+        del cx, cy
+        _, order = torch.sort(cid, stable=True)
+        off = torch.zeros(cells * cells + 1, dtype=torch.int64, device=device)
+        off[1:] = torch.cumsum(torch.bincount(cid, minlength=cells * cells), 0)
+        return p[order].contiguous(), off
+
+    src, soff = partition(src)
+    tgt, toff = partition(tgt)
+    return dict(src=src, src_off=soff, tgt=tgt, tgt_off=toff, P=cells * cells, L=L,
+                max_src=int((soff[1:] - soff[:-1]).max().item()), max_tgt=int((toff[1:] - toff[:-1]).max().item()))
+
+
+def correspondences_from_nn_device(src, src_off, tgt, tgt_off, nn):
+    """`correspondences_from_nn` with torch tensors on any device."""
+    import torch
+    P = src_off.shape[0] - 1
+    cnt = src_off[1:] - src_off[:-1]
+    pid = torch.repeat_interleave(torch.arange(P, dtype=torch.int64, device=src.device), cnt)
+    keep = nn >= 0
+    cs = src[keep]
+    ct = tgt[tgt_off[pid[keep]] + nn[keep].to(torch.int64)]
+    off = torch.zeros(P + 1, dtype=torch.int64, device=src.device)
+    off[1:] = torch.cumsum(torch.bincount(pid[keep], minlength=P), 0)
+    return cs.contiguous(), ct.contiguous(), off

@@ -1,0 +1,166 @@
+"""GPU tests at BASELINE.json's full sizes (configs[2] "C3_10M_20k", configs[3] "C4_50M_100k"): the oracle cannot run whole
+clouds of that size in seconds, so each test checks size-independent properties of the whole result and a bounded sample
+of patches (>= 24, the largest patch among them) against the CPU oracle in float64 mode, through the same fused launch
+`bench.py` times (f4l_patch_loop: Kabsch init -> 20 fixed ICP iterations -> displacement rows).
+
+Tolerances (float64 search = the reference's arithmetic): displacement of every patch point under the two transforms
+<= 1e-9 m, fitness equal to 1e-12, rmse to 1e-10 -- the figures of tests/test_gpu_parity.py.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+from oracle import oracle as O  # noqa: E402
+
+MAX_CORR, MAX_ITER = 0.1, 20
+
+
+@pytest.fixture(scope="module")
+def eng():
+    assert torch.cuda.is_available(), "these tests need the GPU"
+    from fusion4landslide_amd import engine
+    return engine
+
+
+def _problem(eng, name, seed=0):
+    from fusion4landslide_amd import synthetic
+    c = synthetic.CONFIGS[name]
+    dev = torch.device("cuda")
+    d = synthetic.make_patches_device(c["n"], c["cells"], c["resolution"], dev, seed=seed)
+    P = d["P"]
+    eye = torch.eye(4, dtype=torch.float64, device=dev).repeat(P, 1, 1)
+    nn, _ = eng.nn_refine(d["src"], d["src_off"], d["tgt"], d["tgt_off"], eye,
+                          torch.full((P,), 2 * MAX_CORR, dtype=torch.float64, device=dev), max_tgt_patch=d["max_tgt"],
+                          return_rows=False)
+    cs, ct, coff = synthetic.correspondences_from_nn_device(d["src"], d["src_off"], d["tgt"], d["tgt_off"], nn)
+    return d, cs, ct, coff, nn
+
+
+def _step(eng, d, cs, ct, coff, **kw):
+    return eng.patch_loop(d["src"], d["src_off"], d["tgt"], d["tgt_off"], cs, ct, coff, None, 0.0, 1e-6, max_corr_dist=MAX_CORR,
+                          max_iter=MAX_ITER, fixed_iters=True, max_src_patch=d["max_src"], max_tgt_patch=d["max_tgt"], **kw)
+
+
+def _check_properties(d, out, n):
+    T = out["T"]
+    assert bool((out["iters"] == MAX_ITER).all())
+    R = T[:, :3, :3]
+    assert float((R @ R.transpose(1, 2) - torch.eye(3, dtype=torch.float64, device=T.device)).abs().max()) < 1e-9
+    assert float((torch.linalg.det(R) - 1.0).abs().max()) < 1e-9
+    assert bool((T[:, 3, :] == torch.tensor([0.0, 0.0, 0.0, 1.0], dtype=torch.float64, device=T.device)).all())
+    fit, rmse = out["fitness"], out["rmse"]
+    assert bool(((fit >= 0) & (fit <= 1)).all()) and bool((rmse <= MAX_CORR).all()) and bool(torch.isfinite(T).all())
+    rows = out["rows"]
+    assert rows.shape == (n, 6) and torch.equal(rows[:, :3], d["src"])
+    # rows[:, 3:] is T_p s for every point (checked in double on the device against the returned transforms)
+    cnt = d["src_off"][1:] - d["src_off"][:-1]
+    pid = torch.repeat_interleave(torch.arange(d["P"], device=T.device), cnt, output_size=n)
+    lo = 0
+    worst = 0.0
+    while lo < n:  # chunked: the (n, 3, 3) gather of a 50 M cloud would be 3.6 GB at once
+        hi = min(n, lo + 5_000_000)
+        Tp = T[pid[lo:hi]]
+        s = d["src"][lo:hi].to(torch.float64)
+        q = torch.einsum("nij,nj->ni", Tp[:, :3, :3], s) + Tp[:, :3, 3]
+        worst = max(worst, float((q - rows[lo:hi, 3:].to(torch.float64)).abs().max()))
+        lo = hi
+    assert worst <= 2e-5, worst  # float32 rounding of coordinates up to ~440 m (C4); the arithmetic is double
+    return fit
+
+
+def _check_sample_against_oracle(d, cs, ct, coff, out, pick):
+    so, to, co = d["src_off"].cpu().numpy(), d["tgt_off"].cpu().numpy(), coff.cpu().numpy()
+    T, fit, rmse = out["T"].cpu().numpy(), out["fitness"].cpu().numpy(), out["rmse"].cpu().numpy()
+    worst = 0.0
+    for p in pick:
+        s = d["src"][so[p]:so[p + 1]].cpu().numpy()
+        t = d["tgt"][to[p]:to[p + 1]].cpu().numpy()
+        a, b = cs[co[p]:co[p + 1]].cpu().numpy(), ct[co[p]:co[p + 1]].cpu().numpy()
+        T0 = np.eye(4)
+        if len(a):
+            R, tt = O.kabsch_batched(a, b, np.array([0, len(a)], dtype=np.int64), eps=1e-6)
+            T0[:3, :3], T0[:3, 3] = R[0], tt[0]
+        one = O.icp(s, t, init_T=T0, max_corr_dist=MAX_CORR, max_iter=MAX_ITER, fixed_iters=True)
+        s64 = s.astype(np.float64)
+        ref = s64 @ one["est_transform"][:3, :3].T + one["est_transform"][:3, 3]
+        got = s64 @ T[p, :3, :3].T + T[p, :3, 3]
+        dev = float(np.abs(got - ref).max()) if len(s) else 0.0
+        worst = max(worst, dev)
+        assert dev <= 1e-9, (p, len(s), len(t), dev)
+        assert abs(fit[p] - one["fitness"]) < 1e-12 and abs(rmse[p] - one["inlier_rmse"]) < 1e-10, p
+    return worst
+
+
+def test_full_size_C4_50M_100k(eng):
+    """BASELINE.json configs[3] / the metric's own cloud on one GPU: 50 M points per epoch, 99 856 patches."""
+    d, cs, ct, coff, _ = _problem(eng, "C4_50M_100k")
+    n = 50_000_000
+    assert d["P"] == 316 * 316 and d["src"].shape == (n, 3) and int(d["src_off"][-1]) == n
+    out = _step(eng, d, cs, ct, coff)
+    fit = _check_properties(d, out, n)
+    assert float(fit.mean()) > 0.5  # 70 % of the blocks are displaced by less than the radius
+    rng = np.random.default_rng(0)
+    size = (d["src_off"][1:] - d["src_off"][:-1]).cpu().numpy()
+    pick = np.unique(np.r_[np.linspace(0, d["P"] - 1, 24).astype(int), int(size.argmax()), int(size.argmin()),
+                           rng.integers(0, d["P"], 6)])
+    _check_sample_against_oracle(d, cs, ct, coff, out, pick)
+    # idempotence: restarting ICP from the result moves nothing beyond the tolerance on the converged patches
+    again = eng.piecewise_icp(d["src"], d["src_off"], d["tgt"], d["tgt_off"], init_T=out["T"], max_corr_dist=MAX_CORR, max_iter=30,
+                              max_src_patch=d["max_src"], max_tgt_patch=d["max_tgt"])
+    moved = (again["T"][:, :3, 3] - out["T"][:, :3, 3]).abs().amax(dim=1)
+    assert float(moved.median()) < 1e-4
+    # run-to-run bit reproducible at full size
+    out2 = _step(eng, d, cs, ct, coff, return_rows=False)
+    assert torch.equal(out2["T"], out["T"]) and torch.equal(out2["rmse"], out["rmse"])
+
+
+def test_sharded_C4_equals_single_launch(eng):
+    """The multi-GPU split of bench.py (--gpus 2: LPT shares of ONE cloud) run share by share on this GPU: per-patch results
+    scattered back to global order are bit-equal to the single launch over the whole cloud (a patch's result does not
+    depend on which launch, or which workgroup, it ran in).  On a 4 M-point cloud of the C4 density."""
+    from fusion4landslide_amd import sharding, synthetic
+    dev = torch.device("cuda")
+    cloud = synthetic.make_patches_device(4_000_000, 90, 1.386, dev, seed=5)
+    P = cloud["P"]
+
+    def run(d):
+        eye = torch.eye(4, dtype=torch.float64, device=dev).repeat(d["P"], 1, 1)
+        nn, _ = eng.nn_refine(d["src"], d["src_off"], d["tgt"], d["tgt_off"], eye,
+                              torch.full((d["P"],), 2 * MAX_CORR, dtype=torch.float64, device=dev), max_tgt_patch=d["max_tgt"],
+                              return_rows=False)
+        cs, ct, coff = synthetic.correspondences_from_nn_device(d["src"], d["src_off"], d["tgt"], d["tgt_off"], nn)
+        return _step(eng, d, cs, ct, coff, return_rows=False)
+
+    whole = run(cloud)
+    T = torch.zeros_like(whole["T"])
+    fit = torch.zeros_like(whole["fitness"])
+    seen = torch.zeros(P, dtype=torch.int32, device=dev)
+    for rank in range(2):
+        d, ids = sharding.shard_cloud(cloud, rank, 2)
+        out = run(d)
+        mine = torch.from_numpy(ids[rank]).to(dev)
+        T[mine], fit[mine] = out["T"], out["fitness"]
+        seen[mine] += 1
+    assert bool((seen == 1).all())
+    assert torch.equal(T, whole["T"]) and torch.equal(fit, whole["fitness"])
+
+
+def test_full_size_C3_10M_20k_dense(eng):
+    """BASELINE.json configs[2]: 10 M points in 0.1 m patches, correspondence radius = patch size (every query has
+    hundreds of targets inside its radius; the border patches collect the points the motion field pushed outside and
+    exceed 4096 points)."""
+    d, cs, ct, coff, _ = _problem(eng, "C3_10M_20k")
+    n = 10_000_000
+    assert d["P"] == 141 * 141 and int(d["src_off"][-1]) == n
+    size_s = (d["src_off"][1:] - d["src_off"][:-1]).cpu().numpy()
+    size_t = (d["tgt_off"][1:] - d["tgt_off"][:-1]).cpu().numpy()
+    assert max(size_s.max(), size_t.max()) > 4096
+    out = _step(eng, d, cs, ct, coff)
+    _check_properties(d, out, n)
+    rng = np.random.default_rng(1)
+    big = np.argsort(-np.maximum(size_s, size_t))[:3]  # the largest patches (targets beyond 4096)
+    pick = np.unique(np.r_[np.linspace(0, d["P"] - 1, 24).astype(int), big, rng.integers(0, d["P"], 5)])
+    _check_sample_against_oracle(d, cs, ct, coff, out, pick)

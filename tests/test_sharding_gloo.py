@@ -54,6 +54,10 @@ def test_lpt_assign_balances_and_covers():
     off = np.array([0, 3, 3, 7, 10])
     sub, so = sharding.take_patches(pts, off, np.array([2, 0]))
     assert np.array_equal(so, [0, 4, 7]) and np.array_equal(sub, np.concatenate([pts[3:7], pts[0:3]]))
+    sub_t, so_t = sharding.take_patches(torch.from_numpy(pts), torch.from_numpy(off), np.array([2, 0]))
+    assert np.array_equal(so_t.numpy(), so) and np.array_equal(sub_t.numpy(), sub)
+    sub, so = sharding.take_patches(pts, off, np.array([1]))
+    assert sub.shape == (0, 3) and np.array_equal(so, [0, 0])
 
 
 @pytest.mark.timeout(300)
@@ -79,34 +83,46 @@ def test_sharded_icp_world2_matches_single_process():
     assert sorted(ids0[0] + ids0[1]) == list(range(16)) and ids0 == res[1][4]
 
 
+def _oracle_patch_loop(d):
+    """Checker standing in for the per-rank engine (f4l_patch_loop) on torch CPU tensors."""
+    from oracle import oracle as O
+    r = O.piecewise_icp(d["src"].numpy(), d["src_off"].numpy(), d["tgt"].numpy(), d["tgt_off"].numpy(), max_corr_dist=0.1,
+                        max_iter=20, fixed_iters=True)
+    return dict(T=torch.from_numpy(r["T"]), fitness=torch.from_numpy(r["fitness"]), rmse=torch.from_numpy(r["rmse"]),
+                iters=torch.from_numpy(r["iters"]))
+
+
 def _gather_worker(rank, world, port, q):
+    """The code path of `bench.py --gpus N`: the same cloud built by every rank, shard_cloud, a step per rank, the
+    double-buffered all-gather, results read back in global patch order."""
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from fusion4landslide_amd.sharding import TileResultGather
-    P = 7
-    g = TileResultGather(dist, torch, world, P, torch.device("cpu"))
+    from fusion4landslide_amd import sharding, synthetic
+    cloud = synthetic.make_patches_device(8000, 5, 1.386, torch.device("cpu"), seed=4)
+    d, ids = sharding.shard_cloud(cloud, rank, world)
+    g = sharding.PatchResultGather(dist, torch, ids, rank, torch.device("cpu"))
+    out = _oracle_patch_loop(d)
     seen = []
     for step in range(5):  # more steps than buffer sets: the third submit must wait for the first
-        T = torch.eye(4, dtype=torch.float64).repeat(P, 1, 1) * (100 * step + 10 * rank + 1)
-        out = dict(T=T, fitness=torch.full((P,), step + 0.5 * rank, dtype=torch.float64),
-                   rmse=torch.full((P,), 0.25 * step, dtype=torch.float64), iters=torch.full((P,), 20 + rank, dtype=torch.int32))
-        g.submit(out)
-        if step % 2 == 1:  # look at a finished step now and then
+        o = dict(out, rmse=out["rmse"] + step)
+        g.submit(o)
+        if step % 2 == 1:
             g.drain()
-            seen.append([t.clone() for t in g.latest()])
+            seen.append({k: v.clone().numpy() for k, v in g.latest().items()})
     g.drain()
-    seen.append([t.clone() for t in g.latest()])
-    q.put((rank, [[t.numpy() for t in s] for s in seen]))
+    seen.append({k: v.clone().numpy() for k, v in g.latest().items()})
+    q.put((rank, seen, [i.tolist() for i in ids], d["P"], d["n_src"]))
     dist.barrier()
     dist.destroy_process_group()
 
 
 @pytest.mark.timeout(300)
-def test_tile_result_gather_world2_double_buffered():
-    """The exchange of `bench.py --gpus N` (every rank all-gathers the per-patch results of its tile, two buffer sets in
-    flight) with two gloo ranks: every rank ends up with every rank's rows, for the steps looked at."""
+def test_sharded_cloud_world2_gathers_global_order():
+    """Two gloo ranks shard ONE cloud, run their shares and all-gather: every rank ends up with every patch's result in
+    global patch order, equal to the single-process run, for every step looked at."""
+    from fusion4landslide_amd import sharding, synthetic
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -117,10 +133,34 @@ def test_tile_result_gather_world2_double_buffered():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    for rank, seen in res:
+    cloud = synthetic.make_patches_device(8000, 5, 1.386, torch.device("cpu"), seed=4)
+    ref = _oracle_patch_loop(cloud)
+    assert sorted(res[0][2][0] + res[0][2][1]) == list(range(25)) and res[0][2] == res[1][2]
+    assert res[0][3] + res[1][3] == 25 and res[0][4] + res[1][4] == 8000
+    costs = sharding.patch_costs(cloud["src_off"], cloud["tgt_off"])
+    loads = [costs[np.array(i)].sum() for i in res[0][2]]
+    assert abs(loads[0] - loads[1]) <= costs.max()
+    for rank, seen, ids, P, n in res:
         for k, step in enumerate((1, 3, 4)):
-            for r in range(world):
-                row = seen[k][r]
-                assert row.shape == (7, 19)
-                assert row[0, 0] == 100 * step + 10 * r + 1 and row[0, 5] == 100 * step + 10 * r + 1 and row[0, 1] == 0
-                assert (row[:, 16] == step + 0.5 * r).all() and (row[:, 17] == 0.25 * step).all() and (row[:, 18] == 20 + r).all()
+            assert np.array_equal(seen[k]["T"], ref["T"].numpy()) and np.array_equal(seen[k]["fitness"], ref["fitness"].numpy())
+            assert np.array_equal(seen[k]["rmse"], ref["rmse"].numpy() + step) and (seen[k]["iters"] == 20).all()
+
+
+@pytest.mark.timeout(300)
+def test_bench_gpus2_dry_run_starts_two_ranks():
+    """`python bench.py --gpus 2` without a launcher around it starts two ranks itself (orchestration dry run: gloo, CPU
+    tensors, a stub launch) and prints ONE line with n_gpus == 2; a WORLD_SIZE that disagrees with --gpus is an error."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--config", "C1_50k_64",
+                        "--steps", "3", "--warmup", "1"], capture_output=True, text=True, env=env, timeout=240)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["dry_run"] and line["dry_run_gather_ok"] and line["value"] is None
+    assert line["scaling"] == "strong" and line["config"]["patches"] == 64 and line["config"]["patches_on_rank0"] == 32
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], capture_output=True, text=True,
+                       env=dict(env, WORLD_SIZE="4"), timeout=60)
+    assert r.returncode == 2 and "WORLD_SIZE=4" in r.stderr

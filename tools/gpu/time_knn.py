@@ -2,7 +2,7 @@ import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from fusion4landslide_amd import engine, synthetic
-c = synthetic.two_epoch_cloud(1_000_000, 45, 1.386, seed=0)
+c = synthetic.two_epoch_cloud(1_000_000, 45, 1.386, seed=0)  # numpy: a few seconds
 xyz = torch.from_numpy(c["src"]).cuda()
 def t(fn, n=5):
     fn(); torch.cuda.synchronize()
