@@ -45,6 +45,10 @@ SIGNATURES = {
     "f4l_nn_query": (C.c_int, [_P, _I64, _P, _I64, _I, _P, _P, _P, _SZ, _P]),
     "f4l_supervoxel_workspace_bytes": (_SZ, [_I64, _I]),
     "f4l_supervoxel": (C.c_int, [_P, _I64, _I, _D, _P, _P, _P, _P, _P, _SZ, _P]),
+    "f4l_supervoxel_segment_device_workspace_bytes": (_SZ, [_I64, _I]),
+    "f4l_supervoxel_segment_device": (C.c_int, [_P, _P, _P, _I64, _I, _D, _P, _P, _P, _P, _SZ, _P]),
+    "f4l_supervoxel_parallel_workspace_bytes": (_SZ, [_I64, _I]),
+    "f4l_supervoxel_parallel": (C.c_int, [_P, _I64, _I, _D, _P, _P, _P, _P, _P, _P, _SZ, _P]),
     "f4l_supervoxel_segment_host": (C.c_int, [_P, _P, _P, _I64, _I, _D, _P, _P]),
     "f4l_write_partition_txt": (C.c_int, [C.c_char_p, _P, _P, _I64, C.c_int32]),
     "f4l_labels_to_csr_workspace_bytes": (_SZ, [_I64, _I64]),

@@ -22,6 +22,7 @@
 #include <vector>
 
 #include "f4l_device.h"
+#include "sv_metric.h"
 
 namespace f4l {
 
@@ -306,16 +307,7 @@ extern "C" int f4l_supervoxel_segment_host(const float *xyz_host, const double *
 }
 
 namespace f4l {
-// The VCCS metric on the device, the same operations in the same order as Segmenter::metric (no contraction; the
-// double sqrt and division of the device library are correctly rounded): bit-identical values.
 #pragma clang fp contract(off)
-__device__ __forceinline__ double sv_metric(const float *__restrict__ xyz, const double *__restrict__ nrm, int64_t a,
-                                            int64_t b, double resolution) {
-    const double dot = nrm[3 * a] * nrm[3 * b] + nrm[3 * a + 1] * nrm[3 * b + 1] + nrm[3 * a + 2] * nrm[3 * b + 2];
-    const double t1 = (double)xyz[3 * a] - xyz[3 * b], t2 = (double)xyz[3 * a + 1] - xyz[3 * b + 1],
-                 t3 = (double)xyz[3 * a + 2] - xyz[3 * b + 2];
-    return 1.0 - fabs(dot) + sqrt(t1 * t1 + t2 * t2 + t3 * t3) / resolution * 0.4;
-}
 __global__ void sv_min_metric_kernel(const float *__restrict__ xyz, const double *__restrict__ nrm,
                                      const int32_t *__restrict__ knn, int64_t n, int k, double resolution,
                                      double *__restrict__ dis0) {

@@ -1,0 +1,572 @@
+// supervoxel_gpu.hip -- the boundary-preserving supervoxel segmentation entirely on the device, without any host
+// round trip: the parallel variant of codelibrary/geometry/point_cloud/supervoxel_segmentation.h:65-248 (+ the count of
+// grid_sample.h:31-75, DisjointSet disjoint_set.h:59-85, Median median.h:22-31).
+//
+// The reference's fusion (:117-176) visits the representatives one after the other and is order dependent, so a parallel
+// run cannot be label-identical (f4l_supervoxel keeps the sequential replay for that).  This variant keeps the
+// algorithm's structure and every criterion, and replaces only the visiting order:
+//
+//   K        number of occupied cells of the resolution grid (grid_sample.h:48-68): bounding box by atomics, cell keys,
+//            device radix sort, count of distinct keys -- never leaves the device.
+//   lambda0  max(DBL_EPSILON, upper median of every point's smallest neighbour metric) (:105-113): device sort.
+//   fusion   for lambda = lambda0, 2 lambda0, 4 lambda0 ... (:117): SUB-ROUNDS of conflict-free fusion on the graph of
+//            representatives (directed edges u -> v: "v is a neighbour of a member of u", the reference's `adjacents`):
+//            every representative draws a coin per sub-round; a tails representative v may be absorbed by a heads
+//            neighbour u when the reference's own criterion holds, sizes[v] * metric(u, v) < lambda (:146-149), and
+//            proposes to the u of smallest metric (ties: smallest index).  Heads are never absorbed and tails never
+//            absorb in the same sub-round, so all proposals can be applied at once (Link(v, u), sizes[u] += sizes[v]).
+//            Exactly like the reference's `if (--number_of_supervoxels == n_supervoxels) break` (:160), a sub-round never
+//            goes below K: when it holds more proposals than representatives to spare, only the best (smallest loss;
+//            ties by index) are applied -- an exact radix select on the device.
+//            Edges are re-pointed to the current representatives every sub-round, self loops dropped and parallel edges
+//            merged (hash set on the device) once per lambda.
+//   labels   label = Find (:179-182) by pointer jumping.
+//   exchange the boundary refinement (:186-237) as iterated relaxation: every sweep gives each point the label of the
+//            neighbour's representative that is strictly closer than its own (the minimum over its neighbour list,
+//            what the reference's scan over `neighbors[i]` ends with), double buffered; sweeps repeat until nothing
+//            changes: the fixed point of the reference's queue ("no point has a neighbour whose representative is
+//            strictly closer").
+//   relabel  0..K-1 in ascending order of the representative's index (:241-247).
+//
+// Nothing here synchronises the stream or copies to the host: loop bounds live in a device-side state block, every
+// kernel runs on a fixed grid and reads its trip counts from that block, and the host enqueues a fixed schedule of
+// launches whose tail turns into no-ops once the target count is reached (a no-op launch costs a few microseconds).
+// Results are deterministic (no result depends on the order atomics land in).
+#include <cfloat>
+#include <cstring>
+
+#include <rocprim/rocprim.hpp>
+
+#include "f4l_device.h"
+#include "sv_metric.h"
+
+namespace f4l {
+namespace svg {
+
+constexpr int LAMBDA_ROUNDS = 56;  // lambda0 * 2^55 exceeds any size * metric of a 2^31-point cloud
+constexpr int SUBROUNDS = 3;
+constexpr int SWEEPS = 96;
+constexpr unsigned GRID = 2048, BLOCK = 256;
+constexpr unsigned long long DEAD = ~0ULL;
+
+struct State {
+    double lambda;
+    unsigned long long tau_excl;  // proposals with key < tau_excl are applied
+    unsigned int bb[6];           // bounding box as order-preserving unsigned images of the floats (min x,y,z, max x,y,z)
+    int32_t live, K;              // representatives now / wanted
+    int32_t n_edges, n_edges_new;
+    int32_t n_prop, round;
+    int32_t stalled;              // the graph of representatives has no edges left but live > K
+    int32_t sweeps_done, sweep_on, changed, full_sweep;
+    int32_t n_labels;
+};
+
+__device__ __forceinline__ unsigned int f2ord(float f) {
+    const unsigned int u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ord2f(unsigned int o) {
+    return __uint_as_float((o & 0x80000000u) ? (o & 0x7fffffffu) : ~o);
+}
+__device__ __forceinline__ unsigned long long d2ord(double d) {
+    const unsigned long long u = (unsigned long long)__double_as_longlong(d);
+    return (u >> 63) ? ~u : (u | 0x8000000000000000ULL);
+}
+__device__ __forceinline__ double ord2d(unsigned long long o) {
+    return __longlong_as_double((long long)((o >> 63) ? (o & 0x7fffffffffffffffULL) : ~o));
+}
+__device__ __forceinline__ bool heads(int32_t v, int32_t round) {
+    unsigned int h = (unsigned int)v * 0x9E3779B1u ^ ((unsigned int)round + 1u) * 0x85EBCA6Bu;
+    h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12; h *= 0x297A2D39u; h ^= h >> 15;
+    return (h & 1u) != 0u;
+}
+#define SV_FOR(i, n) for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (int64_t)(n); i += (int64_t)gridDim.x * blockDim.x)
+
+// ---- K: occupied cells of the resolution grid ------------------------------------------------------------------------
+__global__ void init_state_kernel(State *st, int32_t n) {
+    st->lambda = 0.0; st->tau_excl = 0ULL;
+    for (int d = 0; d < 3; ++d) { st->bb[d] = 0xffffffffu; st->bb[3 + d] = 0u; }
+    st->live = n; st->K = 0; st->n_edges = 0; st->n_edges_new = 0; st->n_prop = 0; st->round = 0; st->stalled = 0;
+    st->sweeps_done = 0; st->sweep_on = 1; st->changed = 0; st->full_sweep = 1; st->n_labels = 0;
+}
+__global__ void bbox_kernel(const float *__restrict__ xyz, int64_t n, State *st) {
+    unsigned int mn[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, mx[3] = {0u, 0u, 0u};
+    SV_FOR(i, n) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const unsigned int o = f2ord(xyz[3 * i + d]);
+            mn[d] = o < mn[d] ? o : mn[d];
+            mx[d] = o > mx[d] ? o : mx[d];
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            const unsigned int a = (unsigned int)__shfl_xor((int)mn[d], m, 64), b = (unsigned int)__shfl_xor((int)mx[d], m, 64);
+            mn[d] = a < mn[d] ? a : mn[d];
+            mx[d] = b > mx[d] ? b : mx[d];
+        }
+    }
+    if (lane_id() == 0) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) { atomicMin(&st->bb[d], mn[d]); atomicMax(&st->bb[3 + d], mx[d]); }
+    }
+}
+// grid_sample.h:48-68: size = int(len / res + 1), cell = clamp(int((p - min) / res)), all in double
+__global__ void grid_key_kernel(const float *__restrict__ xyz, int64_t n, double resolution, const State *st,
+                                unsigned long long *__restrict__ keys) {
+#pragma clang fp contract(off)
+    double mn[3];
+    int size[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        mn[d] = (double)ord2f(st->bb[d]);
+        size[d] = (int)(((double)ord2f(st->bb[3 + d]) - mn[d]) / resolution + 1);
+    }
+    SV_FOR(i, n) {
+        int c[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            c[d] = (int)(((double)xyz[3 * i + d] - mn[d]) / resolution);
+            c[d] = c[d] < 0 ? 0 : (c[d] > size[d] - 1 ? size[d] - 1 : c[d]);
+        }
+        keys[i] = ((unsigned long long)c[0] * (unsigned long long)size[1] + (unsigned long long)c[1]) * (unsigned long long)size[2] +
+                  (unsigned long long)c[2];
+    }
+}
+__global__ void count_distinct_kernel(const unsigned long long *__restrict__ sorted, int64_t n, State *st) {
+    int cnt = 0;
+    SV_FOR(i, n) cnt += (i == 0 || sorted[i] != sorted[i - 1]) ? 1 : 0;
+    cnt = wave_sum(cnt);
+    if (lane_id() == 0 && cnt) atomicAdd(&st->K, cnt);
+}
+
+// ---- lambda0 -----------------------------------------------------------------------------------------------------
+#pragma clang fp contract(off)
+__global__ void min_metric_kernel(const float *__restrict__ xyz, const double *__restrict__ nrm, const int32_t *__restrict__ knn,
+                                  int64_t n, int k, double resolution, double *__restrict__ dis0) {
+    SV_FOR(i, n) {
+        double best = DBL_MAX;
+        for (int j = 0; j < k; ++j) {
+            const int64_t q = knn[i * k + j];
+            if (q != i) {
+                const double m = sv_metric(xyz, nrm, i, q, resolution);
+                best = m < best ? m : best;
+            }
+        }
+        dis0[i] = best;
+    }
+}
+__global__ void start_kernel(State *st, const double *__restrict__ dis_sorted, int64_t n, int k) {
+    const double med = dis_sorted[n / 2];  // median.h:27-30: nth_element at size / 2
+    st->lambda = med > DBL_EPSILON ? med : DBL_EPSILON;
+    st->n_edges = (int32_t)0;  // set by init_edges_kernel's grid
+    (void)k;
+}
+__global__ void init_points_kernel(int64_t n, int32_t *__restrict__ parent, int32_t *__restrict__ size,
+                                   unsigned long long *__restrict__ bestm, int32_t *__restrict__ bestu) {
+    SV_FOR(i, n) { parent[i] = (int32_t)i; size[i] = 1; bestm[i] = ~0ULL; bestu[i] = 0x7fffffff; }
+}
+__global__ void init_edges_kernel(const int32_t *__restrict__ knn, int64_t n, int k, unsigned long long *__restrict__ edges, State *st) {
+    const int64_t total = n * k;
+    SV_FOR(e, total) {
+        const int64_t i = e / k;
+        const int32_t q = knn[e];
+        edges[e] = (q == (int32_t)i || q < 0 || q >= n) ? DEAD : (((unsigned long long)i << 32) | (unsigned int)q);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) st->n_edges = (int32_t)(total > 0x7fffffffLL ? 0x7fffffffLL : total);
+}
+
+__device__ __forceinline__ bool fusing(const State *st) { return st->live > st->K && !st->stalled; }
+
+// ---- one sub-round of conflict-free fusion -------------------------------------------------------------------------
+// cand: re-point every edge to the current representatives; an edge u -> v with u heads, v tails and
+//       sizes[v] * metric(u, v) < lambda offers u to v: bestm[v] = min metric.
+template <bool TIE>
+__global__ void cand_kernel(const float *__restrict__ xyz, const double *__restrict__ nrm, double resolution, State *st,
+                            unsigned long long *__restrict__ edges, const int32_t *__restrict__ parent,
+                            const int32_t *__restrict__ size, unsigned long long *__restrict__ bestm, int32_t *__restrict__ bestu) {
+    if (!fusing(st)) return;
+    if (!TIE && blockIdx.x == 0 && threadIdx.x == 0) st->n_prop = 0;  // (the previous sub-round's apply has finished)
+    const int32_t ne = st->n_edges, round = st->round;
+    const double lambda = st->lambda;
+    SV_FOR(e, ne) {
+        unsigned long long key = edges[e];
+        if (key == DEAD) continue;
+        int32_t u = (int32_t)(key >> 32), v = (int32_t)(key & 0xffffffffULL);
+        if (!TIE) {
+            u = parent[u];  // both were representatives at the last re-pointing: one hop reaches the current ones
+            v = parent[v];
+            key = u == v ? DEAD : (((unsigned long long)(unsigned int)u << 32) | (unsigned int)v);
+            edges[e] = key;
+            if (u == v) continue;
+        }
+        if (!heads(u, round) || heads(v, round)) continue;
+        const double m = sv_metric(xyz, nrm, u, v, resolution);
+        const double loss = (double)size[v] * m;
+        if (!(lambda - loss > 0.0)) continue;  // :147-149 `improvement > 0.0`
+        const unsigned long long mo = d2ord(m);
+        if (!TIE) atomicMin(&bestm[v], mo);
+        else if (bestm[v] == mo) atomicMin(&bestu[v], u);
+    }
+}
+// collect: every tails representative with an offer becomes a proposal (key = float image of the loss : index)
+__global__ void collect_kernel(State *st, int64_t n, const int32_t *__restrict__ size, unsigned long long *__restrict__ bestm,
+                               int32_t *__restrict__ bestu, unsigned long long *__restrict__ prop_key, int32_t *__restrict__ prop_u) {
+    if (!fusing(st)) return;
+    SV_FOR(v, n) {
+        const int32_t u = bestu[v];
+        if (u == 0x7fffffff) {
+            if (bestm[v] != ~0ULL) bestm[v] = ~0ULL;
+            continue;
+        }
+        const double loss = (double)size[v] * ord2d(bestm[v]);
+        const unsigned long long key = ((unsigned long long)f2ord((float)loss) << 32) | (unsigned int)v;
+        const int32_t at = atomicAdd(&st->n_prop, 1);
+        prop_key[at] = key;
+        prop_u[at] = u;
+        bestm[v] = ~0ULL;
+        bestu[v] = 0x7fffffff;
+    }
+}
+// select (one workgroup): all proposals when there are representatives to spare, else exactly the (live - K) smallest
+// keys -- radix select, 8 passes of 8 bits over the proposal list.
+__global__ __launch_bounds__(1024) void select_kernel(State *st, const unsigned long long *__restrict__ prop_key) {
+    if (!fusing(st)) return;
+    __shared__ unsigned int hist[256];
+    __shared__ unsigned long long s_prefix;
+    __shared__ int s_rank;
+    const int a = st->n_prop, budget = st->live - st->K;
+    const int tid = (int)threadIdx.x;
+    if (a <= budget) {
+        if (tid == 0) { st->tau_excl = ~0ULL; st->round += 1; }
+        return;
+    }
+    if (tid == 0) { s_prefix = 0ULL; s_rank = budget; }  // 1-based rank of the last key to keep
+    __syncthreads();
+    for (int pass = 0; pass < 8; ++pass) {
+        const int shift = 56 - 8 * pass;
+        if (tid < 256) hist[tid] = 0u;
+        __syncthreads();
+        const unsigned long long prefix = s_prefix;
+        for (int i = tid; i < a; i += 1024) {
+            const unsigned long long key = prop_key[i];
+            if (pass == 0 || (key >> (shift + 8)) == prefix) atomicAdd(&hist[(unsigned int)(key >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int r = s_rank, b = 0;
+            unsigned int cum = 0;
+            for (; b < 256; ++b) {
+                if (cum + hist[b] >= (unsigned int)r) break;
+                cum += hist[b];
+            }
+            s_rank = r - (int)cum;
+            s_prefix = (prefix << 8) | (unsigned long long)b;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) { st->tau_excl = s_prefix + 1ULL; st->round += 1; }  // keys are unique (index in the low word)
+}
+__global__ void apply_kernel(State *st, const unsigned long long *__restrict__ prop_key, const int32_t *__restrict__ prop_u,
+                             int32_t *__restrict__ parent, int32_t *__restrict__ size) {
+    if (!fusing(st)) return;
+    const int a = st->n_prop;
+    const unsigned long long tau = st->tau_excl;
+    int dropped = 0;
+    SV_FOR(i, a) {
+        const unsigned long long key = prop_key[i];
+        if (key >= tau) continue;
+        const int32_t v = (int32_t)(key & 0xffffffffULL), u = prop_u[i];
+        parent[v] = u;                  // Link(v, u), disjoint_set.h:77-85
+        atomicAdd(&size[u], size[v]);   // sizes[i] += sizes[j], :153
+        ++dropped;
+    }
+    dropped = wave_sum(dropped);
+    if (lane_id() == 0 && dropped) atomicSub(&st->live, dropped);
+}
+
+// ---- once per lambda: flatten the forest, merge parallel edges, double lambda ---------------------------------------
+__global__ void flatten_kernel(const State *st, int64_t n, int32_t *__restrict__ parent, bool always) {
+    if (!always && !fusing(st)) return;
+    SV_FOR(i, n) {
+        int32_t r = parent[i];
+        while (parent[r] != r) r = parent[r];  // (roots are stable while this kernel runs)
+        if (r != parent[i]) parent[i] = r;
+    }
+}
+__device__ __forceinline__ int64_t table_size(int32_t n_edges) { return n_edges < 512 ? 1024 : 2 * (int64_t)n_edges; }
+__global__ void table_clear_kernel(const State *st, unsigned long long *__restrict__ table) {
+    if (!fusing(st)) return;
+    const int64_t ts = table_size(st->n_edges);
+    SV_FOR(i, ts) table[i] = DEAD;
+}
+__global__ void dedup_kernel(State *st, const unsigned long long *__restrict__ edges, const int32_t *__restrict__ parent,
+                             unsigned long long *__restrict__ table, unsigned long long *__restrict__ edges_out) {
+    if (!fusing(st)) return;
+    const int32_t ne = st->n_edges;
+    const unsigned long long ts = (unsigned long long)table_size(ne);
+    SV_FOR(e, ne) {
+        const unsigned long long old = edges[e];
+        if (old == DEAD) continue;
+        const int32_t u = parent[(int32_t)(old >> 32)], v = parent[(int32_t)(old & 0xffffffffULL)];
+        if (u == v) continue;
+        const unsigned long long key = ((unsigned long long)(unsigned int)u << 32) | (unsigned int)v;
+        unsigned long long h = key * 0x9E3779B97F4A7C15ULL;
+        h ^= h >> 29;
+        unsigned long long slot = h % ts;
+        for (;;) {
+            const unsigned long long seen = atomicCAS(&table[slot], DEAD, key);
+            if (seen == DEAD) {  // first of its kind
+                edges_out[atomicAdd(&st->n_edges_new, 1)] = key;
+                break;
+            }
+            if (seen == key) break;
+            slot = slot + 1 == ts ? 0 : slot + 1;
+        }
+    }
+}
+__global__ void next_lambda_kernel(State *st) {
+    if (!fusing(st)) return;
+    st->n_edges = st->n_edges_new;
+    st->n_edges_new = 0;
+    st->lambda *= 2.0;  // :117
+    if (st->n_edges == 0) st->stalled = 1;  // disconnected graph of representatives: the reference would never return
+}
+
+// ---- labels, boundary exchange, relabel ------------------------------------------------------------------------------
+#pragma clang fp contract(off)
+__global__ void labels_init_kernel(const float *__restrict__ xyz, const double *__restrict__ nrm, double resolution, int64_t n,
+                                   const int32_t *__restrict__ parent, int32_t *__restrict__ la, int32_t *__restrict__ lb,
+                                   double *__restrict__ dis) {
+    SV_FOR(i, n) {
+        const int32_t r = parent[i];
+        la[i] = r;
+        lb[i] = r;
+        dis[i] = sv_metric(xyz, nrm, i, (int64_t)r, resolution);  // :186-189
+    }
+}
+// One sweep of the exchange (:214-226 for every point at once, reading the labels of the previous sweep).  A point is
+// looked at when it, or a point that lists it or that it lists, changed in the previous sweep (`dirty`); `full_sweep`
+// looks at every point (the first sweep, and the verification sweep that ends the relaxation).
+__global__ void sweep_kernel(const float *__restrict__ xyz, const double *__restrict__ nrm, const int32_t *__restrict__ knn,
+                             double resolution, int64_t n, int k, State *st, int32_t *__restrict__ l0, int32_t *__restrict__ l1,
+                             double *__restrict__ dis, unsigned char *__restrict__ d0, unsigned char *__restrict__ d1) {
+    if (!st->sweep_on) return;
+    const bool odd = (st->sweeps_done & 1) != 0, full = st->full_sweep != 0;
+    const int32_t *__restrict__ lin = odd ? l1 : l0;
+    int32_t *__restrict__ lout = odd ? l0 : l1;
+    const unsigned char *__restrict__ din = odd ? d1 : d0;
+    unsigned char *__restrict__ dout = odd ? d0 : d1;
+    bool any = false;
+    SV_FOR(i, n) {
+        const int32_t a = lin[i];
+        int32_t bl = a;
+        if (full || din[i]) {
+            double best = dis[i];
+            for (int j = 0; j < k; ++j) {
+                const int32_t b = lin[knn[i * k + j]];
+                if (b == a || b == bl) continue;
+                const double d = sv_metric(xyz, nrm, i, (int64_t)b, resolution);
+                if (d < best) { best = d; bl = b; }
+            }
+            if (bl != a) {
+                dis[i] = best;
+                any = true;
+                dout[i] = 1;  // looked at again next sweep, together with the points it lists (:228-236)
+                for (int j = 0; j < k; ++j) dout[knn[i * k + j]] = 1;
+            }
+        }
+        lout[i] = bl;
+    }
+    if (__ballot(any) != 0ULL && lane_id() == 0) atomicOr(&st->changed, 1);
+}
+__global__ void sweep_end_kernel(State *st) {
+    if (!st->sweep_on) return;
+    st->sweeps_done += 1;
+    if (st->changed) { st->changed = 0; st->full_sweep = 0; }
+    else if (!st->full_sweep) st->full_sweep = 1;                        // nothing left on the dirty lists: verify with a full sweep
+    else st->sweep_on = 0;                                               // a full sweep changed nothing: fixed point
+}
+__global__ void dirty_clear_kernel(const State *st, int64_t n, unsigned char *__restrict__ d0, unsigned char *__restrict__ d1) {
+    if (!st->sweep_on) return;
+    unsigned char *__restrict__ dout = (st->sweeps_done & 1) ? d0 : d1;  // the buffer the coming sweep writes
+    SV_FOR(i, n) dout[i] = 0;
+}
+__global__ void root_flag_kernel(int64_t n, const int32_t *__restrict__ parent, int32_t *__restrict__ flag) {
+    SV_FOR(i, n) flag[i] = parent[i] == (int32_t)i ? 1 : 0;
+}
+__global__ void relabel_kernel(State *st, int64_t n, const int32_t *__restrict__ l0, const int32_t *__restrict__ l1,
+                               const int32_t *__restrict__ flag, const int32_t *__restrict__ rank, int32_t *__restrict__ labels_out,
+                               int32_t *__restrict__ reps_out, int32_t *__restrict__ info_out) {
+    const int32_t *__restrict__ lab = (st->sweeps_done & 1) ? l1 : l0;
+    SV_FOR(i, n) {
+        labels_out[i] = rank[lab[i]];  // :241-247: position of the representative in ascending index order
+        if (reps_out && flag[i]) reps_out[rank[i]] = (int32_t)i;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && info_out) {
+        info_out[0] = rank[n - 1] + flag[n - 1];  // supervoxels produced
+        info_out[1] = st->K;                      // occupied grid cells (the target)
+        info_out[2] = (st->stalled ? 1 : 0) | (st->live > st->K && !st->stalled ? 2 : 0) | (st->sweep_on ? 4 : 0);
+        info_out[3] = st->sweeps_done;
+    }
+}
+
+static inline size_t align_up(size_t v) { return (v + 255) / 256 * 256; }
+
+struct Ws {
+    State *st;
+    unsigned long long *keys_a, *keys_b, *edges_a, *edges_b, *table, *bestm, *prop_key;
+    double *dis, *dis_sorted;
+    int32_t *parent, *size, *bestu, *prop_u, *la, *lb, *flag, *rank;
+    unsigned char *d0, *d1;
+    void *prim;
+    size_t prim_bytes, total;
+};
+static int layout(int64_t n, int k, Ws &w, unsigned char *base) {
+    size_t sort_u = 0, sort_d = 0, scan_b = 0;
+    unsigned long long *u0 = nullptr;
+    double *f0 = nullptr;
+    int32_t *i0 = nullptr;
+    if (rocprim::radix_sort_keys(nullptr, sort_u, u0, u0, (size_t)n, 0, 64, 0, false) != hipSuccess) return F4L_EHIP;
+    if (rocprim::radix_sort_keys(nullptr, sort_d, f0, f0, (size_t)n, 0, 64, 0, false) != hipSuccess) return F4L_EHIP;
+    if (rocprim::exclusive_scan(nullptr, scan_b, i0, i0, 0, (size_t)n, rocprim::plus<int32_t>(), 0, false) != hipSuccess) return F4L_EHIP;
+    size_t prim = sort_u > sort_d ? sort_u : sort_d;
+    prim = prim > scan_b ? prim : scan_b;
+    size_t o = 0;
+    auto carve = [&](size_t bytes) { size_t at = o; o += align_up(bytes); return base ? base + at : (unsigned char *)nullptr; };
+    const size_t ne = (size_t)n * (size_t)k;
+    w.st = (State *)carve(sizeof(State));
+    w.edges_a = (unsigned long long *)carve(ne * 8);
+    w.edges_b = (unsigned long long *)carve(ne * 8);
+    w.table = (unsigned long long *)carve((ne < 512 ? 1024 : 2 * ne) * 8);
+    // the grid keys and the sorted metrics are dead before the edge table is first used: they alias it
+    w.keys_a = w.table;
+    w.keys_b = w.table ? w.table + n : nullptr;
+    w.dis_sorted = (double *)w.keys_a;
+    w.bestm = (unsigned long long *)carve((size_t)n * 8);
+    w.prop_key = (unsigned long long *)carve((size_t)n * 8);
+    w.dis = (double *)carve((size_t)n * 8);
+    w.parent = (int32_t *)carve((size_t)n * 4);
+    w.size = (int32_t *)carve((size_t)n * 4);
+    w.bestu = (int32_t *)carve((size_t)n * 4);
+    w.prop_u = (int32_t *)carve((size_t)n * 4);
+    w.la = (int32_t *)carve((size_t)n * 4);
+    w.lb = (int32_t *)carve((size_t)n * 4);
+    w.flag = (int32_t *)carve((size_t)n * 4);
+    w.rank = (int32_t *)carve((size_t)n * 4);
+    w.d0 = carve((size_t)n);
+    w.d1 = carve((size_t)n);
+    w.prim = carve(prim);
+    w.prim_bytes = prim;
+    w.total = o;
+    return F4L_OK;
+}
+}  // namespace svg
+}  // namespace f4l
+
+extern "C" size_t f4l_supervoxel_segment_device_workspace_bytes(int64_t n, int k) {
+    if (n <= 0 || k < 1) return 0;
+    f4l::svg::Ws w;
+    if (f4l::svg::layout(n, k, w, nullptr) != F4L_OK) return 0;
+    return w.total;
+}
+
+// Enqueues the whole segmentation on `stream`; never synchronises, never touches host memory.
+extern "C" int f4l_supervoxel_segment_device(const float *xyz, const double *normals, const int32_t *knn, int64_t n, int k,
+                                             double resolution, int32_t *labels_out, int32_t *reps_out, int32_t *info_out,
+                                             void *workspace, size_t workspace_bytes, void *stream) {
+    using namespace f4l;
+    using namespace f4l::svg;
+    if (!xyz || !normals || !knn || n <= 0 || k < 1 || !(resolution > 0.0) || !labels_out || !workspace) return F4L_EINVAL;
+    if (n > 0x7fffffffLL || (double)n * (double)k > 2147483647.0) return F4L_EUNSUPPORTED;
+    Ws w;
+    int rc = layout(n, k, w, (unsigned char *)workspace);
+    if (rc != F4L_OK) return rc;
+    if (workspace_bytes < w.total) return F4L_EWORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 g(GRID), b(BLOCK), one(1);
+
+    hipLaunchKernelGGL(init_state_kernel, one, one, 0, st, w.st, (int32_t)n);
+    // K
+    hipLaunchKernelGGL(svg::bbox_kernel, g, b, 0, st, xyz, n, w.st);
+    hipLaunchKernelGGL(grid_key_kernel, g, b, 0, st, xyz, n, resolution, w.st, w.keys_a);
+    F4L_LAUNCH_CHECK();
+    size_t tb = w.prim_bytes;
+    F4L_HIP_CHECK(rocprim::radix_sort_keys(w.prim, tb, w.keys_a, w.keys_b, (size_t)n, 0, 64, st, false));
+    hipLaunchKernelGGL(count_distinct_kernel, g, b, 0, st, w.keys_b, n, w.st);
+    // lambda0
+    hipLaunchKernelGGL(min_metric_kernel, g, b, 0, st, xyz, normals, knn, n, k, resolution, w.dis);
+    F4L_LAUNCH_CHECK();
+    tb = w.prim_bytes;
+    F4L_HIP_CHECK(rocprim::radix_sort_keys(w.prim, tb, w.dis, w.dis_sorted, (size_t)n, 0, 64, st, false));
+    hipLaunchKernelGGL(start_kernel, one, one, 0, st, w.st, w.dis_sorted, n, k);
+    hipLaunchKernelGGL(init_points_kernel, g, b, 0, st, n, w.parent, w.size, w.bestm, w.bestu);
+    hipLaunchKernelGGL(init_edges_kernel, g, b, 0, st, knn, n, k, w.edges_a, w.st);
+    F4L_LAUNCH_CHECK();
+    // fusion: a fixed schedule; everything after the target count is reached returns at once
+    unsigned long long *cur = w.edges_a, *nxt = w.edges_b;
+    for (int r = 0; r < LAMBDA_ROUNDS; ++r) {
+        for (int s = 0; s < SUBROUNDS; ++s) {
+            hipLaunchKernelGGL(cand_kernel<false>, g, b, 0, st, xyz, normals, resolution, w.st, cur, w.parent, w.size, w.bestm, w.bestu);
+            hipLaunchKernelGGL(cand_kernel<true>, g, b, 0, st, xyz, normals, resolution, w.st, cur, w.parent, w.size, w.bestm, w.bestu);
+            hipLaunchKernelGGL(collect_kernel, g, b, 0, st, w.st, n, w.size, w.bestm, w.bestu, w.prop_key, w.prop_u);
+            hipLaunchKernelGGL(select_kernel, one, dim3(1024), 0, st, w.st, w.prop_key);
+            hipLaunchKernelGGL(apply_kernel, g, b, 0, st, w.st, w.prop_key, w.prop_u, w.parent, w.size);
+        }
+        hipLaunchKernelGGL(flatten_kernel, g, b, 0, st, w.st, n, w.parent, false);
+        hipLaunchKernelGGL(table_clear_kernel, g, b, 0, st, w.st, w.table);
+        hipLaunchKernelGGL(dedup_kernel, g, b, 0, st, w.st, cur, w.parent, w.table, nxt);
+        hipLaunchKernelGGL(next_lambda_kernel, one, one, 0, st, w.st);
+        F4L_LAUNCH_CHECK();
+        unsigned long long *t = cur; cur = nxt; nxt = t;
+    }
+    // labels and the boundary exchange
+    hipLaunchKernelGGL(flatten_kernel, g, b, 0, st, w.st, n, w.parent, true);
+    hipLaunchKernelGGL(labels_init_kernel, g, b, 0, st, xyz, normals, resolution, n, w.parent, w.la, w.lb, w.dis);
+    F4L_HIP_CHECK(hipMemsetAsync(w.d0, 0, (size_t)n, st));
+    F4L_HIP_CHECK(hipMemsetAsync(w.d1, 0, (size_t)n, st));
+    for (int s = 0; s < SWEEPS; ++s) {
+        hipLaunchKernelGGL(dirty_clear_kernel, g, b, 0, st, w.st, n, w.d0, w.d1);
+        hipLaunchKernelGGL(sweep_kernel, g, b, 0, st, xyz, normals, knn, resolution, n, k, w.st, w.la, w.lb, w.dis, w.d0, w.d1);
+        hipLaunchKernelGGL(sweep_end_kernel, one, one, 0, st, w.st);
+    }
+    F4L_LAUNCH_CHECK();
+    // relabel 0..K-1 in ascending order of the representative's index
+    hipLaunchKernelGGL(root_flag_kernel, g, b, 0, st, n, w.parent, w.flag);
+    F4L_LAUNCH_CHECK();
+    tb = w.prim_bytes;
+    F4L_HIP_CHECK(rocprim::exclusive_scan(w.prim, tb, w.flag, w.rank, 0, (size_t)n, rocprim::plus<int32_t>(), st, false));
+    hipLaunchKernelGGL(relabel_kernel, g, b, 0, st, w.st, n, w.la, w.lb, w.flag, w.rank, labels_out, reps_out, info_out);
+    F4L_LAUNCH_CHECK();
+    return F4L_OK;
+}
+
+extern "C" size_t f4l_supervoxel_parallel_workspace_bytes(int64_t n, int k) {
+    if (n <= 0 || k < 1) return 0;
+    const size_t a = f4l_knn_workspace_bytes(n, k), s = f4l_supervoxel_segment_device_workspace_bytes(n, k);
+    const size_t idx = ((size_t)n * k * 4 + 255) / 256 * 256, nrm = ((size_t)n * 24 + 255) / 256 * 256;
+    return (a > s ? a : s) + idx + nrm;  // the kNN workspace is dead when the segmentation starts
+}
+
+// kNN + normals + segmentation, all on the device.  f4l_knn synchronises `stream` once while it sizes its grid (bounding
+// box and cell count are read back); nothing after that does.
+extern "C" int f4l_supervoxel_parallel(const float *xyz, int64_t n, int k, double resolution, int32_t *labels_out,
+                                       int32_t *reps_out, int32_t *info_out, int32_t *knn_out, double *normals_out,
+                                       void *workspace, size_t workspace_bytes, void *stream) {
+    if (!xyz || n <= 0 || k < 1 || k >= n || !(resolution > 0.0) || !labels_out || !workspace) return F4L_EINVAL;  // supervoxel.cpp:100
+    if (k > F4L_MAX_K || n > 0x7fffffffLL) return F4L_EUNSUPPORTED;
+    if (workspace_bytes < f4l_supervoxel_parallel_workspace_bytes(n, k)) return F4L_EWORKSPACE;
+    const size_t a = f4l_knn_workspace_bytes(n, k), s = f4l_supervoxel_segment_device_workspace_bytes(n, k);
+    const size_t shared = a > s ? a : s;
+    const size_t idx_b = ((size_t)n * k * 4 + 255) / 256 * 256;
+    unsigned char *base = (unsigned char *)workspace;
+    int32_t *idx = knn_out ? knn_out : (int32_t *)(base + shared);
+    double *nrm = normals_out ? normals_out : (double *)(base + shared + idx_b);
+    int rc = f4l_knn(xyz, n, k, idx, nullptr, workspace, a, stream);
+    if (rc != F4L_OK) return rc;
+    rc = f4l_normals(xyz, n, idx, k, nrm, stream);
+    if (rc != F4L_OK) return rc;
+    return f4l_supervoxel_segment_device(xyz, nrm, idx, n, k, resolution, labels_out, reps_out, info_out, workspace, s, stream);
+}

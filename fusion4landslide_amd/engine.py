@@ -393,6 +393,52 @@ def supervoxel(xyz, k, resolution, return_intermediates=False):
     return labels, nsv.value
 
 
+def supervoxel_segment_device(xyz, normals, knn_idx, resolution, return_reps=False):
+    """The segmentation stage entirely on the device, asynchronously (f4l_supervoxel_segment_device: the parallel variant
+    of supervoxel_segmentation.h:65-248; NOT label-identical to the sequential reference, same invariants).
+    Returns labels (n,) int32 and info (4,) int32 = [supervoxels, K wanted, status bits, sweeps], both ON THE DEVICE
+    (reading `info` is the caller's synchronisation point)[, reps (n,) int32: the first info[0] entries are the
+    representative point of every supervoxel]."""
+    torch = require_gpu()
+    xyz = _dev(xyz, torch.float32, "xyz", (3,))
+    normals = _dev(normals, torch.float64, "normals", (3,))
+    knn_idx = _dev(knn_idx, torch.int32, "knn_idx")
+    n, k = knn_idx.shape
+    if xyz.shape[0] != n or normals.shape[0] != n:
+        raise ValueError("xyz, normals and knn_idx must describe the same points")
+    labels = torch.empty((n,), dtype=torch.int32, device=xyz.device)
+    info = torch.zeros((4,), dtype=torch.int32, device=xyz.device)
+    reps = torch.empty((n,), dtype=torch.int32, device=xyz.device) if return_reps else None
+    nbytes = lib().f4l_supervoxel_segment_device_workspace_bytes(n, k)
+    ws = torch.empty((max(int(nbytes), 1),), dtype=torch.uint8, device=xyz.device)
+    check(lib().f4l_supervoxel_segment_device(ptr(xyz), ptr(normals), ptr(knn_idx), n, int(k), float(resolution), ptr(labels),
+                                              ptr(reps), ptr(info), ptr(ws), C.c_size_t(nbytes), stream_ptr()),
+          "f4l_supervoxel_segment_device")
+    return (labels, info, reps) if return_reps else (labels, info)
+
+
+def supervoxel_parallel(xyz, k, resolution, return_intermediates=False):
+    """Whole partition on the device (f4l_supervoxel_parallel: kNN + normals + the parallel segmentation).  Returns labels
+    (n,) int32 on the GPU and K (reads the device-side count: the one synchronisation)[, knn, normals, reps, info]."""
+    torch = require_gpu()
+    xyz = _dev(xyz, torch.float32, "xyz", (3,))
+    n = xyz.shape[0]
+    labels = torch.empty((n,), dtype=torch.int32, device=xyz.device)
+    info = torch.zeros((4,), dtype=torch.int32, device=xyz.device)
+    knn_out = torch.empty((n, k), dtype=torch.int32, device=xyz.device) if return_intermediates else None
+    nrm_out = torch.empty((n, 3), dtype=torch.float64, device=xyz.device) if return_intermediates else None
+    reps = torch.empty((n,), dtype=torch.int32, device=xyz.device) if return_intermediates else None
+    nbytes = lib().f4l_supervoxel_parallel_workspace_bytes(n, k)
+    ws = torch.empty((max(int(nbytes), 1),), dtype=torch.uint8, device=xyz.device)
+    check(lib().f4l_supervoxel_parallel(ptr(xyz), n, int(k), float(resolution), ptr(labels), ptr(reps), ptr(info), ptr(knn_out),
+                                        ptr(nrm_out), ptr(ws), C.c_size_t(nbytes), stream_ptr()), "f4l_supervoxel_parallel")
+    info_h = info.cpu()
+    K = int(info_h[0])
+    if return_intermediates:
+        return labels, K, knn_out, nrm_out, reps[:K], info_h
+    return labels, K
+
+
 def labels_to_csr(labels, K):
     """Sort-by-label -> (order (n,) int32, off (K+1,) int64); replaces prepare_pts2spt_dict's mask loop
     (src/coarse_to_fine_matching_base.py:1327-1332)."""

@@ -207,6 +207,31 @@ int f4l_supervoxel(const float *xyz, int64_t n, int k, double resolution, int32_
                    int32_t *n_supervoxels_host, int32_t *knn_out, double *normals_out, void *workspace,
                    size_t workspace_bytes, void *stream);
 
+/* The segmentation stage ENTIRELY ON THE DEVICE (rows a5-a7 without the host): the parallel variant of
+ * codelibrary/geometry/point_cloud/supervoxel_segmentation.h:65-248 with the count of grid_sample.h:31-75.  Same structure
+ * and the same criteria as the reference (K = occupied cells of the resolution grid; lambda from the median of the smallest
+ * neighbour metric, doubled per round; a representative v is fused into a neighbouring representative u when
+ * sizes[v] * metric(u, v) < lambda; never below K; boundary exchange until no point has a neighbour whose representative is
+ * strictly closer; labels 0..K-1 in ascending order of the representative's index), but the representatives of a round are
+ * fused in conflict-free parallel sub-rounds instead of one after the other, so the labels are NOT those of the
+ * sequential reference (f4l_supervoxel keeps the label-identical replay); they satisfy the same invariants and are
+ * deterministic.  Never synchronises `stream`, never touches host memory: a fixed schedule of launches whose trip counts
+ * live on the device.
+ *   xyz float32 [n][3], normals double [n][3], knn int32 [n][k] (device; e.g. from f4l_knn / f4l_normals)
+ *   labels_out int32 [n];  reps_out int32 [n] or NULL: reps_out[l] = index of supervoxel l's representative point;
+ *   info_out int32 [4] (device) or NULL: {supervoxels produced, K wanted, status bits, exchange sweeps run};
+ *   status bit 0: the graph of representatives ran out of edges above K (disconnected cloud; the reference would not
+ *   return), bit 1: lambda schedule exhausted above K, bit 2: exchange stopped by the sweep budget before its fixed point.
+ * f4l_supervoxel_parallel = f4l_knn + f4l_normals + this (f4l_knn synchronises once while it sizes its grid). */
+size_t f4l_supervoxel_segment_device_workspace_bytes(int64_t n, int k);
+int f4l_supervoxel_segment_device(const float *xyz, const double *normals, const int32_t *knn, int64_t n, int k,
+                                  double resolution, int32_t *labels_out, int32_t *reps_out, int32_t *info_out,
+                                  void *workspace, size_t workspace_bytes, void *stream);
+size_t f4l_supervoxel_parallel_workspace_bytes(int64_t n, int k);
+int f4l_supervoxel_parallel(const float *xyz, int64_t n, int k, double resolution, int32_t *labels_out, int32_t *reps_out,
+                            int32_t *info_out, int32_t *knn_out, double *normals_out, void *workspace,
+                            size_t workspace_bytes, void *stream);
+
 /* Host-only helper (no device work): the sequential segmentation stage on host arrays.  Exposed so the
  * Python shim can re-segment cached kNN/normals; same semantics as inside f4l_supervoxel. */
 int f4l_supervoxel_segment_host(const float *xyz_host, const double *normals_host, const int32_t *knn_host,
