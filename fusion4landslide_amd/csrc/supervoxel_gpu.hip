@@ -80,6 +80,24 @@ __device__ __forceinline__ bool heads(int32_t v, int32_t round) {
     h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12; h *= 0x297A2D39u; h ^= h >> 15;
     return (h & 1u) != 0u;
 }
+// One atomicAdd per WORKGROUP for all lanes with `take` (same-address atomics are slow: ~10 ns each): returns this lane's
+// slot (valid where take).  Every thread of the block must call it (two barriers inside).
+__device__ __forceinline__ int32_t block_append(int32_t *counter, bool take, int32_t *s_cnt /* [waves + 1] */) {
+    const unsigned long long m = __ballot(take);
+    const int wave = (int)(threadIdx.x >> 6), nw = (int)(blockDim.x >> 6);
+    if (lane_id() == 0) s_cnt[wave] = (int32_t)__popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int32_t tot = 0;
+        for (int w = 0; w < nw; ++w) { const int32_t c = s_cnt[w]; s_cnt[w] = tot; tot += c; }
+        s_cnt[nw] = tot ? atomicAdd(counter, tot) : 0;
+    }
+    __syncthreads();
+    const int32_t base = s_cnt[nw] + s_cnt[wave];
+    __syncthreads();  // (s_cnt is reused by the next call)
+    const unsigned int below = __builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u));
+    return base + (int32_t)below;
+}
 #define SV_FOR(i, n) for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (int64_t)(n); i += (int64_t)gridDim.x * blockDim.x)
 
 // ---- K: occupied cells of the resolution grid ------------------------------------------------------------------------
@@ -212,19 +230,19 @@ __global__ void cand_kernel(const float *__restrict__ xyz, const double *__restr
     }
 }
 // collect: every tails representative with an offer becomes a proposal (key = float image of the loss : index)
-__global__ void collect_kernel(State *st, int64_t n, const int32_t *__restrict__ size, unsigned long long *__restrict__ bestm,
+__global__ __launch_bounds__(1024) void collect_kernel(State *st, int64_t n, const int32_t *__restrict__ size, unsigned long long *__restrict__ bestm,
                                int32_t *__restrict__ bestu, unsigned long long *__restrict__ prop_key, int32_t *__restrict__ prop_u) {
     if (!fusing(st)) return;
-    SV_FOR(v, n) {
-        const int32_t u = bestu[v];
-        if (u == 0x7fffffff) {
-            if (bestm[v] != ~0ULL) bestm[v] = ~0ULL;
-            continue;
-        }
+    __shared__ int32_t s_cnt[17];
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t v0 = (int64_t)blockIdx.x * blockDim.x; v0 < n; v0 += stride) {  // whole workgroups iterate together
+        const int64_t v = v0 + threadIdx.x;
+        const int32_t u = v < n ? bestu[v] : 0x7fffffff;
+        const bool has = u != 0x7fffffff;
+        const int32_t at = block_append(&st->n_prop, has, s_cnt);
+        if (!has) continue;
         const double loss = (double)size[v] * ord2d(bestm[v]);
-        const unsigned long long key = ((unsigned long long)f2ord((float)loss) << 32) | (unsigned int)v;
-        const int32_t at = atomicAdd(&st->n_prop, 1);
-        prop_key[at] = key;
+        prop_key[at] = ((unsigned long long)f2ord((float)loss) << 32) | (unsigned int)v;
         prop_u[at] = u;
         bestm[v] = ~0ULL;
         bestu[v] = 0x7fffffff;
@@ -297,34 +315,47 @@ __global__ void flatten_kernel(const State *st, int64_t n, int32_t *__restrict__
     }
 }
 __device__ __forceinline__ int64_t table_size(int32_t n_edges) { return n_edges < 512 ? 1024 : 2 * (int64_t)n_edges; }
+// Parallel edges are merged through the hash set only once they dominate the list (more than 40 edges per representative);
+// before that the pass just drops the self loops -- the list of a young forest holds few duplicates and 30 M random table
+// accesses cost more than they save.
+__device__ __forceinline__ bool use_hash(const State *st) { return (int64_t)st->n_edges > 40LL * (int64_t)st->live; }
 __global__ void table_clear_kernel(const State *st, unsigned long long *__restrict__ table) {
-    if (!fusing(st)) return;
+    if (!fusing(st) || !use_hash(st)) return;
     const int64_t ts = table_size(st->n_edges);
     SV_FOR(i, ts) table[i] = DEAD;
 }
-__global__ void dedup_kernel(State *st, const unsigned long long *__restrict__ edges, const int32_t *__restrict__ parent,
+__global__ __launch_bounds__(1024) void dedup_kernel(State *st, const unsigned long long *__restrict__ edges, const int32_t *__restrict__ parent,
                              unsigned long long *__restrict__ table, unsigned long long *__restrict__ edges_out) {
     if (!fusing(st)) return;
     const int32_t ne = st->n_edges;
     const unsigned long long ts = (unsigned long long)table_size(ne);
-    SV_FOR(e, ne) {
-        const unsigned long long old = edges[e];
-        if (old == DEAD) continue;
-        const int32_t u = parent[(int32_t)(old >> 32)], v = parent[(int32_t)(old & 0xffffffffULL)];
-        if (u == v) continue;
-        const unsigned long long key = ((unsigned long long)(unsigned int)u << 32) | (unsigned int)v;
-        unsigned long long h = key * 0x9E3779B97F4A7C15ULL;
-        h ^= h >> 29;
-        unsigned long long slot = h % ts;
-        for (;;) {
-            const unsigned long long seen = atomicCAS(&table[slot], DEAD, key);
-            if (seen == DEAD) {  // first of its kind
-                edges_out[atomicAdd(&st->n_edges_new, 1)] = key;
-                break;
+    __shared__ int32_t s_cnt[17];
+    const bool hashed = use_hash(st);
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e0 = (int64_t)blockIdx.x * blockDim.x; e0 < ne; e0 += stride) {  // whole workgroups iterate together
+        const int64_t e = e0 + threadIdx.x;
+        const unsigned long long old = e < ne ? edges[e] : DEAD;
+        bool fresh = false;
+        unsigned long long key = DEAD;
+        if (old != DEAD) {
+            const int32_t u = parent[(int32_t)(old >> 32)], v = parent[(int32_t)(old & 0xffffffffULL)];
+            if (u != v) {
+                key = ((unsigned long long)(unsigned int)u << 32) | (unsigned int)v;
+                fresh = !hashed;  // compaction only: every edge between two representatives is kept
+                unsigned long long h = key * 0x9E3779B97F4A7C15ULL;
+                h ^= h >> 29;
+                unsigned long long slot = h % ts;
+                while (hashed) {
+                    unsigned long long seen = __atomic_load_n(&table[slot], __ATOMIC_RELAXED);  // most parallel edges stop here
+                    if (seen == DEAD) seen = atomicCAS(&table[slot], DEAD, key);
+                    if (seen == DEAD) { fresh = true; break; }  // first of its kind
+                    if (seen == key) break;
+                    slot = slot + 1 == ts ? 0 : slot + 1;
+                }
             }
-            if (seen == key) break;
-            slot = slot + 1 == ts ? 0 : slot + 1;
         }
+        const int32_t at = block_append(&st->n_edges_new, fresh, s_cnt);  // one counter update per workgroup, not per edge
+        if (fresh) edges_out[at] = key;
     }
 }
 __global__ void next_lambda_kernel(State *st) {
@@ -511,13 +542,13 @@ extern "C" int f4l_supervoxel_segment_device(const float *xyz, const double *nor
         for (int s = 0; s < SUBROUNDS; ++s) {
             hipLaunchKernelGGL(cand_kernel<false>, g, b, 0, st, xyz, normals, resolution, w.st, cur, w.parent, w.size, w.bestm, w.bestu);
             hipLaunchKernelGGL(cand_kernel<true>, g, b, 0, st, xyz, normals, resolution, w.st, cur, w.parent, w.size, w.bestm, w.bestu);
-            hipLaunchKernelGGL(collect_kernel, g, b, 0, st, w.st, n, w.size, w.bestm, w.bestu, w.prop_key, w.prop_u);
+            hipLaunchKernelGGL(collect_kernel, g, dim3(1024), 0, st, w.st, n, w.size, w.bestm, w.bestu, w.prop_key, w.prop_u);
             hipLaunchKernelGGL(select_kernel, one, dim3(1024), 0, st, w.st, w.prop_key);
             hipLaunchKernelGGL(apply_kernel, g, b, 0, st, w.st, w.prop_key, w.prop_u, w.parent, w.size);
         }
         hipLaunchKernelGGL(flatten_kernel, g, b, 0, st, w.st, n, w.parent, false);
         hipLaunchKernelGGL(table_clear_kernel, g, b, 0, st, w.st, w.table);
-        hipLaunchKernelGGL(dedup_kernel, g, b, 0, st, w.st, cur, w.parent, w.table, nxt);
+        hipLaunchKernelGGL(dedup_kernel, g, dim3(1024), 0, st, w.st, cur, w.parent, w.table, nxt);
         hipLaunchKernelGGL(next_lambda_kernel, one, one, 0, st, w.st);
         F4L_LAUNCH_CHECK();
         unsigned long long *t = cur; cur = nxt; nxt = t;
