@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libf4l_hip.so")
+LIB_PATH = os.environ.get("F4L_LIB_PATH") or os.path.join(_HERE, "lib", "libf4l_hip.so")  # (override: A/B builds of the kernels)
 
 F4L_OK = 0
 ICP_POINT2POINT = 0
@@ -38,6 +38,7 @@ SIGNATURES = {
     "f4l_nn_refine": (C.c_int, [_P, _P, _P, _P, _I64, _P, _P, _I64, _P, _P, _P]),
     "f4l_knn_workspace_bytes": (_SZ, [_I64, _I]),
     "f4l_knn": (C.c_int, [_P, _I64, _I, _P, _P, _P, _SZ, _P]),
+    "f4l_knn_normals": (C.c_int, [_P, _I64, _I, _P, _P, _P, _P, _SZ, _P]),
     "f4l_normals": (C.c_int, [_P, _I64, _P, _I, _P, _P]),
     "f4l_voxel_downsample_workspace_bytes": (_SZ, [_I64]),
     "f4l_voxel_downsample": (C.c_int, [_P, _I64, _D, _I, _P, _P, _P, _P, _P, _SZ, _P]),

@@ -24,6 +24,8 @@
 // The kernel is bounded by VALU/issue (top-k maintenance), not HBM; bench.py reports the achieved GB/s.
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include <rocprim/rocprim.hpp>
@@ -36,13 +38,14 @@ namespace f4l {
 struct GridSpec {
     double minx, miny, minz;
     double inv_h, h;
+    double inv_hz;  // = inv_h, or 0 for a flat cloud (one layer of cells along z: nz = 1, every point in layer 0)
     int nx, ny, nz;
 };
 
 __device__ __forceinline__ void cell_of(const GridSpec &g, float x, float y, float z, int &cx, int &cy, int &cz) {
     cx = (int)(((double)x - g.minx) * g.inv_h);
     cy = (int)(((double)y - g.miny) * g.inv_h);
-    cz = (int)(((double)z - g.minz) * g.inv_h);
+    cz = (int)(((double)z - g.minz) * g.inv_hz);
     cx = cx < 0 ? 0 : (cx >= g.nx ? g.nx - 1 : cx);
     cy = cy < 0 ? 0 : (cy >= g.ny ? g.ny - 1 : cy);
     cz = cz < 0 ? 0 : (cz >= g.nz ? g.nz - 1 : cz);
@@ -98,13 +101,34 @@ __global__ void cell_key_kernel(const float *__restrict__ xyz, int64_t n, GridSp
     }
 }
 
+// the same keys as 32-bit words (grids of fewer than 2^32 cells: nearly all): half the bytes through the radix sort
+__global__ void cell_key32_kernel(const float *__restrict__ xyz, int64_t n, GridSpec g, unsigned int *__restrict__ keys,
+                                  int32_t *__restrict__ ids) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        int cx, cy, cz;
+        cell_of(g, xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], cx, cy, cz);
+        keys[i] = (unsigned int)key_of(g, cx, cy, cz);
+        ids[i] = (int32_t)i;
+    }
+}
+__global__ void widen_keys_kernel(const unsigned int *__restrict__ k32, const int32_t *__restrict__ count, unsigned long long *__restrict__ k64) {
+    const int m = *count;
+    for (int i = (int)(blockIdx.x * blockDim.x + threadIdx.x); i < m; i += (int)(gridDim.x * blockDim.x)) k64[i] = k32[i];
+}
+
 __global__ void relayout_kernel(const float *__restrict__ xyz, const int32_t *__restrict__ ids, int64_t n,
                                 float4 *__restrict__ sorted) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const int32_t j = ids[i];
-        sorted[i] = make_float4(xyz[3 * (int64_t)j], xyz[3 * (int64_t)j + 1], xyz[3 * (int64_t)j + 2], __int_as_float(j));
+        const float x = xyz[3 * (int64_t)j], y = xyz[3 * (int64_t)j + 1], z = xyz[3 * (int64_t)j + 2];
+        sorted[i] = make_float4(x, y, z, __int_as_float(j));
     }
 }
+
+// (cell_runs_kernel, below) Per occupied cell c = (cx, cy, cz) and r = (dy + 1) + 3 (dz + 1): the run of the sorted array that holds the cells
+// cx - 1 .. cx + 1 of row (cy + dy, cz + dz): run_lo[9 c + r] = first point with key >= key(cx - 1, ..), run_hi[9 c + r] = first
+// point with key > key(cx + 1, ..) (both 0 for a row outside the grid).  A wave whose queries span the cells c_first .. c_last
+// of one row takes [run_lo[c_first], run_hi[c_last]).  Also the cell index of every sorted point.
 
 // first index in [0, m) with keys[idx] >= v
 __device__ __forceinline__ int lower_bound_u64(const unsigned long long *__restrict__ keys, int m, unsigned long long v) {
@@ -117,6 +141,28 @@ __device__ __forceinline__ int lower_bound_u64(const unsigned long long *__restr
 }
 
 constexpr int KNN_NW = 4;
+
+__global__ void cell_runs_kernel(const unsigned long long *__restrict__ cell_keys, const int32_t *__restrict__ cell_start, int M,
+                                 GridSpec g, int32_t *__restrict__ run_lo, int32_t *__restrict__ run_hi, int32_t *__restrict__ pcell) {
+    const int t = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (t >= 9 * M) return;
+    const int c = t / 9, r = t % 9;
+    const unsigned long long key = cell_keys[c];
+    const int cx = (int)(key % (unsigned long long)g.nx);
+    const int cy = (int)((key / (unsigned long long)g.nx) % (unsigned long long)g.ny);
+    const int cz = (int)(key / ((unsigned long long)g.nx * (unsigned long long)g.ny));
+    const int yy = cy + (r % 3) - 1, zz = cz + (r / 3) - 1;
+    int lo = 0, hi = 0;
+    if (yy >= 0 && yy < g.ny && zz >= 0 && zz < g.nz) {
+        const int x0 = cx - 1 < 0 ? 0 : cx - 1, x1 = cx + 1 >= g.nx ? g.nx - 1 : cx + 1;
+        lo = cell_start[lower_bound_u64(cell_keys, M, key_of(g, x0, yy, zz))];
+        hi = cell_start[lower_bound_u64(cell_keys, M, key_of(g, x1, yy, zz) + 1ULL)];
+    }
+    run_lo[t] = lo;
+    run_hi[t] = hi;
+    if (r == 4)  // (dy, dz) = (0, 0): this thread also tags the cell's own points
+        for (int i = cell_start[c]; i < cell_start[c + 1]; ++i) pcell[i] = c;
+}
 
 struct KnnArgs {
     const float4 *sorted;             // [n] {x,y,z,id}
@@ -136,6 +182,104 @@ struct KnnArgs {
     double *d2_out;
 };
 
+// Rows of the R = 1 block of cell (cx, cy, cz), one per lane (lanes 0..8): [lo, hi) of the sorted array.
+__device__ __forceinline__ void block1_rows(const KnnArgs &a, int cx, int cy, int cz, int &row_lo1, int &row_hi1) {
+    const GridSpec &g = a.g;
+    const int lane = lane_id();
+    row_lo1 = 0; row_hi1 = 0;
+    if (lane < 9) {
+        const int yy = cy + (lane % 3) - 1, zz = cz + (lane / 3) - 1;
+        if (yy >= 0 && yy < g.ny && zz >= 0 && zz < g.nz) {
+            const int x0 = cx - 1 < 0 ? 0 : cx - 1, x1 = cx + 1 >= g.nx ? g.nx - 1 : cx + 1;
+            const int ca = lower_bound_u64(a.cell_keys, a.M, key_of(g, x0, yy, zz));
+            const int cb = lower_bound_u64(a.cell_keys, a.M, key_of(g, x1, yy, zz) + 1ULL);
+            row_lo1 = a.cell_start[ca];
+            row_hi1 = a.cell_start[cb];
+        }
+    }
+}
+
+// One query answered by one wavefront: streams the block's rows nearest first into the wave-resident top-k, grows the
+// block until the k-th distance lies inside it.  (cx, cy, cz) is the query's cell, row_lo1 / row_hi1 from block1_rows.
+__device__ __forceinline__ void knn_query_wave(const KnnArgs &a, const float4 qp, int cx, int cy, int cz, int row_lo1,
+                                               int row_hi1, WaveTopK &best) {
+    const GridSpec &g = a.g;
+    const int lane = lane_id();
+    const int k = a.k;
+    const int max_dim = max(g.nx, max(g.ny, g.nz));
+    // distance from the query to the faces of its own cell, per axis (conservative by 1e-6 h)
+    const double fx = ((double)qp.x - g.minx) - (double)cx * g.h, fy = ((double)qp.y - g.miny) - (double)cy * g.h,
+                 fz = ((double)qp.z - g.minz) - (double)cz * g.h;
+    for (int R = 1;;) {
+        best.reset();
+        bool first = true;  // uniform
+        // rows of the block that lie inside the grid (R = 1: the fixed 3 x 3 of row_lo1 / row_hi1)
+        const int y0 = cy - R < 0 ? 0 : cy - R, y1 = cy + R >= g.ny ? g.ny - 1 : cy + R;
+        const int z0 = cz - R < 0 ? 0 : cz - R, z1 = cz + R >= g.nz ? g.nz - 1 : cz + R;
+        const int side = R == 1 ? 3 : y1 - y0 + 1, rows = R == 1 ? 9 : side * (z1 - z0 + 1);
+        for (int r0 = 0; r0 < rows; r0 += 64) {
+            int lo = 0, hi = 0;
+            if (R == 1) { lo = row_lo1; hi = row_hi1; }
+            else {
+                const int r = r0 + lane;
+                if (r < rows) {
+                    const int yy = y0 + (r % side), zz = z0 + (r / side);
+                    const int x0 = cx - R < 0 ? 0 : cx - R, x1 = cx + R >= g.nx ? g.nx - 1 : cx + R;
+                    const int ca = lower_bound_u64(a.cell_keys, a.M, key_of(g, x0, yy, zz));
+                    const int cb = lower_bound_u64(a.cell_keys, a.M, key_of(g, x1, yy, zz) + 1ULL);
+                    lo = a.cell_start[ca];
+                    hi = a.cell_start[cb];
+                }
+            }
+            const int nrow = rows - r0 < 64 ? rows - r0 : 64;
+            // wider blocks (queries far from the cloud): most rows are empty, visit only the others
+            unsigned long long todo = R == 1 ? 0ULL : __ballot(hi > lo);
+            for (int rq = 0; R == 1 ? rq < nrow : todo != 0ULL; ++rq) {
+                int rr = rq;
+                if (R != 1) {
+                    rr = __ffsll((long long)todo) - 1;
+                    todo &= todo - 1ULL;
+                } else {
+                    // nearest rows first (own row, the four face neighbours, the four corners): the list tightens
+                    // early, and a row that lies beyond the current k-th distance is not streamed at all
+                    rr = (int)((0x862075314ULL >> (4 * rq)) & 15ULL);
+                    const int dy = rr % 3 - 1, dz = rr / 3 - 1;
+                    const double ey = dy < 0 ? fy : (dy > 0 ? g.h - fy : 0.0), ez = dz < 0 ? fz : (dz > 0 ? g.h - fz : 0.0);
+                    const double ey0 = ey > 1e-6 * g.h ? ey - 1e-6 * g.h : 0.0, ez0 = ez > 1e-6 * g.h ? ez - 1e-6 * g.h : 0.0;
+                    if (ey0 * ey0 + ez0 * ez0 > best.kth(k)) continue;  // uniform (k-th entry is +inf until the list is full)
+                }
+                const int s = __builtin_amdgcn_readlane(lo, rr), e = __builtin_amdgcn_readlane(hi, rr);
+                for (int b = s; b < e; b += 64) {
+                    const int ci = b + lane;
+                    double cd = __builtin_inf();
+                    int cid = 0x7fffffff;
+                    if (ci < e) {
+                        const float4 cp = a.sorted[ci];
+                        cd = dist2_exact(cp.x, cp.y, cp.z, qp.x, qp.y, qp.z);
+                        cid = __float_as_int(cp.w);
+                    }
+                    if (first) { best.fill_sorted(cd, cid); first = false; }
+                    else best.offer(cd, cid, k);
+                }
+            }
+        }
+        // exactness: k-th distance strictly inside the searched block (faces at the grid border do not count)
+        double margin = __builtin_inf();
+        const double eps = 1e-6 * g.h;
+        if (cx - R > 0) margin = fmin(margin, fx + (double)R * g.h - eps);
+        if (cx + R < g.nx - 1) margin = fmin(margin, ((double)(R + 1)) * g.h - fx - eps);
+        if (cy - R > 0) margin = fmin(margin, fy + (double)R * g.h - eps);
+        if (cy + R < g.ny - 1) margin = fmin(margin, ((double)(R + 1)) * g.h - fy - eps);
+        if (cz - R > 0) margin = fmin(margin, fz + (double)R * g.h - eps);
+        if (cz + R < g.nz - 1) margin = fmin(margin, ((double)(R + 1)) * g.h - fz - eps);
+        const double dk = best.kth(k);
+        if (dk < margin * margin || R >= max_dim) break;  // uniform: dk, margin are wave-uniform
+        // fewer than k points in the whole block (queries far from the cloud): double it instead of one more layer
+        R = dk == __builtin_inf() ? (2 * R < max_dim ? 2 * R : max_dim) : R + 1;
+    }
+}
+
+// One wavefront per occupied query cell, its queries one after the other (f4l_nn_query, and f4l_knn for k > KR_MAX_K).
 __global__ __launch_bounds__(KNN_NW * 64) void knn_cells_kernel(KnnArgs a) {
     const int lane = lane_id();
     const int c = (int)blockIdx.x * KNN_NW + (int)(threadIdx.x >> 6);
@@ -147,97 +291,13 @@ __global__ __launch_bounds__(KNN_NW * 64) void knn_cells_kernel(KnnArgs a) {
     const int cz = (int)(key / ((unsigned long long)g.nx * (unsigned long long)g.ny));
     const int q_begin = a.q_cell_start[c], q_end = a.q_cell_start[c + 1];
     const int k = a.k;
-    const int max_dim = max(g.nx, max(g.ny, g.nz));
-
-    // rows of the R = 1 block, one per lane (lanes 0..8), computed once per cell
-    int row_lo1 = 0, row_hi1 = 0;
-    if (lane < 9) {
-        const int yy = cy + (lane % 3) - 1, zz = cz + (lane / 3) - 1;
-        if (yy >= 0 && yy < g.ny && zz >= 0 && zz < g.nz) {
-            const int x0 = cx - 1 < 0 ? 0 : cx - 1, x1 = cx + 1 >= g.nx ? g.nx - 1 : cx + 1;
-            const int ca = lower_bound_u64(a.cell_keys, a.M, key_of(g, x0, yy, zz));
-            const int cb = lower_bound_u64(a.cell_keys, a.M, key_of(g, x1, yy, zz) + 1ULL);
-            row_lo1 = a.cell_start[ca];
-            row_hi1 = a.cell_start[cb];
-        }
-    }
-
+    int row_lo1, row_hi1;
+    block1_rows(a, cx, cy, cz, row_lo1, row_hi1);
     for (int q = q_begin; q < q_end; ++q) {
         const float4 qp = a.q_sorted[q];
         const int qid = __float_as_int(qp.w);
-        // distance from the query to the faces of its own cell, per axis (conservative by 1e-6 h)
-        const double fx = ((double)qp.x - g.minx) - (double)cx * g.h, fy = ((double)qp.y - g.miny) - (double)cy * g.h,
-                     fz = ((double)qp.z - g.minz) - (double)cz * g.h;
         WaveTopK best;
-        for (int R = 1;;) {
-            best.reset();
-            bool first = true;  // uniform
-            // rows of the block that lie inside the grid (R = 1: the fixed 3 x 3 of row_lo1 / row_hi1)
-            const int y0 = cy - R < 0 ? 0 : cy - R, y1 = cy + R >= g.ny ? g.ny - 1 : cy + R;
-            const int z0 = cz - R < 0 ? 0 : cz - R, z1 = cz + R >= g.nz ? g.nz - 1 : cz + R;
-            const int side = R == 1 ? 3 : y1 - y0 + 1, rows = R == 1 ? 9 : side * (z1 - z0 + 1);
-            for (int r0 = 0; r0 < rows; r0 += 64) {
-                int lo = 0, hi = 0;
-                if (R == 1) { lo = row_lo1; hi = row_hi1; }
-                else {
-                    const int r = r0 + lane;
-                    if (r < rows) {
-                        const int yy = y0 + (r % side), zz = z0 + (r / side);
-                        {
-                            const int x0 = cx - R < 0 ? 0 : cx - R, x1 = cx + R >= g.nx ? g.nx - 1 : cx + R;
-                            const int ca = lower_bound_u64(a.cell_keys, a.M, key_of(g, x0, yy, zz));
-                            const int cb = lower_bound_u64(a.cell_keys, a.M, key_of(g, x1, yy, zz) + 1ULL);
-                            lo = a.cell_start[ca];
-                            hi = a.cell_start[cb];
-                        }
-                    }
-                }
-                const int nrow = rows - r0 < 64 ? rows - r0 : 64;
-                // wider blocks (queries far from the cloud): most rows are empty, visit only the others
-                unsigned long long todo = R == 1 ? 0ULL : __ballot(hi > lo);
-                for (int rq = 0; R == 1 ? rq < nrow : todo != 0ULL; ++rq) {
-                    int rr = rq;
-                    if (R != 1) {
-                        rr = __ffsll((long long)todo) - 1;
-                        todo &= todo - 1ULL;
-                    } else {
-                        // nearest rows first (own row, the four face neighbours, the four corners): the list tightens
-                        // early, and a row that lies beyond the current k-th distance is not streamed at all
-                        rr = (int)((0x862075314ULL >> (4 * rq)) & 15ULL);
-                        const int dy = rr % 3 - 1, dz = rr / 3 - 1;
-                        const double ey = dy < 0 ? fy : (dy > 0 ? g.h - fy : 0.0), ez = dz < 0 ? fz : (dz > 0 ? g.h - fz : 0.0);
-                        const double ey0 = ey > 1e-6 * g.h ? ey - 1e-6 * g.h : 0.0, ez0 = ez > 1e-6 * g.h ? ez - 1e-6 * g.h : 0.0;
-                        if (ey0 * ey0 + ez0 * ez0 > best.kth(k)) continue;  // uniform (k-th entry is +inf until the list is full)
-                    }
-                    const int s = __builtin_amdgcn_readlane(lo, rr), e = __builtin_amdgcn_readlane(hi, rr);
-                    for (int b = s; b < e; b += 64) {
-                        const int ci = b + lane;
-                        double cd = __builtin_inf();
-                        int cid = 0x7fffffff;
-                        if (ci < e) {
-                            const float4 cp = a.sorted[ci];
-                            cd = dist2_exact(cp.x, cp.y, cp.z, qp.x, qp.y, qp.z);
-                            cid = __float_as_int(cp.w);
-                        }
-                        if (first) { best.fill_sorted(cd, cid); first = false; }
-                        else best.offer(cd, cid, k);
-                    }
-                }
-            }
-            // exactness: k-th distance strictly inside the searched block (faces at the grid border do not count)
-            double margin = __builtin_inf();
-            const double eps = 1e-6 * g.h;
-            if (cx - R > 0) margin = fmin(margin, fx + (double)R * g.h - eps);
-            if (cx + R < g.nx - 1) margin = fmin(margin, ((double)(R + 1)) * g.h - fx - eps);
-            if (cy - R > 0) margin = fmin(margin, fy + (double)R * g.h - eps);
-            if (cy + R < g.ny - 1) margin = fmin(margin, ((double)(R + 1)) * g.h - fy - eps);
-            if (cz - R > 0) margin = fmin(margin, fz + (double)R * g.h - eps);
-            if (cz + R < g.nz - 1) margin = fmin(margin, ((double)(R + 1)) * g.h - fz - eps);
-            const double dk = best.kth(k);
-            if (dk < margin * margin || R >= max_dim) break;  // uniform: dk, margin are wave-uniform
-            // fewer than k points in the whole block (queries far from the cloud): double it instead of one more layer
-            R = dk == __builtin_inf() ? (2 * R < max_dim ? 2 * R : max_dim) : R + 1;
-        }
+        knn_query_wave(a, qp, cx, cy, cz, row_lo1, row_hi1, best);
         if (lane < k) {
             a.idx_out[(int64_t)qid * k + lane] = best.i;
             if (a.d2_out) a.d2_out[(int64_t)qid * k + lane] = best.d;
@@ -245,13 +305,453 @@ __global__ __launch_bounds__(KNN_NW * 64) void knn_cells_kernel(KnnArgs a) {
     }
 }
 
+// The queries the one-lane-per-query kernel below could not certify (listed by their position in the sorted array):
+// one wavefront per query, the search above.
+__global__ __launch_bounds__(KNN_NW * 64) void knn_listed_kernel(KnnArgs a, const int32_t *__restrict__ list,
+                                                                const int32_t *__restrict__ count) {
+    const int lane = lane_id();
+    const int n_list = *count;
+    const int k = a.k;
+    const GridSpec g = a.g;
+    for (int i = (int)blockIdx.x * KNN_NW + (int)(threadIdx.x >> 6); i < n_list; i += (int)gridDim.x * KNN_NW) {
+        const float4 qp = a.q_sorted[list[i]];
+        const int qid = __float_as_int(qp.w);
+        int cx, cy, cz;
+        cell_of(g, qp.x, qp.y, qp.z, cx, cy, cz);
+        int row_lo1, row_hi1;
+        block1_rows(a, cx, cy, cz, row_lo1, row_hi1);
+        WaveTopK best;
+        knn_query_wave(a, qp, cx, cy, cz, row_lo1, row_hi1, best);
+        if (lane < k) {
+            a.idx_out[(int64_t)qid * k + lane] = best.i;
+            if (a.d2_out) a.d2_out[(int64_t)qid * k + lane] = best.d;
+        }
+    }
+}
+
+// ---- fast path of f4l_knn: one LANE per query -------------------------------------------------------------------------
+// A wavefront takes 64 CONSECUTIVE points of the sorted array.  They lie in a few x-adjacent cells of one (y, z) row of
+// cells (a wave that straddles the end of a row takes one turn per row), so they share one candidate set: the 3 x 3 rows
+// around theirs, from one cell before the first query's cell to one cell after the last one's -- nine contiguous runs of
+// the sorted array.  The wave streams those runs through a 1 KB tile of its own in LDS (64 candidates per coalesced load,
+// made relative to the wave's first query in double and rounded to float32 once, by the loading lane) and every lane
+// measures each candidate against its own query with one broadcast ds_read_b128 and float32 arithmetic:
+//   pass 1  histogram of the approximate d2 per lane, in LDS (32 bins, a quarter octave of d2 each: scale free, a bin near
+//           the k-th neighbour holds ~ 0.19 k points whatever the local density);
+//           -> the first bin T at which the count reaches k;
+//   pass 2  the candidates below bin T's upper edge, widened by far more than the float32 error of a wave-relative
+//           coordinate (1e-4 relative + 1e-6 h^2), go to the lane's list in LDS: a superset of the k nearest, k plus a handful;
+//   sort    the list is loaded into registers with the EXACT d2 (double, from the float coordinates, separately rounded
+//           multiply and add: what the reference computes) and sorted by a bitonic network on registers -- no cross-lane
+//           traffic, no divergence; exact ties by point index.
+// A query is certified when its k-th distance lies inside the searched block (same test as the wave-per-query search);
+// the few that are not (sparse borders, more survivors than the list holds, fewer than k candidates) are listed and redone
+// by knn_listed_kernel.
+// (Candidates through scalar loads -- coordinates in SGPRs, no LDS -- were measured first: 2.4 ms per 1 M points; the scalar
+// cache misses to L2 one line at a time and nothing overlaps them.)
+constexpr int KR_NB = 32;      // histogram bins
+constexpr int KR_CAP = 43;     // survivors a lane can keep
+constexpr int KR_MAX_K = 36;   // largest k the fast path takes (room for the threshold bin's overshoot)
+constexpr int KR_NW = 4;       // waves per workgroup (8 KB histogram + 11.25 KB list + 0.8 KB tile each: two workgroups per CU)
+
+struct KnnLanesArgs {
+    KnnArgs a;
+    const int32_t *run_lo, *run_hi;  // [9 M] candidate runs per occupied cell (cell_runs_kernel)
+    const int32_t *pcell;            // [n] cell index of every sorted point
+    int32_t *fb_list;   // sorted positions of the queries to redo
+    int32_t *fb_count;
+    const float *xyz;   // the cloud in input order (fused normals)
+    double *normals_out;
+    int bin_base;       // bin of d2 = (its float image >> 21) - bin_base, clamped to [0, KR_NB)
+    float edge_slack;   // 1e-6 h^2
+    unsigned long long *prof;  // profiling build (-DF4L_KNN_PROF): cycles per phase, summed over the waves
+};
+#ifdef F4L_KNN_PROF
+#define KR_TICK(slot)                                                                              \
+    do {                                                                                           \
+        const unsigned long long now__ = __builtin_readcyclecounter();                             \
+        if (lane_id() == 0 && ra.prof) atomicAdd(&ra.prof[slot], now__ - tick__);                  \
+        tick__ = __builtin_readcyclecounter();                                                     \
+    } while (0)
+#else
+#define KR_TICK(slot) do { } while (0)
+#endif
+
+__device__ __forceinline__ double dist2_d(double ax, double ay, double az, double bx, double by, double bz) {
+#pragma clang fp contract(off)
+    const double dx = ax - bx, dy = ay - by, dz = az - bz;
+    double t = dx * dx;
+    t = t + dy * dy;
+    t = t + dz * dz;
+    return t;
+}
+// compare-exchange on registers, ascending; equal keys keep their places (their order is settled afterwards)
+__device__ __forceinline__ void kr_ce(double &ka, int &pa, double &kb, int &pb) {
+    const bool sw = kb < ka;
+    const double lo = __builtin_fmin(ka, kb), hi = __builtin_fmax(ka, kb);  // (no NaNs here: distances and +inf padding)
+    const int plo = sw ? pb : pa, phi = sw ? pa : pb;
+    ka = lo; kb = hi; pa = plo; pb = phi;
+}
+// pca_estimate_normals.h:43-108 on k points held in registers (the arithmetic of normals_kernel)
+template <int MAXK>
+__device__ __forceinline__ void pca_normal_regs(const float (&px)[MAXK], const float (&py)[MAXK], const float (&pz)[MAXK], int k,
+                                                double &nx, double &ny, double &nz) {
+#pragma clang fp contract(off)
+    double cx = 0.0, cy = 0.0, cz = 0.0, sum = 0.0;
+#pragma unroll
+    for (int j = 0; j < MAXK; ++j)
+        if (j < k) { cx += (double)px[j]; cy += (double)py[j]; cz += (double)pz[j]; sum += 1.0; }
+    const double inv = 1.0 / sum;
+    cx *= inv; cy *= inv; cz *= inv;
+    double a00 = 0, a01 = 0, a02 = 0, a11 = 0, a12 = 0, a22 = 0, ws = 0;
+#pragma unroll
+    for (int j = 0; j < MAXK; ++j)
+        if (j < k) {
+            const double x = (double)px[j] - cx, y = (double)py[j] - cy, z = (double)pz[j] - cz;
+            a00 += x * x; a01 += x * y; a02 += x * z; a11 += y * y; a12 += y * z; a22 += z * z;
+            ws += 1.0;
+        }
+    const double t = 1.0 / ws;
+    a00 *= t; a01 *= t; a02 *= t; a11 *= t; a12 *= t; a22 *= t;
+    const double q = (a00 + a11 + a22) / 3.0;
+    double pq = (a00 - q) * (a00 - q) + (a11 - q) * (a11 - q) + (a22 - q) * (a22 - q) + 2.0 * (a01 * a01 + a02 * a02 + a12 * a12);
+    pq = sqrt(pq / 6.0);
+    const double mpq = pow(1.0 / pq, 3.0);
+    const double det_b = mpq * ((a00 - q) * ((a11 - q) * (a22 - q) - a12 * a12) - a01 * (a01 * (a22 - q) - a12 * a02) +
+                                a02 * (a01 * a12 - (a11 - q) * a02));
+    const double r = 0.5 * det_b;
+    double phi;
+    if (r <= -1.0) phi = 3.14159265358979323846 / 3.0;
+    else if (r >= 1.0) phi = 0.0;
+    else phi = acos(r) / 3.0;
+    const double eig = q + 2.0 * pq * cos(phi + 3.14159265358979323846 * (2.0 / 3.0));
+    nx = a01 * a12 - a02 * (a11 - eig);
+    ny = a01 * a02 - a12 * (a00 - eig);
+    nz = (a00 - eig) * (a11 - eig) - a01 * a01;
+    const double norm = sqrt(nx * nx + ny * ny + nz * nz);
+    if (norm == 0.0) { nx = 0.0; ny = 0.0; nz = 1.0; }
+    else { const double s = 1.0 / norm; nx *= s; ny *= s; nz *= s; }
+}
+
+// Walks the nine candidate runs of a block (lane r < 9 holds run r as [lo, hi)) through the wave's LDS tile, KR_U candidates
+// per step, coordinates relative to the wave origin.  The tile is three arrays (x, y, z) so that one broadcast ds_read_b128
+// brings the same coordinate of four candidates and packed float32 instructions work on them in pairs.  Every step is split
+// in two so that LDS latency stays off the critical path at two waves per SIMD:
+//     R = measure(index of the first, x[KR_U], y[KR_U], z[KR_U], how many are real)      registers only
+//     <the NEXT step's tile reads are issued here>
+//     commit(R)                                                                           the step's LDS writes / atomics
+// (LDS operations of a wave complete in order: reads issued before the commit's writes are not held up by them.)
+// The next 64 candidates are requested from global memory before the current 64 are used.
+constexpr int KR_U = 8;
+struct KrStep { float4 x[KR_U / 4], y[KR_U / 4], z[KR_U / 4]; };
+__device__ __forceinline__ void kr_read(const float *tile, int u, KrStep &t) {
+#pragma unroll
+    for (int v = 0; v < KR_U / 4; ++v) {
+        t.x[v] = *reinterpret_cast<const float4 *>(tile + u + 4 * v);
+        t.y[v] = *reinterpret_cast<const float4 *>(tile + 68 + u + 4 * v);
+        t.z[v] = *reinterpret_cast<const float4 *>(tile + 136 + u + 4 * v);
+    }
+}
+template <class R, class F1, class F2>
+__device__ __forceinline__ void kr_walk(const float4 *__restrict__ sorted, float *tile /* [3][64 + 4] */, int lo, int hi, double ox,
+                                        double oy, double oz, F1 &&measure, F2 &&commit) {
+    const int lane = lane_id();
+    // tiles of <= 64 candidates, run after run; the load of the NEXT tile (of this run or of the next non-empty one) is in
+    // flight while the current tile is consumed: nothing waits for global memory except the very first tile
+    int r = 0, s = 0, e = 0;
+    for (; r < 9; ++r) {
+        s = __builtin_amdgcn_readlane(lo, r);
+        e = __builtin_amdgcn_readlane(hi, r);
+        if (s < e) break;
+    }
+    if (r == 9) return;
+    int base = s;
+    float4 nxt = sorted[base + lane < e ? base + lane : e - 1];
+    while (r < 9) {
+        tile[lane] = (float)((double)nxt.x - ox);
+        tile[68 + lane] = (float)((double)nxt.y - oy);
+        tile[136 + lane] = (float)((double)nxt.z - oz);
+        const int cbase = base, m = e - base < 64 ? e - base : 64;
+        base += 64;
+        if (base >= e) {
+            for (++r; r < 9; ++r) {
+                s = __builtin_amdgcn_readlane(lo, r);
+                e = __builtin_amdgcn_readlane(hi, r);
+                if (s < e) break;
+            }
+            base = s;
+        }
+        {   // (unconditional on purpose: a load under `if (r < 9)` makes the compiler copy the loaded registers into the loop's
+            //  own right behind the load, i.e. wait for it at once, and the tile's latency is back on the critical path)
+            const int at = r < 9 ? (base + lane < e ? base + lane : e - 1) : 0;
+            nxt = sorted[at];
+        }
+        // two register sets used in turn (a single set would be copied from the prefetched one every step)
+        KrStep t0, t1;
+        kr_read(tile, 0, t0);
+        for (int u = 0; u < m; u += 2 * KR_U) {
+            {
+                const R res = measure(cbase + u, t0, m - u);
+                __builtin_amdgcn_sched_barrier(0);
+                if (u + KR_U < m) kr_read(tile, u + KR_U, t1);
+                __builtin_amdgcn_sched_barrier(0);
+                commit(res);
+            }
+            if (u + KR_U < m) {
+                const R res = measure(cbase + u + KR_U, t1, m - u - KR_U);
+                __builtin_amdgcn_sched_barrier(0);
+                if (u + 2 * KR_U < m) kr_read(tile, u + 2 * KR_U, t0);
+                __builtin_amdgcn_sched_barrier(0);
+                commit(res);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(KR_NW * 64, 2) void knn_lanes_kernel(KnnLanesArgs ra) {
+    __shared__ unsigned int s_hist[KR_NW][KR_NB * 64];
+    __shared__ unsigned int s_list[KR_NW][(KR_CAP + 1) * 64];  // (+ 1: the row predicated-off writes of pass 2 land in)
+    __shared__ __attribute__((aligned(16))) float s_tile[KR_NW][3 * 68];
+    const KnnArgs &a = ra.a;
+    const GridSpec g = a.g;
+    const int lane = lane_id(), wave = (int)(threadIdx.x >> 6);
+    unsigned int *hist = s_hist[wave] + lane, *list = s_list[wave] + lane;
+    float *tile = s_tile[wave];
+    const int64_t q = ((int64_t)blockIdx.x * KR_NW + wave) * 64 + lane;
+    const bool valid = q < a.n;
+    const int k = a.k;
+#ifdef F4L_KNN_PROF
+    unsigned long long tick__ = __builtin_readcyclecounter();
+#endif
+    const float4 qp = a.q_sorted[valid ? q : 0];
+    const int pc = ra.pcell[valid ? q : 0];
+    int cx, cy, cz;
+    cell_of(g, qp.x, qp.y, qp.z, cx, cy, cz);
+    const double qx = (double)qp.x, qy = (double)qp.y, qz = (double)qp.z;
+    // wave origin: the first query (the wave's queries and candidates lie within a few cells of it)
+    const double ox = (double)__int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(qp.x))),
+                 oy = (double)__int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(qp.y))),
+                 oz = (double)__int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(qp.z)));
+    const float rx = (float)(qx - ox), ry_ = (float)(qy - oy), rz_ = (float)(qz - oz);
+#pragma unroll
+    for (int b = 0; b < KR_NB; ++b) hist[b * 64] = 0u;
+    int cnt = 0;
+    bool fb = false;
+    unsigned long long remaining = __ballot(valid);
+    while (remaining != 0ULL) {  // one turn per (y, z) row of cells among the wave's queries: nearly always one
+        const int leader = __ffsll((long long)remaining) - 1;
+        const int ry = __builtin_amdgcn_readlane(cy, leader), rz = __builtin_amdgcn_readlane(cz, leader);
+        const bool mine = valid && cy == ry && cz == rz;
+        const unsigned long long act = __ballot(mine);
+        remaining &= ~act;
+        // the sorted order is x-fastest: the first / last lane of the row sit in its first / last cell; the runs come from
+        // the per-cell table (cell_runs_kernel)
+        const int c_first = __builtin_amdgcn_readlane(pc, __ffsll((long long)act) - 1);
+        const int c_last = __builtin_amdgcn_readlane(pc, 63 - __clzll((long long)act));
+        int lo = 0, hi = 0;
+        if (lane < 9) {
+            lo = ra.run_lo[9 * c_first + lane];
+            hi = ra.run_hi[9 * c_last + lane];
+        }
+        const unsigned int one = mine ? 1u : 0u;
+        KR_TICK(0);
+        // pass 1: per-lane histogram of the approximate d2 over the block's candidates
+        struct Bins { int addr[KR_U]; unsigned int inc[KR_U]; };
+        kr_walk<Bins>(a.sorted, tile, lo, hi, ox, oy, oz,
+            [&](int, const KrStep &t, int real) {
+                Bins o;
+#pragma unroll
+                for (int v = 0; v < KR_U / 4; ++v) {
+                    const float xs[4] = {t.x[v].x, t.x[v].y, t.x[v].z, t.x[v].w}, ys[4] = {t.y[v].x, t.y[v].y, t.y[v].z, t.y[v].w},
+                                zs[4] = {t.z[v].x, t.z[v].y, t.z[v].z, t.z[v].w};
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) {
+                        const float dx = xs[w] - rx, dy = ys[w] - ry_, dz = zs[w] - rz_;
+                        const float d2 = dx * dx + dy * dy + dz * dz;
+                        int b = (int)(__float_as_uint(d2) >> 21) - ra.bin_base;
+                        b = b < 0 ? 0 : (b > KR_NB - 1 ? KR_NB - 1 : b);
+                        o.addr[4 * v + w] = b * 64;
+                        o.inc[4 * v + w] = 4 * v + w < real ? one : 0u;
+                    }
+                }
+                return o;
+            },
+            [&](const Bins &o) {
+#pragma unroll
+                for (int w = 0; w < KR_U; ++w) atomicAdd(&hist[o.addr[w]], o.inc[w]);
+            });
+        KR_TICK(1);
+        // the first bin at which the count reaches k
+        int T = KR_NB;
+        unsigned int cum = 0u;
+#pragma unroll
+        for (int b = 0; b < KR_NB; ++b) {
+            const unsigned int h = hist[b * 64];
+            hist[b * 64] = 0u;
+            if (T == KR_NB && cum + h >= (unsigned int)k) T = b;
+            cum += h;
+        }
+        if (mine && T == KR_NB) fb = true;  // fewer than k points in the block
+        // upper edge of bin T, widened far beyond the float32 error of the wave-relative arithmetic; lanes of other rows: nothing
+        float edge = T >= KR_NB - 1 ? __builtin_inff() : __uint_as_float((unsigned int)(T + ra.bin_base + 1) << 21) * 1.0001f + ra.edge_slack;
+        edge = mine ? edge : -1.0f;
+        KR_TICK(2);
+        // pass 2: the candidates below it go to the lane's list (branch free: a lane that does not take a candidate writes
+        // it to the spare row)
+        struct Takes { int row[KR_U]; unsigned int index; };
+        kr_walk<Takes>(a.sorted, tile, lo, hi, ox, oy, oz,
+            [&](int c_index, const KrStep &t, int real) {
+                Takes o;
+                o.index = (unsigned int)c_index;
+#pragma unroll
+                for (int v = 0; v < KR_U / 4; ++v) {
+                    const float xs[4] = {t.x[v].x, t.x[v].y, t.x[v].z, t.x[v].w}, ys[4] = {t.y[v].x, t.y[v].y, t.y[v].z, t.y[v].w},
+                                zs[4] = {t.z[v].x, t.z[v].y, t.z[v].z, t.z[v].w};
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) {
+                        const float dx = xs[w] - rx, dy = ys[w] - ry_, dz = zs[w] - rz_;
+                        const float d2 = dx * dx + dy * dy + dz * dz;
+                        const bool take = d2 < edge && 4 * v + w < real;
+                        const int at = cnt < KR_CAP ? cnt : KR_CAP;
+                        o.row[4 * v + w] = (take ? at : KR_CAP) * 64;
+                        cnt += take ? 1 : 0;
+                    }
+                }
+                return o;
+            },
+            [&](const Takes &o) {
+#pragma unroll
+                for (int w = 0; w < KR_U; ++w) list[o.row[w]] = o.index + (unsigned int)w;
+            });
+    }
+    KR_TICK(3);
+    if (cnt > KR_CAP) { fb = true; cnt = KR_CAP; }
+
+    // the survivors, exact d2 from the float coordinates (dist2_exact: what the reference computes), sorted on registers
+    double key[KR_CAP];
+    int pay[KR_CAP];
+#pragma unroll
+    for (int j = 0; j < KR_CAP; ++j) {
+        const bool ok = j < cnt;
+        const unsigned int slot = ok ? list[j * 64] : 0u;
+        const float4 p = a.sorted[slot];
+        const double d = dist2_exact(p.x, p.y, p.z, qp.x, qp.y, qp.z);
+        key[j] = ok ? d : __builtin_inf();
+        pay[j] = ok ? __float_as_int(p.w) : 0x7fffffff;
+    }
+    KR_TICK(4);
+    // bitonic network of 64 with ascending comparators only (per merge size one mirrored stage, then the half-cleaners).
+    // Entries KR_CAP..63 would be +inf padding; in an all-ascending network the largest elements at the top never move, so
+    // every comparator that touches them is a no-op and is left out (and the padding needs no registers).
+#pragma unroll
+    for (int lm = 1; lm <= 6; ++lm) {
+#pragma unroll
+        for (int i = 0; i < 64; ++i) {
+            const int l = i ^ ((1 << lm) - 1);
+            if (l > i && l < KR_CAP) kr_ce(key[i], pay[i], key[l < KR_CAP ? l : 0], pay[l < KR_CAP ? l : 0]);
+        }
+#pragma unroll
+        for (int lj = lm - 2; lj >= 0; --lj) {
+#pragma unroll
+            for (int i = 0; i < 64; ++i) {
+                const int l = i ^ (1 << lj);
+                if (l > i && l < KR_CAP) kr_ce(key[i], pay[i], key[l < KR_CAP ? l : 0], pay[l < KR_CAP ? l : 0]);
+            }
+        }
+    }
+    KR_TICK(5);
+    // exactly equal distances (gridded or duplicated points): order by point index, like the wave-resident list
+    bool anyeq = false;
+#pragma unroll
+    for (int j = 0; j + 1 < KR_CAP; ++j) anyeq = anyeq | ((key[j] == key[j + 1]) & (pay[j] > pay[j + 1]));  // (padding: equal indices)
+    if (__ballot(anyeq) != 0ULL) {  // rare: odd-even transposition inside groups of equal keys until nothing moves
+        for (int pass = 0; pass < KR_CAP; ++pass) {
+            bool moved = false;
+#pragma unroll
+            for (int j = 0; j + 1 < KR_CAP; j += 2)
+            {
+                const bool sw = (key[j] == key[j + 1]) & (pay[j] > pay[j + 1]);
+                const int lo = sw ? pay[j + 1] : pay[j], hi = sw ? pay[j] : pay[j + 1];
+                pay[j] = lo; pay[j + 1] = hi; moved = moved | sw;
+            }
+#pragma unroll
+            for (int j = 1; j + 1 < KR_CAP; j += 2) {
+                const bool sw = (key[j] == key[j + 1]) & (pay[j] > pay[j + 1]);
+                const int lo = sw ? pay[j + 1] : pay[j], hi = sw ? pay[j] : pay[j + 1];
+                pay[j] = lo; pay[j + 1] = hi; moved = moved | sw;
+            }
+            if (__ballot(moved) == 0ULL) break;
+        }
+    }
+    // certified when the k-th distance lies strictly inside the searched block (faces at the grid border do not count)
+    double dk = __builtin_inf();
+#pragma unroll
+    for (int j = 0; j < KR_MAX_K; ++j)
+        if (j == k - 1) dk = key[j];
+    {
+        const double fx = (qx - g.minx) - (double)cx * g.h, fy = (qy - g.miny) - (double)cy * g.h, fz = (qz - g.minz) - (double)cz * g.h;
+        double margin = __builtin_inf();
+        const double eps = 1e-6 * g.h;
+        if (cx - 1 > 0) margin = fmin(margin, fx + g.h - eps);
+        if (cx + 1 < g.nx - 1) margin = fmin(margin, 2.0 * g.h - fx - eps);
+        if (cy - 1 > 0) margin = fmin(margin, fy + g.h - eps);
+        if (cy + 1 < g.ny - 1) margin = fmin(margin, 2.0 * g.h - fy - eps);
+        if (cz - 1 > 0) margin = fmin(margin, fz + g.h - eps);
+        if (cz + 1 < g.nz - 1) margin = fmin(margin, 2.0 * g.h - fz - eps);
+        if (!(dk < margin * margin)) fb = true;
+    }
+    fb = fb && valid;
+    {   // the uncertified queries go to the list of knn_listed_kernel (one counter update per wave)
+        const unsigned long long m = __ballot(fb);
+        if (m != 0ULL) {
+            const int leader = __ffsll((long long)m) - 1;
+            int base = 0;
+            if (lane == leader) base = atomicAdd(ra.fb_count, (int)__popcll(m));
+            base = __builtin_amdgcn_readlane(base, leader);
+            if (fb) ra.fb_list[base + (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u))] = (int32_t)q;
+        }
+    }
+    KR_TICK(6);
+    {   // neighbour rows: staged in LDS (the list's space) and written out two rows per instruction, 120 contiguous bytes each
+        // at k = 30, instead of 64 scattered dwords per instruction
+        unsigned int *stage = s_list[wave];
+        int *qid_of = reinterpret_cast<int *>(s_tile[wave]);
+        qid_of[lane] = valid && !fb ? __float_as_int(qp.w) : -1;
+#pragma unroll
+        for (int j = 0; j < KR_MAX_K; ++j)
+            if (j < k) stage[lane * k + j] = (unsigned int)pay[j];
+        const float inv_k = 1.0f / (float)k;
+        for (int t = lane; t < 64 * k; t += 64) {
+            const int r = (int)(((float)t + 0.5f) * inv_k), c = t - r * k;
+            const int id = qid_of[r];
+            if (id >= 0) a.idx_out[(int64_t)id * k + c] = (int32_t)stage[t];
+        }
+    }
+    if (!valid || fb) return;
+    const int64_t row = (int64_t)__float_as_int(qp.w) * k;
+    if (a.d2_out) {
+#pragma unroll
+        for (int j = 0; j < KR_MAX_K; ++j)
+            if (j < k) a.d2_out[row + j] = key[j];
+    }
+    if (ra.normals_out) {
+        float px[KR_MAX_K], py[KR_MAX_K], pz[KR_MAX_K];
+#pragma unroll
+        for (int j = 0; j < KR_MAX_K; ++j) {
+            const int64_t id = j < k ? pay[j] : pay[0];
+            px[j] = ra.xyz[3 * id]; py[j] = ra.xyz[3 * id + 1]; pz[j] = ra.xyz[3 * id + 2];
+        }
+        double nx, ny, nz;
+        pca_normal_regs<KR_MAX_K>(px, py, pz, k, nx, ny, nz);
+        double *o = ra.normals_out + 3 * (int64_t)__float_as_int(qp.w);
+        o[0] = nx; o[1] = ny; o[2] = nz;
+    }
+    KR_TICK(7);
+}
+
 // ---- PCA normals (pca_estimate_normals.h:43-108, unit weights), one thread per point ----------------
 #pragma clang fp contract(off)
-__global__ void normals_kernel(const float *__restrict__ xyz, int64_t n, const int32_t *__restrict__ knn, int k,
-                               double *__restrict__ normals) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int32_t *nb = knn + i * k;
+__device__ __forceinline__ void pca_normal_row(const float *__restrict__ xyz, const int32_t *__restrict__ nb, int k, double *__restrict__ out) {
     double cx = 0.0, cy = 0.0, cz = 0.0, sum = 0.0;
     for (int j = 0; j < k; ++j) {
         const int64_t q = nb[j];
@@ -288,7 +788,22 @@ __global__ void normals_kernel(const float *__restrict__ xyz, int64_t n, const i
     const double norm = sqrt(nx * nx + ny * ny + nz * nz);
     if (norm == 0.0) { nx = 0.0; ny = 0.0; nz = 1.0; }
     else { const double s = 1.0 / norm; nx *= s; ny *= s; nz *= s; }
-    normals[3 * i] = nx; normals[3 * i + 1] = ny; normals[3 * i + 2] = nz;
+    out[0] = nx; out[1] = ny; out[2] = nz;
+}
+__global__ void normals_kernel(const float *__restrict__ xyz, int64_t n, const int32_t *__restrict__ knn, int k,
+                               double *__restrict__ normals) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    pca_normal_row(xyz, knn + i * k, k, normals + 3 * i);
+}
+__global__ void normals_listed_kernel(const float *__restrict__ xyz, const float4 *__restrict__ q_sorted, const int32_t *__restrict__ list,
+                                      const int32_t *__restrict__ count, const int32_t *__restrict__ knn, int k,
+                                      double *__restrict__ normals) {
+    const int m = *count;
+    for (int i = (int)(blockIdx.x * blockDim.x + threadIdx.x); i < m; i += (int)(gridDim.x * blockDim.x)) {
+        const int64_t id = __float_as_int(q_sorted[list[i]].w);
+        pca_normal_row(xyz, knn + id * k, k, normals + 3 * id);
+    }
 }
 
 __global__ void iota_kernel(int32_t *v, int64_t n) {
@@ -312,6 +827,7 @@ struct KnnWs {
     unsigned long long *keys_a, *keys_b, *cell_keys;
     int32_t *ids_a, *ids_b, *cell_counts, *cell_start, *n_cells;
     float4 *sorted;
+    int32_t *fb_list, *fb_count, *run_lo, *run_hi, *pcell;
     float *bbox_partial;
     void *prim_temp;
     size_t prim_bytes, total;
@@ -323,6 +839,14 @@ static int knn_ws_layout(int64_t n, KnnWs &w, unsigned char *base) {
     int32_t *i0 = nullptr;
     if (rocprim::radix_sort_pairs(nullptr, sort_b, k0, k0, i0, i0, (size_t)n, 0, 64, 0, false) != hipSuccess) return F4L_EHIP;
     if (rocprim::run_length_encode(nullptr, rle_b, k0, (unsigned int)n, k0, i0, i0, 0, false) != hipSuccess) return F4L_EHIP;
+    {
+        size_t s32 = 0, r32 = 0;
+        unsigned int *q0 = nullptr;
+        if (rocprim::radix_sort_pairs(nullptr, s32, q0, q0, i0, i0, (size_t)n, 0, 32, 0, false) != hipSuccess) return F4L_EHIP;
+        if (rocprim::run_length_encode(nullptr, r32, q0, (unsigned int)n, q0, i0, i0, 0, false) != hipSuccess) return F4L_EHIP;
+        sort_b = sort_b > s32 ? sort_b : s32;
+        rle_b = rle_b > r32 ? rle_b : r32;
+    }
     if (rocprim::exclusive_scan(nullptr, scan_b, i0, i0, 0, (size_t)n + 1, rocprim::plus<int32_t>(), 0, false) != hipSuccess) return F4L_EHIP;
     size_t prim = sort_b > rle_b ? sort_b : rle_b;
     prim = prim > scan_b ? prim : scan_b;
@@ -337,6 +861,11 @@ static int knn_ws_layout(int64_t n, KnnWs &w, unsigned char *base) {
     w.cell_start = (int32_t *)carve(((size_t)n + 1) * 4);
     w.n_cells = (int32_t *)carve(256);
     w.sorted = (float4 *)carve((size_t)n * 16);
+    w.fb_list = (int32_t *)carve((size_t)n * 4);
+    w.fb_count = (int32_t *)carve(256);
+    w.run_lo = (int32_t *)carve((size_t)n * 9 * 4);
+    w.run_hi = (int32_t *)carve((size_t)n * 9 * 4);
+    w.pcell = (int32_t *)carve((size_t)n * 4);
     w.bbox_partial = (float *)carve(256 * 6 * 4);
     w.prim_temp = carve(prim);
     w.prim_bytes = prim;
@@ -403,19 +932,36 @@ static int knn_build_grid(const float *xyz, int64_t n, int k, KnnWs &w, hipStrea
         const double hmin = (e[2] > 0 ? e[2] : 1.0) / 1048000.0;
         if (h < hmin) h = hmin;
         g.minx = mn[0]; g.miny = mn[1]; g.minz = mn[2];
-        g.h = h; g.inv_h = 1.0 / h;
+        g.h = h; g.inv_h = 1.0 / h; g.inv_hz = g.inv_h;
         g.nx = (int)(ext[0] / h) + 1; g.ny = (int)(ext[1] / h) + 1; g.nz = (int)(ext[2] / h) + 1;
-        hipLaunchKernelGGL(cell_key_kernel, dim3(grid_for(n)), dim3(256), 0, st, xyz, n, g, w.keys_a, w.ids_a);
-        F4L_LAUNCH_CHECK();
+        // A cloud that is flat along z (terrain: the case this library is for) gets ONE layer of cells: with cubic cells a
+        // row of cells at fixed (y, z) breaks wherever the surface leaves the layer, and the lane-per-query kernel, whose
+        // waves take consecutive points of a row, would see candidate runs 1.8x longer than needed (measured).  The search
+        // stays exact for any cell shape: z then never limits a block.
+        if (g.nz > 1 && 5 * g.nz < (g.nx < g.ny ? g.nx : g.ny)) { g.nz = 1; g.inv_hz = 0.0; }
         const double ncell = (double)g.nx * (double)g.ny * (double)g.nz;
         int end_bit = 1;
         while (end_bit < 63 && (double)(1ULL << end_bit) < ncell) ++end_bit;
         size_t tb = w.prim_bytes;
-        F4L_HIP_CHECK(rocprim::radix_sort_pairs(w.prim_temp, tb, w.keys_a, w.keys_b, w.ids_a, w.ids_b, (size_t)n, 0,
-                                                (unsigned)end_bit, st, false));
-        tb = w.prim_bytes;
-        F4L_HIP_CHECK(rocprim::run_length_encode(w.prim_temp, tb, w.keys_b, (unsigned int)n, w.cell_keys, w.cell_counts,
-                                                 w.n_cells, st, false));
+        if (end_bit <= 32) {
+            unsigned int *k32a = reinterpret_cast<unsigned int *>(w.keys_a), *k32b = reinterpret_cast<unsigned int *>(w.keys_b);
+            unsigned int *u32 = k32b + n;  // (second half of the 64-bit buffer)
+            hipLaunchKernelGGL(cell_key32_kernel, dim3(grid_for(n)), dim3(256), 0, st, xyz, n, g, k32a, w.ids_a);
+            F4L_LAUNCH_CHECK();
+            F4L_HIP_CHECK(rocprim::radix_sort_pairs(w.prim_temp, tb, k32a, k32b, w.ids_a, w.ids_b, (size_t)n, 0, (unsigned)end_bit, st, false));
+            tb = w.prim_bytes;
+            F4L_HIP_CHECK(rocprim::run_length_encode(w.prim_temp, tb, k32b, (unsigned int)n, u32, w.cell_counts, w.n_cells, st, false));
+            hipLaunchKernelGGL(widen_keys_kernel, dim3(256), dim3(256), 0, st, u32, w.n_cells, w.cell_keys);
+            F4L_LAUNCH_CHECK();
+        } else {
+            hipLaunchKernelGGL(cell_key_kernel, dim3(grid_for(n)), dim3(256), 0, st, xyz, n, g, w.keys_a, w.ids_a);
+            F4L_LAUNCH_CHECK();
+            F4L_HIP_CHECK(rocprim::radix_sort_pairs(w.prim_temp, tb, w.keys_a, w.keys_b, w.ids_a, w.ids_b, (size_t)n, 0,
+                                                    (unsigned)end_bit, st, false));
+            tb = w.prim_bytes;
+            F4L_HIP_CHECK(rocprim::run_length_encode(w.prim_temp, tb, w.keys_b, (unsigned int)n, w.cell_keys, w.cell_counts,
+                                                     w.n_cells, st, false));
+        }
         F4L_HIP_CHECK(hipMemcpyAsync(&M, w.n_cells, 4, hipMemcpyDeviceToHost, st));
         F4L_HIP_CHECK(hipStreamSynchronize(st));
         if (M <= 0) return F4L_EHIP;
@@ -438,13 +984,16 @@ static int knn_build_grid(const float *xyz, int64_t n, int k, KnnWs &w, hipStrea
 }
 }  // namespace f4l
 
-// Synchronises `stream` (the bounding box and the occupied-cell count are read back to size the grid).
-extern "C" int f4l_knn(const float *xyz, int64_t n, int k, int32_t *idx_out, double *d2_out, void *workspace,
-                       size_t workspace_bytes, void *stream) {
-    using namespace f4l;
+namespace f4l {
+// normals of listed queries from their finished neighbour rows (the queries knn_listed_kernel redid)
+__global__ void normals_listed_kernel(const float *__restrict__ xyz, const float4 *__restrict__ q_sorted, const int32_t *__restrict__ list,
+                                      const int32_t *__restrict__ count, const int32_t *__restrict__ knn, int k,
+                                      double *__restrict__ normals);
+
+static int knn_self(const float *xyz, int64_t n, int k, int32_t *idx_out, double *d2_out, double *normals_out, void *workspace,
+                    size_t workspace_bytes, hipStream_t st) {
     if (!xyz || n <= 0 || k < 1 || k > n || !idx_out || !workspace) return F4L_EINVAL;
     if (k > F4L_MAX_K || n > 0x7fffffffLL) return F4L_EUNSUPPORTED;
-    hipStream_t st = (hipStream_t)stream;
     KnnWs w;
     int rc = knn_ws_layout(n, w, (unsigned char *)workspace);
     if (rc != F4L_OK) return rc;
@@ -453,14 +1002,76 @@ extern "C" int f4l_knn(const float *xyz, int64_t n, int k, int32_t *idx_out, dou
     int M = 0;
     rc = knn_build_grid(xyz, n, k, w, st, g, M);
     if (rc != F4L_OK) return rc;
-    // 5. one wave per occupied cell
     KnnArgs a;
     a.sorted = w.sorted; a.cell_keys = w.cell_keys; a.cell_start = w.cell_start; a.M = M; a.n = n; a.k = k; a.g = g;
     a.q_sorted = w.sorted; a.q_cell_keys = w.cell_keys; a.q_cell_start = w.cell_start; a.Mq = M;
     a.idx_out = idx_out; a.d2_out = d2_out;
-    hipLaunchKernelGGL(knn_cells_kernel, dim3((unsigned)((M + KNN_NW - 1) / KNN_NW)), dim3(KNN_NW * 64), 0, st, a);
+    const bool lanes = k <= KR_MAX_K && !getenv("F4L_KNN_WAVE_PER_QUERY");  // (switch: A/B timing, and the test that both agree)
+    if (!lanes) {
+        // one wave per occupied cell, its queries one after the other
+        hipLaunchKernelGGL(knn_cells_kernel, dim3((unsigned)((M + KNN_NW - 1) / KNN_NW)), dim3(KNN_NW * 64), 0, st, a);
+        F4L_LAUNCH_CHECK();
+        if (normals_out) {
+            hipLaunchKernelGGL(normals_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, xyz, n, idx_out, k, normals_out);
+            F4L_LAUNCH_CHECK();
+        }
+        return F4L_OK;
+    }
+    // one lane per query; the queries it cannot certify are listed and redone one wave each
+    F4L_HIP_CHECK(hipMemsetAsync(w.fb_count, 0, 4, st));
+    hipLaunchKernelGGL(cell_runs_kernel, dim3((unsigned)((9 * (int64_t)M + 255) / 256)), dim3(256), 0, st, w.cell_keys, w.cell_start, M,
+                       g, w.run_lo, w.run_hi, w.pcell);
     F4L_LAUNCH_CHECK();
+    KnnLanesArgs ra;
+    ra.run_lo = w.run_lo; ra.run_hi = w.run_hi; ra.pcell = w.pcell;
+    ra.prof = nullptr;
+#ifdef F4L_KNN_PROF
+    ra.prof = (unsigned long long *)(w.fb_count + 8);  // (the counter's 256-byte slot has room: 8 phases)
+    F4L_HIP_CHECK(hipMemsetAsync(w.fb_count + 8, 0, 64, st));
+#endif
+    ra.a = a; ra.edge_slack = (float)(1e-6 * g.h * g.h); ra.fb_list = w.fb_list; ra.fb_count = w.fb_count; ra.xyz = xyz; ra.normals_out = normals_out;
+    {
+        const float top = (float)(4.0 * g.h * g.h);  // d2 = (2 h)^2 falls into the last bin
+        unsigned int bits;
+        memcpy(&bits, &top, 4);
+        ra.bin_base = (int)(bits >> 21) - (KR_NB - 1);
+    }
+    hipLaunchKernelGGL(knn_lanes_kernel, dim3((unsigned)((n + KR_NW * 64 - 1) / (KR_NW * 64))), dim3(KR_NW * 64), 0, st, ra);
+    F4L_LAUNCH_CHECK();
+    hipLaunchKernelGGL(knn_listed_kernel, dim3(2048), dim3(KNN_NW * 64), 0, st, a, w.fb_list, w.fb_count);
+    F4L_LAUNCH_CHECK();
+#ifdef F4L_KNN_PROF
+    {
+        unsigned long long hp[8];
+        int fbc = 0;
+        F4L_HIP_CHECK(hipMemcpyAsync(hp, w.fb_count + 8, 64, hipMemcpyDeviceToHost, st));
+        F4L_HIP_CHECK(hipMemcpyAsync(&fbc, w.fb_count, 4, hipMemcpyDeviceToHost, st));
+        F4L_HIP_CHECK(hipStreamSynchronize(st));
+        const double waves = (double)((n + 63) / 64);
+        fprintf(stderr, "[knn prof] n=%lld k=%d cells=%d redone=%d | cycles per wave: setup %.0f pass1 %.0f thr %.0f pass2 %.0f load %.0f sort %.0f ties+check %.0f out %.0f\n",
+                (long long)n, k, M, fbc, hp[0] / waves, hp[1] / waves, hp[2] / waves, hp[3] / waves, hp[4] / waves, hp[5] / waves, hp[6] / waves, hp[7] / waves);
+    }
+#endif
+    if (normals_out) {
+        hipLaunchKernelGGL(normals_listed_kernel, dim3(256), dim3(256), 0, st, xyz, w.sorted, w.fb_list, w.fb_count, idx_out, k, normals_out);
+        F4L_LAUNCH_CHECK();
+    }
     return F4L_OK;
+}
+}  // namespace f4l
+
+// Synchronises `stream` (the bounding box and the occupied-cell count are read back to size the grid).
+extern "C" int f4l_knn(const float *xyz, int64_t n, int k, int32_t *idx_out, double *d2_out, void *workspace,
+                       size_t workspace_bytes, void *stream) {
+    return f4l::knn_self(xyz, n, k, idx_out, d2_out, nullptr, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+// f4l_knn with the PCA normal of every point's neighbour list (f4l_normals) computed in the same kernel, while the
+// neighbours are in registers: supervoxel.cpp:105-113 in one launch.
+extern "C" int f4l_knn_normals(const float *xyz, int64_t n, int k, int32_t *idx_out, double *d2_out, double *normals_out,
+                               void *workspace, size_t workspace_bytes, void *stream) {
+    if (!normals_out) return F4L_EINVAL;
+    return f4l::knn_self(xyz, n, k, idx_out, d2_out, normals_out, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 // ---- k nearest points of ANOTHER cloud --------------------------------------------------------------------------

@@ -389,9 +389,7 @@ extern "C" int f4l_supervoxel(const float *xyz, int64_t n, int k, double resolut
     double *nrm = normals_out ? normals_out : (double *)(base + knn_ws + idx_b);
     double *d_dis = (double *)(base + knn_ws + idx_b + nrm_b);
     uint8_t *d_flag = (uint8_t *)(base + knn_ws + idx_b + nrm_b + dis_b);
-    int rc = f4l_knn(xyz, n, k, idx, nullptr, workspace, knn_ws, stream);
-    if (rc != F4L_OK) return rc;
-    rc = f4l_normals(xyz, n, idx, k, nrm, stream);
+    int rc = f4l_knn_normals(xyz, n, k, idx, nullptr, nrm, workspace, knn_ws, stream);
     if (rc != F4L_OK) return rc;
     // the starting lambda's sweep (smallest metric to a neighbour, per point) on the device
     hipLaunchKernelGGL(f4l::sv_min_metric_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, xyz, nrm, idx, n, k,

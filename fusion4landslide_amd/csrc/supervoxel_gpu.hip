@@ -595,9 +595,7 @@ extern "C" int f4l_supervoxel_parallel(const float *xyz, int64_t n, int k, doubl
     unsigned char *base = (unsigned char *)workspace;
     int32_t *idx = knn_out ? knn_out : (int32_t *)(base + shared);
     double *nrm = normals_out ? normals_out : (double *)(base + shared + idx_b);
-    int rc = f4l_knn(xyz, n, k, idx, nullptr, workspace, a, stream);
-    if (rc != F4L_OK) return rc;
-    rc = f4l_normals(xyz, n, idx, k, nrm, stream);
+    int rc = f4l_knn_normals(xyz, n, k, idx, nullptr, nrm, workspace, a, stream);
     if (rc != F4L_OK) return rc;
     return f4l_supervoxel_segment_device(xyz, nrm, idx, n, k, resolution, labels_out, reps_out, info_out, workspace, s, stream);
 }

@@ -297,6 +297,22 @@ def knn(xyz, k, return_d2=False):
     return (idx, d2) if return_d2 else idx
 
 
+def knn_normals(xyz, k, return_d2=False):
+    """Exact kNN and the PCA normal of every neighbour list in ONE launch (f4l_knn_normals; supervoxel.cpp:105-113)
+    -> (n, k) int32, (n, 3) float64[, (n, k) f64]."""
+    torch = require_gpu()
+    xyz = _dev(xyz, torch.float32, "xyz", (3,))
+    n = xyz.shape[0]
+    idx = torch.empty((n, k), dtype=torch.int32, device=xyz.device)
+    nrm = torch.empty((n, 3), dtype=torch.float64, device=xyz.device)
+    d2 = torch.empty((n, k), dtype=torch.float64, device=xyz.device) if return_d2 else None
+    nbytes = lib().f4l_knn_workspace_bytes(n, k)
+    ws = torch.empty((max(int(nbytes), 1),), dtype=torch.uint8, device=xyz.device)
+    check(lib().f4l_knn_normals(ptr(xyz), n, int(k), ptr(idx), ptr(d2), ptr(nrm), ptr(ws), C.c_size_t(nbytes), stream_ptr()),
+          "f4l_knn_normals")
+    return (idx, nrm, d2) if return_d2 else (idx, nrm)
+
+
 def nn_query(cloud, queries, k=1, return_d2=False):
     """The k nearest points of `cloud` for every query point -- `cKDTree(cloud).query(queries, k)` as used by
     `_voxel_subsampling` (src/coarse_to_fine_matching_base.py:1042-1046) -> (m, k) int32[, (m, k) f64 squared]."""

@@ -202,6 +202,12 @@ size_t f4l_knn_workspace_bytes(int64_t n, int k);
 int f4l_knn(const float *xyz, int64_t n, int k, int32_t *idx_out, double *d2_out, void *workspace,
             size_t workspace_bytes, void *stream);
 int f4l_normals(const float *xyz, int64_t n, const int32_t *knn_idx, int k, double *normals_out, void *stream);
+/* f4l_knn and f4l_normals in one launch (supervoxel.cpp:105-113: the loop that finds the neighbours AND estimates the
+ * normal of every point): the normal is computed while the neighbour list is still in registers, which saves the 120 B per
+ * point the separate pass re-reads and its scattered gathers.  Same results as the two calls.  Synchronises `stream` once
+ * (grid sizing, like f4l_knn). */
+int f4l_knn_normals(const float *xyz, int64_t n, int k, int32_t *idx_out, double *d2_out, double *normals_out,
+                    void *workspace, size_t workspace_bytes, void *stream);
 size_t f4l_supervoxel_workspace_bytes(int64_t n, int k);
 int f4l_supervoxel(const float *xyz, int64_t n, int k, double resolution, int32_t *labels_out,
                    int32_t *n_supervoxels_host, int32_t *knn_out, double *normals_out, void *workspace,

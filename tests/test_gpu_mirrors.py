@@ -100,6 +100,15 @@ def test_compute_supervoxel_shim_and_partition_file(golden_dir, tmp_path):
     assert np.array_equal(np.asarray(ret2), labels)
     with pytest.raises(ValueError):
         supervoxel.computeSupervoxel(ply, 2000, 0.1)
+    # the all-device mode behind the same call: same K, a valid partition file, not the reference's labels
+    supervoxel.SEGMENTATION = "parallel"
+    try:
+        ret3 = np.asarray(supervoxel.computeSupervoxel(ply, int(g["k"]), float(g["resolution"]), out_txt))
+    finally:
+        supervoxel.SEGMENTATION = "identical"
+    assert ret3.shape == (2000,) and ret3.min() == 0 and ret3.max() == int(g["n_supervoxels"]) - 1
+    assert len(np.unique(ret3)) == int(g["n_supervoxels"])
+    assert np.array_equal(np.loadtxt(out_txt)[:, 6].astype(np.int64), ret3)
 
 
 def test_piecewise_icp_entry_writes_reference_files(tmp_path):

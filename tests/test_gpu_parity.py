@@ -614,6 +614,44 @@ def test_knn_edge_cases(eng):
         eng.knn(dev(tiny), 65)
 
 
+def test_knn_lane_per_query_equals_wave_per_query(eng, monkeypatch):
+    """f4l_knn's fast path (one lane per query: scalar-loaded candidates, per-lane d2 histogram, survivors sorted on
+    registers; uncertified queries redone one wave each) against the wave-per-query search it replaced: identical indices
+    and bit-equal d2 -- on a surface, a volume, a lattice (exact ties everywhere), duplicated points (more ties than the
+    survivor list holds: the fallback), a cloud with sparse outliers (queries whose block is too small), and k up to the
+    fast path's limit.  The fused normals equal f4l_normals on the same lists bit for bit."""
+    rng = np.random.default_rng(3)
+    surf = np.c_[rng.uniform(0, 20, (120_000, 2)), np.zeros(120_000)]
+    surf[:, 2] = np.sin(surf[:, 0]) * np.cos(0.7 * surf[:, 1]) + rng.normal(0, 0.004, 120_000)
+    vol = rng.uniform(0, 3, (60_000, 3))
+    gx = np.arange(40, dtype=np.float64) * 0.25
+    lattice = np.stack(np.meshgrid(gx, gx, gx[:12], indexing="ij"), -1).reshape(-1, 3)
+    dup = np.repeat(rng.uniform(0, 2, (400, 3)), 60, axis=0)  # every point 60 times: 59 exact zero distances
+    sparse = np.concatenate([rng.uniform(0, 1, (30_000, 3)) * [5, 5, 0.05], rng.uniform(-40, 40, (300, 3))])
+    georef = surf + np.array([2.6e6, 1.2e6, 1500.0])  # Swiss-grid magnitudes: float32 spacing 0.25 m in x
+    cases = [("surface", surf, 30), ("volume", vol, 30), ("lattice", lattice, 27), ("duplicates", dup, 30), ("sparse", sparse, 30),
+             ("georef", georef, 30), ("k=1", vol, 1), ("k=40", surf[:30_000], 40), ("k=41 (wave path only)", surf[:30_000], 41)]
+    for name, pts, k in cases:
+        xyz = dev(pts.astype(np.float32))
+        monkeypatch.delenv("F4L_KNN_WAVE_PER_QUERY", raising=False)
+        idx, nrm, d2 = eng.knn_normals(xyz, k, return_d2=True)
+        idx2, d2b = eng.knn(xyz, k, return_d2=True)
+        monkeypatch.setenv("F4L_KNN_WAVE_PER_QUERY", "1")
+        ridx, rd2 = eng.knn(xyz, k, return_d2=True)
+        monkeypatch.delenv("F4L_KNN_WAVE_PER_QUERY")
+        assert torch.equal(d2, rd2) and torch.equal(d2b, rd2), name
+        assert torch.equal(idx, ridx) and torch.equal(idx2, ridx), name
+        assert torch.equal(nrm, eng.normals(xyz, ridx)) or bool((torch.isnan(nrm) == torch.isnan(eng.normals(xyz, ridx))).all()), name
+        ok = ~torch.isnan(nrm)
+        assert torch.equal(nrm[ok], eng.normals(xyz, ridx)[ok]), name
+    # against the CPU oracle on a sample (the wave path is pinned by the golden vectors; this pins the whole chain once more)
+    pts = surf[:20_000].astype(np.float32)
+    idx, d2 = eng.knn(dev(pts), 30, return_d2=True)
+    oi, od = O.knn(pts, 30)
+    ok, bad = knn_equal_within_ties(idx.cpu().numpy(), oi, d2.cpu().numpy(), od)
+    assert ok, bad
+
+
 def test_labels_to_csr_and_gather(eng):
     rng = np.random.default_rng(4)
     K, n = 37, 5000

@@ -1,0 +1,18 @@
+import os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from fusion4landslide_amd import engine, synthetic
+d = synthetic.make_patches_device(1_000_000, 45, 1.386, torch.device("cuda"), seed=0)
+xyz = d["src"]
+for _ in range(3): engine.knn(xyz, 30)
+torch.cuda.synchronize()
+ts = []
+for _ in range(10):
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record(); engine.knn(xyz, 30); b.record(); torch.cuda.synchronize(); ts.append(a.elapsed_time(b))
+print("f4l_knn 1M k=30: min %.3f ms median %.3f ms" % (min(ts), sorted(ts)[5]))
+ts = []
+for _ in range(10):
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record(); engine.knn_normals(xyz, 30); b.record(); torch.cuda.synchronize(); ts.append(a.elapsed_time(b))
+print("f4l_knn_normals 1M k=30: min %.3f ms median %.3f ms" % (min(ts), sorted(ts)[5]))
