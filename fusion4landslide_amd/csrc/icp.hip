@@ -66,6 +66,11 @@ struct IcpArgs {
     const int64_t *corr_off;
     double kabsch_w_thresh, kabsch_eps;
     float *rows_out;
+    // rows for another cloud than the one ICP runs on (the reference registers the MUTUAL points of a patch match and applies
+    // the transform to ALL points of the source patch, src/coarse_to_fine_matching_base.py:3348-3374); null: the ICP cloud
+    const float *rows_src;
+    const int64_t *rows_off;
+    int64_t min_corr;  // patch matches with fewer correspondences are skipped (:3338, `num_min_fine_match`)
     const float *tgt_normals;
     double r, r2;
     int max_iter;
@@ -267,7 +272,9 @@ __global__ __launch_bounds__(NW * 64, sizeof(F) == 8 ? ICP_WAVES_PER_EU_F64 : IC
     const int ns = (int)(a.src_off[p + 1] - s0), nt = (int)(a.tgt_off[p + 1] - t0);
     const float *__restrict__ sg = a.src + 3 * s0;
     const float *__restrict__ tg = a.tgt + 3 * t0;
-    const bool active = ns > 0 && a.r2 > 0.0;  // o3d returns the init untouched when max_corr_dist <= 0
+    // a patch match with too few correspondences is not registered at all (:3338-3436: `mask_spt_match_global[i] = False`)
+    const bool skipped = a.corr_off != nullptr && a.corr_off[p + 1] - a.corr_off[p] < a.min_corr;
+    const bool active = ns > 0 && a.r2 > 0.0 && !skipped;  // o3d returns the init untouched when max_corr_dist <= 0
     const bool tgt_in_lds = nt > 0 && nt <= a.tgt_cap;
     const bool use_cert = tgt_in_lds && ns <= a.cert_cap && !(a.debug & 4);
     const bool src_in_lds = ns <= a.src_cap;
@@ -336,7 +343,7 @@ __global__ __launch_bounds__(NW * 64, sizeof(F) == 8 ? ICP_WAVES_PER_EU_F64 : IC
     const bool fused_init = a.corr_off != nullptr;
     if (fused_init) {
         const int64_t c0 = a.corr_off[p];
-        const int nc = (int)(a.corr_off[p + 1] - c0);
+        const int nc = skipped ? 0 : (int)(a.corr_off[p + 1] - c0);
         const float *__restrict__ ks = a.corr_src + 3 * c0, *__restrict__ kr = a.corr_ref + 3 * c0;
         const float *__restrict__ kw = a.corr_w ? a.corr_w + c0 : nullptr;
         double s7[7] = {0, 0, 0, 0, 0, 0, 0};
@@ -788,7 +795,7 @@ __global__ __launch_bounds__(NW * 64, sizeof(F) == 8 ? ICP_WAVES_PER_EU_F64 : IC
         for (int i = 0; i < 9; ++i) Rc[i] = state[i];
         tc[0] = state[9]; tc[1] = state[10]; tc[2] = state[11];
         const double fitness = state[13], rmse = state[14];
-        const int iters = (int)state[15];
+        const int iters = skipped ? -1 : (int)state[15];
         double *T = a.T_out + 16 * p;
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
@@ -804,7 +811,7 @@ __global__ __launch_bounds__(NW * 64, sizeof(F) == 8 ? ICP_WAVES_PER_EU_F64 : IC
     }
     if (!active && a.corr_out)
         for (int i = tid; i < ns; i += NT) a.corr_out[s0 + i] = -1;
-    if (a.rows_out) {
+    if (a.rows_out && !skipped) {
         // fused displacement rows [s, T s] (src/coarse_to_fine_matching_base.py:3371-3374,3408): the arithmetic of
         // apply_transform_kernel on the global 4x4 this thread rebuilds from the final LDS state
         const double o0 = ox, o1 = oy, o2 = oz;
@@ -814,9 +821,12 @@ __global__ __launch_bounds__(NW * 64, sizeof(F) == 8 ? ICP_WAVES_PER_EU_F64 : IC
         tr[0] = state[9] - (r[0] * o0 + r[1] * o1 + r[2] * o2) + o0;
         tr[1] = state[10] - (r[3] * o0 + r[4] * o1 + r[5] * o2) + o1;
         tr[2] = state[11] - (r[6] * o0 + r[7] * o1 + r[8] * o2) + o2;
-        float *__restrict__ out6 = a.rows_out + 6 * s0;
-        for (int i = tid; i < ns; i += NT) {
-            const float xf = sg[3 * i], yf = sg[3 * i + 1], zf = sg[3 * i + 2];
+        const int64_t w0 = a.rows_off ? a.rows_off[p] : s0;
+        const int nrow = a.rows_off ? (int)(a.rows_off[p + 1] - w0) : ns;
+        const float *__restrict__ wg = a.rows_src ? a.rows_src + 3 * w0 : sg;
+        float *__restrict__ out6 = a.rows_out + 6 * w0;
+        for (int i = tid; i < nrow; i += NT) {
+            const float xf = wg[3 * i], yf = wg[3 * i + 1], zf = wg[3 * i + 2];
             const double x = xf, y = yf, z = zf;
             float *o6 = out6 + 6 * i;
             o6[0] = xf; o6[1] = yf; o6[2] = zf;
@@ -957,6 +967,9 @@ struct IcpFusedExtra {
     const int64_t *corr_off = nullptr;
     double w_thresh = 0.0, eps = 1e-7;
     float *rows_out = nullptr;
+    const float *rows_src = nullptr;
+    const int64_t *rows_off = nullptr;
+    int64_t min_corr = 0;
 };
 static int icp_launch_host(const float *src, const int64_t *src_off, const float *tgt, const int64_t *tgt_off,
                            int64_t P, const double *init_T, const float *tgt_normals, double max_corr_dist,
@@ -979,16 +992,19 @@ extern "C" int f4l_piecewise_icp(const float *src, const int64_t *src_off, const
 
 extern "C" int f4l_patch_loop(const float *src, const int64_t *src_off, const float *tgt, const int64_t *tgt_off,
                               int64_t P, const float *corr_src, const float *corr_ref, const float *corr_w,
-                              const int64_t *corr_off, double kabsch_w_thresh, double kabsch_eps,
+                              const int64_t *corr_off, int64_t min_corr, double kabsch_w_thresh, double kabsch_eps,
                               const float *tgt_normals, double max_corr_dist, int max_iter, double rel_fitness,
                               double rel_rmse, int mode, int fixed_iters, int search_precision,
                               int64_t max_src_patch_host, int64_t max_tgt_patch_host, int64_t n_src_host,
                               double *T_out, double *fitness_out, double *rmse_out, int32_t *iters_out,
-                              int32_t *corr_out, float *rows_out, void *stream) {
-    if (!corr_off || ((!corr_src || !corr_ref) && P > 0)) return F4L_EINVAL;
+                              int32_t *corr_out, const float *rows_src, const int64_t *rows_off, float *rows_out,
+                              void *stream) {
+    if (!corr_off || ((!corr_src || !corr_ref) && P > 0) || min_corr < 0) return F4L_EINVAL;
+    if ((rows_src == nullptr) != (rows_off == nullptr)) return F4L_EINVAL;
     f4l::IcpFusedExtra fx;
     fx.corr_src = corr_src; fx.corr_ref = corr_ref; fx.corr_w = corr_w; fx.corr_off = corr_off;
     fx.w_thresh = kabsch_w_thresh; fx.eps = kabsch_eps; fx.rows_out = rows_out;
+    fx.rows_src = rows_src; fx.rows_off = rows_off; fx.min_corr = min_corr;
     return f4l::icp_launch_host(src, src_off, tgt, tgt_off, P, nullptr, tgt_normals, max_corr_dist, max_iter, rel_fitness,
                                 rel_rmse, mode, fixed_iters, search_precision, max_src_patch_host, max_tgt_patch_host,
                                 n_src_host, T_out, fitness_out, rmse_out, iters_out, corr_out, fx, stream);
@@ -1018,6 +1034,7 @@ static int f4l::icp_launch_host(const float *src, const int64_t *src_off, const 
     a.init_T = init_T; a.tgt_normals = tgt_normals;
     a.corr_src = fx.corr_src; a.corr_ref = fx.corr_ref; a.corr_w = fx.corr_w; a.corr_off = fx.corr_off;
     a.kabsch_w_thresh = fx.w_thresh; a.kabsch_eps = fx.eps; a.rows_out = fx.rows_out;
+    a.rows_src = fx.rows_src; a.rows_off = fx.rows_off; a.min_corr = fx.min_corr;
     a.r = max_corr_dist > 0.0 ? max_corr_dist : 0.0;
     a.r2 = a.r * a.r;
     a.max_iter = max_iter; a.rel_fitness = rel_fitness; a.rel_rmse = rel_rmse; a.fixed_iters = fixed_iters;

@@ -324,3 +324,113 @@ extern "C" int f4l_nn_refine(const float *src, const int64_t *src_off, const flo
     F4L_LAUNCH_CHECK();
     return F4L_OK;
 }
+
+// ---- the loop body's steps before the rigid fit (src/coarse_to_fine_matching_base.py:3254-3320) ------------------------
+namespace f4l {
+
+// :3259-3274  `mask = torch.isin(corr[src patch][:, 1], tgt patch)`: for every source point of every patch match, does its
+// correspondent lie in the matched target patch?  One thread per source row; membership by binary search in the target
+// patch's point ids (ascending, as f4l_labels_to_csr emits them).
+__global__ void mutual_mask_kernel(const int64_t *__restrict__ src_ids, const int64_t *__restrict__ src_off,
+                                   const int64_t *__restrict__ tgt_ids, const int64_t *__restrict__ tgt_off, int64_t P,
+                                   const int64_t *__restrict__ corr_tgt, int64_t n_corr, uint8_t *__restrict__ mask,
+                                   int64_t *__restrict__ count) {
+    for (int64_t p = blockIdx.x; p < P; p += gridDim.x) {
+        const int64_t s0 = src_off[p], ns = src_off[p + 1] - s0, t0 = tgt_off[p], nt = tgt_off[p + 1] - t0;
+        const int64_t *__restrict__ tid = tgt_ids + t0;
+        int mine = 0;
+        for (int64_t i = threadIdx.x; i < ns; i += blockDim.x) {
+            const int64_t s = src_ids[s0 + i];
+            const int64_t t = s >= 0 && s < n_corr ? corr_tgt[s] : -1;
+            bool in = false;
+            if (t >= 0) {
+                int64_t lo = 0, hi = nt;
+                while (lo < hi) {
+                    const int64_t mid = (lo + hi) >> 1;
+                    if (tid[mid] < t) lo = mid + 1; else hi = mid;
+                }
+                in = lo < nt && tid[lo] == t;
+            }
+            mask[s0 + i] = in ? 1 : 0;
+            mine += in ? 1 : 0;
+        }
+        mine = wave_sum(mine);
+        __shared__ int s_cnt[16];
+        const int wave = (int)(threadIdx.x >> 6), nw = (int)(blockDim.x >> 6);
+        if (lane_id() == 0) s_cnt[wave] = mine;
+        __syncthreads();
+        if (threadIdx.x == 0 && count) {
+            int tot = 0;
+            for (int w = 0; w < nw; ++w) tot += s_cnt[w];
+            count[p] = tot;
+        }
+        __syncthreads();
+    }
+}
+
+// :3304-3320  rigidity of a patch match from its n mutual pairs: |d(s_i, s_j) - d(t_i, t_j)| over all pairs,
+//   dist_mean    = sum over i < j / (n (n - 1) / 2)
+//   ratio_inlier = (#{(i, j), any order incl. i = j: diff <= thr} - n) / (n (n - 1))
+// One workgroup per patch match; distances in double (the reference's float32 torch.cdist is matched to ~1e-6).
+__global__ __launch_bounds__(256) void rigidity_kernel(const float *__restrict__ cs, const float *__restrict__ ct,
+                                                      const int64_t *__restrict__ off, int64_t P, double thr,
+                                                      double *__restrict__ dist_mean, double *__restrict__ ratio_inlier) {
+    __shared__ double s_sum[4];
+    __shared__ long long s_in[4];
+    for (int64_t p = blockIdx.x; p < P; p += gridDim.x) {
+        const int64_t o = off[p];
+        const int n = (int)(off[p + 1] - o);
+        const float *__restrict__ a = cs + 3 * o, *__restrict__ b = ct + 3 * o;
+        double sum = 0.0;
+        long long inl = 0;
+        // pairs (i, j), i < j, dealt round-robin by row: thread t takes rows t, t + 256, ... (row i has n - 1 - i pairs)
+        for (int i = (int)threadIdx.x; i < n; i += 256) {
+            const double ax = a[3 * i], ay = a[3 * i + 1], az = a[3 * i + 2], bx = b[3 * i], by = b[3 * i + 1], bz = b[3 * i + 2];
+            for (int j = i + 1; j < n; ++j) {
+                const double dx = ax - (double)a[3 * j], dy = ay - (double)a[3 * j + 1], dz = az - (double)a[3 * j + 2];
+                const double ex = bx - (double)b[3 * j], ey = by - (double)b[3 * j + 1], ez = bz - (double)b[3 * j + 2];
+                const double diff = fabs(sqrt(dx * dx + dy * dy + dz * dz) - sqrt(ex * ex + ey * ey + ez * ez));
+                sum += diff;
+                inl += diff <= thr ? 1 : 0;
+            }
+        }
+        sum = wave_sum(sum);
+        int in32 = (int)inl;  // (a row has < 2^31 pairs)
+        long long tot_in = (long long)wave_sum(in32);
+        if (lane_id() == 0) { s_sum[threadIdx.x >> 6] = sum; s_in[threadIdx.x >> 6] = tot_in; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const double pairs = (double)n * (double)(n - 1) / 2.0;
+            const double tsum = s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];
+            const long long tin = s_in[0] + s_in[1] + s_in[2] + s_in[3];
+            // both triangles count in the reference's `sum(diff <= thr)`, the diagonal (always 0 <= thr) is taken off again
+            dist_mean[p] = n > 1 ? tsum / pairs : 0.0;
+            ratio_inlier[p] = n > 1 ? (double)(2 * tin) / (pairs * 2.0) : 0.0;
+        }
+        __syncthreads();
+    }
+}
+}  // namespace f4l
+
+extern "C" int f4l_mutual_correspondences(const int64_t *src_ids, const int64_t *src_off, const int64_t *tgt_ids,
+                                          const int64_t *tgt_off, int64_t P, const int64_t *corr_tgt, int64_t n_corr,
+                                          uint8_t *mask_out, int64_t *count_out, void *stream) {
+    if (P < 0 || !src_off || !tgt_off || !mask_out || (P > 0 && (!src_ids || !tgt_ids || !corr_tgt)) || n_corr < 0) return F4L_EINVAL;
+    if (P == 0) return F4L_OK;
+    const unsigned grid = (unsigned)(P < 65535 * 8 ? P : 65535 * 8);
+    hipLaunchKernelGGL(f4l::mutual_mask_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, src_ids, src_off, tgt_ids, tgt_off, P,
+                       corr_tgt, n_corr, mask_out, count_out);
+    F4L_LAUNCH_CHECK();
+    return F4L_OK;
+}
+
+extern "C" int f4l_rigidity_check(const float *corr_src, const float *corr_ref, const int64_t *corr_off, int64_t P,
+                                  double thres_dist_diff, double *dist_mean_out, double *ratio_inlier_out, void *stream) {
+    if (P < 0 || !corr_off || !dist_mean_out || !ratio_inlier_out || (P > 0 && (!corr_src || !corr_ref))) return F4L_EINVAL;
+    if (P == 0) return F4L_OK;
+    const unsigned grid = (unsigned)(P < 65535 * 8 ? P : 65535 * 8);
+    hipLaunchKernelGGL(f4l::rigidity_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, corr_src, corr_ref, corr_off, P,
+                       thres_dist_diff, dist_mean_out, ratio_inlier_out);
+    F4L_LAUNCH_CHECK();
+    return F4L_OK;
+}

@@ -198,12 +198,18 @@ def piecewise_icp(src, src_off, tgt, tgt_off, init_T=None, max_corr_dist=0.1, ma
 
 def patch_loop(src, src_off, tgt, tgt_off, corr_src, corr_ref, corr_off, corr_weights=None, weight_thresh=0.0, eps=1e-6,
                max_corr_dist=0.1, max_iter=30, rel_fitness=1e-6, rel_rmse=1e-6, icp_type="point2point", fixed_iters=False,
-               tgt_normals=None, return_corr=False, return_rows=True, max_src_patch=None, max_tgt_patch=None, search="f64"):
-    """The whole per-patch loop body of src/coarse_to_fine_matching_base.py:3254-3436 in one launch (f4l_patch_loop):
-    weighted Kabsch of each patch's correspondences -> ICP from that -> displacement rows [s, T s].
+               tgt_normals=None, return_corr=False, return_rows=True, max_src_patch=None, max_tgt_patch=None, search="f64",
+               rows_src=None, rows_off=None, min_corr=0):
+    """The per-patch loop body of src/coarse_to_fine_matching_base.py:3338-3408 in one launch (f4l_patch_loop):
+    weighted Kabsch of each patch match's correspondences -> ICP from that on (src, tgt) -> displacement rows [s, T s].
 
-    Equivalent to ``T0 = kabsch_transforms(...); out = piecewise_icp(..., init_T=T0); rows = apply_transform(src, src_off,
-    out["T"])``.  Returns the dict of :func:`piecewise_icp` plus ``rows`` (n_src, 6) float32 when ``return_rows``."""
+    For parity with the reference, (src, tgt) are the MUTUAL points of the match (pass ``corr_src, corr_off, corr_ref,
+    corr_off``; :3352-3353) and ``rows_src / rows_off`` all points of the source patch (:3348, 3371-3374); without
+    ``rows_src`` the rows are those of ``src``.  Matches with fewer than ``min_corr`` correspondences are skipped as the
+    reference skips them (:3338): ``iters == -1``, identity transform, rows left unwritten (zero here).
+
+    Equivalent to ``T0 = kabsch_transforms(...); out = piecewise_icp(..., init_T=T0); rows = apply_transform(rows_src,
+    rows_off, out["T"])``.  Returns the dict of :func:`piecewise_icp` plus ``rows`` (n_rows, 6) float32 when ``return_rows``."""
     torch = require_gpu()
     if icp_type not in _ICP_MODES:
         raise ValueError("ICP type not supported")  # utils/o3d_tools.py:43
@@ -235,19 +241,65 @@ def patch_loop(src, src_off, tgt, tgt_off, corr_src, corr_ref, corr_off, corr_we
     rmse = torch.empty((P,), dtype=torch.float64, device=dev)
     iters = torch.empty((P,), dtype=torch.int32, device=dev)
     corr = torch.empty((src.shape[0],), dtype=torch.int32, device=dev) if return_corr else None
-    rows = torch.empty((src.shape[0], 6), dtype=torch.float32, device=dev) if return_rows else None
+    if (rows_src is None) != (rows_off is None):
+        raise ValueError("rows_src and rows_off go together")
+    if rows_src is not None:
+        rows_src = _dev(rows_src, torch.float32, "rows_src", (3,))
+        rows_off = _dev(rows_off, torch.int64, "rows_off")
+        if rows_off.shape[0] - 1 != P:
+            raise ValueError("rows_off must describe the same number of patches")
+    n_rows = src.shape[0] if rows_src is None else rows_src.shape[0]
+    # (zero filled only when matches can be skipped: their rows stay unwritten)
+    rows = (torch.zeros if min_corr > 0 else torch.empty)((n_rows, 6), dtype=torch.float32, device=dev) if return_rows else None
     check(lib().f4l_patch_loop(ptr(src), ptr(src_off), ptr(tgt), ptr(tgt_off), P, ptr(corr_src), ptr(corr_ref), ptr(cw),
-                               ptr(corr_off), float(weight_thresh), float(eps), ptr(tn), float(max_corr_dist), int(max_iter),
-                               float(rel_fitness), float(rel_rmse), mode, int(bool(fixed_iters)),
+                               ptr(corr_off), int(min_corr), float(weight_thresh), float(eps), ptr(tn), float(max_corr_dist),
+                               int(max_iter), float(rel_fitness), float(rel_rmse), mode, int(bool(fixed_iters)),
                                {"f32": _lib.SEARCH_F32, "f64": _lib.SEARCH_F64}[search], int(max_src_patch),
-                               int(max_tgt_patch), int(src.shape[0]), ptr(T), ptr(fit), ptr(rmse), ptr(iters), ptr(corr), ptr(rows),
-                               stream_ptr()), "f4l_patch_loop")
+                               int(max_tgt_patch), int(src.shape[0]), ptr(T), ptr(fit), ptr(rmse), ptr(iters), ptr(corr),
+                               ptr(rows_src), ptr(rows_off), ptr(rows), stream_ptr()), "f4l_patch_loop")
     out = dict(T=T, fitness=fit, rmse=rmse, iters=iters)
     if return_corr:
         out["corr"] = corr
     if return_rows:
         out["rows"] = rows
     return out
+
+
+def mutual_correspondences(src_ids, src_off, tgt_ids, tgt_off, corr_tgt):
+    """`torch.isin(corr[src patch][:, 1], tgt patch)` for all patch matches at once (src/coarse_to_fine_matching_base.py:
+    3259-3274; f4l_mutual_correspondences).  src_ids / tgt_ids: int64 point ids grouped by match (CSR offsets src_off /
+    tgt_off), ids ascending inside every target patch; corr_tgt (n_src_points,) int64: the target point matched to each
+    source point, -1 for none.  Returns (mask (len(src_ids),) bool, count (P,) int64)."""
+    torch = require_gpu()
+    src_ids = _dev(src_ids, torch.int64, "src_ids")
+    tgt_ids = _dev(tgt_ids, torch.int64, "tgt_ids")
+    src_off = _dev(src_off, torch.int64, "src_off")
+    tgt_off = _dev(tgt_off, torch.int64, "tgt_off")
+    corr_tgt = _dev(corr_tgt, torch.int64, "corr_tgt")
+    P = src_off.shape[0] - 1
+    if tgt_off.shape[0] - 1 != P:
+        raise ValueError("src_off and tgt_off must describe the same number of patch matches")
+    mask = torch.empty((src_ids.shape[0],), dtype=torch.uint8, device=src_ids.device)
+    count = torch.empty((P,), dtype=torch.int64, device=src_ids.device)
+    check(lib().f4l_mutual_correspondences(ptr(src_ids), ptr(src_off), ptr(tgt_ids), ptr(tgt_off), P, ptr(corr_tgt),
+                                           corr_tgt.shape[0], ptr(mask), ptr(count), stream_ptr()), "f4l_mutual_correspondences")
+    return mask.to(torch.bool), count
+
+
+def rigidity_check(corr_src, corr_ref, corr_off, thres_dist_diff):
+    """The quality test of a patch match before the rigid fit (src/coarse_to_fine_matching_base.py:3304-3320,
+    f4l_rigidity_check): per match, the mean of |d(s_i, s_j) - d(t_i, t_j)| over its mutual pairs and the share of pairs
+    with that difference <= thres_dist_diff.  Returns (dist_mean (P,), ratio_inlier (P,)) float64."""
+    torch = require_gpu()
+    corr_src = _dev(corr_src, torch.float32, "corr_src", (3,))
+    corr_ref = _dev(corr_ref, torch.float32, "corr_ref", (3,))
+    corr_off = _dev(corr_off, torch.int64, "corr_off")
+    P = corr_off.shape[0] - 1
+    dm = torch.empty((P,), dtype=torch.float64, device=corr_src.device)
+    ri = torch.empty((P,), dtype=torch.float64, device=corr_src.device)
+    check(lib().f4l_rigidity_check(ptr(corr_src), ptr(corr_ref), ptr(corr_off), P, float(thres_dist_diff), ptr(dm), ptr(ri),
+                                   stream_ptr()), "f4l_rigidity_check")
+    return dm, ri
 
 
 def apply_transform(pts, off, T, inverse=False):

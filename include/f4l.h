@@ -125,20 +125,46 @@ int f4l_piecewise_icp(const float *src, const int64_t *src_off, const float *tgt
                       int64_t n_src_host, double *T_out, double *fitness_out, double *rmse_out, int32_t *iters_out,
                       int32_t *corr_out, void *stream);
 
-/* The whole loop body of src/coarse_to_fine_matching_base.py:3254-3436 for P patch matches in ONE launch:
- *   weighted Kabsch of the patch's correspondences (:3341, scripts/weighted_svd.py:58-129; corr_src / corr_ref
- *   float32 [n_corr][3], corr_w float32 [n_corr] or NULL, corr_off int64 [P+1]; a patch without correspondences
- *   starts from the identity)  ->  ICP as f4l_piecewise_icp (:3353-3367)  ->  displacement rows [s, T s] of every
- *   source point (:3371-3374, 3408; rows_out float32 [n_src][6], nullable).
+/* The loop body's steps before the rigid fit, batched over P patch matches.
+ *
+ * f4l_mutual_correspondences (src/coarse_to_fine_matching_base.py:3259-3274): a patch match i is (source patch = point ids
+ *   src_ids[src_off[i]:src_off[i+1]], target patch = tgt_ids[tgt_off[i]:tgt_off[i+1]], ids ascending inside a target
+ *   patch, as f4l_labels_to_csr emits them); corr_tgt int64 [n_corr] holds the target point matched to every source point
+ *   (-1: none; the second column of `corres_3d_voxel_from_3d_idx`).  mask_out uint8 [src_off[P]] = 1 where the source
+ *   point's correspondent lies in the matched target patch (the `torch.isin` of :3260); count_out int64 [P] (nullable) =
+ *   mutual pairs per match.  Compacting the rows the mask keeps gives the CSR correspondence lists of f4l_patch_loop.
+ * f4l_rigidity_check (:3304-3320, `remove_low_quality_patch_matches`): per match, over its n mutual pairs,
+ *   dist_mean = mean over i < j of |d(s_i, s_j) - d(t_i, t_j)|,  ratio_inlier = share of pairs with that difference <=
+ *   thres_dist_diff (the reference counts both triangles and takes the diagonal off again: the same ratio); both 0 for
+ *   n < 2.  The caller drops a match when ratio_inlier <= thres_inlier_ratio or dist_mean >= thres_dist_diff (:3322).
+ *   Distances in double (the reference: float32 torch.cdist). */
+int f4l_mutual_correspondences(const int64_t *src_ids, const int64_t *src_off, const int64_t *tgt_ids,
+                               const int64_t *tgt_off, int64_t P, const int64_t *corr_tgt, int64_t n_corr,
+                               uint8_t *mask_out, int64_t *count_out, void *stream);
+int f4l_rigidity_check(const float *corr_src, const float *corr_ref, const int64_t *corr_off, int64_t P,
+                       double thres_dist_diff, double *dist_mean_out, double *ratio_inlier_out, void *stream);
+
+/* The rest of the loop body of src/coarse_to_fine_matching_base.py:3254-3436 for P patch matches in ONE launch:
+ *   weighted Kabsch of the match's correspondences (:3341, scripts/weighted_svd.py:58-129; corr_src / corr_ref float32
+ *   [n_corr][3], corr_w float32 [n_corr] or NULL, corr_off int64 [P+1])
+ *   ->  ICP as f4l_piecewise_icp from that transform (:3353-3367) on the clouds src / tgt.  For parity with the reference
+ *       these are the MUTUAL points of the match (`tensor2pcd(pts_coord_in_curr_spt_src_mutual)`, :3352-3353), i.e.
+ *       src = corr_src and tgt = corr_ref with src_off = tgt_off = corr_off; any other per-patch clouds are accepted.
+ *   ->  displacement rows [s, T s] (:3371-3374, 3408) of rows_src / rows_off: ALL points of the source patch
+ *       (`pts_coord_in_curr_spt_src`, :3348); rows_src = rows_off = NULL writes the rows of the ICP cloud `src` itself.
+ *       rows_out float32 [rows_off[P] or src_off[P]][6], nullable.
+ *   A match with fewer than min_corr correspondences is skipped like the reference skips it (:3338 `num_min_fine_match`,
+ *   `mask_spt_match_global[i] = False`): T = identity, fitness = rmse = 0, iters = -1, correspondences -1, its rows are
+ *   NOT written.  (min_corr = 0: a match without correspondences starts ICP from the identity.)
  * Same results as f4l_kabsch_transforms -> f4l_piecewise_icp -> f4l_apply_transform (T_out to rounding of the block
  * reductions, rows_out bit-equal to f4l_apply_transform applied to T_out), without the two extra launches. */
 int f4l_patch_loop(const float *src, const int64_t *src_off, const float *tgt, const int64_t *tgt_off, int64_t P,
                    const float *corr_src, const float *corr_ref, const float *corr_w, const int64_t *corr_off,
-                   double kabsch_w_thresh, double kabsch_eps, const float *tgt_normals, double max_corr_dist,
-                   int max_iter, double rel_fitness, double rel_rmse, int mode, int fixed_iters, int search_precision,
-                   int64_t max_src_patch_host, int64_t max_tgt_patch_host, int64_t n_src_host, double *T_out,
-                   double *fitness_out, double *rmse_out, int32_t *iters_out, int32_t *corr_out, float *rows_out,
-                   void *stream);
+                   int64_t min_corr, double kabsch_w_thresh, double kabsch_eps, const float *tgt_normals,
+                   double max_corr_dist, int max_iter, double rel_fitness, double rel_rmse, int mode, int fixed_iters,
+                   int search_precision, int64_t max_src_patch_host, int64_t max_tgt_patch_host, int64_t n_src_host,
+                   double *T_out, double *fitness_out, double *rmse_out, int32_t *iters_out, int32_t *corr_out,
+                   const float *rows_src, const int64_t *rows_off, float *rows_out, void *stream);
 
 /* Per-patch normal estimation as utils/o3d_tools.py:29-30 (`pcd.estimate_normals()` on the patch cloud:
  * kNN(knn=30) inside the patch, self included; smallest-eigenvector of the neighbourhood covariance;
