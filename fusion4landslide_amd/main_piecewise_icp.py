@@ -1,19 +1,20 @@
 """Counterpart of the reference's main_piecewise_icp.py: `--config` (flat yaml) -> cfg -> per tile `Piecewise_ICP(cfg)`.
 
-Same cfg keys and output files (main_piecewise_icp.py:20-102).  The PCL tiler (cpp_core/pcd_tiling, SURVEY.md 8f item
-4) is outside the hot path: tiles already present under `<output_root>/tiled_data/overlap/` are used as they are;
-otherwise the input pair is taken as ONE tile (the reference's limit is 1 M points per tile).
+Same cfg keys and output files (main_piecewise_icp.py:20-102).  Like the reference (:64-80), an empty
+`<output_root>/tiled_data/` is filled by `point_cloud_tiling` (src/functions.py:147-177 -> the tiler mirror
+cpp_core/pcd_tiling/build/pcd_tiling.py); tiles already there are used as they are.
 
     python -m fusion4landslide_amd.main_piecewise_icp --config configs/landslide/piecewise_icp_brienz.yaml [--engine patch_icp]
 """
 import argparse
+import copy
 import glob
 import os
 import os.path as osp
 import re
-import shutil
 import time
 
+from .src.functions import point_cloud_tiling
 from .src.piecewise_icp import Piecewise_ICP
 from .utils.common import AttrDict, access_device, dir_exist, get_logger, load_yaml
 
@@ -37,11 +38,15 @@ def main(argv=None):
     start_time = time.time()
 
     cfg.tile_dir = osp.join(cfg.output_root, 'tiled_data')
-    dir_exist(cfg.tile_dir, ['overlap'])
-    if not glob.glob(osp.join(cfg.tile_dir, 'overlap', 'source_tile_*')):
-        cfg.logging.info('No tiles found: using the input pair as a single tile (pcd_tiling is out of scope).')
-        shutil.copyfile(osp.join(cfg.input_root, cfg.src_pcd), osp.join(cfg.tile_dir, 'overlap', 'source_tile_0_overlap.ply'))
-        shutil.copyfile(osp.join(cfg.input_root, cfg.tgt_pcd), osp.join(cfg.tile_dir, 'overlap', 'target_tile_0_overlap.ply'))
+    dir_exist(cfg.tile_dir)
+    if not any(os.listdir(cfg.tile_dir)):  # main_piecewise_icp.py:66-78
+        config = copy.copy(cfg)
+        config.data_dir = cfg.input_root
+        config.src_name = cfg.src_pcd
+        config.tgt_name = cfg.tgt_pcd
+        point_cloud_tiling(config)
+    else:
+        cfg.logging.info('Skip point cloud tiling. Tiles will be loaded from %s.', cfg.tile_dir)
     src_tiles = sorted(glob.glob(osp.join(cfg.tile_dir, 'overlap', "source_tile_*")),
                        key=lambda x: int(re.search(r'\d+', osp.basename(x)).group()))
     cfg.logging.info(f'Num. of tile(s) from source/target point cloud: {len(src_tiles)}')

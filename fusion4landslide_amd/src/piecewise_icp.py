@@ -143,12 +143,16 @@ def Piecewise_ICP(cfg):
         st = st[torch.from_numpy(lex).to(dev)]
         un = torch.nonzero(~stable).squeeze(1)
         dev_vec = cen_t[nn_idx] - cen_s  # :182-184
-        rows = []
-        for leaves, moved in ((st, False), (un, True)):
-            for leaf in leaves.tolist():
-                p = pts_s[off_s[leaf]:off_s[leaf + 1]]
-                rows.append(torch.cat([p, p + dev_vec[leaf] if moved else p], dim=1))
-        dvfs = torch.cat(rows).cpu().numpy() if rows else np.zeros((0, 6))
+        dev_vec[stable] = 0.0  # stable cells keep their points (:174)
+        # the points of the leaves in that order, one gather (the reference loops over the cells in Python, :170-193)
+        leaves = torch.cat([st, un])
+        cnt_l = cnt_s[leaves]
+        new_off = torch.zeros(leaves.shape[0] + 1, dtype=torch.int64, device=dev)
+        new_off[1:] = torch.cumsum(cnt_l, 0)
+        total = int(new_off[-1])
+        take = torch.repeat_interleave(off_s[:-1][leaves] - new_off[:-1], cnt_l, output_size=total) + torch.arange(total, device=dev)
+        p = pts_s[take]
+        dvfs = torch.cat([p, p + torch.repeat_interleave(dev_vec[leaves], cnt_l, dim=0, output_size=total)], dim=1).cpu().numpy()
         n_stable_pts = int(cnt_s[stable].sum())
     elif mode == 'patch_icp':
         # every kept source leaf is a patch; its target patch is the matched target leaf

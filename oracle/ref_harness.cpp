@@ -13,8 +13,10 @@
 #include <cstdint>
 #include <cfloat>
 #include <cmath>
+#include <random>
 #include <vector>
 
+#include "codelibrary/geometry/io/xyz_io.h"
 #include "codelibrary/geometry/point_cloud/pca_estimate_normals.h"
 #include "codelibrary/geometry/point_cloud/supervoxel_segmentation.h"
 #include "codelibrary/geometry/util/distance_3d.h"
@@ -135,6 +137,26 @@ int f4l_ref_segment(const float* xyz, const double* normals_in, const int32_t* k
     if (labels_out)
         for (int i = 0; i < n_points; ++i) labels_out[i] = labels[i];
     return 0;
+}
+
+// The partition text file written by the reference's own header-only writer (codelibrary/geometry/io/xyz_io.h:192-221),
+// driven like reference supervoxel.cpp:45-64 `WritePoints` (one colour per supervoxel from a default-seeded std::mt19937)
+// on points widened to double like supervoxel.cpp:66-81.  Pins f4l_write_partition_txt byte for byte.
+int f4l_ref_write_points(const char* filename, int32_t n_supervoxels, const float* xyz, const int32_t* labels_in,
+                         int64_t n) {
+    if (!filename || n < 0 || n_supervoxels < 0 || (n > 0 && (!xyz || !labels_in))) return -1;
+    cl::Array<cl::RPoint3D> points;
+    cl::Array<int> labels((int)n);
+    for (int64_t i = 0; i < n; ++i) {
+        points.emplace_back((double)xyz[3 * i], (double)xyz[3 * i + 1], (double)xyz[3 * i + 2]);
+        labels[(int)i] = labels_in[i];
+    }
+    cl::Array<cl::RGB32Color> colors(points.size());
+    std::mt19937 random;
+    cl::Array<cl::RGB32Color> supervoxel_colors(n_supervoxels);
+    for (int i = 0; i < n_supervoxels; ++i) supervoxel_colors[i] = cl::RGB32Color(random());
+    for (int i = 0; i < points.size(); ++i) colors[i] = supervoxel_colors[labels[i]];
+    return cl::geometry::io::WriteXYZPoints(filename, points, colors, labels) ? 0 : -2;
 }
 
 // Reference PCAEstimateNormal (pca_estimate_normals.h:118-121) on one neighbourhood of m points.

@@ -93,3 +93,45 @@ def test_reference_module_layout_is_importable():
     assert callable(pt.tile_point_clouds) and callable(pt.resave_point_cloud)
     sv = importlib.import_module("fusion4landslide_amd.cpp_core.supervoxel_segmentation.build.supervoxel")
     assert callable(sv.computeSupervoxel) and callable(sv.WritePoints)
+
+
+def test_partition_text_file_is_byte_identical_to_the_reference_writer(golden_dir, tmp_path):
+    """f4l_write_partition_txt (host only, no GPU needed) against the bytes the reference's own header-only writer produced
+    (xyz_io.h:192-221 driven like supervoxel.cpp:45-64; tests/golden/partition_txt_ref.npz from
+    tools/make_golden_supervoxel.py) -- and, where the reference-backed harness is present (the build container), against
+    that writer run now on a golden cloud."""
+    import ctypes as C
+
+    import numpy as np
+
+    from fusion4landslide_amd._lib import lib
+
+    def ours(path, xyz, labels, K):
+        xyz, labels = np.ascontiguousarray(xyz, np.float32), np.ascontiguousarray(labels, np.int32)
+        rc = lib().f4l_write_partition_txt(str(path).encode(), xyz.ctypes.data_as(C.c_void_p), labels.ctypes.data_as(C.c_void_p),
+                                           len(xyz), int(K))
+        assert rc == 0
+        return open(path, "rb").read()
+
+    g = np.load(os.path.join(golden_dir, "partition_txt_ref.npz"))
+    assert ours(tmp_path / "a.txt", g["xyz"], g["labels"], g["n_supervoxels"]) == g["text"].tobytes()
+    from oracle import oracle as O
+    if O.have_ref() and hasattr(O.ref(), "f4l_ref_write_points"):
+        c = np.load(os.path.join(golden_dir, "supervoxel_georef_s3_n3000_k30.npz"))
+        O.ref_write_points(tmp_path / "ref.txt", int(c["n_supervoxels"]), c["xyz"], c["labels"])
+        assert ours(tmp_path / "b.txt", c["xyz"], c["labels"], c["n_supervoxels"]) == open(tmp_path / "ref.txt", "rb").read()
+
+
+def test_sanitizer_run_of_the_oracle_and_the_host_code():
+    """`make -C oracle asan`: the C oracle and the product library's host-only code (the sequential segmentation and the
+    text writer, csrc/supervoxel_host.cpp) under AddressSanitizer + UndefinedBehaviorSanitizer on the CPU; both
+    segmentations must agree and no report may fire."""
+    import shutil
+    import subprocess
+
+    import pytest
+    if not os.path.exists("/opt/rocm/lib/llvm/bin/clang++") or shutil.which("make") is None:
+        pytest.skip("no clang with sanitizer runtimes here")
+    r = subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "asan"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "sanitize_check ok" in r.stdout and "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr

@@ -137,6 +137,13 @@ def test_piecewise_icp_entry_writes_reference_files(tmp_path):
             # stable cells keep their points, unstable ones move rigidly by a centroid difference
             still = np.all(dvfs[:, :3] == dvfs[:, 3:], axis=1)
             assert 0.3 < still.mean() < 1.0
+            # against the independent pointer-octree restatement of src/piecewise_icp.py:17-235 (oracle/piecewise_octree.py):
+            # the same rows in the same order (centroid sums differ in their last bits: 1e-9)
+            from oracle import piecewise_octree as PO
+            ref = PO.piecewise_icp(c["src"].astype(np.float64), c["tgt"].astype(np.float64), 1.4, 10, "brienz_tls")
+            assert ref["dvfs"].shape == dvfs.shape
+            assert np.abs(ref["dvfs"] - dvfs).max() < 1e-9 and np.abs(ref["dvfms"] - dvfms).max() < 1e-9
+            assert np.abs(ref["visualize"] - vis).max() < 1e-9
         else:
             assert np.median(dvfms[:, 3]) < 0.2
 

@@ -60,5 +60,29 @@ def main():
               f"-> {os.path.getsize(path)} bytes")
 
 
+def partition_text_fixture():
+    """tests/golden/partition_txt_ref.npz: a small labelled cloud and the bytes the reference's own writer
+    (codelibrary/geometry/io/xyz_io.h:192-221, driven like supervoxel.cpp:45-64) puts into the partition text file for it:
+    coordinates of every magnitude the 12-significant-digit formatting treats differently (georeferenced, sub-millimetre,
+    negative, exact integers, values that print in scientific notation)."""
+    import tempfile
+    rng = np.random.default_rng(7)
+    xyz = np.concatenate([
+        rng.uniform(-5, 5, (60, 3)), rng.uniform(0, 1, (40, 3)) + [2647123.0, 1177456.0, 1500.0], rng.uniform(-1e-4, 1e-4, (30, 3)),
+        np.array([[0.0, 1.0, -2.0], [1e-7, -3e-9, 5e10], [123456.789, 0.5, 0.25], [1e15, 3.0, -0.0]]), rng.normal(0, 1e3, (40, 3))]).astype(np.float32)
+    K = 23
+    labels = rng.integers(0, K, len(xyz)).astype(np.int32)
+    labels[:K] = np.arange(K)
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "ref.txt")
+        O.ref_write_points(path, K, xyz, labels)
+        text = np.frombuffer(open(path, "rb").read(), dtype=np.uint8)
+    out = os.path.join(ROOT, "tests", "golden", "partition_txt_ref.npz")
+    np.savez_compressed(out, xyz=xyz, labels=labels, n_supervoxels=np.int32(K), text=text)
+    print(f"partition_txt_ref: {len(xyz)} points, {len(text)} bytes of text -> {os.path.getsize(out)} bytes")
+
+
 if __name__ == "__main__":
-    main()
+    if "--text-only" not in sys.argv:
+        main()
+    partition_text_fixture()
