@@ -1129,45 +1129,62 @@ static int f4l::icp_launch_host(const float *src, const int64_t *src_off, const 
     hipStream_t st = (hipStream_t)stream;
     int *buf = nullptr;
     const size_t buf_bytes = ((size_t)cb.n * (size_t)P + (size_t)cb.n) * sizeof(int);
-    F4L_HIP_CHECK(hipMallocAsync((void **)&buf, buf_bytes, st));
-    int *cnt = buf + (size_t)cb.n * (size_t)P;
-    F4L_HIP_CHECK(hipMemsetAsync(cnt, 0, (size_t)cb.n * sizeof(int), st));
-    hipLaunchKernelGGL(icp_bin_patches, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st, src_off, tgt_off, (int)P, cb, cnt, buf);
-    F4L_LAUNCH_CHECK();
-    // The classes are independent and none of them fills the machine to its end (a class of a few large patches is one
-    // long chain on a few CUs): they run side by side, the largest on the caller's stream, the others on streams of
-    // this library's own that fork from it after the binning and join it again (events; no host synchronisation).
-    const bool side = !getenv("F4L_ICP_SERIAL_CLASSES");
-    hipEvent_t forked = nullptr, joined[ICP_MAX_CLASSES] = {};
-    if (side) {
-        F4L_HIP_CHECK(hipEventCreateWithFlags(&forked, hipEventDisableTiming));
-        F4L_HIP_CHECK(hipEventRecord(forked, st));
-    }
+    // One exit for every outcome (`fail` records the HIP error and jumps there): whatever was launched on a helper stream is
+    // joined back to the caller's stream, the events are destroyed and the binning buffer is released before returning, so
+    // that an error return never leaves side-stream kernels reading the caller's tensors or leaks the temporaries.
     int rc = F4L_OK;
-    for (int k = cb.n - 1; k >= 0 && rc == F4L_OK; --k) {
-        const int64_t ms = max_src_patch_host < cb.bound[k] ? max_src_patch_host : cb.bound[k];
-        const int64_t mt = max_tgt_patch_host < cb.bound[k] ? max_tgt_patch_host : cb.bound[k];
-        const IcpPlan pk = icp_plan(ms, mt, f64, mode);
-        IcpArgs ak = a;
-        ak.tgt_cap = pk.tgt_cap; ak.cert_cap = pk.cert_cap; ak.cell_cap = pk.cell_cap; ak.src_cap = pk.src_cap; ak.pp_cap = pk.pp_cap;
-        ak.list = buf + (size_t)k * (size_t)P; ak.list_cnt = cnt + k;
-        hipStream_t sk = st;
-        if (side && k != cb.n - 1) {
-            sk = class_stream(cb.n - 2 - k);
-            if (!sk) { rc = F4L_EHIP; break; }
-            F4L_HIP_CHECK(hipStreamWaitEvent(sk, forked, 0));
+    hipEvent_t forked = nullptr, joined[ICP_MAX_CLASSES] = {};
+    hipStream_t used[ICP_MAX_CLASSES] = {};
+    auto fail = [&](hipError_t e) {
+        if (e == hipSuccess) return false;
+        f4l_tls_hip_error = (int)e;
+        rc = F4L_EHIP;
+        return true;
+    };
+    do {
+        if (fail(hipMallocAsync((void **)&buf, buf_bytes, st))) { buf = nullptr; break; }
+        int *cnt = buf + (size_t)cb.n * (size_t)P;
+        if (fail(hipMemsetAsync(cnt, 0, (size_t)cb.n * sizeof(int), st))) break;
+        hipLaunchKernelGGL(icp_bin_patches, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st, src_off, tgt_off, (int)P, cb, cnt, buf);
+        if (fail(hipGetLastError())) break;
+        // The classes are independent and none of them fills the machine to its end (a class of a few large patches is one
+        // long chain on a few CUs): they run side by side, the largest on the caller's stream, the others on streams of
+        // this library's own that fork from it after the binning and join it again (events; no host synchronisation).
+        const bool side = !getenv("F4L_ICP_SERIAL_CLASSES");
+        if (side) {
+            if (fail(hipEventCreateWithFlags(&forked, hipEventDisableTiming))) { forked = nullptr; break; }
+            if (fail(hipEventRecord(forked, st))) break;
         }
-        rc = f64 ? launch_icp<double>(ak, mode, pk.nw, pk.lds, sk) : launch_icp<float>(ak, mode, pk.nw, pk.lds, sk);
-        if (rc == F4L_OK && sk != st) {
-            F4L_HIP_CHECK(hipEventCreateWithFlags(&joined[k], hipEventDisableTiming));
-            F4L_HIP_CHECK(hipEventRecord(joined[k], sk));
-            F4L_HIP_CHECK(hipStreamWaitEvent(st, joined[k], 0));
+        for (int k = cb.n - 1; k >= 0 && rc == F4L_OK; --k) {
+            const int64_t ms = max_src_patch_host < cb.bound[k] ? max_src_patch_host : cb.bound[k];
+            const int64_t mt = max_tgt_patch_host < cb.bound[k] ? max_tgt_patch_host : cb.bound[k];
+            const IcpPlan pk = icp_plan(ms, mt, f64, mode);
+            IcpArgs ak = a;
+            ak.tgt_cap = pk.tgt_cap; ak.cert_cap = pk.cert_cap; ak.cell_cap = pk.cell_cap; ak.src_cap = pk.src_cap; ak.pp_cap = pk.pp_cap;
+            ak.list = buf + (size_t)k * (size_t)P; ak.list_cnt = cnt + k;
+            hipStream_t sk = st;
+            if (side && k != cb.n - 1) {
+                sk = class_stream(cb.n - 2 - k);
+                if (!sk) { rc = F4L_EHIP; break; }
+                if (fail(hipStreamWaitEvent(sk, forked, 0))) break;
+                used[k] = sk;  // from here on the helper stream may hold work that reads the caller's buffers
+            }
+            rc = f64 ? launch_icp<double>(ak, mode, pk.nw, pk.lds, sk) : launch_icp<float>(ak, mode, pk.nw, pk.lds, sk);
+        }
+    } while (false);
+    // join every helper stream that was handed work (also after an error), then release
+    for (int k = 0; k < ICP_MAX_CLASSES; ++k) {
+        if (!used[k]) continue;
+        if (hipEventCreateWithFlags(&joined[k], hipEventDisableTiming) != hipSuccess) { joined[k] = nullptr; (void)hipStreamSynchronize(used[k]); continue; }
+        if (hipEventRecord(joined[k], used[k]) != hipSuccess || hipStreamWaitEvent(st, joined[k], 0) != hipSuccess) {
+            if (rc == F4L_OK) { f4l_tls_hip_error = (int)hipGetLastError(); rc = F4L_EHIP; }
+            (void)hipStreamSynchronize(used[k]);  // last resort: the caller's buffers must outlive the helper's kernels
         }
     }
     // (destroying an event whose work is still in flight only defers the release)
     if (forked) (void)hipEventDestroy(forked);
     for (int k = 0; k < ICP_MAX_CLASSES; ++k)
         if (joined[k]) (void)hipEventDestroy(joined[k]);
-    F4L_HIP_CHECK(hipFreeAsync(buf, st));
+    if (buf && hipFreeAsync(buf, st) != hipSuccess && rc == F4L_OK) { f4l_tls_hip_error = (int)hipGetLastError(); rc = F4L_EHIP; }
     return rc;
 }

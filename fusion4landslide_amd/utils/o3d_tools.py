@@ -30,10 +30,16 @@ def icp_registration(src_pcd, tgt_pcd, initial_transform, threshold=0.1, icp_typ
     tgt = as_points(tgt_pcd)
     if hasattr(initial_transform, "detach"):
         initial_transform = initial_transform.detach().cpu().numpy()
-    T0 = np.asarray(initial_transform, dtype=np.float64).reshape(4, 4)
+    T0 = np.asarray(initial_transform, dtype=np.float64).reshape(4, 4).copy()
     dev = torch.device("cuda")
-    s = torch.from_numpy(src.astype(np.float32)).to(dev)
-    t = torch.from_numpy(tgt.astype(np.float32)).to(dev)
+    # Open3D clouds are float64; the kernel's clouds are float32.  Georeferenced coordinates (~1e6 m: float32 spacing 0.06-
+    # 0.25 m, above the 0.1 m correspondence distance) must not be cast as they are: both clouds are first moved, in double, by
+    # an origin near the target (whole metres, so clouds that came from float32 keep their exact values), the transform is
+    # carried along (q - o = R (p - o) + t'  <=>  t' = t - o + R o) and carried back afterwards.
+    o = np.floor(np.asarray(tgt if len(tgt) else src, dtype=np.float64).min(axis=0)) if (len(tgt) or len(src)) else np.zeros(3)
+    T0[:3, 3] = T0[:3, 3] - o + T0[:3, :3] @ o
+    s = torch.from_numpy((np.asarray(src, dtype=np.float64) - o).astype(np.float32)).to(dev)
+    t = torch.from_numpy((np.asarray(tgt, dtype=np.float64) - o).astype(np.float32)).to(dev)
     so = torch.tensor([0, s.shape[0]], dtype=torch.int64, device=dev)
     to = torch.tensor([0, t.shape[0]], dtype=torch.int64, device=dev)
     tn = None
@@ -46,6 +52,8 @@ def icp_registration(src_pcd, tgt_pcd, initial_transform, threshold=0.1, icp_typ
     out = engine.piecewise_icp(s, so, t, to, init_T=torch.from_numpy(T0[None]).to(dev), max_corr_dist=threshold,
                                max_iter=30, rel_fitness=1e-6, rel_rmse=1e-6, icp_type=icp_type,
                                tgt_normals=tn if icp_type == 'point2plane' else None, return_corr=True, search=search)
+    T = out["T"][0].cpu().numpy()
+    T[:3, 3] = T[:3, 3] + o - T[:3, :3] @ o
     corr = out["corr"].cpu().numpy()
     sel = np.nonzero(corr >= 0)[0]
     corr_set = np.stack([sel, corr[sel]], axis=1).astype(np.int32) if len(sel) else np.zeros((0, 2), np.int32)
@@ -53,7 +61,7 @@ def icp_registration(src_pcd, tgt_pcd, initial_transform, threshold=0.1, icp_typ
         "fitness": float(out["fitness"][0].item()),
         "inlier_rmse": float(out["rmse"][0].item()),
         "correspondence_set": corr_set,
-        "est_transform": out["T"][0].cpu().numpy(),
+        "est_transform": T,
         "src_corr_pts": src[corr_set[:, 0]],
         "tgt_corr_pts": tgt[corr_set[:, 1]],
     }

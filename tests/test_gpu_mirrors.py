@@ -71,6 +71,18 @@ def test_icp_registration_mirror():
     assert tgt_pcd.has_normals() and src_pcd.has_normals()  # the reference mutates its inputs too
     with pytest.raises(ValueError):
         icp_registration(src_pcd, tgt_pcd, np.eye(4), icp_type="point2line")
+    # float64 clouds at georeferenced magnitudes (Open3D's clouds are double): float32 spacing there is 0.25 m, above the
+    # 0.1 m correspondence distance -- the mirror moves both clouds to a local origin in double before its float32 cast
+    off = np.array([2647123.4, 1177456.7, 1500.2])
+    s64, t64 = s.astype(np.float64) + off, t.astype(np.float64) + off
+    init = np.eye(4)
+    init[:3, 3] = [0.01, -0.02, 0.005]
+    res = icp_registration(tensor2pcd(torch.from_numpy(s64)), tensor2pcd(torch.from_numpy(t64)), init, threshold=0.1)
+    ref = O.icp(s64, t64, init, 0.1, 30)
+    moved = s64 @ res["est_transform"][:3, :3].T + res["est_transform"][:3, 3]
+    want = s64 @ ref["est_transform"][:3, :3].T + ref["est_transform"][:3, 3]
+    assert np.abs(moved - want).max() < 2e-4  # float32 of the local coordinates (1e-7 x ~3 m), not of the georeferenced ones
+    assert abs(res["fitness"] - ref["fitness"]) < 5e-3 and res["fitness"] > 0.5
 
 
 def test_compute_supervoxel_shim_and_partition_file(golden_dir, tmp_path):
