@@ -49,7 +49,7 @@ SIGNATURES = {
     "f4l_supervoxel_workspace_bytes": (_SZ, [_I64, _I]),
     "f4l_supervoxel": (C.c_int, [_P, _I64, _I, _D, _P, _P, _P, _P, _P, _SZ, _P]),
     "f4l_supervoxel_segment_device_workspace_bytes": (_SZ, [_I64, _I]),
-    "f4l_supervoxel_segment_device": (C.c_int, [_P, _P, _P, _I64, _I, _D, _P, _P, _P, _P, _SZ, _P]),
+    "f4l_supervoxel_segment_device": (C.c_int, [_P, _P, _P, _I64, _I, _D, _P, _P, _P, _P, _P, _SZ, _P]),
     "f4l_supervoxel_parallel_workspace_bytes": (_SZ, [_I64, _I]),
     "f4l_supervoxel_parallel": (C.c_int, [_P, _I64, _I, _D, _P, _P, _P, _P, _P, _P, _SZ, _P]),
     "f4l_supervoxel_segment_host": (C.c_int, [_P, _P, _P, _I64, _I, _D, _P, _P]),

@@ -101,9 +101,13 @@ __device__ __forceinline__ int32_t block_append(int32_t *counter, bool take, int
 #define SV_FOR(i, n) for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (int64_t)(n); i += (int64_t)gridDim.x * blockDim.x)
 
 // ---- K: occupied cells of the resolution grid ------------------------------------------------------------------------
-__global__ void init_state_kernel(State *st, int32_t n) {
+struct GridBox { int given; float mn[3], mx[3]; };
+__global__ void init_state_kernel(State *st, int32_t n, GridBox box) {
     st->lambda = 0.0; st->tau_excl = 0ULL;
-    for (int d = 0; d < 3; ++d) { st->bb[d] = 0xffffffffu; st->bb[3 + d] = 0u; }
+    for (int d = 0; d < 3; ++d) {  // the grid's anchor and extent: the cloud's own bounding box unless the caller gave one
+        st->bb[d] = box.given ? f2ord(box.mn[d]) : 0xffffffffu;
+        st->bb[3 + d] = box.given ? f2ord(box.mx[d]) : 0u;
+    }
     st->live = n; st->K = 0; st->n_edges = 0; st->n_edges_new = 0; st->n_prop = 0; st->round = 0; st->stalled = 0;
     st->sweeps_done = 0; st->sweep_on = 1; st->changed = 0; st->full_sweep = 1; st->n_labels = 0;
 }
@@ -168,7 +172,7 @@ __global__ void min_metric_kernel(const float *__restrict__ xyz, const double *_
         double best = DBL_MAX;
         for (int j = 0; j < k; ++j) {
             const int64_t q = knn[i * k + j];
-            if (q != i) {
+            if (q != i && q >= 0) {  // (a negative entry = "no neighbour here": a point outside the caller's slab)
                 const double m = sv_metric(xyz, nrm, i, q, resolution);
                 best = m < best ? m : best;
             }
@@ -397,7 +401,8 @@ __global__ void sweep_kernel(const float *__restrict__ xyz, const double *__rest
         if (full || din[i]) {
             double best = dis[i];
             for (int j = 0; j < k; ++j) {
-                const int32_t b = lin[knn[i * k + j]];
+                const int32_t q = knn[i * k + j];
+                const int32_t b = q >= 0 ? lin[q] : a;
                 if (b == a || b == bl) continue;
                 const double d = sv_metric(xyz, nrm, i, (int64_t)b, resolution);
                 if (d < best) { best = d; bl = b; }
@@ -406,7 +411,10 @@ __global__ void sweep_kernel(const float *__restrict__ xyz, const double *__rest
                 dis[i] = best;
                 any = true;
                 dout[i] = 1;  // looked at again next sweep, together with the points it lists (:228-236)
-                for (int j = 0; j < k; ++j) dout[knn[i * k + j]] = 1;
+                for (int j = 0; j < k; ++j) {
+                    const int32_t q = knn[i * k + j];
+                    if (q >= 0) dout[q] = 1;
+                }
             }
         }
         lout[i] = bl;
@@ -506,11 +514,19 @@ extern "C" size_t f4l_supervoxel_segment_device_workspace_bytes(int64_t n, int k
 
 // Enqueues the whole segmentation on `stream`; never synchronises, never touches host memory.
 extern "C" int f4l_supervoxel_segment_device(const float *xyz, const double *normals, const int32_t *knn, int64_t n, int k,
-                                             double resolution, int32_t *labels_out, int32_t *reps_out, int32_t *info_out,
-                                             void *workspace, size_t workspace_bytes, void *stream) {
+                                             double resolution, const float *grid_bbox_host, int32_t *labels_out,
+                                             int32_t *reps_out, int32_t *info_out, void *workspace, size_t workspace_bytes,
+                                             void *stream) {
     using namespace f4l;
     using namespace f4l::svg;
     if (!xyz || !normals || !knn || n <= 0 || k < 1 || !(resolution > 0.0) || !labels_out || !workspace) return F4L_EINVAL;
+    GridBox box;
+    box.given = grid_bbox_host ? 1 : 0;
+    for (int d = 0; d < 3; ++d) {
+        box.mn[d] = grid_bbox_host ? grid_bbox_host[d] : 0.f;
+        box.mx[d] = grid_bbox_host ? grid_bbox_host[3 + d] : 0.f;
+        if (grid_bbox_host && !(box.mx[d] >= box.mn[d])) return F4L_EINVAL;
+    }
     if (n > 0x7fffffffLL || (double)n * (double)k > 2147483647.0) return F4L_EUNSUPPORTED;
     Ws w;
     int rc = layout(n, k, w, (unsigned char *)workspace);
@@ -519,9 +535,9 @@ extern "C" int f4l_supervoxel_segment_device(const float *xyz, const double *nor
     hipStream_t st = (hipStream_t)stream;
     const dim3 g(GRID), b(BLOCK), one(1);
 
-    hipLaunchKernelGGL(init_state_kernel, one, one, 0, st, w.st, (int32_t)n);
+    hipLaunchKernelGGL(init_state_kernel, one, one, 0, st, w.st, (int32_t)n, box);
     // K
-    hipLaunchKernelGGL(svg::bbox_kernel, g, b, 0, st, xyz, n, w.st);
+    if (!box.given) hipLaunchKernelGGL(svg::bbox_kernel, g, b, 0, st, xyz, n, w.st);
     hipLaunchKernelGGL(grid_key_kernel, g, b, 0, st, xyz, n, resolution, w.st, w.keys_a);
     F4L_LAUNCH_CHECK();
     size_t tb = w.prim_bytes;
@@ -597,5 +613,5 @@ extern "C" int f4l_supervoxel_parallel(const float *xyz, int64_t n, int k, doubl
     double *nrm = normals_out ? normals_out : (double *)(base + shared + idx_b);
     int rc = f4l_knn_normals(xyz, n, k, idx, nullptr, nrm, workspace, a, stream);
     if (rc != F4L_OK) return rc;
-    return f4l_supervoxel_segment_device(xyz, nrm, idx, n, k, resolution, labels_out, reps_out, info_out, workspace, s, stream);
+    return f4l_supervoxel_segment_device(xyz, nrm, idx, n, k, resolution, nullptr, labels_out, reps_out, info_out, workspace, s, stream);
 }

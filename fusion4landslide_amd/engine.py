@@ -461,12 +461,13 @@ def supervoxel(xyz, k, resolution, return_intermediates=False):
     return labels, nsv.value
 
 
-def supervoxel_segment_device(xyz, normals, knn_idx, resolution, return_reps=False):
+def supervoxel_segment_device(xyz, normals, knn_idx, resolution, return_reps=False, grid_bbox=None):
     """The segmentation stage entirely on the device, asynchronously (f4l_supervoxel_segment_device: the parallel variant
     of supervoxel_segmentation.h:65-248; NOT label-identical to the sequential reference, same invariants).
     Returns labels (n,) int32 and info (4,) int32 = [supervoxels, K wanted, status bits, sweeps], both ON THE DEVICE
     (reading `info` is the caller's synchronisation point)[, reps (n,) int32: the first info[0] entries are the
-    representative point of every supervoxel]."""
+    representative point of every supervoxel].  `grid_bbox` (6 floats: min xyz, max xyz) anchors the resolution grid whose
+    occupied cells set the count (default: the cloud's own box); knn entries < 0 or equal to their row are "no neighbour"."""
     torch = require_gpu()
     xyz = _dev(xyz, torch.float32, "xyz", (3,))
     normals = _dev(normals, torch.float64, "normals", (3,))
@@ -479,7 +480,8 @@ def supervoxel_segment_device(xyz, normals, knn_idx, resolution, return_reps=Fal
     reps = torch.empty((n,), dtype=torch.int32, device=xyz.device) if return_reps else None
     nbytes = lib().f4l_supervoxel_segment_device_workspace_bytes(n, k)
     ws = torch.empty((max(int(nbytes), 1),), dtype=torch.uint8, device=xyz.device)
-    check(lib().f4l_supervoxel_segment_device(ptr(xyz), ptr(normals), ptr(knn_idx), n, int(k), float(resolution), ptr(labels),
+    box = None if grid_bbox is None else (C.c_float * 6)(*[float(v) for v in grid_bbox])
+    check(lib().f4l_supervoxel_segment_device(ptr(xyz), ptr(normals), ptr(knn_idx), n, int(k), float(resolution), box, ptr(labels),
                                               ptr(reps), ptr(info), ptr(ws), C.c_size_t(nbytes), stream_ptr()),
           "f4l_supervoxel_segment_device")
     return (labels, info, reps) if return_reps else (labels, info)

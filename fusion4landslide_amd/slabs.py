@@ -1,0 +1,152 @@
+"""Multi-GPU split of the PARTITION stage (kNN + normals + supervoxels) of one large cloud: slabs along x with a halo
+(BASELINE.json configs[4]).  The per-patch loop shards by patches (sharding.py, no data-path collective); the
+partition is the one stage of the path with a real exchange step, because a point's neighbours can lie on another GPU.
+
+One process per GPU (`torch.distributed`: backend "nccl" = RCCL over xGMI on the GPUs, "gloo" in the CPU tests).  Every rank
+starts with an arbitrary chunk of the cloud (e.g. its share of the file) and ends with the supervoxel labels of the points it
+OWNS.  Steps, with their collectives:
+
+  1. grid     all_reduce(MIN / MAX) of the bounding box; the resolution grid of `GridSample`
+              (codelibrary/geometry/point_cloud/grid_sample.h:48-68) is anchored at the WHOLE cloud's minimum.
+  2. cuts     histogram of the points per x-column of that grid, all_reduce(SUM); the slabs are runs of whole columns with
+              balanced point counts, so every grid cell lies in exactly one slab and the slabs' supervoxel targets (occupied
+              cells) add up to the whole cloud's.
+  3. owners   all_to_all (variable sizes) of the points to the rank that owns their column.
+  4. halo     each rank sends its two neighbours the owned points within `halo` metres of the common cut (point-to-point
+              volume only: on the xGMI mesh neighbours are directly linked) -- realised as the same variable all_to_all with
+              empty messages for non-neighbours.
+  5. kNN      exact kNN + PCA normals of owned + halo points on the rank's GPU (f4l_knn_normals).  An owned point's list is
+              the WHOLE cloud's list when its k-th distance does not reach past the halo's outer edge; the count of points
+              for which that fails is all_reduced and returned (0 for a halo of a few neighbour spacings; the caller widens
+              the halo otherwise).
+  6. segment  supervoxels of the owned points only (f4l_supervoxel_segment_device, neighbours in the halo dropped: a
+              supervoxel never crosses a cut -- the seam is a straight supervoxel boundary along a grid line), counted in the
+              whole cloud's grid.
+  7. labels   all_gather of the per-slab counts; global label = exclusive prefix + local label: 0 .. K-1, K = the whole
+              cloud's occupied cells.
+
+If the neighbour graph proves fragile for a data set (e.g. slabs thinner than the halo), the fallback SURVEY.md 8(e) names
+stands: tiles (<= 1 M points, cpp_core/pcd_tiling) are independent, one replica of the single-GPU partition per tile.
+"""
+import numpy as np
+
+
+def _a2a_v(dist, torch, payload, dest, world):
+    """Variable-size all_to_all of the rows of `payload` (n, c) float64 to ranks `dest` (n,) int64.  Returns the received rows
+    (ordered by source rank, original order inside a source)."""
+    order = torch.argsort(dest, stable=True)
+    send = payload[order].contiguous()
+    counts = torch.bincount(dest, minlength=world).to(torch.int64)
+    if world == 1:
+        return send
+    got = torch.zeros(world, dtype=torch.int64, device=payload.device)
+    dist.all_to_all_single(got, counts)
+    recv = torch.empty((int(got.sum()), payload.shape[1]), dtype=payload.dtype, device=payload.device)
+    c = payload.shape[1]
+    dist.all_to_all_single(recv.view(-1), send.view(-1), output_split_sizes=(got * c).tolist(), input_split_sizes=(counts * c).tolist())
+    return recv
+
+
+def plan_slabs(local_xyz, resolution, dist, world):
+    """Steps 1-2.  local_xyz (n, 3) float32 torch tensor (any device).  Returns dict(grid_min, grid_max float32 (3,) numpy,
+    bounds (world + 1,) int64 numpy: slab r owns the grid columns bounds[r] .. bounds[r + 1] - 1, n_total)."""
+    import torch
+    dev = local_xyz.device
+    big = torch.finfo(torch.float32).max
+    mn = local_xyz.min(dim=0).values if local_xyz.shape[0] else torch.full((3,), big, device=dev)
+    mx = local_xyz.max(dim=0).values if local_xyz.shape[0] else torch.full((3,), -big, device=dev)
+    if world > 1:
+        dist.all_reduce(mn, op=dist.ReduceOp.MIN)
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+    gmin, gmax = mn.double(), mx.double()
+    ncol = int((gmax[0] - gmin[0]) / resolution + 1)  # grid_sample.h:49
+    col = torch.clamp(((local_xyz[:, 0].double() - gmin[0]) / resolution).to(torch.int64), 0, ncol - 1)
+    hist = torch.bincount(col, minlength=ncol).to(torch.int64)
+    if world > 1:
+        dist.all_reduce(hist, op=dist.ReduceOp.SUM)
+    cum = torch.cumsum(hist, 0).cpu().numpy()
+    n_total = int(cum[-1])
+    bounds = np.zeros(world + 1, dtype=np.int64)
+    for r in range(1, world):
+        bounds[r] = max(bounds[r - 1], int(np.searchsorted(cum, r * n_total / world, side="left")) + 1)
+    bounds[world] = ncol
+    bounds = np.minimum(bounds, ncol)
+    return dict(grid_min=mn.cpu().numpy(), grid_max=mx.cpu().numpy(), bounds=bounds, n_total=n_total, ncol=ncol)
+
+
+def slab_supervoxel(local_xyz, local_gid, k, resolution, dist, rank, world, halo, knn_normals_fn=None, segment_fn=None):
+    """Steps 3-7 (and 1-2 through plan_slabs).  local_xyz (n, 3) float32, local_gid (n,) int64 global point ids of this rank's
+    chunk.  knn_normals_fn(xyz) -> (idx (m, k) int, d2 (m, k) float64, normals (m, 3) float64) and segment_fn(xyz, normals, knn,
+    resolution, grid_bbox) -> (labels (m,) int, K) default to the HIP path (f4l_knn_normals, f4l_supervoxel_segment_device);
+    the CPU tests inject checkers.  Returns dict(xyz, gid, labels (global), knn_gid (n_owned, k) neighbour GLOBAL ids, d2,
+    normals, K_local, K_total, offset, n_uncertified (whole job), plan)."""
+    import torch
+    dev = local_xyz.device
+    plan = plan_slabs(local_xyz, resolution, dist, world)
+    b = plan["bounds"]
+    x0 = float(plan["grid_min"][0])
+    cuts = x0 + b.astype(np.float64) * resolution  # slab r = [cuts[r], cuts[r + 1]) in x (the last one closed by the clamp)
+    width = np.diff(cuts)
+    if world > 1 and halo > width[(width > 0)].min():
+        raise ValueError(f"halo {halo} m is wider than the thinnest slab ({width.min():.3f} m): use fewer ranks or tiles")
+    col = torch.clamp(((local_xyz[:, 0].double() - x0) / resolution).to(torch.int64), 0, plan["ncol"] - 1)
+    owner = torch.bucketize(col, torch.from_numpy(b[1:-1]).to(dev), right=True) if world > 1 else torch.zeros_like(col)
+    packed = torch.cat([local_xyz.double(), local_gid.double()[:, None]], dim=1)  # (ids < 2^53 travel exactly as doubles)
+    own = _a2a_v(dist, torch, packed, owner, world)
+    # halo: owned points within `halo` of a cut go to the rank on the other side
+    x = own[:, 0]
+    parts, dests = [], []
+    if rank > 0:
+        m = x < cuts[rank] + halo
+        parts.append(own[m]); dests.append(torch.full((int(m.sum()),), rank - 1, dtype=torch.int64, device=dev))
+    if rank < world - 1:
+        m = x >= cuts[rank + 1] - halo
+        parts.append(own[m]); dests.append(torch.full((int(m.sum()),), rank + 1, dtype=torch.int64, device=dev))
+    out = torch.cat(parts) if parts else own[:0]
+    dst = torch.cat(dests) if dests else torch.zeros(0, dtype=torch.int64, device=dev)
+    halo_pts = _a2a_v(dist, torch, out, dst, world) if world > 1 else own[:0]
+    n_own = own.shape[0]
+    allp = torch.cat([own, halo_pts])
+    xyz_all = allp[:, :3].float().contiguous()
+    gid_all = allp[:, 3].to(torch.int64)
+
+    if knn_normals_fn is None:
+        from . import engine
+
+        def knn_normals_fn(p):
+            idx, nrm, d2 = engine.knn_normals(p, k, return_d2=True)
+            return idx, d2, nrm
+    idx, d2, nrm = knn_normals_fn(xyz_all)
+    idx, d2, nrm = idx[:n_own].to(torch.int64), d2[:n_own], nrm[:n_own]
+    # certified: the k-th neighbour lies inside slab + halo whatever lies beyond
+    dk = torch.sqrt(d2[:, -1])
+    xo = own[:, 0]
+    ok = torch.ones(n_own, dtype=torch.bool, device=dev)
+    if rank > 0:
+        ok &= dk < xo - (cuts[rank] - halo)
+    if rank < world - 1:
+        ok &= dk < (cuts[rank + 1] + halo) - xo
+    bad = torch.tensor([int((~ok).sum())], dtype=torch.int64, device=dev)
+    if world > 1:
+        dist.all_reduce(bad, op=dist.ReduceOp.SUM)
+
+    # segmentation of the owned points; neighbours in the halo are "no neighbour" there
+    knn_local = torch.where(idx < n_own, idx, torch.full_like(idx, -1))
+    box = np.concatenate([plan["grid_min"], plan["grid_max"]]).astype(np.float32)
+    if segment_fn is None:
+        from . import engine
+
+        def segment_fn(p, normals, knn_, res, grid_bbox):
+            labels, info = engine.supervoxel_segment_device(p, normals, knn_.to(torch.int32), res, grid_bbox=grid_bbox)
+            return labels, int(info.cpu()[0])
+    if n_own:
+        labels, K_local = segment_fn(xyz_all[:n_own].contiguous(), nrm, knn_local, resolution, box)
+    else:
+        labels, K_local = torch.zeros(0, dtype=torch.int64, device=dev), 0
+    counts = torch.zeros(world, dtype=torch.int64, device=dev)
+    counts[rank] = K_local
+    if world > 1:
+        dist.all_reduce(counts, op=dist.ReduceOp.SUM)
+    offset = int(counts[:rank].sum())
+    return dict(xyz=xyz_all[:n_own], gid=gid_all[:n_own], labels=labels.to(torch.int64) + offset, knn_gid=gid_all[idx], d2=d2, normals=nrm,
+                K_local=int(K_local), K_total=int(counts.sum()), offset=offset, n_uncertified=int(bad.item()), plan=plan, n_halo=int(halo_pts.shape[0]))

@@ -249,7 +249,11 @@ int f4l_supervoxel(const float *xyz, int64_t n, int k, double resolution, int32_
  * sequential reference (f4l_supervoxel keeps the label-identical replay); they satisfy the same invariants and are
  * deterministic.  Never synchronises `stream`, never touches host memory: a fixed schedule of launches whose trip counts
  * live on the device.
- *   xyz float32 [n][3], normals double [n][3], knn int32 [n][k] (device; e.g. from f4l_knn / f4l_normals)
+ *   xyz float32 [n][3], normals double [n][3], knn int32 [n][k] (device; e.g. from f4l_knn / f4l_normals); a knn entry
+ *   equal to its own row, or negative, is "no neighbour" (how a slab of a larger cloud drops neighbours it does not own)
+ *   grid_bbox_host: HOST float32 [6] = {min x, y, z, max x, y, z} anchoring the resolution grid whose occupied cells are
+ *   counted, or NULL for the cloud's own bounding box (grid_sample.h:48-51); a slab passes the WHOLE cloud's box so that the
+ *   slabs' counts add up to the whole cloud's
  *   labels_out int32 [n];  reps_out int32 [n] or NULL: reps_out[l] = index of supervoxel l's representative point;
  *   info_out int32 [4] (device) or NULL: {supervoxels produced, K wanted, status bits, exchange sweeps run};
  *   status bit 0: the graph of representatives ran out of edges above K (disconnected cloud; the reference would not
@@ -257,8 +261,8 @@ int f4l_supervoxel(const float *xyz, int64_t n, int k, double resolution, int32_
  * f4l_supervoxel_parallel = f4l_knn + f4l_normals + this (f4l_knn synchronises once while it sizes its grid). */
 size_t f4l_supervoxel_segment_device_workspace_bytes(int64_t n, int k);
 int f4l_supervoxel_segment_device(const float *xyz, const double *normals, const int32_t *knn, int64_t n, int k,
-                                  double resolution, int32_t *labels_out, int32_t *reps_out, int32_t *info_out,
-                                  void *workspace, size_t workspace_bytes, void *stream);
+                                  double resolution, const float *grid_bbox_host, int32_t *labels_out, int32_t *reps_out,
+                                  int32_t *info_out, void *workspace, size_t workspace_bytes, void *stream);
 size_t f4l_supervoxel_parallel_workspace_bytes(int64_t n, int k);
 int f4l_supervoxel_parallel(const float *xyz, int64_t n, int k, double resolution, int32_t *labels_out, int32_t *reps_out,
                             int32_t *info_out, int32_t *knn_out, double *normals_out, void *workspace,

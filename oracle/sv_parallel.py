@@ -25,10 +25,14 @@ def metric(xyz, nrm, a, b, resolution):
     return 1.0 - np.abs(dot) + np.sqrt(t1 * t1 + t2 * t2 + t3 * t3) / resolution * 0.4
 
 
-def occupied_cells(xyz, resolution):
-    """grid_sample.h:48-68: number of occupied cells of the grid anchored at the bounding box minimum."""
+def occupied_cells(xyz, resolution, grid_bbox=None):
+    """grid_sample.h:48-68: number of occupied cells of the grid anchored at the bounding box minimum (of the cloud, or the
+    box given: a slab counts its cells in the whole cloud's grid)."""
     p = xyz.astype(np.float64)
-    mn, mx = p.min(axis=0), p.max(axis=0)
+    if grid_bbox is None:
+        mn, mx = p.min(axis=0), p.max(axis=0)
+    else:
+        mn, mx = (np.asarray(grid_bbox, dtype=np.float32).astype(np.float64)[i:i + 3] for i in (0, 3))
     size = ((mx - mn) / resolution + 1).astype(np.int64)
     c = np.clip(((p - mn) / resolution).astype(np.int64), 0, size - 1)
     key = (c[:, 0] * size[1] + c[:, 1]) * size[2] + c[:, 2]
@@ -61,13 +65,15 @@ def _find(parent):
         r = rr
 
 
-def segment(xyz, nrm, knn, resolution):
-    """Returns dict(labels (n,) int32, reps (K,) int32, n_supervoxels, K_target, status, sweeps, lambda0)."""
+def segment(xyz, nrm, knn, resolution, grid_bbox=None):
+    """Returns dict(labels (n,) int32, reps (K,) int32, n_supervoxels, K_target, status, sweeps, lambda0).  A knn entry < 0 (or
+    equal to its row) is "no neighbour"."""
     xyz = np.ascontiguousarray(xyz, dtype=np.float32)
     nrm = np.ascontiguousarray(nrm, dtype=np.float64)
     knn = np.ascontiguousarray(knn, dtype=np.int64)
     n, k = knn.shape
-    K = occupied_cells(xyz, resolution)
+    knn = np.where(knn < 0, np.arange(n)[:, None], knn)
+    K = occupied_cells(xyz, resolution, grid_bbox)
     idx = np.repeat(np.arange(n), k)
     flat = knn.reshape(-1)
     notself = flat != idx

@@ -134,3 +134,16 @@ def test_device_segmentation_1M_invariants_and_no_host_round_trip(eng):
     # >= 20x over the 1.9 s of the sequential host stage: well under 95 ms
     assert ms < 95.0, ms
     print(f"device segmentation of 1 M points: {ms:.1f} ms, K = {K}, sweeps = {info[3]}")
+
+
+def test_slab_pipeline_single_rank_equals_the_whole_partition(eng):
+    """fusion4landslide_amd/slabs.py with its default (HIP) kernels at world_size 1: the multi-GPU partition pipeline reduces to
+    f4l_supervoxel_parallel (the N > 1 orchestration is covered by tests/test_slabs_gloo.py)."""
+    from fusion4landslide_amd import slabs
+    rng = np.random.default_rng(8)
+    xyz = np.c_[rng.uniform(0, 5, (20_000, 2)), np.zeros(20_000)].astype(np.float32)
+    xyz[:, 2] = 0.2 * np.sin(2 * xyz[:, 0]) * np.cos(3 * xyz[:, 1])
+    out = slabs.slab_supervoxel(dev(xyz), torch.arange(20_000, device="cuda"), 30, 0.5, None, 0, 1, halo=0.3)
+    labels, K = eng.supervoxel_parallel(dev(xyz), 30, 0.5)
+    assert out["K_total"] == out["K_local"] == K and out["n_uncertified"] == 0 and out["offset"] == 0
+    assert torch.equal(out["labels"].to(torch.int32), labels) and torch.equal(out["gid"], torch.arange(20_000, device="cuda"))

@@ -1,0 +1,103 @@
+"""CPU suite: the multi-GPU split of the partition stage (fusion4landslide_amd/slabs.py: slabs along x, halo exchange, seam
+ownership) with world_size 2 and 3 on gloo.  The per-rank kernels are injected (the oracle's kNN / normals and the numpy model
+of the device segmentation act as the checkers here); on a GPU node the defaults are the HIP path over RCCL."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+N, K_NN, RES, HALO = 9000, 12, 0.5, 0.4
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _cloud():
+    rng = np.random.default_rng(11)
+    xy = rng.uniform(0, 1, (N, 2)) * [6.0, 3.0]
+    z = 0.2 * np.sin(2 * xy[:, 0]) * np.cos(3 * xy[:, 1]) + rng.normal(0, 0.003, N)
+    return np.c_[xy, z].astype(np.float32)
+
+
+def _knn_normals(p):
+    from oracle import oracle as O
+    idx, d2 = O.knn(p.numpy(), K_NN)
+    return torch.from_numpy(idx), torch.from_numpy(d2), torch.from_numpy(O.normals_from_knn(p.numpy(), idx))
+
+
+def _segment(p, normals, knn, res, grid_bbox):
+    from oracle import sv_parallel as M
+    r = M.segment(p.numpy(), normals.numpy(), knn.numpy(), res, grid_bbox=grid_bbox)
+    assert r["status"] == 0
+    return torch.from_numpy(r["labels"]), r["n_supervoxels"]
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from fusion4landslide_amd import slabs
+    xyz = _cloud()
+    mine = np.arange(rank, N, world)  # an arbitrary chunk per rank: every world-th point
+    out = slabs.slab_supervoxel(torch.from_numpy(xyz[mine]), torch.from_numpy(mine.astype(np.int64)), K_NN, RES, dist, rank, world, HALO,
+                                knn_normals_fn=_knn_normals, segment_fn=_segment)
+    q.put((rank, {k: (v.numpy() if hasattr(v, "numpy") else v) for k, v in out.items() if k != "plan"}, out["plan"]["bounds"].tolist()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("world", [2, 3])
+def test_slab_split_matches_the_whole_cloud(world):
+    from oracle import oracle as O
+    from oracle import sv_parallel as M
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=500) for _ in range(world)], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    xyz = _cloud()
+    gidx, gd2 = O.knn(xyz, K_NN)
+    bounds = res[0][2]
+    assert all(r[2] == bounds for r in res) and bounds[0] == 0 and sorted(bounds) == bounds
+    # ownership: every point on exactly one rank, on the rank whose columns hold it; balanced
+    gids = np.concatenate([r[1]["gid"] for r in res])
+    assert np.array_equal(np.sort(gids), np.arange(N))
+    x0 = xyz[:, 0].min()
+    for rank, out, _ in res:
+        col = np.clip(((out["xyz"][:, 0].astype(np.float64) - x0) / RES).astype(int), 0, bounds[-1] - 1)
+        assert ((col >= bounds[rank]) & (col < bounds[rank + 1])).all()
+        assert np.array_equal(out["xyz"], xyz[out["gid"]])
+        assert abs(len(out["gid"]) - N / world) < 0.25 * N / world
+        assert out["n_uncertified"] == 0 and (out["n_halo"] > 0) == (world > 1)
+        # the owned points' neighbour lists ARE the whole cloud's (ids and squared distances)
+        assert np.array_equal(out["d2"], gd2[out["gid"]])
+        assert np.array_equal(out["knn_gid"], gidx[out["gid"]])
+    # supervoxels: the slabs' counts add up to the whole cloud's occupied cells; labels contiguous; none crosses a cut
+    K = M.occupied_cells(xyz, RES)
+    assert all(r[1]["K_total"] == K for r in res) and sum(r[1]["K_local"] for r in res) == K
+    labels = np.empty(N, dtype=np.int64)
+    for rank, out, _ in res:
+        labels[out["gid"]] = out["labels"]
+        assert out["labels"].min() == out["offset"] and out["labels"].max() == out["offset"] + out["K_local"] - 1
+    assert np.array_equal(np.unique(labels), np.arange(K))
+    owner = np.empty(N, dtype=np.int64)
+    for rank, out, _ in res:
+        owner[out["gid"]] = rank
+    for lab in range(K):
+        assert len(set(owner[labels == lab])) == 1
