@@ -233,8 +233,10 @@ __device__ __noinline__ void icp_prepass(const PrepassArgs<F, NT> &q) {
     // (every thread wrote its own points only, and phase 1 reads them with the same thread: no barrier)
 }
 
-template <int MODE, int NW, typename F>
-__global__ __launch_bounds__(NW * 64, sizeof(F) == 8 ? ICP_WAVES_PER_EU_F64 : ICP_WAVES_PER_EU) void icp_kernel(IcpArgs a) {
+// WIDE = the register budget of three waves per SIMD (170 VGPRs) instead of four (128): the float64 build keeps ~50 VGPRs
+// in scratch at 128.  Worth it only for two-wave workgroups in the throughput regime (see icp_shape).
+template <int MODE, int NW, typename F, bool WIDE = false>
+__global__ __launch_bounds__(NW * 64, WIDE ? 3 : (sizeof(F) == 8 ? ICP_WAVES_PER_EU_F64 : ICP_WAVES_PER_EU)) void icp_kernel(IcpArgs a) {
     constexpr int NV = (MODE == F4L_ICP_POINT2POINT) ? 17 : 29;
     constexpr int NT = NW * 64;
     // Correspondence sums.  float32 search + point-to-point: per-lane partial sums and the in-wave reduction are
@@ -867,25 +869,25 @@ __global__ void icp_bin_patches(const int64_t *__restrict__ src_off, const int64
     }
 }
 
-template <int MODE, int NW, typename F>
+template <int MODE, int NW, typename F, bool WIDE = false>
 static int launch_icp_one(const IcpArgs &a, size_t lds, hipStream_t st) {
     if (lds > 64 * 1024)  // opt in to > 64 KiB of dynamic LDS
-        F4L_HIP_CHECK(hipFuncSetAttribute((const void *)icp_kernel<MODE, NW, F>,
+        F4L_HIP_CHECK(hipFuncSetAttribute((const void *)icp_kernel<MODE, NW, F, WIDE>,
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((icp_kernel<MODE, NW, F>), dim3((unsigned)a.P), dim3(NW * 64), lds, st, a);
+    hipLaunchKernelGGL((icp_kernel<MODE, NW, F, WIDE>), dim3((unsigned)a.P), dim3(NW * 64), lds, st, a);
     F4L_LAUNCH_CHECK();
     return F4L_OK;
 }
 
 template <typename F>
-static int launch_icp(const IcpArgs &a, int mode, int nw, size_t lds, hipStream_t st) {
+static int launch_icp(const IcpArgs &a, int mode, int nw, size_t lds, hipStream_t st, bool wide = false) {
     if (mode == F4L_ICP_POINT2POINT) {
         if (nw == 1) return launch_icp_one<0, 1, F>(a, lds, st);
-        if (nw == 2) return launch_icp_one<0, 2, F>(a, lds, st);
+        if (nw == 2) return wide ? launch_icp_one<0, 2, F, true>(a, lds, st) : launch_icp_one<0, 2, F>(a, lds, st);
         return launch_icp_one<0, 4, F>(a, lds, st);
     }
     if (nw == 1) return launch_icp_one<1, 1, F>(a, lds, st);
-    if (nw == 2) return launch_icp_one<1, 2, F>(a, lds, st);
+    if (nw == 2) return wide ? launch_icp_one<1, 2, F, true>(a, lds, st) : launch_icp_one<1, 2, F>(a, lds, st);
     return launch_icp_one<1, 4, F>(a, lds, st);
 }
 
@@ -912,15 +914,23 @@ static hipStream_t class_stream(int which) {
 }
 
 // Workgroup shape and LDS layout for patches of at most max_src sources and max_tgt targets.
-struct IcpPlan { int nw, tgt_cap, cell_cap, cert_cap, src_cap, pp_cap; size_t lds; };
-static IcpPlan icp_plan(int64_t max_src_patch_host, int64_t max_tgt_patch_host, bool f64, int mode) {
+struct IcpPlan { int nw, tgt_cap, cell_cap, cert_cap, src_cap, pp_cap; size_t lds; bool wide; };
+// `throughput`: the launch holds many rounds of workgroups (see icp_launch_host): the shape that moves the most patches per
+// second wins, not the one that finishes a single patch soonest.
+static IcpPlan icp_plan(int64_t max_src_patch_host, int64_t max_tgt_patch_host, bool f64, int mode, bool throughput = false) {
     const size_t pt = sizeof(GridPt<float>);  // 16 B in both modes
-    // waves per patch: four measured best from 2 k to 32 k patches of ~500 points (the LDS a patch needs limits a CU to
-    // ~4 patches, and a patch keeps 4 waves busier than 2); patches that fit one or two wavefronts get just those
+    // Waves per patch.  A patch's pass is a chain (certify, search, reduce, solve, three barriers): four waves finish it
+    // soonest, which is what counts while a launch is only a few rounds of workgroups (C2: 0.72 ms against 0.80 ms with two
+    // waves).  In the throughput regime two waves with the register budget of three waves per SIMD (no scratch) and five to
+    // six workgroups per CU move more patches: C4 22.9 instead of 26.1 ms (measured grid: DESIGN.md section 5).  Patches
+    // that fit one or two wavefronts get just those.
     int nw = 4;
+    bool wide = false;
     if (max_src_patch_host <= 64) nw = 1;
     else if (max_src_patch_host <= 128) nw = 2;
-    { const char *e = getenv("F4L_ICP_WAVES"); if (e) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) nw = v; } }
+    else if (throughput && f64 && !getenv("F4L_ICP_NOWIDE")) { nw = 2; wide = true; }
+    { const char *e = getenv("F4L_ICP_WAVES"); if (e) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) { nw = v; wide = wide && v == 2; } } }
+    if (getenv("F4L_ICP_WIDE")) wide = nw == 2;
 
     // LDS plan: targets first (they make the grid possible), then the prefix table, then the certificate arrays
     // (partial-sum region: as SCRATCH in icp_kernel)
@@ -949,14 +959,27 @@ static IcpPlan icp_plan(int64_t max_src_patch_host, int64_t max_tgt_patch_host, 
     {
         const size_t pb = (size_t)((max_src_patch_host + 3) & ~(int64_t)3) * 3 * 4;
         const size_t sb = (size_t)((max_src_patch_host + 3) & ~(int64_t)3) * 3 * (f64 ? 8 : 4);
-        auto fits = [&](size_t extra) { return lds + extra <= (size_t)ICP_LDS_BUDGET && (lds + extra <= 40 * 1024 || lds > 40 * 1024); };
+        // LDS per workgroup up to which the optional arrays are added: four workgroups per CU (of four waves), or five of two
+        // waves at three waves per SIMD
+        size_t keep = 40 * 1024;
+        if (wide) {  // six workgroups of two waves fill three waves per SIMD: stay in the tier the mandatory arrays reach
+            int tier = 6;
+            while (tier > 1 && lds > (size_t)(160 * 1024) / tier) --tier;
+            keep = (size_t)(160 * 1024) / tier;
+        }
+        if (const char *e = getenv("F4L_ICP_LDS_KEEP")) keep = (size_t)atoi(e) * 1024;
+        auto fits = [&](size_t extra) { return lds + extra <= (size_t)ICP_LDS_BUDGET && (lds + extra <= keep || lds > keep); };
         if (cert_cap && !getenv("F4L_ICP_NOPP") && fits(pb)) { pp_cap = cert_cap; lds += pb; }
         if (fits(sb)) { src_cap = (int)max_src_patch_host; lds += sb; }
     }
     lds = (lds + 15) & ~(size_t)15;
+    if (getenv("F4L_ICP_PLAN_DEBUG"))
+        fprintf(stderr, "[icp plan] max_src %lld max_tgt %lld nw %d: lds %zu B (tgt_cap %d cell_cap %d cert_cap %d pp_cap %d src_cap %d) -> %d workgroups per CU\n",
+                (long long)max_src_patch_host, (long long)max_tgt_patch_host, nw, lds, tgt_cap, cell_cap, cert_cap, pp_cap, src_cap, (int)(160 * 1024 / lds));
     IcpPlan pl;
     pl.nw = nw; pl.tgt_cap = tgt_cap; pl.cell_cap = cell_cap; pl.cert_cap = cert_cap; pl.src_cap = src_cap; pl.pp_cap = pp_cap;
     pl.lds = lds;
+    pl.wide = wide;
     return pl;
 }
 }  // namespace f4l
@@ -1045,7 +1068,12 @@ static int f4l::icp_launch_host(const float *src, const int64_t *src_off, const 
     { const char *e = getenv("F4L_ICP_MU"); if (e && atof(e) > 0.0) a.mu_frac = atof(e); }
     a.T_out = T_out; a.fitness_out = fitness_out; a.rmse_out = rmse_out; a.iters_out = iters_out; a.corr_out = corr_out;
 
-    const IcpPlan pl = icp_plan(max_src_patch_host, max_tgt_patch_host, f64, mode);
+    // throughput regime: tens of rounds of workgroups (1024 slots of four waves on the chip), where patches per second count
+    // and not one patch's latency.  (Dense batches -- correspondence radius ~ patch size, C3 -- prefer four waves at 20 k
+    // patches; at 32 k and more the rule below would take them too: override with F4L_ICP_WAVES=4.)
+    bool throughput = P >= 32768;
+    if (const char *e = getenv("F4L_ICP_THROUGHPUT")) throughput = atoi(e) != 0;
+    const IcpPlan pl = icp_plan(max_src_patch_host, max_tgt_patch_host, f64, mode, throughput);
     const int nw = pl.nw, tgt_cap = pl.tgt_cap, cell_cap = pl.cell_cap, cert_cap = pl.cert_cap, src_cap = pl.src_cap;
     const size_t lds = pl.lds;
     a.tgt_cap = tgt_cap; a.cert_cap = cert_cap; a.cell_cap = cell_cap; a.src_cap = src_cap; a.pp_cap = pl.pp_cap;
@@ -1059,7 +1087,7 @@ static int f4l::icp_launch_host(const float *src, const int64_t *src_off, const 
         F4L_HIP_CHECK(hipMemset(dp, 0, prof_bytes));
         a.prof = dp;
         a.prof_max_n = getenv("F4L_ICP_PROF_MAXN") ? atoi(getenv("F4L_ICP_PROF_MAXN")) : 0x7fffffff;
-        int rc = f64 ? launch_icp<double>(a, mode, nw, lds, (hipStream_t)stream) : launch_icp<float>(a, mode, nw, lds, (hipStream_t)stream);
+        int rc = f64 ? launch_icp<double>(a, mode, nw, lds, (hipStream_t)stream, pl.wide) : launch_icp<float>(a, mode, nw, lds, (hipStream_t)stream, pl.wide);
         F4L_HIP_CHECK(hipDeviceSynchronize());
         F4L_HIP_CHECK(hipMemcpy(hp, dp, sizeof(hp), hipMemcpyDeviceToHost));
         if (getenv("F4L_ICP_PROF_WG")) {  // per-workgroup start/end (100 MHz ticks) -> schedule statistics
@@ -1111,7 +1139,16 @@ static int f4l::icp_launch_host(const float *src, const int64_t *src_off, const 
     // (median 58 points, largest 153).  Evenly sized patches (C2: mean 494, largest 574) stay one launch.
     const bool wave_classes = nw > 1 && P >= 512 &&
                               (getenv("F4L_ICP_SMALLCLASSES") || (n_src_host > 0 && 4 * n_src_host <= 3 * P * max_src_patch_host));
-    if ((lds_classes || wave_classes) && P >= 64 && !getenv("F4L_ICP_NOCLASSES"))
+    // ... and in the throughput regime, when a few patches are much larger than the rest (border patches that collect what
+    // moved out of the tile: 902 targets against a mean of 500 at C4), the bulk gets a class of its own whose LDS is sized
+    // for IT: one more workgroup per CU for 99 % of the patches.
+    int64_t bulk = 0;
+    if (throughput && n_src_host > 0 && P >= 4096 && !getenv("F4L_ICP_NOSPLIT")) {
+        const int64_t mean = n_src_host / P;
+        const int64_t b = ((5 * mean / 4) + 63) / 64 * 64;
+        if (b > 128 && 13 * mean <= 10 * big && b < big) bulk = b;
+    }
+    if ((lds_classes || wave_classes || bulk) && P >= 64 && !getenv("F4L_ICP_NOCLASSES"))
     {
         int step = 4;  // ratio between class bounds: 4 (256, 1024, 4096), 2, or 1 = sqrt(2)
         if (const char *e = getenv("F4L_ICP_CLASS_STEP")) step = atoi(e);
@@ -1121,10 +1158,20 @@ static int f4l::icp_launch_host(const float *src, const int64_t *src_off, const 
             cb.bound[cb.n++] = (int)b;
             b = step == 4 ? b * 4 : (step == 2 ? b * 2 : ((cb.n & 1) ? (b * 3) / 2 : (b * 4) / 3));
         }
+        if (bulk && cb.n < ICP_MAX_CLASSES - 1) {  // insert in ascending order, unless a bound that close exists already
+            int at = 0;
+            while (at < cb.n && cb.bound[at] < bulk) ++at;
+            const bool near = (at < cb.n && cb.bound[at] <= bulk + bulk / 4) || (at > 0 && cb.bound[at - 1] >= bulk - bulk / 4);
+            if (!near) {
+                for (int i = cb.n; i > at; --i) cb.bound[i] = cb.bound[i - 1];
+                cb.bound[at] = (int)bulk;
+                ++cb.n;
+            }
+        }
     }
     if (cb.n == 0)
-        return f64 ? launch_icp<double>(a, mode, nw, lds, (hipStream_t)stream)
-                   : launch_icp<float>(a, mode, nw, lds, (hipStream_t)stream);
+        return f64 ? launch_icp<double>(a, mode, nw, lds, (hipStream_t)stream, pl.wide)
+                   : launch_icp<float>(a, mode, nw, lds, (hipStream_t)stream, pl.wide);
     cb.bound[cb.n++] = (int)(big > 0x7fffffff ? 0x7fffffff : big);
     hipStream_t st = (hipStream_t)stream;
     int *buf = nullptr;
@@ -1158,7 +1205,7 @@ static int f4l::icp_launch_host(const float *src, const int64_t *src_off, const 
         for (int k = cb.n - 1; k >= 0 && rc == F4L_OK; --k) {
             const int64_t ms = max_src_patch_host < cb.bound[k] ? max_src_patch_host : cb.bound[k];
             const int64_t mt = max_tgt_patch_host < cb.bound[k] ? max_tgt_patch_host : cb.bound[k];
-            const IcpPlan pk = icp_plan(ms, mt, f64, mode);
+            const IcpPlan pk = icp_plan(ms, mt, f64, mode, throughput);
             IcpArgs ak = a;
             ak.tgt_cap = pk.tgt_cap; ak.cert_cap = pk.cert_cap; ak.cell_cap = pk.cell_cap; ak.src_cap = pk.src_cap; ak.pp_cap = pk.pp_cap;
             ak.list = buf + (size_t)k * (size_t)P; ak.list_cnt = cnt + k;
@@ -1169,7 +1216,7 @@ static int f4l::icp_launch_host(const float *src, const int64_t *src_off, const 
                 if (fail(hipStreamWaitEvent(sk, forked, 0))) break;
                 used[k] = sk;  // from here on the helper stream may hold work that reads the caller's buffers
             }
-            rc = f64 ? launch_icp<double>(ak, mode, pk.nw, pk.lds, sk) : launch_icp<float>(ak, mode, pk.nw, pk.lds, sk);
+            rc = f64 ? launch_icp<double>(ak, mode, pk.nw, pk.lds, sk, pk.wide) : launch_icp<float>(ak, mode, pk.nw, pk.lds, sk, pk.wide);
         }
     } while (false);
     // join every helper stream that was handed work (also after an error), then release
