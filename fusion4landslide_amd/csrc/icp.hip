@@ -928,7 +928,8 @@ static IcpPlan icp_plan(int64_t max_src_patch_host, int64_t max_tgt_patch_host, 
     bool wide = false;
     if (max_src_patch_host <= 64) nw = 1;
     else if (max_src_patch_host <= 128) nw = 2;
-    else if (throughput && f64 && !getenv("F4L_ICP_NOWIDE")) { nw = 2; wide = true; }
+    else if (throughput && !getenv("F4L_ICP_NOWIDE")) { nw = 2; wide = f64; }  // (the float32 build fits 128 VGPRs without scratch)
+    const bool tiers = throughput && nw == 2;
     { const char *e = getenv("F4L_ICP_WAVES"); if (e) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) { nw = v; wide = wide && v == 2; } } }
     if (getenv("F4L_ICP_WIDE")) wide = nw == 2;
 
@@ -962,8 +963,8 @@ static IcpPlan icp_plan(int64_t max_src_patch_host, int64_t max_tgt_patch_host, 
         // LDS per workgroup up to which the optional arrays are added: four workgroups per CU (of four waves), or five of two
         // waves at three waves per SIMD
         size_t keep = 40 * 1024;
-        if (wide) {  // six workgroups of two waves fill three waves per SIMD: stay in the tier the mandatory arrays reach
-            int tier = 6;
+        if (tiers) {  // six (eight at 128 VGPRs) workgroups of two waves fill the SIMDs: stay in the tier the mandatory arrays reach
+            int tier = wide ? 6 : 8;
             while (tier > 1 && lds > (size_t)(160 * 1024) / tier) --tier;
             keep = (size_t)(160 * 1024) / tier;
         }

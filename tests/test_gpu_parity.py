@@ -469,6 +469,53 @@ def test_icp_size_classes_match_single_launch_and_oracle(eng, mix, monkeypatch):
     assert np.median(disp) <= 1e-5 and (disp <= 1e-4).mean() >= 0.85
 
 
+@pytest.mark.parametrize("search,icp_type", [("f64", "point2point"), ("f32", "point2point"), ("f64", "point2plane")])
+def test_icp_throughput_shape_equals_the_latency_shape(eng, search, icp_type, monkeypatch):
+    """Batches of tens of thousands of patches run as two-wave workgroups with the register budget of three waves per SIMD
+    (float64) and a size class of their own for the bulk of the patches (icp_launch_host: `throughput`); smaller batches as
+    four-wave workgroups.  Forced onto a small uneven batch, the throughput shape must give the results of the default shape
+    (points meet other lanes, so the sums round differently: the same trajectories to 1e-9 m in float64, the same
+    correspondences and fitness exactly) and the oracle's."""
+    from fusion4landslide_amd import synthetic
+    d = synthetic.make_patches(60_000, 11, 1.386, seed=23, roughness=0.1)  # 121 patches of ~500 points
+    rng = np.random.default_rng(5)
+    big = rng.choice(d["P"], 6, replace=False)  # a few patches get three times the targets: the "border patches" of a tile
+    tl, to = [], [0]
+    for p in range(d["P"]):
+        t = d["tgt"][d["tgt_off"][p]:d["tgt_off"][p + 1]]
+        if p in big:
+            t = np.concatenate([t, t + rng.normal(0, 0.02, t.shape).astype(np.float32), t + rng.normal(0, 0.02, t.shape).astype(np.float32)])
+        tl.append(t)
+        to.append(to[-1] + len(t))
+    tgt, toff = np.concatenate(tl), np.array(to, dtype=np.int64)
+    args = (dev(d["src"]), dev(d["src_off"]), dev(tgt), dev(toff))
+    kw = dict(max_corr_dist=0.1, max_iter=20, fixed_iters=True, search=search, icp_type=icp_type, return_corr=True)
+    monkeypatch.setenv("F4L_ICP_THROUGHPUT", "0")
+    ref = eng.piecewise_icp(*args, **kw)
+    monkeypatch.setenv("F4L_ICP_THROUGHPUT", "1")
+    monkeypatch.setenv("F4L_ICP_PLAN_DEBUG", "1")
+    out = eng.piecewise_icp(*args, **kw)
+    monkeypatch.delenv("F4L_ICP_THROUGHPUT")
+    monkeypatch.delenv("F4L_ICP_PLAN_DEBUG")
+    dd = dict(src=d["src"], src_off=d["src_off"], P=d["P"])
+    per = _disp_per_patch(dd, out["T"].cpu().numpy(), ref["T"].cpu().numpy())
+    assert torch.equal(out["iters"], ref["iters"])
+    # (a patch whose blocks moved beyond the correspondence radius is ill-posed: it may settle elsewhere after the first
+    #  rounding difference, on any two shapes and against the oracle alike -- DESIGN.md section 4; one such patch here)
+    well = (ref["fitness"] > 0.8).cpu().numpy()
+    assert well.mean() > 0.6
+    if search == "f64":
+        assert per[well].max() <= (1e-9 if icp_type == "point2point" else 1e-6), per[well].max()
+        wt = torch.from_numpy(well).cuda()
+        assert torch.equal(out["fitness"][wt], ref["fitness"][wt])
+        assert float((out["rmse"] - ref["rmse"])[wt].abs().max()) < 1e-10
+    else:  # float32 mode: ill-posed patches may settle elsewhere after the first rounding difference (DESIGN.md section 4)
+        assert np.median(per) <= 1e-5 and (per <= 1e-4).mean() >= 0.85, per
+    if search == "f64" and icp_type == "point2point":
+        o = O.piecewise_icp(d["src"], d["src_off"], tgt, toff, max_corr_dist=0.1, max_iter=20, fixed_iters=True)
+        assert _disp_per_patch(dd, out["T"].cpu().numpy(), o["T"])[well].max() <= 1e-9
+
+
 def test_icp_vs_open3d_goldens_when_present(eng, golden_dir):
     """Fixtures written by tools/dump_o3d_goldens.py where Open3D 0.19.0 exists; absent in this repository's build
     container (then skipped: the ICP parity is anchored on the CPU oracle)."""
