@@ -340,6 +340,20 @@ def extras(torch, engine, synthetic, prob, dev, args):
                      "algorithmic_GBs": round(528.0 * c["n"] / s / 1e9, 1), "frac_of_hbm_peak": round(528.0 * c["n"] / s / 1e9 / HBM_PEAK_GBS, 5)}
         del p, d
         torch.cuda.empty_cache()
+    # configs[4] on one GPU: the whole hot path of a tile -- supervoxel partition (all on the device), patches, point matches,
+    # Kabsch + 20-iteration ICP + rows, nearest-neighbour refinement -- end to end, stage by stage
+    from fusion4landslide_amd import pipeline
+    for n_pts, cells in ((1_000_000, 45), (10_000_000, 142)):
+        c = synthetic.make_patches_device(n_pts, cells, 1.386, dev, seed=0)
+        src, tgt = c["src"], c["tgt"]
+        del c
+        pipeline.full_path(src, tgt, max_iter=MAX_ITER, fixed_iters=True)  # warm-up
+        r = pipeline.full_path(src, tgt, max_iter=MAX_ITER, fixed_iters=True)
+        out[f"full_path_{n_pts // 1_000_000}M"] = {"value": round(n_pts / r["stage_ms"]["total"] / 1e3, 3), "unit": "Mpts/s", "supervoxels": int(r["K"]),
+                                                    "resolution_m": round(r["resolution"], 4), "stage_ms": {k: round(v, 3) for k, v in r["stage_ms"].items()},
+                                                    "mean_fitness": round(float(r["fitness"].mean().item()), 4)}
+        del src, tgt, r
+        torch.cuda.empty_cache()
     return out
 
 

