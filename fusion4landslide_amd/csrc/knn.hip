@@ -142,12 +142,15 @@ __device__ __forceinline__ int lower_bound_u64(const unsigned long long *__restr
 
 constexpr int KNN_NW = 4;
 
-__global__ void cell_runs_kernel(const unsigned long long *__restrict__ cell_keys, const int32_t *__restrict__ cell_start, int M,
+// (q_keys / q_start / Mq: the occupied cells of the QUERIES -- the cloud's own table for f4l_knn, the query cloud's, binned into
+//  the same grid, for f4l_nn_query; cell_keys / cell_start / M: the cloud searched)
+__global__ void cell_runs_kernel(const unsigned long long *__restrict__ q_keys, const int32_t *__restrict__ q_start, int Mq,
+                                 const unsigned long long *__restrict__ cell_keys, const int32_t *__restrict__ cell_start, int M,
                                  GridSpec g, int32_t *__restrict__ run_lo, int32_t *__restrict__ run_hi, int32_t *__restrict__ pcell) {
     const int t = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-    if (t >= 9 * M) return;
+    if (t >= 9 * Mq) return;
     const int c = t / 9, r = t % 9;
-    const unsigned long long key = cell_keys[c];
+    const unsigned long long key = q_keys[c];
     const int cx = (int)(key % (unsigned long long)g.nx);
     const int cy = (int)((key / (unsigned long long)g.nx) % (unsigned long long)g.ny);
     const int cz = (int)(key / ((unsigned long long)g.nx * (unsigned long long)g.ny));
@@ -160,8 +163,8 @@ __global__ void cell_runs_kernel(const unsigned long long *__restrict__ cell_key
     }
     run_lo[t] = lo;
     run_hi[t] = hi;
-    if (r == 4)  // (dy, dz) = (0, 0): this thread also tags the cell's own points
-        for (int i = cell_start[c]; i < cell_start[c + 1]; ++i) pcell[i] = c;
+    if (r == 4)  // (dy, dz) = (0, 0): this thread also tags the cell's own queries
+        for (int i = q_start[c]; i < q_start[c + 1]; ++i) pcell[i] = c;
 }
 
 struct KnnArgs {
@@ -1020,7 +1023,7 @@ static int knn_self(const float *xyz, int64_t n, int k, int32_t *idx_out, double
     // one lane per query; the queries it cannot certify are listed and redone one wave each
     F4L_HIP_CHECK(hipMemsetAsync(w.fb_count, 0, 4, st));
     hipLaunchKernelGGL(cell_runs_kernel, dim3((unsigned)((9 * (int64_t)M + 255) / 256)), dim3(256), 0, st, w.cell_keys, w.cell_start, M,
-                       g, w.run_lo, w.run_hi, w.pcell);
+                       w.cell_keys, w.cell_start, M, g, w.run_lo, w.run_hi, w.pcell);
     F4L_LAUNCH_CHECK();
     KnnLanesArgs ra;
     ra.run_lo = w.run_lo; ra.run_hi = w.run_hi; ra.pcell = w.pcell;
@@ -1134,7 +1137,30 @@ extern "C" int f4l_nn_query(const float *cloud, int64_t n, const float *queries,
     a.sorted = w.sorted; a.cell_keys = w.cell_keys; a.cell_start = w.cell_start; a.M = M; a.n = n; a.k = k; a.g = g;
     a.q_sorted = wq.sorted; a.q_cell_keys = wq.cell_keys; a.q_cell_start = wq.cell_start; a.Mq = Mq;
     a.idx_out = idx_out; a.d2_out = d2_out;
-    hipLaunchKernelGGL(knn_cells_kernel, dim3((unsigned)((Mq + KNN_NW - 1) / KNN_NW)), dim3(KNN_NW * 64), 0, st, a);
+    if (k > KR_MAX_K || getenv("F4L_KNN_WAVE_PER_QUERY")) {
+        hipLaunchKernelGGL(knn_cells_kernel, dim3((unsigned)((Mq + KNN_NW - 1) / KNN_NW)), dim3(KNN_NW * 64), 0, st, a);
+        F4L_LAUNCH_CHECK();
+        return F4L_OK;
+    }
+    // one lane per query (see knn_lanes_kernel); the runs of every occupied QUERY cell are looked up in the cloud's cell table
+    F4L_HIP_CHECK(hipMemsetAsync(wq.fb_count, 0, 4, st));
+    hipLaunchKernelGGL(cell_runs_kernel, dim3((unsigned)((9 * (int64_t)Mq + 255) / 256)), dim3(256), 0, st, wq.cell_keys, wq.cell_start, Mq,
+                       w.cell_keys, w.cell_start, M, g, wq.run_lo, wq.run_hi, wq.pcell);
+    F4L_LAUNCH_CHECK();
+    KnnLanesArgs ra;
+    a.n = m;  // the lane kernel's query count
+    ra.a = a; ra.run_lo = wq.run_lo; ra.run_hi = wq.run_hi; ra.pcell = wq.pcell; ra.fb_list = wq.fb_list; ra.fb_count = wq.fb_count;
+    ra.xyz = nullptr; ra.normals_out = nullptr; ra.prof = nullptr; ra.edge_slack = (float)(1e-6 * g.h * g.h);
+    {
+        const float top = (float)(4.0 * g.h * g.h);
+        unsigned int bits;
+        memcpy(&bits, &top, 4);
+        ra.bin_base = (int)(bits >> 21) - (KR_NB - 1);
+    }
+    hipLaunchKernelGGL(knn_lanes_kernel, dim3((unsigned)((m + KR_NW * 64 - 1) / (KR_NW * 64))), dim3(KR_NW * 64), 0, st, ra);
+    F4L_LAUNCH_CHECK();
+    a.n = n;
+    hipLaunchKernelGGL(knn_listed_kernel, dim3(2048), dim3(KNN_NW * 64), 0, st, a, wq.fb_list, wq.fb_count);
     F4L_LAUNCH_CHECK();
     return F4L_OK;
 }

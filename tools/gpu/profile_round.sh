@@ -5,7 +5,8 @@
 #   stats_<cfg>/ , stats_<cfg>.csv      rocprofv3 --kernel-trace --stats of `bench.py --config <cfg> --steps 50 --warmup 5`
 #   fetch_<cfg>/ , write_<cfg>/         FETCH_SIZE and WRITE_SIZE of the same command in SEPARATE --pmc passes
 #                                       (MI355X_MICROARCH.md: they do not fit one pass), 3 timed steps
-#   stats_knn / fetch_knn / write_knn   the same three for tools/gpu/time_knn.py (f4l_knn, f4l_normals, f4l_supervoxel, 1 M points)
+#   stats_knn / fetch_knn / write_knn   the same three for tools/gpu/knn_only.py (f4l_knn and f4l_knn_normals, 1 M points, 13 launches each)
+#   stats_sv                            kernel stats of tools/gpu/time_supervoxel.py (the device segmentation, 1 M points)
 #   traffic_raw.json                    per-kernel means of the counters, in the counters' own unit
 TAG=${1:-r2}
 R=$GRAFT_REPO_ROOT
@@ -21,11 +22,13 @@ for CFG in C4_50M_100k C3_10M_20k C2_1M_2k; do
   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch_$CFG -- $B --steps 3 --warmup 1 > $OUT/fetch_$CFG.log 2>&1
   rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write_$CFG -- $B --steps 3 --warmup 1 > $OUT/write_$CFG.log 2>&1
 done
-K="python3 tools/gpu/time_knn.py"
+K="python3 tools/gpu/knn_only.py"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_knn -- $K > $OUT/stats_knn.log 2>&1
 cp $OUT/stats_knn/*/*_kernel_stats.csv $OUT/stats_knn.csv
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch_knn -- $K > $OUT/fetch_knn.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write_knn -- $K > $OUT/write_knn.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_sv -- python3 tools/gpu/time_supervoxel.py > $OUT/stats_sv.log 2>&1
+cp $OUT/stats_sv/*/*_kernel_stats.csv $OUT/stats_sv.csv
 python3 - "$OUT" <<'PY'
 import csv, glob, json, sys, collections
 out = sys.argv[1]
@@ -37,7 +40,7 @@ for run in ("C4_50M_100k", "C3_10M_20k", "C2_1M_2k", "knn"):
         if fs:
             for row in csv.DictReader(open(fs[0])):
                 kn = row["Kernel_Name"]
-                k = next((t for t in ("icp_kernel", "knn_cells_kernel", "knn_block_kernel", "normals_kernel", "nn_refine_kernel", "sv_") if t in kn), None)
+                k = next((t for t in ("icp_kernel", "knn_lanes_kernel", "knn_listed_kernel", "knn_cells_kernel", "normals_kernel", "nn_refine_kernel", "sv_") if t in kn), None)
                 if k:
                     if k == "sv_": k = kn.split("(")[0].split("::")[-1]
                     acc[(k, row["Counter_Name"])].append(float(row["Counter_Value"]))
