@@ -140,13 +140,29 @@ __device__ __forceinline__ int lower_bound_u64(const unsigned long long *__restr
     return lo;
 }
 
+// [lo, hi) of the sorted array for the cells with keys k0 .. k1 (one row of cells along x).  `dense` (when the grid is small
+// enough for one word per cell, see knn_build_grid): dense[c] = number of points in cells with keys below c -- two loads
+// instead of two binary searches over the occupied cells.
+__device__ __forceinline__ void cell_range(const int32_t *__restrict__ dense, const unsigned long long *__restrict__ cell_keys,
+                                           const int32_t *__restrict__ cell_start, int M, unsigned long long k0, unsigned long long k1,
+                                           int &lo, int &hi) {
+    if (dense) { lo = dense[k0]; hi = dense[k1 + 1ULL]; }
+    else { lo = cell_start[lower_bound_u64(cell_keys, M, k0)]; hi = cell_start[lower_bound_u64(cell_keys, M, k1 + 1ULL)]; }
+}
+__global__ void dense_scatter_kernel(const unsigned long long *__restrict__ cell_keys, const int32_t *__restrict__ cell_counts, int M,
+                                     int32_t *__restrict__ dense) {
+    const int j = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (j < M) dense[cell_keys[j] + 1ULL] = cell_counts[j];
+}
+
 constexpr int KNN_NW = 4;
 
 // (q_keys / q_start / Mq: the occupied cells of the QUERIES -- the cloud's own table for f4l_knn, the query cloud's, binned into
 //  the same grid, for f4l_nn_query; cell_keys / cell_start / M: the cloud searched)
 __global__ void cell_runs_kernel(const unsigned long long *__restrict__ q_keys, const int32_t *__restrict__ q_start, int Mq,
                                  const unsigned long long *__restrict__ cell_keys, const int32_t *__restrict__ cell_start, int M,
-                                 GridSpec g, int32_t *__restrict__ run_lo, int32_t *__restrict__ run_hi, int32_t *__restrict__ pcell) {
+                                 const int32_t *__restrict__ dense, GridSpec g, int32_t *__restrict__ run_lo, int32_t *__restrict__ run_hi,
+                                 int32_t *__restrict__ pcell) {
     const int t = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     if (t >= 9 * Mq) return;
     const int c = t / 9, r = t % 9;
@@ -158,8 +174,7 @@ __global__ void cell_runs_kernel(const unsigned long long *__restrict__ q_keys, 
     int lo = 0, hi = 0;
     if (yy >= 0 && yy < g.ny && zz >= 0 && zz < g.nz) {
         const int x0 = cx - 1 < 0 ? 0 : cx - 1, x1 = cx + 1 >= g.nx ? g.nx - 1 : cx + 1;
-        lo = cell_start[lower_bound_u64(cell_keys, M, key_of(g, x0, yy, zz))];
-        hi = cell_start[lower_bound_u64(cell_keys, M, key_of(g, x1, yy, zz) + 1ULL)];
+        cell_range(dense, cell_keys, cell_start, M, key_of(g, x0, yy, zz), key_of(g, x1, yy, zz), lo, hi);
     }
     run_lo[t] = lo;
     run_hi[t] = hi;
@@ -172,6 +187,7 @@ struct KnnArgs {
     const unsigned long long *cell_keys;  // [M] ascending
     const int32_t *cell_start;        // [M+1] first sorted index of each occupied cell
     int M;
+    const int32_t *dense;             // [cells + 1] points below each cell of the grid, or nullptr (cell_range)
     // the queries, binned into the cells of the SAME grid (f4l_knn: the cloud itself; f4l_nn_query: another cloud,
     // points outside the grid clamped into its border cells)
     const float4 *q_sorted;
@@ -194,10 +210,7 @@ __device__ __forceinline__ void block1_rows(const KnnArgs &a, int cx, int cy, in
         const int yy = cy + (lane % 3) - 1, zz = cz + (lane / 3) - 1;
         if (yy >= 0 && yy < g.ny && zz >= 0 && zz < g.nz) {
             const int x0 = cx - 1 < 0 ? 0 : cx - 1, x1 = cx + 1 >= g.nx ? g.nx - 1 : cx + 1;
-            const int ca = lower_bound_u64(a.cell_keys, a.M, key_of(g, x0, yy, zz));
-            const int cb = lower_bound_u64(a.cell_keys, a.M, key_of(g, x1, yy, zz) + 1ULL);
-            row_lo1 = a.cell_start[ca];
-            row_hi1 = a.cell_start[cb];
+            cell_range(a.dense, a.cell_keys, a.cell_start, a.M, key_of(g, x0, yy, zz), key_of(g, x1, yy, zz), row_lo1, row_hi1);
         }
     }
 }
@@ -228,10 +241,7 @@ __device__ __forceinline__ void knn_query_wave(const KnnArgs &a, const float4 qp
                 if (r < rows) {
                     const int yy = y0 + (r % side), zz = z0 + (r / side);
                     const int x0 = cx - R < 0 ? 0 : cx - R, x1 = cx + R >= g.nx ? g.nx - 1 : cx + R;
-                    const int ca = lower_bound_u64(a.cell_keys, a.M, key_of(g, x0, yy, zz));
-                    const int cb = lower_bound_u64(a.cell_keys, a.M, key_of(g, x1, yy, zz) + 1ULL);
-                    lo = a.cell_start[ca];
-                    hi = a.cell_start[cb];
+                    cell_range(a.dense, a.cell_keys, a.cell_start, a.M, key_of(g, x0, yy, zz), key_of(g, x1, yy, zz), lo, hi);
                 }
             }
             const int nrow = rows - r0 < 64 ? rows - r0 : 64;
@@ -277,8 +287,15 @@ __device__ __forceinline__ void knn_query_wave(const KnnArgs &a, const float4 qp
         if (cz + R < g.nz - 1) margin = fmin(margin, ((double)(R + 1)) * g.h - fz - eps);
         const double dk = best.kth(k);
         if (dk < margin * margin || R >= max_dim) break;  // uniform: dk, margin are wave-uniform
-        // fewer than k points in the whole block (queries far from the cloud): double it instead of one more layer
-        R = dk == __builtin_inf() ? (2 * R < max_dim ? 2 * R : max_dim) : R + 1;
+        // fewer than k points in the whole block (queries far from the cloud): double it instead of one more layer; else
+        // straight to the first block whose faces lie beyond the k-th distance found (it can only shrink: that block ends the
+        // search -- queries displaced against the cloud, e.g. a moving slope's epoch 2 against epoch 1)
+        if (dk == __builtin_inf()) R = 2 * R < max_dim ? 2 * R : max_dim;
+        else {
+            const double need = (sqrt(dk) + eps) * g.inv_h + 1.0;
+            const int Rj = need < (double)max_dim ? (int)need : max_dim;
+            R = Rj > R + 1 ? Rj : R + 1;
+        }
     }
 }
 
@@ -831,6 +848,8 @@ struct KnnWs {
     int32_t *ids_a, *ids_b, *cell_counts, *cell_start, *n_cells;
     float4 *sorted;
     int32_t *fb_list, *fb_count, *run_lo, *run_hi, *pcell;
+    int32_t *dense;      // [2 n + 4] (cell_range); in use when has_dense
+    bool has_dense;
     float *bbox_partial;
     void *prim_temp;
     size_t prim_bytes, total;
@@ -851,6 +870,11 @@ static int knn_ws_layout(int64_t n, KnnWs &w, unsigned char *base) {
         rle_b = rle_b > r32 ? rle_b : r32;
     }
     if (rocprim::exclusive_scan(nullptr, scan_b, i0, i0, 0, (size_t)n + 1, rocprim::plus<int32_t>(), 0, false) != hipSuccess) return F4L_EHIP;
+    {
+        size_t d_b = 0;
+        if (rocprim::inclusive_scan(nullptr, d_b, i0, i0, 2 * (size_t)n + 4, rocprim::plus<int32_t>(), 0, false) != hipSuccess) return F4L_EHIP;
+        scan_b = scan_b > d_b ? scan_b : d_b;
+    }
     size_t prim = sort_b > rle_b ? sort_b : rle_b;
     prim = prim > scan_b ? prim : scan_b;
     size_t o = 0;
@@ -869,6 +893,8 @@ static int knn_ws_layout(int64_t n, KnnWs &w, unsigned char *base) {
     w.run_lo = (int32_t *)carve((size_t)n * 9 * 4);
     w.run_hi = (int32_t *)carve((size_t)n * 9 * 4);
     w.pcell = (int32_t *)carve((size_t)n * 4);
+    w.dense = (int32_t *)carve((2 * (size_t)n + 4) * 4);
+    w.has_dense = false;
     w.bbox_partial = (float *)carve(256 * 6 * 4);
     w.prim_temp = carve(prim);
     w.prim_bytes = prim;
@@ -983,6 +1009,20 @@ static int knn_build_grid(const float *xyz, int64_t n, int k, KnnWs &w, hipStrea
     // 4. sorted float4 layout
     hipLaunchKernelGGL(relayout_kernel, dim3(grid_for(n)), dim3(256), 0, st, xyz, w.ids_b, n, w.sorted);
     F4L_LAUNCH_CHECK();
+    // 5. one word per cell of the whole grid while that stays within two words per point (terrain tiles: always)
+    w.has_dense = false;
+    {
+        const double ncell = (double)g.nx * (double)g.ny * (double)g.nz;
+        if (ncell <= 2.0 * (double)n + 2.0 && !getenv("F4L_KNN_NO_DENSE")) {
+            const size_t nc = (size_t)ncell;
+            F4L_HIP_CHECK(hipMemsetAsync(w.dense, 0, (nc + 1) * 4, st));
+            hipLaunchKernelGGL(dense_scatter_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, w.cell_keys, w.cell_counts, M, w.dense);
+            F4L_LAUNCH_CHECK();
+            tb = w.prim_bytes;
+            F4L_HIP_CHECK(rocprim::inclusive_scan(w.prim_temp, tb, w.dense, w.dense, nc + 1, rocprim::plus<int32_t>(), st, false));
+            w.has_dense = true;
+        }
+    }
     return F4L_OK;
 }
 }  // namespace f4l
@@ -1007,6 +1047,7 @@ static int knn_self(const float *xyz, int64_t n, int k, int32_t *idx_out, double
     if (rc != F4L_OK) return rc;
     KnnArgs a;
     a.sorted = w.sorted; a.cell_keys = w.cell_keys; a.cell_start = w.cell_start; a.M = M; a.n = n; a.k = k; a.g = g;
+    a.dense = w.has_dense ? w.dense : nullptr;
     a.q_sorted = w.sorted; a.q_cell_keys = w.cell_keys; a.q_cell_start = w.cell_start; a.Mq = M;
     a.idx_out = idx_out; a.d2_out = d2_out;
     const bool lanes = k <= KR_MAX_K && !getenv("F4L_KNN_WAVE_PER_QUERY");  // (switch: A/B timing, and the test that both agree)
@@ -1023,7 +1064,7 @@ static int knn_self(const float *xyz, int64_t n, int k, int32_t *idx_out, double
     // one lane per query; the queries it cannot certify are listed and redone one wave each
     F4L_HIP_CHECK(hipMemsetAsync(w.fb_count, 0, 4, st));
     hipLaunchKernelGGL(cell_runs_kernel, dim3((unsigned)((9 * (int64_t)M + 255) / 256)), dim3(256), 0, st, w.cell_keys, w.cell_start, M,
-                       w.cell_keys, w.cell_start, M, g, w.run_lo, w.run_hi, w.pcell);
+                       w.cell_keys, w.cell_start, M, a.dense, g, w.run_lo, w.run_hi, w.pcell);
     F4L_LAUNCH_CHECK();
     KnnLanesArgs ra;
     ra.run_lo = w.run_lo; ra.run_hi = w.run_hi; ra.pcell = w.pcell;
@@ -1135,6 +1176,7 @@ extern "C" int f4l_nn_query(const float *cloud, int64_t n, const float *queries,
     F4L_LAUNCH_CHECK();
     KnnArgs a;
     a.sorted = w.sorted; a.cell_keys = w.cell_keys; a.cell_start = w.cell_start; a.M = M; a.n = n; a.k = k; a.g = g;
+    a.dense = w.has_dense ? w.dense : nullptr;
     a.q_sorted = wq.sorted; a.q_cell_keys = wq.cell_keys; a.q_cell_start = wq.cell_start; a.Mq = Mq;
     a.idx_out = idx_out; a.d2_out = d2_out;
     if (k > KR_MAX_K || getenv("F4L_KNN_WAVE_PER_QUERY")) {
@@ -1145,7 +1187,7 @@ extern "C" int f4l_nn_query(const float *cloud, int64_t n, const float *queries,
     // one lane per query (see knn_lanes_kernel); the runs of every occupied QUERY cell are looked up in the cloud's cell table
     F4L_HIP_CHECK(hipMemsetAsync(wq.fb_count, 0, 4, st));
     hipLaunchKernelGGL(cell_runs_kernel, dim3((unsigned)((9 * (int64_t)Mq + 255) / 256)), dim3(256), 0, st, wq.cell_keys, wq.cell_start, Mq,
-                       w.cell_keys, w.cell_start, M, g, wq.run_lo, wq.run_hi, wq.pcell);
+                       w.cell_keys, w.cell_start, M, a.dense, g, wq.run_lo, wq.run_hi, wq.pcell);
     F4L_LAUNCH_CHECK();
     KnnLanesArgs ra;
     a.n = m;  // the lane kernel's query count
@@ -1162,6 +1204,13 @@ extern "C" int f4l_nn_query(const float *cloud, int64_t n, const float *queries,
     a.n = n;
     hipLaunchKernelGGL(knn_listed_kernel, dim3(2048), dim3(KNN_NW * 64), 0, st, a, wq.fb_list, wq.fb_count);
     F4L_LAUNCH_CHECK();
+    if (getenv("F4L_KNN_DEBUG")) {  // (synchronises: measurements only)
+        int fbc = 0;
+        F4L_HIP_CHECK(hipMemcpyAsync(&fbc, wq.fb_count, 4, hipMemcpyDeviceToHost, st));
+        F4L_HIP_CHECK(hipStreamSynchronize(st));
+        fprintf(stderr, "[nn_query] n %lld m %lld k %d: h %.4f grid %d x %d x %d, %d cells (%d with queries), %d queries to the wave-per-query search\n",
+                (long long)n, (long long)m, k, g.h, g.nx, g.ny, g.nz, M, Mq, fbc);
+    }
     return F4L_OK;
 }
 

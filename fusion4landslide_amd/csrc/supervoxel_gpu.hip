@@ -130,9 +130,20 @@ __global__ void bbox_kernel(const float *__restrict__ xyz, int64_t n, State *st)
             mx[d] = b > mx[d] ? b : mx[d];
         }
     }
+    // one atomic per workgroup and bound (same-address atomics serialise: a launch of 256 workgroups, see the call)
+    __shared__ unsigned int part[16][6];
+    const int wave = (int)(threadIdx.x >> 6), nw = (int)(blockDim.x >> 6);
     if (lane_id() == 0) {
 #pragma unroll
-        for (int d = 0; d < 3; ++d) { atomicMin(&st->bb[d], mn[d]); atomicMax(&st->bb[3 + d], mx[d]); }
+        for (int d = 0; d < 3; ++d) { part[wave][d] = mn[d]; part[wave][3 + d] = mx[d]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        const int d = (int)threadIdx.x;
+        unsigned int v = part[0][d];
+        for (int w = 1; w < nw; ++w) v = d < 3 ? (part[w][d] < v ? part[w][d] : v) : (part[w][d] > v ? part[w][d] : v);
+        if (d < 3) atomicMin(&st->bb[d], v);
+        else atomicMax(&st->bb[d], v);
     }
 }
 // grid_sample.h:48-68: size = int(len / res + 1), cell = clamp(int((p - min) / res)), all in double
@@ -537,7 +548,7 @@ extern "C" int f4l_supervoxel_segment_device(const float *xyz, const double *nor
 
     hipLaunchKernelGGL(init_state_kernel, one, one, 0, st, w.st, (int32_t)n, box);
     // K
-    if (!box.given) hipLaunchKernelGGL(svg::bbox_kernel, g, b, 0, st, xyz, n, w.st);
+    if (!box.given) hipLaunchKernelGGL(svg::bbox_kernel, dim3(256), b, 0, st, xyz, n, w.st);
     hipLaunchKernelGGL(grid_key_kernel, g, b, 0, st, xyz, n, resolution, w.st, w.keys_a);
     F4L_LAUNCH_CHECK();
     size_t tb = w.prim_bytes;

@@ -229,6 +229,14 @@ def test_nn_query_vs_kdtree():
         # distances really are those of the returned indices
         got = ((cloud[idx.reshape(-1)].astype(np.float64) - np.repeat(q.astype(np.float64), k, axis=0)) ** 2).sum(1)
         assert np.abs(got - d2.reshape(-1)).max() <= 1e-12 * max(1.0, d2.max())
+    # the per-cell table of the whole grid (two loads per row of cells) against the binary searches over the occupied cells
+    import os
+    os.environ["F4L_KNN_NO_DENSE"] = "1"
+    try:
+        idx2, d22 = engine.nn_query(torch.from_numpy(cloud).cuda(), torch.from_numpy(q).cuda(), 4, return_d2=True)
+    finally:
+        del os.environ["F4L_KNN_NO_DENSE"]
+    assert (idx2.cpu().numpy() == idx).all() and (d22.cpu().numpy() == d2).all()
     # a single query, a single-point cloud, no queries
     one = engine.nn_query(torch.from_numpy(cloud[:1]).cuda(), torch.from_numpy(q[:7]).cuda(), 1)
     assert (one.cpu().numpy() == 0).all()
