@@ -1069,10 +1069,12 @@ static int f4l::icp_launch_host(const float *src, const int64_t *src_off, const 
     { const char *e = getenv("F4L_ICP_MU"); if (e && atof(e) > 0.0) a.mu_frac = atof(e); }
     a.T_out = T_out; a.fitness_out = fitness_out; a.rmse_out = rmse_out; a.iters_out = iters_out; a.corr_out = corr_out;
 
-    // throughput regime: tens of rounds of workgroups (1024 slots of four waves on the chip), where patches per second count
-    // and not one patch's latency.  (Dense batches -- correspondence radius ~ patch size, C3 -- prefer four waves at 20 k
-    // patches; at 32 k and more the rule below would take them too: override with F4L_ICP_WAVES=4.)
-    bool throughput = P >= 32768;
+    // throughput regime: six and more rounds of workgroups (1024 slots of four waves on the chip), where patches per second
+    // count and not one patch's latency: measured crossover between 2025 patches (C2: 0.68 ms against 0.80 ms in the
+    // throughput shape) and 8100 (2.08 against 2.30 ms; 32 400: 6.6 against 8.5 ms).  Batches with patches far larger than
+    // the rest (the size classes below; C3, whose patches are also much denser than the radius) stay with four waves:
+    // 27.1 against 30.0 ms there.
+    bool throughput = P >= 6144 && icp_plan(max_src_patch_host, max_tgt_patch_host, f64, mode, false).lds <= 48 * 1024;
     if (const char *e = getenv("F4L_ICP_THROUGHPUT")) throughput = atoi(e) != 0;
     const IcpPlan pl = icp_plan(max_src_patch_host, max_tgt_patch_host, f64, mode, throughput);
     const int nw = pl.nw, tgt_cap = pl.tgt_cap, cell_cap = pl.cell_cap, cert_cap = pl.cert_cap, src_cap = pl.src_cap;
@@ -1151,7 +1153,9 @@ static int f4l::icp_launch_host(const float *src, const int64_t *src_off, const 
     }
     if ((lds_classes || wave_classes || bulk) && P >= 64 && !getenv("F4L_ICP_NOCLASSES"))
     {
-        int step = 4;  // ratio between class bounds: 4 (256, 1024, 4096), 2, or 1 = sqrt(2)
+        // ratio between class bounds: 4 (256, 1024, 4096), 2, or 1 = ~sqrt(2) (256, 384, 512, 768, ...): every class pays
+        // for its own largest patch only -- C3 27.3 / 24.3 / 22.3 ms
+        int step = 1;
         if (const char *e = getenv("F4L_ICP_CLASS_STEP")) step = atoi(e);
         if (wave_classes)  // patches that fit one or two wavefronts get workgroups of just those
             for (int64_t b = 64; b <= 128 && 3 * b <= 2 * big; b *= 2) cb.bound[cb.n++] = (int)b;

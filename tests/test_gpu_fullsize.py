@@ -120,10 +120,12 @@ def test_full_size_C4_50M_100k(eng):
 def test_sharded_C4_equals_single_launch(eng):
     """The multi-GPU split of bench.py (--gpus 2: LPT shares of ONE cloud) run share by share on this GPU: per-patch results
     scattered back to global order are bit-equal to the single launch over the whole cloud (a patch's result does not
-    depend on which launch, or which workgroup, it ran in).  On a 4 M-point cloud of the C4 density."""
+    depend on which launch, or which workgroup, it ran in -- while the launches have the same shape: both shares and the
+    whole are throughput-shape batches here, >= 6144 patches; across shapes the sums are taken in another order and the
+    results agree to rounding, test_icp_throughput_shape_equals_the_latency_shape).  On a 16 M-point cloud of the C4 density."""
     from fusion4landslide_amd import sharding, synthetic
     dev = torch.device("cuda")
-    cloud = synthetic.make_patches_device(4_000_000, 90, 1.386, dev, seed=5)
+    cloud = synthetic.make_patches_device(16_000_000, 180, 1.386, dev, seed=5)
     P = cloud["P"]
 
     def run(d):
