@@ -33,8 +33,11 @@
 // launches whose tail turns into no-ops once the target count is reached (a no-op launch costs a few microseconds).
 // Results are deterministic (no result depends on the order atomics land in).
 #include <cfloat>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
+#include <hip/hip_cooperative_groups.h>
 #include <rocprim/rocprim.hpp>
 
 #include "f4l_device.h"
@@ -46,6 +49,9 @@ namespace svg {
 constexpr int LAMBDA_ROUNDS = 56;  // lambda0 * 2^55 exceeds any size * metric of a 2^31-point cloud
 constexpr int SUBROUNDS = 3;
 constexpr int SWEEPS = 96;
+// what the schedule of LAUNCHES covers when the rest can run in one cooperative kernel (segment_rest_kernel): a 1 M-point
+// terrain tile at the reference's resolutions needs 11-14 rounds and 9-15 sweeps
+constexpr int SCHED_ROUNDS = 16, SCHED_SWEEPS = 16;
 constexpr unsigned GRID = 2048, BLOCK = 256;
 constexpr unsigned long long DEAD = ~0ULL;
 
@@ -59,6 +65,11 @@ struct State {
     int32_t stalled;              // the graph of representatives has no edges left but live > K
     int32_t sweeps_done, sweep_on, changed, full_sweep;
     int32_t n_labels;
+    // grid barrier of segment_rest_kernel: BAR_GROUPS groups of workgroups, each with its own arrival counter and generation word
+    // (a cache line apart), one more counter for the groups' last arrivals
+    unsigned int bar_top, bar_pad[31];
+    unsigned int bar[2 * 16][32];
+    int32_t bar_timeout;              // a workgroup gave up waiting at the barrier (never expected: status bit 3)
 };
 
 __device__ __forceinline__ unsigned int f2ord(float f) {
@@ -110,6 +121,8 @@ __global__ void init_state_kernel(State *st, int32_t n, GridBox box) {
     }
     st->live = n; st->K = 0; st->n_edges = 0; st->n_edges_new = 0; st->n_prop = 0; st->round = 0; st->stalled = 0;
     st->sweeps_done = 0; st->sweep_on = 1; st->changed = 0; st->full_sweep = 1; st->n_labels = 0;
+    st->bar_top = 0u; st->bar_timeout = 0;
+    for (int i = 0; i < 2 * 16; ++i) st->bar[i][0] = 0u;
 }
 __global__ void bbox_kernel(const float *__restrict__ xyz, int64_t n, State *st) {
     unsigned int mn[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, mx[3] = {0u, 0u, 0u};
@@ -217,10 +230,9 @@ __device__ __forceinline__ bool fusing(const State *st) { return st->live > st->
 // cand: re-point every edge to the current representatives; an edge u -> v with u heads, v tails and
 //       sizes[v] * metric(u, v) < lambda offers u to v: bestm[v] = min metric.
 template <bool TIE>
-__global__ void cand_kernel(const float *__restrict__ xyz, const double *__restrict__ nrm, double resolution, State *st,
-                            unsigned long long *__restrict__ edges, const int32_t *__restrict__ parent,
-                            const int32_t *__restrict__ size, unsigned long long *__restrict__ bestm, int32_t *__restrict__ bestu) {
-    if (!fusing(st)) return;
+__device__ __forceinline__ void cand_body(const float *__restrict__ xyz, const double *__restrict__ nrm, double resolution, State *st,
+                                          unsigned long long *__restrict__ edges, const int32_t *__restrict__ parent,
+                                          const int32_t *__restrict__ size, unsigned long long *__restrict__ bestm, int32_t *__restrict__ bestu) {
     if (!TIE && blockIdx.x == 0 && threadIdx.x == 0) st->n_prop = 0;  // (the previous sub-round's apply has finished)
     const int32_t ne = st->n_edges, round = st->round;
     const double lambda = st->lambda;
@@ -244,10 +256,16 @@ __global__ void cand_kernel(const float *__restrict__ xyz, const double *__restr
         else if (bestm[v] == mo) atomicMin(&bestu[v], u);
     }
 }
-// collect: every tails representative with an offer becomes a proposal (key = float image of the loss : index)
-__global__ __launch_bounds__(1024) void collect_kernel(State *st, int64_t n, const int32_t *__restrict__ size, unsigned long long *__restrict__ bestm,
-                               int32_t *__restrict__ bestu, unsigned long long *__restrict__ prop_key, int32_t *__restrict__ prop_u) {
+template <bool TIE>
+__global__ void cand_kernel(const float *__restrict__ xyz, const double *__restrict__ nrm, double resolution, State *st,
+                            unsigned long long *__restrict__ edges, const int32_t *__restrict__ parent,
+                            const int32_t *__restrict__ size, unsigned long long *__restrict__ bestm, int32_t *__restrict__ bestu) {
     if (!fusing(st)) return;
+    cand_body<TIE>(xyz, nrm, resolution, st, edges, parent, size, bestm, bestu);
+}
+// collect: every tails representative with an offer becomes a proposal (key = float image of the loss : index)
+__device__ __forceinline__ void collect_body(State *st, int64_t n, const int32_t *__restrict__ size, unsigned long long *__restrict__ bestm,
+                                             int32_t *__restrict__ bestu, unsigned long long *__restrict__ prop_key, int32_t *__restrict__ prop_u) {
     __shared__ int32_t s_cnt[17];
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t v0 = (int64_t)blockIdx.x * blockDim.x; v0 < n; v0 += stride) {  // whole workgroups iterate together
@@ -263,10 +281,14 @@ __global__ __launch_bounds__(1024) void collect_kernel(State *st, int64_t n, con
         bestu[v] = 0x7fffffff;
     }
 }
+__global__ __launch_bounds__(1024) void collect_kernel(State *st, int64_t n, const int32_t *__restrict__ size, unsigned long long *__restrict__ bestm,
+                               int32_t *__restrict__ bestu, unsigned long long *__restrict__ prop_key, int32_t *__restrict__ prop_u) {
+    if (!fusing(st)) return;
+    collect_body(st, n, size, bestm, bestu, prop_key, prop_u);
+}
 // select (one workgroup): all proposals when there are representatives to spare, else exactly the (live - K) smallest
 // keys -- radix select, 8 passes of 8 bits over the proposal list.
-__global__ __launch_bounds__(1024) void select_kernel(State *st, const unsigned long long *__restrict__ prop_key) {
-    if (!fusing(st)) return;
+__device__ __forceinline__ void select_body(State *st, const unsigned long long *__restrict__ prop_key) {  // (1024 threads)
     __shared__ unsigned int hist[256];
     __shared__ unsigned long long s_prefix;
     __shared__ int s_rank;
@@ -302,9 +324,12 @@ __global__ __launch_bounds__(1024) void select_kernel(State *st, const unsigned 
     }
     if (tid == 0) { st->tau_excl = s_prefix + 1ULL; st->round += 1; }  // keys are unique (index in the low word)
 }
-__global__ void apply_kernel(State *st, const unsigned long long *__restrict__ prop_key, const int32_t *__restrict__ prop_u,
-                             int32_t *__restrict__ parent, int32_t *__restrict__ size) {
+__global__ __launch_bounds__(1024) void select_kernel(State *st, const unsigned long long *__restrict__ prop_key) {
     if (!fusing(st)) return;
+    select_body(st, prop_key);
+}
+__device__ __forceinline__ void apply_body(State *st, const unsigned long long *__restrict__ prop_key, const int32_t *__restrict__ prop_u,
+                                           int32_t *__restrict__ parent, int32_t *__restrict__ size) {
     const int a = st->n_prop;
     const unsigned long long tau = st->tau_excl;
     int dropped = 0;
@@ -319,29 +344,40 @@ __global__ void apply_kernel(State *st, const unsigned long long *__restrict__ p
     dropped = wave_sum(dropped);
     if (lane_id() == 0 && dropped) atomicSub(&st->live, dropped);
 }
+__global__ void apply_kernel(State *st, const unsigned long long *__restrict__ prop_key, const int32_t *__restrict__ prop_u,
+                             int32_t *__restrict__ parent, int32_t *__restrict__ size) {
+    if (!fusing(st)) return;
+    apply_body(st, prop_key, prop_u, parent, size);
+}
 
 // ---- once per lambda: flatten the forest, merge parallel edges, double lambda ---------------------------------------
-__global__ void flatten_kernel(const State *st, int64_t n, int32_t *__restrict__ parent, bool always) {
-    if (!always && !fusing(st)) return;
+__device__ __forceinline__ void flatten_body(int64_t n, int32_t *__restrict__ parent) {
     SV_FOR(i, n) {
         int32_t r = parent[i];
-        while (parent[r] != r) r = parent[r];  // (roots are stable while this kernel runs)
+        while (parent[r] != r) r = parent[r];  // (roots are stable while this pass runs)
         if (r != parent[i]) parent[i] = r;
     }
+}
+__global__ void flatten_kernel(const State *st, int64_t n, int32_t *__restrict__ parent, bool always) {
+    if (!always && !fusing(st)) return;
+    flatten_body(n, parent);
 }
 __device__ __forceinline__ int64_t table_size(int32_t n_edges) { return n_edges < 512 ? 1024 : 2 * (int64_t)n_edges; }
 // Parallel edges are merged through the hash set only once they dominate the list (more than 40 edges per representative);
 // before that the pass just drops the self loops -- the list of a young forest holds few duplicates and 30 M random table
 // accesses cost more than they save.
 __device__ __forceinline__ bool use_hash(const State *st) { return (int64_t)st->n_edges > 40LL * (int64_t)st->live; }
-__global__ void table_clear_kernel(const State *st, unsigned long long *__restrict__ table) {
-    if (!fusing(st) || !use_hash(st)) return;
+__device__ __forceinline__ void table_clear_body(const State *st, unsigned long long *__restrict__ table) {
+    if (!use_hash(st)) return;
     const int64_t ts = table_size(st->n_edges);
     SV_FOR(i, ts) table[i] = DEAD;
 }
-__global__ __launch_bounds__(1024) void dedup_kernel(State *st, const unsigned long long *__restrict__ edges, const int32_t *__restrict__ parent,
-                             unsigned long long *__restrict__ table, unsigned long long *__restrict__ edges_out) {
+__global__ void table_clear_kernel(const State *st, unsigned long long *__restrict__ table) {
     if (!fusing(st)) return;
+    table_clear_body(st, table);
+}
+__device__ __forceinline__ void dedup_body(State *st, const unsigned long long *__restrict__ edges, const int32_t *__restrict__ parent,
+                                           unsigned long long *__restrict__ table, unsigned long long *__restrict__ edges_out) {
     const int32_t ne = st->n_edges;
     const unsigned long long ts = (unsigned long long)table_size(ne);
     __shared__ int32_t s_cnt[17];
@@ -373,19 +409,27 @@ __global__ __launch_bounds__(1024) void dedup_kernel(State *st, const unsigned l
         if (fresh) edges_out[at] = key;
     }
 }
-__global__ void next_lambda_kernel(State *st) {
+__global__ __launch_bounds__(1024) void dedup_kernel(State *st, const unsigned long long *__restrict__ edges, const int32_t *__restrict__ parent,
+                             unsigned long long *__restrict__ table, unsigned long long *__restrict__ edges_out) {
     if (!fusing(st)) return;
+    dedup_body(st, edges, parent, table, edges_out);
+}
+__device__ __forceinline__ void next_lambda_body(State *st) {
     st->n_edges = st->n_edges_new;
     st->n_edges_new = 0;
     st->lambda *= 2.0;  // :117
     if (st->n_edges == 0) st->stalled = 1;  // disconnected graph of representatives: the reference would never return
 }
+__global__ void next_lambda_kernel(State *st) {
+    if (!fusing(st)) return;
+    next_lambda_body(st);
+}
 
 // ---- labels, boundary exchange, relabel ------------------------------------------------------------------------------
 #pragma clang fp contract(off)
-__global__ void labels_init_kernel(const float *__restrict__ xyz, const double *__restrict__ nrm, double resolution, int64_t n,
-                                   const int32_t *__restrict__ parent, int32_t *__restrict__ la, int32_t *__restrict__ lb,
-                                   double *__restrict__ dis) {
+__device__ __forceinline__ void labels_init_body(const float *__restrict__ xyz, const double *__restrict__ nrm, double resolution, int64_t n,
+                                                 const int32_t *__restrict__ parent, int32_t *__restrict__ la, int32_t *__restrict__ lb,
+                                                 double *__restrict__ dis) {
     SV_FOR(i, n) {
         const int32_t r = parent[i];
         la[i] = r;
@@ -393,23 +437,31 @@ __global__ void labels_init_kernel(const float *__restrict__ xyz, const double *
         dis[i] = sv_metric(xyz, nrm, i, (int64_t)r, resolution);  // :186-189
     }
 }
+__global__ void labels_init_kernel(const float *__restrict__ xyz, const double *__restrict__ nrm, double resolution, int64_t n,
+                                   const int32_t *__restrict__ parent, int32_t *__restrict__ la, int32_t *__restrict__ lb,
+                                   double *__restrict__ dis) {
+    labels_init_body(xyz, nrm, resolution, n, parent, la, lb, dis);
+}
 // One sweep of the exchange (:214-226 for every point at once, reading the labels of the previous sweep).  A point is
 // looked at when it, or a point that lists it or that it lists, changed in the previous sweep (`dirty`); `full_sweep`
 // looks at every point (the first sweep, and the verification sweep that ends the relaxation).
-__global__ void sweep_kernel(const float *__restrict__ xyz, const double *__restrict__ nrm, const int32_t *__restrict__ knn,
-                             double resolution, int64_t n, int k, State *st, int32_t *__restrict__ l0, int32_t *__restrict__ l1,
-                             double *__restrict__ dis, unsigned char *__restrict__ d0, unsigned char *__restrict__ d1) {
-    if (!st->sweep_on) return;
+__device__ __forceinline__ void sweep_body(const float *__restrict__ xyz, const double *__restrict__ nrm, const int32_t *__restrict__ knn,
+                                           double resolution, int64_t n, int k, State *st, int32_t *__restrict__ l0, int32_t *__restrict__ l1,
+                                           double *__restrict__ dis, unsigned char *__restrict__ d0, unsigned char *__restrict__ d1) {
     const bool odd = (st->sweeps_done & 1) != 0, full = st->full_sweep != 0;
     const int32_t *__restrict__ lin = odd ? l1 : l0;
     int32_t *__restrict__ lout = odd ? l0 : l1;
-    const unsigned char *__restrict__ din = odd ? d1 : d0;
+    // (a point reads only its OWN flag of the previous sweep and clears it on the way: the buffer is clean again when the
+    // next sweep writes its flags into it)
+    unsigned char *__restrict__ din = odd ? d1 : d0;
     unsigned char *__restrict__ dout = odd ? d0 : d1;
     bool any = false;
     SV_FOR(i, n) {
         const int32_t a = lin[i];
         int32_t bl = a;
-        if (full || din[i]) {
+        const bool look = full || din[i] != 0;
+        din[i] = 0;
+        if (look) {
             double best = dis[i];
             for (int j = 0; j < k; ++j) {
                 const int32_t q = knn[i * k + j];
@@ -432,17 +484,21 @@ __global__ void sweep_kernel(const float *__restrict__ xyz, const double *__rest
     }
     if (__ballot(any) != 0ULL && lane_id() == 0) atomicOr(&st->changed, 1);
 }
-__global__ void sweep_end_kernel(State *st) {
+__global__ void sweep_kernel(const float *__restrict__ xyz, const double *__restrict__ nrm, const int32_t *__restrict__ knn,
+                             double resolution, int64_t n, int k, State *st, int32_t *__restrict__ l0, int32_t *__restrict__ l1,
+                             double *__restrict__ dis, unsigned char *__restrict__ d0, unsigned char *__restrict__ d1) {
     if (!st->sweep_on) return;
+    sweep_body(xyz, nrm, knn, resolution, n, k, st, l0, l1, dis, d0, d1);
+}
+__device__ __forceinline__ void sweep_end_body(State *st) {
     st->sweeps_done += 1;
     if (st->changed) { st->changed = 0; st->full_sweep = 0; }
     else if (!st->full_sweep) st->full_sweep = 1;                        // nothing left on the dirty lists: verify with a full sweep
     else st->sweep_on = 0;                                               // a full sweep changed nothing: fixed point
 }
-__global__ void dirty_clear_kernel(const State *st, int64_t n, unsigned char *__restrict__ d0, unsigned char *__restrict__ d1) {
+__global__ void sweep_end_kernel(State *st) {
     if (!st->sweep_on) return;
-    unsigned char *__restrict__ dout = (st->sweeps_done & 1) ? d0 : d1;  // the buffer the coming sweep writes
-    SV_FOR(i, n) dout[i] = 0;
+    sweep_end_body(st);
 }
 __global__ void root_flag_kernel(int64_t n, const int32_t *__restrict__ parent, int32_t *__restrict__ flag) {
     SV_FOR(i, n) flag[i] = parent[i] == (int32_t)i ? 1 : 0;
@@ -458,9 +514,133 @@ __global__ void relabel_kernel(State *st, int64_t n, const int32_t *__restrict__
     if (blockIdx.x == 0 && threadIdx.x == 0 && info_out) {
         info_out[0] = rank[n - 1] + flag[n - 1];  // supervoxels produced
         info_out[1] = st->K;                      // occupied grid cells (the target)
-        info_out[2] = (st->stalled ? 1 : 0) | (st->live > st->K && !st->stalled ? 2 : 0) | (st->sweep_on ? 4 : 0);
+        info_out[2] = (st->stalled ? 1 : 0) | (st->live > st->K && !st->stalled ? 2 : 0) | (st->sweep_on ? 4 : 0) | (st->bar_timeout ? 8 : 0);
         info_out[3] = st->sweeps_done;
     }
+}
+
+
+// ---- the rest of the fusion / of the exchange as ONE cooperative launch ---------------------------------------------------
+// The host cannot know how many lambda rounds and sweeps a cloud needs (no synchronisation), and a schedule long enough for
+// every cloud (56 rounds, 96 sweeps: ~1350 launches) is mostly launches that return at once -- 2.6 us each, 2.6 of the
+// 14.9 ms of a 1 M-point tile, which needs 14 rounds and 9 sweeps.  So the schedule of launches covers what clouds
+// normally need (SCHED_ROUNDS, SCHED_SWEEPS), and whatever is left after it runs inside ONE kernel of as many workgroups as
+// the chip holds at once: the same passes (the same device functions) separated by grid-wide barriers, in loops that END
+// when the state says so.  Every decision to leave a loop reads state that was last written before the preceding barrier:
+// all workgroups take the same branch and meet at the same barriers.  A barrier costs ~12 us against ~3 us for a kernel
+// boundary (measured: the whole segmentation inside this kernel takes 14.4 ms, as launches 13.6 ms), which is why the
+// passes that normally DO run stay launches.
+struct SegArgs {
+    const float *xyz;
+    const double *nrm;
+    const int32_t *knn;
+    int64_t n;
+    int k;
+    double resolution;
+    State *st;
+    unsigned long long *edges_a, *edges_b, *table, *bestm, *prop_key;
+    int32_t *parent, *size, *bestu, *prop_u, *la, *lb;
+    double *dis;
+    unsigned char *d0, *d1;
+    int first_round;  // fusion: lambda rounds first_round .. LAMBDA_ROUNDS - 1 (the launches did the others); < 0: the sweeps
+    int first_sweep;
+};
+// Grid-wide barrier between two passes.  Every wave first waits until its own stores have reached the L2 (vmcnt(0)); after
+// the workgroup barrier ONE thread per workgroup writes the L2 back (release at agent scope), arrives, waits for the
+// generation to change, and invalidates the caches (acquire at agent scope) -- 512 write-backs per barrier instead of one
+// per wave (cooperative_groups' grid.sync() fences in every wave: 25 ms instead of 14 for the 1 M tile).  The wait is
+// bounded (about a second): a workgroup that gives up sets bar_timeout and everything after runs to its end without
+// waiting, so that the grid always drains.
+constexpr unsigned int BAR_GROUPS = 16;
+struct GridBarrier {
+    State *st;
+    unsigned int nblocks;
+    __device__ __forceinline__ void sync() const {
+        __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0) lgkmcnt(0)
+        __syncthreads();
+        if (threadIdx.x == 0 && !__hip_atomic_load(&st->bar_timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            const unsigned int g = blockIdx.x % BAR_GROUPS;
+            const unsigned int members = nblocks / BAR_GROUPS + (g < nblocks % BAR_GROUPS ? 1u : 0u);
+            const unsigned int groups = nblocks < BAR_GROUPS ? nblocks : BAR_GROUPS;
+            unsigned int *cnt = &st->bar[2 * g][0], *gen_w = &st->bar[2 * g + 1][0];
+            const unsigned int gen = __hip_atomic_load(gen_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            bool wait = true;
+            if (__hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == members - 1u) {
+                __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (__hip_atomic_fetch_add(&st->bar_top, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == groups - 1u) {
+                    __hip_atomic_store(&st->bar_top, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    for (unsigned int q = 0; q < groups; ++q)
+                        __hip_atomic_store(&st->bar[2 * q + 1][0], gen + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                    wait = false;
+                }
+            }
+            if (wait) {
+                int spins = 0;
+                while (__hip_atomic_load(gen_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen) {
+                    __builtin_amdgcn_s_sleep(8);
+                    if (++spins > (1 << 22)) { __hip_atomic_store(&st->bar_timeout, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        __syncthreads();
+    }
+};
+__global__ __launch_bounds__(1024, 8) void segment_rest_kernel(SegArgs a) {
+    State *st = a.st;
+    const GridBarrier grid{st, gridDim.x};
+    if (a.first_round >= 0) {
+        // (an even number of rounds was scheduled: the edge list is back in edges_a)
+        unsigned long long *cur = (a.first_round & 1) ? a.edges_b : a.edges_a, *nxt = (a.first_round & 1) ? a.edges_a : a.edges_b;
+        for (int r = a.first_round; r < LAMBDA_ROUNDS && fusing(st); ++r) {
+            for (int s = 0; s < SUBROUNDS && fusing(st); ++s) {
+                cand_body<false>(a.xyz, a.nrm, a.resolution, st, cur, a.parent, a.size, a.bestm, a.bestu);
+                grid.sync();
+                cand_body<true>(a.xyz, a.nrm, a.resolution, st, cur, a.parent, a.size, a.bestm, a.bestu);
+                grid.sync();
+                collect_body(st, a.n, a.size, a.bestm, a.bestu, a.prop_key, a.prop_u);
+                grid.sync();
+                if (blockIdx.x == 0) select_body(st, a.prop_key);
+                grid.sync();
+                apply_body(st, a.prop_key, a.prop_u, a.parent, a.size);
+                grid.sync();
+            }
+            if (!fusing(st)) break;
+            flatten_body(a.n, a.parent);
+            table_clear_body(st, a.table);  // (independent of the flattening: no barrier between them)
+            grid.sync();
+            dedup_body(st, cur, a.parent, a.table, nxt);
+            grid.sync();
+            if (blockIdx.x == 0 && threadIdx.x == 0) next_lambda_body(st);
+            grid.sync();
+            unsigned long long *t = cur; cur = nxt; nxt = t;
+        }
+    } else {
+        for (int s = a.first_sweep; s < SWEEPS && st->sweep_on; ++s) {
+            sweep_body(a.xyz, a.nrm, a.knn, a.resolution, a.n, a.k, st, a.la, a.lb, a.dis, a.d0, a.d1);
+            grid.sync();
+            if (blockIdx.x == 0 && threadIdx.x == 0) sweep_end_body(st);
+            grid.sync();
+        }
+    }
+}
+// Workgroups of segment_rest_kernel the device holds at once (0: no cooperative launches here -> the schedule of launches).
+static int segment_grid() {
+    static int cached[16] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 0;
+    if (cached[dev]) return cached[dev] < 0 ? 0 : cached[dev];
+    int coop = 0, cus = 0, per_cu = 0;
+    if (hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, dev) != hipSuccess || !coop ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, segment_rest_kernel, 1024, 0) != hipSuccess || per_cu < 1) {
+        (void)hipGetLastError();
+        cached[dev] = -1;
+        return 0;
+    }
+    cached[dev] = cus * per_cu;
+    return cached[dev];
 }
 
 static inline size_t align_up(size_t v) { return (v + 255) / 256 * 256; }
@@ -563,9 +743,24 @@ extern "C" int f4l_supervoxel_segment_device(const float *xyz, const double *nor
     hipLaunchKernelGGL(init_points_kernel, g, b, 0, st, n, w.parent, w.size, w.bestm, w.bestu);
     hipLaunchKernelGGL(init_edges_kernel, g, b, 0, st, knn, n, k, w.edges_a, w.st);
     F4L_LAUNCH_CHECK();
-    // fusion: a fixed schedule; everything after the target count is reached returns at once
+    // fusion, labels and the exchange: the schedule of launches clouds normally need, then one cooperative launch for
+    // whatever is left (see segment_rest_kernel).  F4L_SV_LAUNCHES=1, or a device without cooperative launches: the whole
+    // schedule as launches, whose tail returns at once.  F4L_SV_SCHEDULED="rounds,sweeps" overrides the split (tests run
+    // "2,1": nearly everything inside the cooperative kernel).
+    const int coop_grid = getenv("F4L_SV_LAUNCHES") ? 0 : segment_grid();
+    int sched_rounds = coop_grid > 0 ? SCHED_ROUNDS : LAMBDA_ROUNDS, sched_sweeps = coop_grid > 0 ? SCHED_SWEEPS : SWEEPS;
+    if (const char *e = getenv("F4L_SV_SCHEDULED")) {
+        int a = 0, c = 0;
+        if (coop_grid > 0 && sscanf(e, "%d,%d", &a, &c) == 2 && a >= 0 && a <= LAMBDA_ROUNDS && c >= 0 && c <= SWEEPS) { sched_rounds = a; sched_sweeps = c; }
+    }
+    SegArgs sa;
+    sa.xyz = xyz; sa.nrm = normals; sa.knn = knn; sa.n = n; sa.k = k; sa.resolution = resolution; sa.st = w.st;
+    sa.edges_a = w.edges_a; sa.edges_b = w.edges_b; sa.table = w.table; sa.bestm = w.bestm; sa.prop_key = w.prop_key;
+    sa.parent = w.parent; sa.size = w.size; sa.bestu = w.bestu; sa.prop_u = w.prop_u; sa.la = w.la; sa.lb = w.lb;
+    sa.dis = w.dis; sa.d0 = w.d0; sa.d1 = w.d1;
+    void *params[] = {&sa};
     unsigned long long *cur = w.edges_a, *nxt = w.edges_b;
-    for (int r = 0; r < LAMBDA_ROUNDS; ++r) {
+    for (int r = 0; r < sched_rounds; ++r) {
         for (int s = 0; s < SUBROUNDS; ++s) {
             hipLaunchKernelGGL(cand_kernel<false>, g, b, 0, st, xyz, normals, resolution, w.st, cur, w.parent, w.size, w.bestm, w.bestu);
             hipLaunchKernelGGL(cand_kernel<true>, g, b, 0, st, xyz, normals, resolution, w.st, cur, w.parent, w.size, w.bestm, w.bestu);
@@ -580,15 +775,22 @@ extern "C" int f4l_supervoxel_segment_device(const float *xyz, const double *nor
         F4L_LAUNCH_CHECK();
         unsigned long long *t = cur; cur = nxt; nxt = t;
     }
+    if (sched_rounds < LAMBDA_ROUNDS) {
+        sa.first_round = sched_rounds; sa.first_sweep = 0;
+        F4L_HIP_CHECK(hipLaunchCooperativeKernel((const void *)segment_rest_kernel, dim3((unsigned)coop_grid), dim3(1024), params, 0, st));
+    }
     // labels and the boundary exchange
     hipLaunchKernelGGL(flatten_kernel, g, b, 0, st, w.st, n, w.parent, true);
     hipLaunchKernelGGL(labels_init_kernel, g, b, 0, st, xyz, normals, resolution, n, w.parent, w.la, w.lb, w.dis);
     F4L_HIP_CHECK(hipMemsetAsync(w.d0, 0, (size_t)n, st));
     F4L_HIP_CHECK(hipMemsetAsync(w.d1, 0, (size_t)n, st));
-    for (int s = 0; s < SWEEPS; ++s) {
-        hipLaunchKernelGGL(dirty_clear_kernel, g, b, 0, st, w.st, n, w.d0, w.d1);
+    for (int s = 0; s < sched_sweeps; ++s) {
         hipLaunchKernelGGL(sweep_kernel, g, b, 0, st, xyz, normals, knn, resolution, n, k, w.st, w.la, w.lb, w.dis, w.d0, w.d1);
         hipLaunchKernelGGL(sweep_end_kernel, one, one, 0, st, w.st);
+    }
+    if (sched_sweeps < SWEEPS) {
+        sa.first_round = -1; sa.first_sweep = sched_sweeps;
+        F4L_HIP_CHECK(hipLaunchCooperativeKernel((const void *)segment_rest_kernel, dim3((unsigned)coop_grid), dim3(1024), params, 0, st));
     }
     F4L_LAUNCH_CHECK();
     // relabel 0..K-1 in ascending order of the representative's index

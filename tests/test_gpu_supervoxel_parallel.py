@@ -45,6 +45,16 @@ def test_device_segmentation_equals_its_numpy_model(eng, path):
     # run-to-run identical
     again, _ = eng.supervoxel_segment_device(dev(xyz), dev(nrm), dev(knn.astype(np.int32)), res)
     assert torch.equal(again, labels)
+    # ... and the same however the passes are split between the schedule of launches and the cooperative kernel that runs
+    # what the schedule did not cover: everything as launches (devices without cooperative launches), and two rounds and one
+    # sweep as launches with all the rest inside the cooperative kernel
+    for name, value in (("F4L_SV_LAUNCHES", "1"), ("F4L_SV_SCHEDULED", "2,1"), ("F4L_SV_SCHEDULED", "0,0")):
+        os.environ[name] = value
+        try:
+            other, info2 = eng.supervoxel_segment_device(dev(xyz), dev(nrm), dev(knn.astype(np.int32)), res)
+        finally:
+            del os.environ[name]
+        assert torch.equal(other, labels) and np.array_equal(info2.cpu().numpy(), info), (name, value)
 
 
 def test_whole_partition_on_the_device_and_edge_cases(eng):
