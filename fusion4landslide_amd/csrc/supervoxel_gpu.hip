@@ -30,8 +30,9 @@
 //
 // Nothing here synchronises the stream or copies to the host: loop bounds live in a device-side state block, every
 // kernel runs on a fixed grid and reads its trip counts from that block, and the host enqueues a fixed schedule of
-// launches whose tail turns into no-ops once the target count is reached (a no-op launch costs a few microseconds).
-// Results are deterministic (no result depends on the order atomics land in).
+// launches (the rounds and sweeps clouds normally need; those past the target count return at once) followed by one
+// cooperative kernel that loops over whatever is left (segment_rest_kernel).
+// Results are deterministic (no result depends on the order atomics land in, nor on how the passes are split).
 #include <cfloat>
 #include <cstdio>
 #include <cstdlib>
@@ -232,7 +233,8 @@ __device__ __forceinline__ bool fusing(const State *st) { return st->live > st->
 template <bool TIE>
 __device__ __forceinline__ void cand_body(const float *__restrict__ xyz, const double *__restrict__ nrm, double resolution, State *st,
                                           unsigned long long *__restrict__ edges, const int32_t *__restrict__ parent,
-                                          const int32_t *__restrict__ size, unsigned long long *__restrict__ bestm, int32_t *__restrict__ bestu) {
+                                          const int32_t *__restrict__ size, unsigned long long *__restrict__ bestm, int32_t *__restrict__ bestu,
+                                          bool hop) {
     if (!TIE && blockIdx.x == 0 && threadIdx.x == 0) st->n_prop = 0;  // (the previous sub-round's apply has finished)
     const int32_t ne = st->n_edges, round = st->round;
     const double lambda = st->lambda;
@@ -240,12 +242,14 @@ __device__ __forceinline__ void cand_body(const float *__restrict__ xyz, const d
         unsigned long long key = edges[e];
         if (key == DEAD) continue;
         int32_t u = (int32_t)(key >> 32), v = (int32_t)(key & 0xffffffffULL);
-        if (!TIE) {
-            u = parent[u];  // both were representatives at the last re-pointing: one hop reaches the current ones
-            v = parent[v];
-            key = u == v ? DEAD : (((unsigned long long)(unsigned int)u << 32) | (unsigned int)v);
-            edges[e] = key;
-            if (u == v) continue;
+        if (!TIE && hop) {  // (not in the first sub-round of a lambda: the list was re-pointed when it was merged)
+            const int32_t pu = parent[u], pv = parent[v];  // both were representatives at the last re-pointing: one hop reaches the current ones
+            if (pu != u || pv != v) {
+                u = pu; v = pv;
+                key = u == v ? DEAD : (((unsigned long long)(unsigned int)u << 32) | (unsigned int)v);
+                edges[e] = key;
+                if (u == v) continue;
+            }
         }
         if (!heads(u, round) || heads(v, round)) continue;
         const double m = sv_metric(xyz, nrm, u, v, resolution);
@@ -259,9 +263,9 @@ __device__ __forceinline__ void cand_body(const float *__restrict__ xyz, const d
 template <bool TIE>
 __global__ void cand_kernel(const float *__restrict__ xyz, const double *__restrict__ nrm, double resolution, State *st,
                             unsigned long long *__restrict__ edges, const int32_t *__restrict__ parent,
-                            const int32_t *__restrict__ size, unsigned long long *__restrict__ bestm, int32_t *__restrict__ bestu) {
+                            const int32_t *__restrict__ size, unsigned long long *__restrict__ bestm, int32_t *__restrict__ bestu, bool hop) {
     if (!fusing(st)) return;
-    cand_body<TIE>(xyz, nrm, resolution, st, edges, parent, size, bestm, bestu);
+    cand_body<TIE>(xyz, nrm, resolution, st, edges, parent, size, bestm, bestu, hop);
 }
 // collect: every tails representative with an offer becomes a proposal (key = float image of the loss : index)
 __device__ __forceinline__ void collect_body(State *st, int64_t n, const int32_t *__restrict__ size, unsigned long long *__restrict__ bestm,
@@ -595,9 +599,9 @@ __global__ __launch_bounds__(1024, 8) void segment_rest_kernel(SegArgs a) {
         unsigned long long *cur = (a.first_round & 1) ? a.edges_b : a.edges_a, *nxt = (a.first_round & 1) ? a.edges_a : a.edges_b;
         for (int r = a.first_round; r < LAMBDA_ROUNDS && fusing(st); ++r) {
             for (int s = 0; s < SUBROUNDS && fusing(st); ++s) {
-                cand_body<false>(a.xyz, a.nrm, a.resolution, st, cur, a.parent, a.size, a.bestm, a.bestu);
+                cand_body<false>(a.xyz, a.nrm, a.resolution, st, cur, a.parent, a.size, a.bestm, a.bestu, s > 0);
                 grid.sync();
-                cand_body<true>(a.xyz, a.nrm, a.resolution, st, cur, a.parent, a.size, a.bestm, a.bestu);
+                cand_body<true>(a.xyz, a.nrm, a.resolution, st, cur, a.parent, a.size, a.bestm, a.bestu, false);
                 grid.sync();
                 collect_body(st, a.n, a.size, a.bestm, a.bestu, a.prop_key, a.prop_u);
                 grid.sync();
@@ -762,8 +766,8 @@ extern "C" int f4l_supervoxel_segment_device(const float *xyz, const double *nor
     unsigned long long *cur = w.edges_a, *nxt = w.edges_b;
     for (int r = 0; r < sched_rounds; ++r) {
         for (int s = 0; s < SUBROUNDS; ++s) {
-            hipLaunchKernelGGL(cand_kernel<false>, g, b, 0, st, xyz, normals, resolution, w.st, cur, w.parent, w.size, w.bestm, w.bestu);
-            hipLaunchKernelGGL(cand_kernel<true>, g, b, 0, st, xyz, normals, resolution, w.st, cur, w.parent, w.size, w.bestm, w.bestu);
+            hipLaunchKernelGGL(cand_kernel<false>, g, b, 0, st, xyz, normals, resolution, w.st, cur, w.parent, w.size, w.bestm, w.bestu, s > 0);
+            hipLaunchKernelGGL(cand_kernel<true>, g, b, 0, st, xyz, normals, resolution, w.st, cur, w.parent, w.size, w.bestm, w.bestu, false);
             hipLaunchKernelGGL(collect_kernel, g, dim3(1024), 0, st, w.st, n, w.size, w.bestm, w.bestu, w.prop_key, w.prop_u);
             hipLaunchKernelGGL(select_kernel, one, dim3(1024), 0, st, w.st, w.prop_key);
             hipLaunchKernelGGL(apply_kernel, g, b, 0, st, w.st, w.prop_key, w.prop_u, w.parent, w.size);
