@@ -31,14 +31,13 @@
 // Nothing here synchronises the stream or copies to the host: loop bounds live in a device-side state block, every
 // kernel runs on a fixed grid and reads its trip counts from that block, and the host enqueues a fixed schedule of
 // launches (the rounds and sweeps clouds normally need; those past the target count return at once) followed by one
-// cooperative kernel that loops over whatever is left (segment_rest_kernel).
+// persistent kernel that loops over whatever is left (segment_rest_kernel).
 // Results are deterministic (no result depends on the order atomics land in, nor on how the passes are split).
 #include <cfloat>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 
-#include <hip/hip_cooperative_groups.h>
 #include <rocprim/rocprim.hpp>
 
 #include "f4l_device.h"
@@ -50,7 +49,7 @@ namespace svg {
 constexpr int LAMBDA_ROUNDS = 56;  // lambda0 * 2^55 exceeds any size * metric of a 2^31-point cloud
 constexpr int SUBROUNDS = 3;
 constexpr int SWEEPS = 96;
-// what the schedule of LAUNCHES covers when the rest can run in one cooperative kernel (segment_rest_kernel): a 1 M-point
+// what the schedule of LAUNCHES covers when the rest can run in one persistent kernel (segment_rest_kernel): a 1 M-point
 // terrain tile at the reference's resolutions needs 11-14 rounds and 9-15 sweeps
 constexpr int SCHED_ROUNDS = 16, SCHED_SWEEPS = 16;
 constexpr unsigned GRID = 2048, BLOCK = 256;
@@ -524,16 +523,18 @@ __global__ void relabel_kernel(State *st, int64_t n, const int32_t *__restrict__
 }
 
 
-// ---- the rest of the fusion / of the exchange as ONE cooperative launch ---------------------------------------------------
+// ---- the rest of the fusion / of the exchange as ONE persistent launch ----------------------------------------------------
 // The host cannot know how many lambda rounds and sweeps a cloud needs (no synchronisation), and a schedule long enough for
-// every cloud (56 rounds, 96 sweeps: ~1350 launches) is mostly launches that return at once -- 2.6 us each, 2.6 of the
-// 14.9 ms of a 1 M-point tile, which needs 14 rounds and 9 sweeps.  So the schedule of launches covers what clouds
+// every cloud (56 rounds, 96 sweeps: ~1350 launches) is mostly launches that return at once -- 1.4 us each, 1.4 of the
+// 13.6 ms of a 1 M-point tile, which needs 14 rounds and 9 sweeps.  So the schedule of launches covers what clouds
 // normally need (SCHED_ROUNDS, SCHED_SWEEPS), and whatever is left after it runs inside ONE kernel of as many workgroups as
 // the chip holds at once: the same passes (the same device functions) separated by grid-wide barriers, in loops that END
 // when the state says so.  Every decision to leave a loop reads state that was last written before the preceding barrier:
 // all workgroups take the same branch and meet at the same barriers.  A barrier costs ~12 us against ~3 us for a kernel
 // boundary (measured: the whole segmentation inside this kernel takes 14.4 ms, as launches 13.6 ms), which is why the
-// passes that normally DO run stay launches.
+// passes that normally DO run stay launches.  The kernel is an ordinary launch on the caller's stream with the grid the
+// occupancy query allows (all workgroups resident at once on an otherwise idle device; the barrier's wait is bounded in any
+// case): hipLaunchCooperativeKernel goes through a queue of its own and cost 5 ms per call inside bench.py's process.
 struct SegArgs {
     const float *xyz;
     const double *nrm;
@@ -552,7 +553,8 @@ struct SegArgs {
 // Grid-wide barrier between two passes.  Every wave first waits until its own stores have reached the L2 (vmcnt(0)); after
 // the workgroup barrier ONE thread per workgroup writes the L2 back (release at agent scope), arrives, waits for the
 // generation to change, and invalidates the caches (acquire at agent scope) -- 512 write-backs per barrier instead of one
-// per wave (cooperative_groups' grid.sync() fences in every wave: 25 ms instead of 14 for the 1 M tile).  The wait is
+// per wave, and the workgroups poll 16 words a cache line apart instead of one (cooperative_groups' grid.sync(): 45 us per
+// barrier, 25 ms instead of 14 for the 1 M tile).  The wait is
 // bounded (about a second): a workgroup that gives up sets bar_timeout and everything after runs to its end without
 // waiting, so that the grid always drains.
 constexpr unsigned int BAR_GROUPS = 16;
@@ -629,15 +631,14 @@ __global__ __launch_bounds__(1024, 8) void segment_rest_kernel(SegArgs a) {
         }
     }
 }
-// Workgroups of segment_rest_kernel the device holds at once (0: no cooperative launches here -> the schedule of launches).
+// Workgroups of segment_rest_kernel the device holds at once (0: unknown -> the whole schedule as launches).
 static int segment_grid() {
     static int cached[16] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 0;
     if (cached[dev]) return cached[dev] < 0 ? 0 : cached[dev];
-    int coop = 0, cus = 0, per_cu = 0;
-    if (hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, dev) != hipSuccess || !coop ||
-        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+    int cus = 0, per_cu = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
         hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, segment_rest_kernel, 1024, 0) != hipSuccess || per_cu < 1) {
         (void)hipGetLastError();
         cached[dev] = -1;
@@ -747,22 +748,21 @@ extern "C" int f4l_supervoxel_segment_device(const float *xyz, const double *nor
     hipLaunchKernelGGL(init_points_kernel, g, b, 0, st, n, w.parent, w.size, w.bestm, w.bestu);
     hipLaunchKernelGGL(init_edges_kernel, g, b, 0, st, knn, n, k, w.edges_a, w.st);
     F4L_LAUNCH_CHECK();
-    // fusion, labels and the exchange: the schedule of launches clouds normally need, then one cooperative launch for
-    // whatever is left (see segment_rest_kernel).  F4L_SV_LAUNCHES=1, or a device without cooperative launches: the whole
+    // fusion, labels and the exchange: the schedule of launches clouds normally need, then one persistent kernel for
+    // whatever is left (see segment_rest_kernel).  F4L_SV_LAUNCHES=1: the whole
     // schedule as launches, whose tail returns at once.  F4L_SV_SCHEDULED="rounds,sweeps" overrides the split (tests run
-    // "2,1": nearly everything inside the cooperative kernel).
-    const int coop_grid = getenv("F4L_SV_LAUNCHES") ? 0 : segment_grid();
-    int sched_rounds = coop_grid > 0 ? SCHED_ROUNDS : LAMBDA_ROUNDS, sched_sweeps = coop_grid > 0 ? SCHED_SWEEPS : SWEEPS;
+    // "2,1": nearly everything inside the persistent kernel).
+    const int rest_grid = getenv("F4L_SV_LAUNCHES") ? 0 : segment_grid();
+    int sched_rounds = rest_grid > 0 ? SCHED_ROUNDS : LAMBDA_ROUNDS, sched_sweeps = rest_grid > 0 ? SCHED_SWEEPS : SWEEPS;
     if (const char *e = getenv("F4L_SV_SCHEDULED")) {
         int a = 0, c = 0;
-        if (coop_grid > 0 && sscanf(e, "%d,%d", &a, &c) == 2 && a >= 0 && a <= LAMBDA_ROUNDS && c >= 0 && c <= SWEEPS) { sched_rounds = a; sched_sweeps = c; }
+        if (rest_grid > 0 && sscanf(e, "%d,%d", &a, &c) == 2 && a >= 0 && a <= LAMBDA_ROUNDS && c >= 0 && c <= SWEEPS) { sched_rounds = a; sched_sweeps = c; }
     }
     SegArgs sa;
     sa.xyz = xyz; sa.nrm = normals; sa.knn = knn; sa.n = n; sa.k = k; sa.resolution = resolution; sa.st = w.st;
     sa.edges_a = w.edges_a; sa.edges_b = w.edges_b; sa.table = w.table; sa.bestm = w.bestm; sa.prop_key = w.prop_key;
     sa.parent = w.parent; sa.size = w.size; sa.bestu = w.bestu; sa.prop_u = w.prop_u; sa.la = w.la; sa.lb = w.lb;
     sa.dis = w.dis; sa.d0 = w.d0; sa.d1 = w.d1;
-    void *params[] = {&sa};
     unsigned long long *cur = w.edges_a, *nxt = w.edges_b;
     for (int r = 0; r < sched_rounds; ++r) {
         for (int s = 0; s < SUBROUNDS; ++s) {
@@ -781,7 +781,7 @@ extern "C" int f4l_supervoxel_segment_device(const float *xyz, const double *nor
     }
     if (sched_rounds < LAMBDA_ROUNDS) {
         sa.first_round = sched_rounds; sa.first_sweep = 0;
-        F4L_HIP_CHECK(hipLaunchCooperativeKernel((const void *)segment_rest_kernel, dim3((unsigned)coop_grid), dim3(1024), params, 0, st));
+        hipLaunchKernelGGL(segment_rest_kernel, dim3((unsigned)rest_grid), dim3(1024), 0, st, sa);
     }
     // labels and the boundary exchange
     hipLaunchKernelGGL(flatten_kernel, g, b, 0, st, w.st, n, w.parent, true);
@@ -794,7 +794,7 @@ extern "C" int f4l_supervoxel_segment_device(const float *xyz, const double *nor
     }
     if (sched_sweeps < SWEEPS) {
         sa.first_round = -1; sa.first_sweep = sched_sweeps;
-        F4L_HIP_CHECK(hipLaunchCooperativeKernel((const void *)segment_rest_kernel, dim3((unsigned)coop_grid), dim3(1024), params, 0, st));
+        hipLaunchKernelGGL(segment_rest_kernel, dim3((unsigned)rest_grid), dim3(1024), 0, st, sa);
     }
     F4L_LAUNCH_CHECK();
     // relabel 0..K-1 in ascending order of the representative's index

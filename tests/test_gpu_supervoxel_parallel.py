@@ -45,9 +45,9 @@ def test_device_segmentation_equals_its_numpy_model(eng, path):
     # run-to-run identical
     again, _ = eng.supervoxel_segment_device(dev(xyz), dev(nrm), dev(knn.astype(np.int32)), res)
     assert torch.equal(again, labels)
-    # ... and the same however the passes are split between the schedule of launches and the cooperative kernel that runs
-    # what the schedule did not cover: everything as launches (devices without cooperative launches), and two rounds and one
-    # sweep as launches with all the rest inside the cooperative kernel
+    # ... and the same however the passes are split between the schedule of launches and the persistent kernel that runs
+    # what the schedule did not cover: everything as launches (devices without a known occupancy), and two rounds and one
+    # sweep as launches with all the rest inside the persistent kernel
     for name, value in (("F4L_SV_LAUNCHES", "1"), ("F4L_SV_SCHEDULED", "2,1"), ("F4L_SV_SCHEDULED", "0,0")):
         os.environ[name] = value
         try:
