@@ -43,23 +43,35 @@ def full_path(src, tgt, k=30, icp_threshold=0.1, voxel_size=0.0, partition="para
     mark("median_resolution")
     labels, K = (engine.supervoxel_parallel if partition == "parallel" else engine.supervoxel)(src, k, float(resolution))
     mark("supervoxel_partition")
+    st = _patches_and_registration(torch, src, tgt, labels, None, K, med, icp_threshold, max_iter, fixed_iters, search, mark)
+    torch.cuda.synchronize()
+    ms = {stages[i]: marks[i - 1].elapsed_time(marks[i]) for i in range(1, len(stages))}
+    ms["total"] = marks[0].elapsed_time(marks[-1])
+    return dict(labels=labels, K=K, resolution=float(resolution), stage_ms=ms, **st)
+
+
+def _patches_and_registration(torch, src, tgt, labels, tgt_nn, K, med, icp_threshold, max_iter, fixed_iters, search, mark):
+    """The stages after the partition, on one device: patches of both epochs (a target point joins the patch of its nearest
+    source point: `tgt_nn` (m,) int64 indices into `src` when the caller has them already, else f4l_nn_query), point matches,
+    the per-patch loop, the refinement.  Returns dict(rows, sparse, T, fitness, rmse, iters, order, src_off, tgt_off)."""
     order_s, off_s = engine.labels_to_csr(labels, K)
-    nn = engine.nn_query(src, tgt, 1)[:, 0].to(torch.int64)
+    nn = engine.nn_query(src, tgt, 1)[:, 0].to(torch.int64) if tgt_nn is None else tgt_nn
     order_t, off_t = engine.labels_to_csr(labels[nn], K)
     ps, pt = engine.gather_points(src, order_s), engine.gather_points(tgt, order_t)
     mark("patches")
     P = K
-    eye = torch.eye(4, dtype=torch.float64, device=src.device).repeat(P, 1, 1)
+    dev = src.device
+    eye = torch.eye(4, dtype=torch.float64, device=dev).repeat(P, 1, 1)
     max_t = int((off_t[1:] - off_t[:-1]).max().item()) if P else 0
     max_s = int((off_s[1:] - off_s[:-1]).max().item()) if P else 0
-    m, _ = engine.nn_refine(ps, off_s, pt, off_t, eye, torch.full((P,), 2.0 * icp_threshold, dtype=torch.float64, device=src.device),
+    m, _ = engine.nn_refine(ps, off_s, pt, off_t, eye, torch.full((P,), 2.0 * icp_threshold, dtype=torch.float64, device=dev),
                             max_tgt_patch=max_t, return_rows=False)
     cnt = off_s[1:] - off_s[:-1]
-    pid = torch.repeat_interleave(torch.arange(P, device=src.device), cnt, output_size=ps.shape[0])
+    pid = torch.repeat_interleave(torch.arange(P, device=dev), cnt, output_size=ps.shape[0])
     keep = m >= 0
     cs = ps[keep]
     ct = pt[off_t[pid[keep]] + m[keep].to(torch.int64)]
-    coff = torch.zeros(P + 1, dtype=torch.int64, device=src.device)
+    coff = torch.zeros(P + 1, dtype=torch.int64, device=dev)
     coff[1:] = torch.cumsum(torch.bincount(pid[keep], minlength=P), 0)
     mark("point_matches")
     out = engine.patch_loop(ps, off_s, pt, off_t, cs.contiguous(), ct.contiguous(), coff, None, 0.0, 1e-6, max_corr_dist=icp_threshold,
@@ -70,8 +82,46 @@ def full_path(src, tgt, k=30, icp_threshold=0.1, voxel_size=0.0, partition="para
     nn2, sparse = engine.nn_refine(ps, off_s, pt, off_t, out["T"], thr, max_tgt_patch=max_t)
     sparse = sparse[nn2 >= 0]
     mark("nn_refine")
+    return dict(rows=out["rows"], sparse=sparse, T=out["T"], fitness=out["fitness"], rmse=out["rmse"], iters=out["iters"],
+                order=order_s, src_off=off_s, tgt_off=off_t)
+
+
+def full_path_slabs(local_src, local_gid, local_tgt, dist, rank, world, halo, resolution, k=30, icp_threshold=0.1, max_iter=30,
+                    fixed_iters=False, search="f64"):
+    """The same path for ONE cloud spread over `world` GPUs (BASELINE.json configs[4]): the partition by slabs
+    along x with a halo (slabs.slab_supervoxel), the second epoch joined to the slabs' patches (slabs.slab_targets), then
+    patches, point matches, the per-patch loop and the refinement on the rank that owns the patches -- a supervoxel never
+    crosses a cut, so nothing after the partition needs another exchange; the caller gathers what it wants of the per-patch
+    results (sharding.PatchResultGather).  local_src / local_tgt: this rank's arbitrary chunks of the two epochs (float32
+    CUDA tensors), local_gid (n,) int64 the source chunk's global point ids.  `resolution` is the supervoxel resolution
+    (base:2668-2671; the median point spacing it derives from is a property of the whole cloud: compute it on a tile).
+    Returns dict(rows (n_own, 6) in patch order, gid (n_own,) the global ids of those rows' source points, T, fitness, rmse,
+    iters per LOCAL patch, K_local, K_total, offset (global patch id = offset + local), sparse, n_uncertified (neighbour
+    lists + target joins of the whole job that the halo could not certify: widen the halo if not 0), stage_ms)."""
+    torch = engine.require_gpu()
+    from . import slabs
+    stages, marks = [], []
+
+    def mark(name):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        marks.append(e)
+        stages.append(name)
+
+    mark("start")
+    med = float(resolution) / (np.sqrt(3.0) * 10.0)
+    sv = slabs.slab_supervoxel(local_src, local_gid, k, float(resolution), dist, rank, world, halo)
+    mark("supervoxel_partition")
+    tg = slabs.slab_targets(local_tgt, sv, dist, rank, world, halo)
+    mark("target_exchange")
+    K = sv["K_local"]
+    if K == 0:
+        raise ValueError("this rank's slab holds no source point: use fewer ranks")
+    st = _patches_and_registration(torch, sv["xyz"].contiguous(), tg["xyz"], sv["labels_local"].to(torch.int32), tg["nn"], K, med, icp_threshold,
+                                   max_iter, fixed_iters, search, mark)
     torch.cuda.synchronize()
     ms = {stages[i]: marks[i - 1].elapsed_time(marks[i]) for i in range(1, len(stages))}
     ms["total"] = marks[0].elapsed_time(marks[-1])
-    return dict(rows=out["rows"], sparse=sparse, labels=labels, K=K, T=out["T"], fitness=out["fitness"], rmse=out["rmse"], iters=out["iters"],
-                order=order_s, src_off=off_s, tgt_off=off_t, resolution=float(resolution), stage_ms=ms)
+    return dict(gid=sv["gid"][st["order"].to(torch.int64)], K_local=K, K_total=sv["K_total"], offset=sv["offset"],
+                n_uncertified=sv["n_uncertified"] + tg["n_uncertified"], n_halo=sv["n_halo"], n_forwarded=tg["n_forwarded"],
+                resolution=float(resolution), stage_ms=ms, **st)

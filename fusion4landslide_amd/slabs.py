@@ -25,10 +25,41 @@ OWNS.  Steps, with their collectives:
   7. labels   all_gather of the per-slab counts; global label = exclusive prefix + local label: 0 .. K-1, K = the whole
               cloud's occupied cells.
 
+The SECOND epoch joins the patches afterwards (`slab_targets`): every target point goes to the rank that owns its grid column,
+which finds its nearest source point among the slab's owned + halo source points (exact when that distance does not reach
+past the halo's outer edge; counted like in step 5); a target point whose nearest source point is a halo point is forwarded
+to the neighbour that owns that point (point-to-point volume again).  Each target point ends on exactly one rank -- the one
+that owns the patch it joins -- so the per-patch loop runs where the patch lives, with no re-sharding of patches and no
+further collective until the per-patch results are gathered (pipeline.full_path_slabs).
+
 If the neighbour graph proves fragile for a data set (e.g. slabs thinner than the halo), the fallback SURVEY.md 8(e) names
 stands: tiles (<= 1 M points, cpp_core/pcd_tiling) are independent, one replica of the single-GPU partition per tile.
 """
 import numpy as np
+
+
+def _staged(dist, t):
+    """gloo moves host tensors only: device tensors are staged through the host there (tests and single-GPU dry runs of the
+    N > 1 path; on a GPU node the backend is "nccl" = RCCL and the tensors stay on the device)."""
+    return t.is_cuda and dist.get_backend() == "gloo"
+
+
+def _all_reduce(dist, t, op):
+    if _staged(dist, t):
+        h = t.cpu()
+        dist.all_reduce(h, op=op)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=op)
+
+
+def _all_to_all(dist, out, inp, out_splits=None, in_splits=None):
+    if _staged(dist, inp):
+        ho = out.cpu()
+        dist.all_to_all_single(ho, inp.cpu(), output_split_sizes=out_splits, input_split_sizes=in_splits)
+        out.copy_(ho)
+    else:
+        dist.all_to_all_single(out, inp, output_split_sizes=out_splits, input_split_sizes=in_splits)
 
 
 def _a2a_v(dist, torch, payload, dest, world):
@@ -40,10 +71,10 @@ def _a2a_v(dist, torch, payload, dest, world):
     if world == 1:
         return send
     got = torch.zeros(world, dtype=torch.int64, device=payload.device)
-    dist.all_to_all_single(got, counts)
+    _all_to_all(dist, got, counts)
     recv = torch.empty((int(got.sum()), payload.shape[1]), dtype=payload.dtype, device=payload.device)
     c = payload.shape[1]
-    dist.all_to_all_single(recv.view(-1), send.view(-1), output_split_sizes=(got * c).tolist(), input_split_sizes=(counts * c).tolist())
+    _all_to_all(dist, recv.view(-1), send.view(-1), (got * c).tolist(), (counts * c).tolist())
     return recv
 
 
@@ -56,14 +87,14 @@ def plan_slabs(local_xyz, resolution, dist, world):
     mn = local_xyz.min(dim=0).values if local_xyz.shape[0] else torch.full((3,), big, device=dev)
     mx = local_xyz.max(dim=0).values if local_xyz.shape[0] else torch.full((3,), -big, device=dev)
     if world > 1:
-        dist.all_reduce(mn, op=dist.ReduceOp.MIN)
-        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        _all_reduce(dist, mn, dist.ReduceOp.MIN)
+        _all_reduce(dist, mx, dist.ReduceOp.MAX)
     gmin, gmax = mn.double(), mx.double()
     ncol = int((gmax[0] - gmin[0]) / resolution + 1)  # grid_sample.h:49
     col = torch.clamp(((local_xyz[:, 0].double() - gmin[0]) / resolution).to(torch.int64), 0, ncol - 1)
     hist = torch.bincount(col, minlength=ncol).to(torch.int64)
     if world > 1:
-        dist.all_reduce(hist, op=dist.ReduceOp.SUM)
+        _all_reduce(dist, hist, dist.ReduceOp.SUM)
     cum = torch.cumsum(hist, 0).cpu().numpy()
     n_total = int(cum[-1])
     bounds = np.zeros(world + 1, dtype=np.int64)
@@ -71,7 +102,7 @@ def plan_slabs(local_xyz, resolution, dist, world):
         bounds[r] = max(bounds[r - 1], int(np.searchsorted(cum, r * n_total / world, side="left")) + 1)
     bounds[world] = ncol
     bounds = np.minimum(bounds, ncol)
-    return dict(grid_min=mn.cpu().numpy(), grid_max=mx.cpu().numpy(), bounds=bounds, n_total=n_total, ncol=ncol)
+    return dict(grid_min=mn.cpu().numpy(), grid_max=mx.cpu().numpy(), bounds=bounds, n_total=n_total, ncol=ncol, resolution=float(resolution))
 
 
 def slab_supervoxel(local_xyz, local_gid, k, resolution, dist, rank, world, halo, knn_normals_fn=None, segment_fn=None):
@@ -128,7 +159,7 @@ def slab_supervoxel(local_xyz, local_gid, k, resolution, dist, rank, world, halo
         ok &= dk < (cuts[rank + 1] + halo) - xo
     bad = torch.tensor([int((~ok).sum())], dtype=torch.int64, device=dev)
     if world > 1:
-        dist.all_reduce(bad, op=dist.ReduceOp.SUM)
+        _all_reduce(dist, bad, dist.ReduceOp.SUM)
 
     # segmentation of the owned points; neighbours in the halo are "no neighbour" there
     knn_local = torch.where(idx < n_own, idx, torch.full_like(idx, -1))
@@ -146,7 +177,68 @@ def slab_supervoxel(local_xyz, local_gid, k, resolution, dist, rank, world, halo
     counts = torch.zeros(world, dtype=torch.int64, device=dev)
     counts[rank] = K_local
     if world > 1:
-        dist.all_reduce(counts, op=dist.ReduceOp.SUM)
+        _all_reduce(dist, counts, dist.ReduceOp.SUM)
     offset = int(counts[:rank].sum())
     return dict(xyz=xyz_all[:n_own], gid=gid_all[:n_own], labels=labels.to(torch.int64) + offset, knn_gid=gid_all[idx], d2=d2, normals=nrm,
-                K_local=int(K_local), K_total=int(counts.sum()), offset=offset, n_uncertified=int(bad.item()), plan=plan, n_halo=int(halo_pts.shape[0]))
+                K_local=int(K_local), K_total=int(counts.sum()), offset=offset, n_uncertified=int(bad.item()), plan=plan, n_halo=int(halo_pts.shape[0]),
+                xyz_all=xyz_all, gid_all=gid_all, n_own=n_own, cuts=cuts, labels_local=labels.to(torch.int64))
+
+
+def slab_targets(local_tgt, sv, dist, rank, world, halo, nn_fn=None):
+    """The second epoch on the slabs of `sv` (the dict slab_supervoxel returned for the first).  local_tgt (m, 3) float32: this
+    rank's arbitrary chunk of the target epoch.  nn_fn(cloud, queries) -> (idx (q,) int, d2 (q,) float64) defaults to the HIP
+    path (f4l_nn_query, k = 1).  Returns dict(xyz (t, 3) float32: the target points whose nearest source point this rank OWNS,
+    nn (t,) int64: that point's index among the owned source points (sv["xyz"]), d2 (t,) float64, n_forwarded (sent to a
+    neighbour), n_uncertified (whole job))."""
+    import torch
+    dev = local_tgt.device
+    plan, cuts, n_own = sv["plan"], sv["cuts"], sv["n_own"]
+    b = plan["bounds"]
+    x0 = float(plan["grid_min"][0])
+    col = torch.clamp(((local_tgt[:, 0].double() - x0) / plan["resolution"]).to(torch.int64), 0, plan["ncol"] - 1)
+    owner = torch.bucketize(col, torch.from_numpy(b[1:-1]).to(dev), right=True) if world > 1 else torch.zeros_like(col)
+    own_t = _a2a_v(dist, torch, local_tgt.double(), owner, world).float().contiguous()
+    if nn_fn is None:
+        from . import engine
+
+        def nn_fn(cloud, queries):
+            idx, d2 = engine.nn_query(cloud, queries, 1, return_d2=True)
+            return idx[:, 0].to(torch.int64), d2[:, 0]
+    if own_t.shape[0] and sv["xyz_all"].shape[0]:
+        idx, d2 = nn_fn(sv["xyz_all"], own_t)
+        idx = idx.to(torch.int64)
+    else:  # (a slab without source points keeps no target point: there is no patch here to join)
+        idx = torch.full((own_t.shape[0],), -1, dtype=torch.int64, device=dev)
+        d2 = torch.full((own_t.shape[0],), float("inf"), dtype=torch.float64, device=dev)
+    # exact while the nearest source point lies inside slab + halo whatever lies beyond
+    d = torch.sqrt(d2)
+    x = own_t[:, 0].double()
+    ok = idx >= 0
+    if rank > 0:
+        ok &= d < x - (cuts[rank] - halo)
+    if rank < world - 1:
+        ok &= d < (cuts[rank + 1] + halo) - x
+    bad = torch.tensor([int((~ok).sum())], dtype=torch.int64, device=dev)
+    if world > 1:
+        _all_reduce(dist, bad, dist.ReduceOp.SUM)
+    mine = (idx >= 0) & (idx < n_own)
+    keep_xyz, keep_nn, keep_d2 = own_t[mine], idx[mine], d2[mine]
+    n_fwd = 0
+    if world > 1:
+        # the nearest source point is a halo point: the target point joins a patch of the neighbour that owns it
+        away = idx >= n_own
+        a_idx = idx[away]
+        a_x = sv["xyz_all"][a_idx, 0].double()
+        dest = torch.where(a_x < cuts[rank], torch.full_like(a_idx, rank - 1), torch.full_like(a_idx, rank + 1))
+        payload = torch.cat([own_t[away].double(), sv["gid_all"][a_idx].double()[:, None], d2[away][:, None]], dim=1)
+        n_fwd = int(away.sum())
+        got = _a2a_v(dist, torch, payload, dest, world)
+        if got.shape[0]:
+            order = torch.argsort(sv["gid"])
+            pos = torch.searchsorted(sv["gid"][order], got[:, 3].to(torch.int64))
+            local = order[torch.clamp(pos, max=max(n_own - 1, 0))]
+            assert bool((sv["gid"][local] == got[:, 3].to(torch.int64)).all()), "forwarded target points must name a source point owned here"
+            keep_xyz = torch.cat([keep_xyz, got[:, :3].float()])
+            keep_nn = torch.cat([keep_nn, local])
+            keep_d2 = torch.cat([keep_d2, got[:, 4]])
+    return dict(xyz=keep_xyz.contiguous(), nn=keep_nn, d2=keep_d2, n_forwarded=n_fwd, n_uncertified=int(bad.item()))

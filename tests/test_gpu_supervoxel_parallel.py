@@ -157,3 +157,21 @@ def test_slab_pipeline_single_rank_equals_the_whole_partition(eng):
     labels, K = eng.supervoxel_parallel(dev(xyz), 30, 0.5)
     assert out["K_total"] == out["K_local"] == K and out["n_uncertified"] == 0 and out["offset"] == 0
     assert torch.equal(out["labels"].to(torch.int32), labels) and torch.equal(out["gid"], torch.arange(20_000, device="cuda"))
+
+
+def test_full_path_over_slabs_single_rank_equals_the_tile_path(eng):
+    """pipeline.full_path_slabs (configs[4] spread over GPUs: slab partition, target epoch joined through the slabs, then the
+    per-patch stages where the patches live) at world_size 1 against pipeline.full_path on the same tile: the same partition,
+    patches, transforms and rows, bit for bit.  (N > 1: tests/test_slabs_gloo.py covers both exchanges.)"""
+    from fusion4landslide_amd import pipeline, synthetic
+    c = synthetic.two_epoch_cloud(60_000, 9, 1.386, seed=4)
+    src, tgt = dev(c["src"]), dev(c["tgt"])
+    res = 0.9
+    whole = pipeline.full_path(src, tgt, resolution=res, max_iter=20, fixed_iters=True)
+    part = pipeline.full_path_slabs(src, torch.arange(src.shape[0], device="cuda"), tgt, None, 0, 1, halo=0.5, resolution=res, max_iter=20,
+                                    fixed_iters=True)
+    assert part["K_local"] == part["K_total"] == whole["K"] and part["offset"] == 0 and part["n_uncertified"] == 0
+    assert torch.equal(part["gid"], whole["order"].to(torch.int64))
+    for key in ("T", "fitness", "rmse", "iters", "rows", "src_off", "tgt_off"):
+        assert torch.equal(part[key], whole[key]), key
+    assert part["stage_ms"]["total"] > 0 and "target_exchange" in part["stage_ms"]

@@ -41,6 +41,20 @@ def _segment(p, normals, knn, res, grid_bbox):
     return torch.from_numpy(r["labels"]), r["n_supervoxels"]
 
 
+def _target_cloud():
+    """The second epoch: the same surface sampled elsewhere and displaced by a few centimetres (more than the point spacing)."""
+    rng = np.random.default_rng(12)
+    xy = rng.uniform(0, 1, (N + 500, 2)) * [6.0, 3.0]
+    z = 0.2 * np.sin(2 * xy[:, 0]) * np.cos(3 * xy[:, 1]) + rng.normal(0, 0.003, N + 500)
+    return (np.c_[xy, z] + [0.07, -0.05, 0.02]).astype(np.float32)
+
+
+def _nn(cloud, queries):
+    from scipy.spatial import cKDTree
+    d, i = cKDTree(cloud.numpy().astype(np.float64)).query(queries.numpy().astype(np.float64), k=1)
+    return torch.from_numpy(i.astype(np.int64)), torch.from_numpy(d * d)
+
+
 def _worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -51,6 +65,11 @@ def _worker(rank, world, port, q):
     mine = np.arange(rank, N, world)  # an arbitrary chunk per rank: every world-th point
     out = slabs.slab_supervoxel(torch.from_numpy(xyz[mine]), torch.from_numpy(mine.astype(np.int64)), K_NN, RES, dist, rank, world, HALO,
                                 knn_normals_fn=_knn_normals, segment_fn=_segment)
+    tgt = _target_cloud()
+    tmine = np.arange(world - 1 - rank, len(tgt), world)
+    tg = slabs.slab_targets(torch.from_numpy(tgt[tmine]), out, dist, rank, world, HALO, nn_fn=_nn)
+    out["tgt_xyz"], out["tgt_src_gid"], out["tgt_d2"] = tg["xyz"], out["gid"][tg["nn"]], tg["d2"]
+    out["tgt_forwarded"], out["tgt_uncertified"] = tg["n_forwarded"], tg["n_uncertified"]
     q.put((rank, {k: (v.numpy() if hasattr(v, "numpy") else v) for k, v in out.items() if k != "plan"}, out["plan"]["bounds"].tolist()))
     dist.barrier()
     dist.destroy_process_group()
@@ -101,3 +120,19 @@ def test_slab_split_matches_the_whole_cloud(world):
         owner[out["gid"]] = rank
     for lab in range(K):
         assert len(set(owner[labels == lab])) == 1
+    # the second epoch: every target point ends on exactly one rank, the one that owns its nearest source point of the WHOLE
+    # first epoch (so that it joins a patch that lives there); points near a cut were forwarded
+    from scipy.spatial import cKDTree
+    tgt = _target_cloud()
+    d_ref, i_ref = cKDTree(xyz.astype(np.float64)).query(tgt.astype(np.float64), k=1)
+    got_xyz = np.concatenate([r[1]["tgt_xyz"] for r in res])
+    got_gid = np.concatenate([r[1]["tgt_src_gid"] for r in res])
+    got_d2 = np.concatenate([r[1]["tgt_d2"] for r in res])
+    assert got_xyz.shape == tgt.shape
+    o_got, o_ref = np.lexsort(got_xyz.T[::-1]), np.lexsort(tgt.T[::-1])
+    assert np.array_equal(got_xyz[o_got], tgt[o_ref])
+    assert np.array_equal(got_gid[o_got], i_ref[o_ref])
+    assert np.abs(np.sqrt(got_d2[o_got]) - d_ref[o_ref]).max() < 1e-12
+    assert all(r[1]["tgt_uncertified"] == 0 for r in res) and sum(r[1]["tgt_forwarded"] for r in res) > 0
+    for rank, out, _ in res:
+        assert (owner[out["tgt_src_gid"]] == rank).all()
