@@ -504,6 +504,9 @@ def supervoxel_parallel(xyz, k, resolution, return_intermediates=False):
                                         ptr(nrm_out), ptr(ws), C.c_size_t(nbytes), stream_ptr()), "f4l_supervoxel_parallel")
     info_h = info.cpu()
     K = int(info_h[0])
+    if int(info_h[2]) & 8:  # (never expected: the persistent kernel's grid barrier gave up -- its workgroups were not all resident)
+        raise RuntimeError("f4l_supervoxel_parallel: the segmentation's grid barrier timed out (another kernel held the device?); "
+                           "rerun, or set F4L_SV_LAUNCHES=1 for the schedule of launches")
     if return_intermediates:
         return labels, K, knn_out, nrm_out, reps[:K], info_h
     return labels, K

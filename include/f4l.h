@@ -257,7 +257,9 @@ int f4l_supervoxel(const float *xyz, int64_t n, int k, double resolution, int32_
  *   labels_out int32 [n];  reps_out int32 [n] or NULL: reps_out[l] = index of supervoxel l's representative point;
  *   info_out int32 [4] (device) or NULL: {supervoxels produced, K wanted, status bits, exchange sweeps run};
  *   status bit 0: the graph of representatives ran out of edges above K (disconnected cloud; the reference would not
- *   return), bit 1: lambda schedule exhausted above K, bit 2: exchange stopped by the sweep budget before its fixed point.
+ *   return), bit 1: lambda schedule exhausted above K, bit 2: exchange stopped by the sweep budget before its fixed point,
+ *   bit 3: the persistent kernel that runs the rounds beyond the scheduled launches gave up waiting at its grid barrier
+ *   (its workgroups were not all resident: another kernel held the device for about a second) -- labels invalid, rerun.
  * f4l_supervoxel_parallel = f4l_knn + f4l_normals + this (f4l_knn synchronises once while it sizes its grid). */
 size_t f4l_supervoxel_segment_device_workspace_bytes(int64_t n, int k);
 int f4l_supervoxel_segment_device(const float *xyz, const double *normals, const int32_t *knn, int64_t n, int k,
