@@ -349,6 +349,64 @@ __global__ __launch_bounds__(KNN_NW * 64) void knn_listed_kernel(KnnArgs a, cons
     }
 }
 
+// The same for k = 1 (f4l_nn_query's label transfer and refinements): one LANE per listed query.  A query displaced against
+// the cloud (a moving slope's second epoch: 0.2-0.5 m against cells of 0.125 m) needs a block of ~11 x 11 cells = ~500
+// candidates; the lane walks the block's rows of cells itself (listed queries come in sorted order: neighbouring lanes walk
+// overlapping ranges of the sorted array), keeps the nearest with the exact distance (ties: smallest index, the order of the
+// wave search) and grows the block by the rule of knn_query_wave.  A quarter of a displaced 1 M tile: 1.2 ms as one wave per
+// query, 0.1 ms here.
+__global__ __launch_bounds__(256) void nn1_listed_kernel(KnnArgs a, const int32_t *__restrict__ list, const int32_t *__restrict__ count) {
+    const int n_list = *count;
+    const GridSpec g = a.g;
+    const int max_dim = max(g.nx, max(g.ny, g.nz));
+    const double eps = 1e-6 * g.h;
+    for (int i = (int)(blockIdx.x * blockDim.x + threadIdx.x); i < n_list; i += (int)(gridDim.x * blockDim.x)) {
+        const float4 qp = a.q_sorted[list[i]];
+        const int qid = __float_as_int(qp.w);
+        int cx, cy, cz;
+        cell_of(g, qp.x, qp.y, qp.z, cx, cy, cz);
+        const double fx = ((double)qp.x - g.minx) - (double)cx * g.h, fy = ((double)qp.y - g.miny) - (double)cy * g.h,
+                     fz = ((double)qp.z - g.minz) - (double)cz * g.h;
+        double best = __builtin_inf();
+        int best_id = 0x7fffffff;
+        for (int R = 1;;) {
+            const int x0 = cx - R < 0 ? 0 : cx - R, x1 = cx + R >= g.nx ? g.nx - 1 : cx + R;
+            const int y0 = cy - R < 0 ? 0 : cy - R, y1 = cy + R >= g.ny ? g.ny - 1 : cy + R;
+            const int z0 = cz - R < 0 ? 0 : cz - R, z1 = cz + R >= g.nz ? g.nz - 1 : cz + R;
+            for (int zz = z0; zz <= z1; ++zz)
+                for (int yy = y0; yy <= y1; ++yy) {
+                    int lo, hi;
+                    cell_range(a.dense, a.cell_keys, a.cell_start, a.M, key_of(g, x0, yy, zz), key_of(g, x1, yy, zz), lo, hi);
+                    for (int j = lo; j < hi; ++j) {
+                        const float4 cp = a.sorted[j];
+                        const double d = dist2_exact(cp.x, cp.y, cp.z, qp.x, qp.y, qp.z);
+                        const int id = __float_as_int(cp.w);
+                        const bool better = d < best || (d == best && id < best_id);
+                        best = better ? d : best;
+                        best_id = better ? id : best_id;
+                    }
+                }
+            // exactness: the distance found lies strictly inside the searched block (faces at the grid border do not count)
+            double margin = __builtin_inf();
+            if (cx - R > 0) margin = fmin(margin, fx + (double)R * g.h - eps);
+            if (cx + R < g.nx - 1) margin = fmin(margin, ((double)(R + 1)) * g.h - fx - eps);
+            if (cy - R > 0) margin = fmin(margin, fy + (double)R * g.h - eps);
+            if (cy + R < g.ny - 1) margin = fmin(margin, ((double)(R + 1)) * g.h - fy - eps);
+            if (cz - R > 0) margin = fmin(margin, fz + (double)R * g.h - eps);
+            if (cz + R < g.nz - 1) margin = fmin(margin, ((double)(R + 1)) * g.h - fz - eps);
+            if (best < margin * margin || R >= max_dim) break;
+            if (best == __builtin_inf()) R = 2 * R < max_dim ? 2 * R : max_dim;
+            else {
+                const double need = (sqrt(best) + eps) * g.inv_h + 1.0;
+                const int Rj = need < (double)max_dim ? (int)need : max_dim;
+                R = Rj > R + 1 ? Rj : R + 1;
+            }
+        }
+        a.idx_out[qid] = best_id;
+        if (a.d2_out) a.d2_out[qid] = best;
+    }
+}
+
 // ---- fast path of f4l_knn: one LANE per query -------------------------------------------------------------------------
 // A wavefront takes 64 CONSECUTIVE points of the sorted array.  They lie in a few x-adjacent cells of one (y, z) row of
 // cells (a wave that straddles the end of a row takes one turn per row), so they share one candidate set: the 3 x 3 rows
@@ -1202,7 +1260,10 @@ extern "C" int f4l_nn_query(const float *cloud, int64_t n, const float *queries,
     hipLaunchKernelGGL(knn_lanes_kernel, dim3((unsigned)((m + KR_NW * 64 - 1) / (KR_NW * 64))), dim3(KR_NW * 64), 0, st, ra);
     F4L_LAUNCH_CHECK();
     a.n = n;
-    hipLaunchKernelGGL(knn_listed_kernel, dim3(2048), dim3(KNN_NW * 64), 0, st, a, wq.fb_list, wq.fb_count);
+    if (k == 1 && !getenv("F4L_KNN_WAVE_LISTED"))
+        hipLaunchKernelGGL(nn1_listed_kernel, dim3(2048), dim3(256), 0, st, a, wq.fb_list, wq.fb_count);
+    else
+        hipLaunchKernelGGL(knn_listed_kernel, dim3(2048), dim3(KNN_NW * 64), 0, st, a, wq.fb_list, wq.fb_count);
     F4L_LAUNCH_CHECK();
     if (getenv("F4L_KNN_DEBUG")) {  // (synchronises: measurements only)
         int fbc = 0;
