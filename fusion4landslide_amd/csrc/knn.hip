@@ -349,27 +349,35 @@ __global__ __launch_bounds__(KNN_NW * 64) void knn_listed_kernel(KnnArgs a, cons
     }
 }
 
-// The same for k = 1 (f4l_nn_query's label transfer and refinements): one LANE per listed query.  A query displaced against
-// the cloud (a moving slope's second epoch: 0.2-0.5 m against cells of 0.125 m) needs a block of ~11 x 11 cells = ~500
-// candidates; the lane walks the block's rows of cells itself (listed queries come in sorted order: neighbouring lanes walk
-// overlapping ranges of the sorted array), keeps the nearest with the exact distance (ties: smallest index, the order of the
-// wave search) and grows the block by the rule of knn_query_wave.  A quarter of a displaced 1 M tile: 1.2 ms as one wave per
-// query, 0.1 ms here.
-__global__ __launch_bounds__(256) void nn1_listed_kernel(KnnArgs a, const int32_t *__restrict__ list, const int32_t *__restrict__ count) {
-    const int n_list = *count;
+// ---- a handful of neighbours (k <= KS_MAX_K): one LANE per query, candidates straight from the sorted array ------------------
+// The 2-NN of `_compute_median_resolution`, the 1-NN of the label transfer and of `_voxel_subsampling`.  With cells of ~4
+// points a query's own 3 x 3 block holds ~36 candidates, but a wave of the lane kernel below shares ONE candidate set, the
+// union of its 64 queries' blocks (~220 points at this cell size): 0.40 ms per 1 M queries whatever k.  Here every lane walks
+// the rows of cells of its own block (queries come in sorted order: neighbouring lanes read overlapping ranges of the sorted
+// array, from L1), measures exactly (dist2_exact) and keeps its k nearest by (d2, index) in registers; the block grows by
+// the rule of knn_query_wave until the k-th distance lies inside it -- a query displaced against the cloud (a moving slope's
+// second epoch: 0.2-0.5 m against cells of 0.125 m) ends with a block of ~11 x 11 cells = ~500 candidates.  1 M queries, k = 1,
+// a quarter of them displaced: 0.25 ms (lane kernel + one wave per uncertified query: 0.40 + 2.9 ms in round 2b).
+// `list` = nullptr: all nq queries of q_sorted; else the listed ones.
+constexpr int KS_MAX_K = 4;
+__global__ __launch_bounds__(256) void nn_small_kernel(KnnArgs a, int nq, const int32_t *__restrict__ list, const int32_t *__restrict__ count) {
+    const int n_q = list ? *count : nq;
     const GridSpec g = a.g;
+    const int k = a.k;
     const int max_dim = max(g.nx, max(g.ny, g.nz));
     const double eps = 1e-6 * g.h;
-    for (int i = (int)(blockIdx.x * blockDim.x + threadIdx.x); i < n_list; i += (int)(gridDim.x * blockDim.x)) {
-        const float4 qp = a.q_sorted[list[i]];
+    for (int i = (int)(blockIdx.x * blockDim.x + threadIdx.x); i < n_q; i += (int)(gridDim.x * blockDim.x)) {
+        const float4 qp = a.q_sorted[list ? list[i] : i];
         const int qid = __float_as_int(qp.w);
         int cx, cy, cz;
         cell_of(g, qp.x, qp.y, qp.z, cx, cy, cz);
         const double fx = ((double)qp.x - g.minx) - (double)cx * g.h, fy = ((double)qp.y - g.miny) - (double)cy * g.h,
                      fz = ((double)qp.z - g.minz) - (double)cz * g.h;
-        double best = __builtin_inf();
-        int best_id = 0x7fffffff;
+        double bd[KS_MAX_K];
+        int bi[KS_MAX_K];
         for (int R = 1;;) {
+#pragma unroll
+            for (int j = 0; j < KS_MAX_K; ++j) { bd[j] = __builtin_inf(); bi[j] = 0x7fffffff; }
             const int x0 = cx - R < 0 ? 0 : cx - R, x1 = cx + R >= g.nx ? g.nx - 1 : cx + R;
             const int y0 = cy - R < 0 ? 0 : cy - R, y1 = cy + R >= g.ny ? g.ny - 1 : cy + R;
             const int z0 = cz - R < 0 ? 0 : cz - R, z1 = cz + R >= g.nz ? g.nz - 1 : cz + R;
@@ -379,14 +387,24 @@ __global__ __launch_bounds__(256) void nn1_listed_kernel(KnnArgs a, const int32_
                     cell_range(a.dense, a.cell_keys, a.cell_start, a.M, key_of(g, x0, yy, zz), key_of(g, x1, yy, zz), lo, hi);
                     for (int j = lo; j < hi; ++j) {
                         const float4 cp = a.sorted[j];
-                        const double d = dist2_exact(cp.x, cp.y, cp.z, qp.x, qp.y, qp.z);
-                        const int id = __float_as_int(cp.w);
-                        const bool better = d < best || (d == best && id < best_id);
-                        best = better ? d : best;
-                        best_id = better ? id : best_id;
+                        double d = dist2_exact(cp.x, cp.y, cp.z, qp.x, qp.y, qp.z);
+                        int id = __float_as_int(cp.w);
+#pragma unroll
+                        for (int t = 0; t < KS_MAX_K; ++t) {  // insertion, ascending by (d2, index); the last falls off
+                            const bool lt = d < bd[t] || (d == bd[t] && id < bi[t]);
+                            const double dn = lt ? bd[t] : d;
+                            const int in = lt ? bi[t] : id;
+                            bd[t] = lt ? d : bd[t];
+                            bi[t] = lt ? id : bi[t];
+                            d = dn; id = in;
+                        }
                     }
                 }
-            // exactness: the distance found lies strictly inside the searched block (faces at the grid border do not count)
+            double dk = bd[0];
+#pragma unroll
+            for (int t = 1; t < KS_MAX_K; ++t)
+                if (t == k - 1) dk = bd[t];
+            // exactness: the k-th distance lies strictly inside the searched block (faces at the grid border do not count)
             double margin = __builtin_inf();
             if (cx - R > 0) margin = fmin(margin, fx + (double)R * g.h - eps);
             if (cx + R < g.nx - 1) margin = fmin(margin, ((double)(R + 1)) * g.h - fx - eps);
@@ -394,16 +412,20 @@ __global__ __launch_bounds__(256) void nn1_listed_kernel(KnnArgs a, const int32_
             if (cy + R < g.ny - 1) margin = fmin(margin, ((double)(R + 1)) * g.h - fy - eps);
             if (cz - R > 0) margin = fmin(margin, fz + (double)R * g.h - eps);
             if (cz + R < g.nz - 1) margin = fmin(margin, ((double)(R + 1)) * g.h - fz - eps);
-            if (best < margin * margin || R >= max_dim) break;
-            if (best == __builtin_inf()) R = 2 * R < max_dim ? 2 * R : max_dim;
+            if (dk < margin * margin || R >= max_dim) break;
+            if (dk == __builtin_inf()) R = 2 * R < max_dim ? 2 * R : max_dim;
             else {
-                const double need = (sqrt(best) + eps) * g.inv_h + 1.0;
+                const double need = (sqrt(dk) + eps) * g.inv_h + 1.0;
                 const int Rj = need < (double)max_dim ? (int)need : max_dim;
                 R = Rj > R + 1 ? Rj : R + 1;
             }
         }
-        a.idx_out[qid] = best_id;
-        if (a.d2_out) a.d2_out[qid] = best;
+#pragma unroll
+        for (int t = 0; t < KS_MAX_K; ++t)
+            if (t < k) {
+                a.idx_out[(int64_t)qid * k + t] = bi[t];
+                if (a.d2_out) a.d2_out[(int64_t)qid * k + t] = bd[t];
+            }
     }
 }
 
@@ -1108,6 +1130,11 @@ static int knn_self(const float *xyz, int64_t n, int k, int32_t *idx_out, double
     a.dense = w.has_dense ? w.dense : nullptr;
     a.q_sorted = w.sorted; a.q_cell_keys = w.cell_keys; a.q_cell_start = w.cell_start; a.Mq = M;
     a.idx_out = idx_out; a.d2_out = d2_out;
+    if (k <= KS_MAX_K && !normals_out && !getenv("F4L_KNN_WAVE_PER_QUERY") && !getenv("F4L_KNN_NO_SMALL")) {
+        hipLaunchKernelGGL(nn_small_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a, (int)n, (const int32_t *)nullptr, (const int32_t *)nullptr);
+        F4L_LAUNCH_CHECK();
+        return F4L_OK;
+    }
     const bool lanes = k <= KR_MAX_K && !getenv("F4L_KNN_WAVE_PER_QUERY");  // (switch: A/B timing, and the test that both agree)
     if (!lanes) {
         // one wave per occupied cell, its queries one after the other
@@ -1220,6 +1247,20 @@ extern "C" int f4l_nn_query(const float *cloud, int64_t n, const float *queries,
     size_t tb = wq.prim_bytes;
     F4L_HIP_CHECK(rocprim::radix_sort_pairs(wq.prim_temp, tb, wq.keys_a, wq.keys_b, wq.ids_a, wq.ids_b, (size_t)m, 0,
                                             (unsigned)end_bit, st, false));
+    if (k <= KS_MAX_K && !getenv("F4L_KNN_WAVE_PER_QUERY") && !getenv("F4L_KNN_NO_SMALL")) {
+        // a handful of neighbours: one lane per query (in cell order, for the locality of neighbouring lanes' reads); the
+        // queries' own cell table is not needed
+        hipLaunchKernelGGL(relayout_kernel, dim3(grid_for(m)), dim3(256), 0, st, queries, wq.ids_b, m, wq.sorted);
+        F4L_LAUNCH_CHECK();
+        KnnArgs a;
+        a.sorted = w.sorted; a.cell_keys = w.cell_keys; a.cell_start = w.cell_start; a.M = M; a.n = n; a.k = k; a.g = g;
+        a.dense = w.has_dense ? w.dense : nullptr;
+        a.q_sorted = wq.sorted; a.q_cell_keys = nullptr; a.q_cell_start = nullptr; a.Mq = 0;
+        a.idx_out = idx_out; a.d2_out = d2_out;
+        hipLaunchKernelGGL(nn_small_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, a, (int)m, (const int32_t *)nullptr, (const int32_t *)nullptr);
+        F4L_LAUNCH_CHECK();
+        return F4L_OK;
+    }
     tb = wq.prim_bytes;
     F4L_HIP_CHECK(rocprim::run_length_encode(wq.prim_temp, tb, wq.keys_b, (unsigned int)m, wq.cell_keys, wq.cell_counts,
                                              wq.n_cells, st, false));
@@ -1260,10 +1301,7 @@ extern "C" int f4l_nn_query(const float *cloud, int64_t n, const float *queries,
     hipLaunchKernelGGL(knn_lanes_kernel, dim3((unsigned)((m + KR_NW * 64 - 1) / (KR_NW * 64))), dim3(KR_NW * 64), 0, st, ra);
     F4L_LAUNCH_CHECK();
     a.n = n;
-    if (k == 1 && !getenv("F4L_KNN_WAVE_LISTED"))
-        hipLaunchKernelGGL(nn1_listed_kernel, dim3(2048), dim3(256), 0, st, a, wq.fb_list, wq.fb_count);
-    else
-        hipLaunchKernelGGL(knn_listed_kernel, dim3(2048), dim3(KNN_NW * 64), 0, st, a, wq.fb_list, wq.fb_count);
+    hipLaunchKernelGGL(knn_listed_kernel, dim3(2048), dim3(KNN_NW * 64), 0, st, a, wq.fb_list, wq.fb_count);
     F4L_LAUNCH_CHECK();
     if (getenv("F4L_KNN_DEBUG")) {  // (synchronises: measurements only)
         int fbc = 0;

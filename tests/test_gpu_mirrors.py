@@ -237,14 +237,15 @@ def test_nn_query_vs_kdtree():
     finally:
         del os.environ["F4L_KNN_NO_DENSE"]
     assert (idx2.cpu().numpy() == idx).all() and (d22.cpu().numpy() == d2).all()
-    # k = 1: the uncertified queries (displaced blocks, far outside points) redone one lane each against one wave each
-    i1, d1 = engine.nn_query(torch.from_numpy(cloud).cuda(), torch.from_numpy(q).cuda(), 1, return_d2=True)
-    os.environ["F4L_KNN_WAVE_LISTED"] = "1"
-    try:
-        i1w, d1w = engine.nn_query(torch.from_numpy(cloud).cuda(), torch.from_numpy(q).cuda(), 1, return_d2=True)
-    finally:
-        del os.environ["F4L_KNN_WAVE_LISTED"]
-    assert torch.equal(i1, i1w) and torch.equal(d1, d1w)
+    # k <= 4 runs one lane per query on its own block (nn_small_kernel): the same answers as the wave-shared candidate sets
+    for k in (1, 4):
+        i1, d1 = engine.nn_query(torch.from_numpy(cloud).cuda(), torch.from_numpy(q).cuda(), k, return_d2=True)
+        os.environ["F4L_KNN_NO_SMALL"] = "1"
+        try:
+            i1w, d1w = engine.nn_query(torch.from_numpy(cloud).cuda(), torch.from_numpy(q).cuda(), k, return_d2=True)
+        finally:
+            del os.environ["F4L_KNN_NO_SMALL"]
+        assert torch.equal(i1, i1w) and torch.equal(d1, d1w)
     # a single query, a single-point cloud, no queries
     one = engine.nn_query(torch.from_numpy(cloud[:1]).cuda(), torch.from_numpy(q[:7]).cuda(), 1)
     assert (one.cpu().numpy() == 0).all()
