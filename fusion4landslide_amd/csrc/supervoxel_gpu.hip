@@ -54,6 +54,7 @@ constexpr int SWEEPS = 96;
 constexpr int SCHED_ROUNDS = 16, SCHED_SWEEPS = 16;
 constexpr unsigned GRID = 2048, BLOCK = 256;
 constexpr unsigned long long DEAD = ~0ULL;
+constexpr size_t OFFER_WAVES = 65536;  // >= waves of any grid the candidate passes run on (2048 x 4; the rest kernel: <= 1024 x 16)
 
 struct State {
     double lambda;
@@ -227,44 +228,90 @@ __global__ void init_edges_kernel(const int32_t *__restrict__ knn, int64_t n, in
 __device__ __forceinline__ bool fusing(const State *st) { return st->live > st->K && !st->stalled; }
 
 // ---- one sub-round of conflict-free fusion -------------------------------------------------------------------------
-// cand: re-point every edge to the current representatives; an edge u -> v with u heads, v tails and
-//       sizes[v] * metric(u, v) < lambda offers u to v: bestm[v] = min metric.
-template <bool TIE>
+// cand:  re-point every edge to the current representatives; an edge u -> v with u heads, v tails and
+//        sizes[v] * metric(u, v) < lambda offers u to v: bestm[v] = min metric (atomicMin on the ordered image of the double).
+//        The offering edges are also written out -- every WAVE owns a contiguous chunk of the edge list and compacts its
+//        offers to the front of the same chunk of `offers` (the other edge buffer, idle until the lambda's merge), count in
+//        `offer_cnt`: no atomics, no barriers --
+// cand2: so that the tie pass (among the offers of smallest metric the smallest u wins: bestu[v] = min u) reads the offers only,
+//        a few per cent of the list, instead of walking all edges again and measuring a quarter of them a second time.
+// Both passes must run on the same grid (the chunks are derived from it).
+__device__ __forceinline__ void wave_chunk(int32_t ne, int64_t &start, int64_t &end, int &wave_id) {
+    const int waves = (int)(gridDim.x * (blockDim.x >> 6));
+    wave_id = (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+    const int64_t chunk = (((int64_t)ne + waves - 1) / waves + 63) & ~(int64_t)63;
+    start = (int64_t)wave_id * chunk;
+    end = start + chunk < (int64_t)ne ? start + chunk : (int64_t)ne;
+}
 __device__ __forceinline__ void cand_body(const float *__restrict__ xyz, const double *__restrict__ nrm, double resolution, State *st,
                                           unsigned long long *__restrict__ edges, const int32_t *__restrict__ parent,
-                                          const int32_t *__restrict__ size, unsigned long long *__restrict__ bestm, int32_t *__restrict__ bestu,
-                                          bool hop) {
-    if (!TIE && blockIdx.x == 0 && threadIdx.x == 0) st->n_prop = 0;  // (the previous sub-round's apply has finished)
+                                          const int32_t *__restrict__ size, unsigned long long *__restrict__ bestm,
+                                          unsigned long long *__restrict__ offers, int32_t *__restrict__ offer_cnt, bool hop) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) st->n_prop = 0;  // (the previous sub-round's apply has finished)
     const int32_t ne = st->n_edges, round = st->round;
     const double lambda = st->lambda;
-    SV_FOR(e, ne) {
-        unsigned long long key = edges[e];
-        if (key == DEAD) continue;
-        int32_t u = (int32_t)(key >> 32), v = (int32_t)(key & 0xffffffffULL);
-        if (!TIE && hop) {  // (not in the first sub-round of a lambda: the list was re-pointed when it was merged)
-            const int32_t pu = parent[u], pv = parent[v];  // both were representatives at the last re-pointing: one hop reaches the current ones
-            if (pu != u || pv != v) {
-                u = pu; v = pv;
-                key = u == v ? DEAD : (((unsigned long long)(unsigned int)u << 32) | (unsigned int)v);
-                edges[e] = key;
-                if (u == v) continue;
+    int64_t start, end;
+    int wave_id;
+    wave_chunk(ne, start, end, wave_id);
+    int cnt = 0;
+    for (int64_t base = start; base < end; base += 64) {  // (uniform per wave)
+        const int64_t e = base + lane_id();
+        bool offer = false;
+        unsigned long long key = DEAD;
+        if (e < end) {
+            key = edges[e];
+            if (key != DEAD) {
+                int32_t u = (int32_t)(key >> 32), v = (int32_t)(key & 0xffffffffULL);
+                if (hop) {  // (not in the first sub-round of a lambda: the list was re-pointed when it was merged)
+                    const int32_t pu = parent[u], pv = parent[v];  // both were representatives at the last re-pointing: one hop reaches the current ones
+                    if (pu != u || pv != v) {
+                        u = pu; v = pv;
+                        key = u == v ? DEAD : (((unsigned long long)(unsigned int)u << 32) | (unsigned int)v);
+                        edges[e] = key;
+                    }
+                }
+                if (key != DEAD && heads(u, round) && !heads(v, round)) {
+                    const double m = sv_metric(xyz, nrm, u, v, resolution);
+                    const double loss = (double)size[v] * m;
+                    if (lambda - loss > 0.0) {  // :147-149 `improvement > 0.0`
+                        atomicMin(&bestm[v], d2ord(m));
+                        offer = true;
+                    }
+                }
             }
         }
-        if (!heads(u, round) || heads(v, round)) continue;
-        const double m = sv_metric(xyz, nrm, u, v, resolution);
-        const double loss = (double)size[v] * m;
-        if (!(lambda - loss > 0.0)) continue;  // :147-149 `improvement > 0.0`
-        const unsigned long long mo = d2ord(m);
-        if (!TIE) atomicMin(&bestm[v], mo);
-        else if (bestm[v] == mo) atomicMin(&bestu[v], u);
+        const unsigned long long mask = __ballot(offer);
+        if (offer)
+            offers[start + cnt + (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)mask, 0u))] = key;
+        cnt += (int)__popcll(mask);
+    }
+    if (lane_id() == 0) offer_cnt[wave_id] = cnt;
+}
+__device__ __forceinline__ void cand2_body(const float *__restrict__ xyz, const double *__restrict__ nrm, double resolution, const State *st,
+                                           const unsigned long long *__restrict__ bestm, int32_t *__restrict__ bestu,
+                                           const unsigned long long *__restrict__ offers, const int32_t *__restrict__ offer_cnt) {
+    int64_t start, end;
+    int wave_id;
+    wave_chunk(st->n_edges, start, end, wave_id);
+    const int cnt = start < end ? offer_cnt[wave_id] : 0;
+    for (int j = lane_id(); j < cnt; j += 64) {
+        const unsigned long long key = offers[start + j];
+        const int32_t u = (int32_t)(key >> 32), v = (int32_t)(key & 0xffffffffULL);
+        if (bestm[v] == d2ord(sv_metric(xyz, nrm, u, v, resolution))) atomicMin(&bestu[v], u);
     }
 }
-template <bool TIE>
 __global__ void cand_kernel(const float *__restrict__ xyz, const double *__restrict__ nrm, double resolution, State *st,
                             unsigned long long *__restrict__ edges, const int32_t *__restrict__ parent,
-                            const int32_t *__restrict__ size, unsigned long long *__restrict__ bestm, int32_t *__restrict__ bestu, bool hop) {
+                            const int32_t *__restrict__ size, unsigned long long *__restrict__ bestm,
+                            unsigned long long *__restrict__ offers, int32_t *__restrict__ offer_cnt, bool hop) {
     if (!fusing(st)) return;
-    cand_body<TIE>(xyz, nrm, resolution, st, edges, parent, size, bestm, bestu, hop);
+    cand_body(xyz, nrm, resolution, st, edges, parent, size, bestm, offers, offer_cnt, hop);
+}
+__global__ void cand2_kernel(const float *__restrict__ xyz, const double *__restrict__ nrm, double resolution, const State *st,
+                             const unsigned long long *__restrict__ bestm, int32_t *__restrict__ bestu,
+                             const unsigned long long *__restrict__ offers, const int32_t *__restrict__ offer_cnt) {
+    if (!fusing(st)) return;
+    cand2_body(xyz, nrm, resolution, st, bestm, bestu, offers, offer_cnt);
 }
 // collect: every tails representative with an offer becomes a proposal (key = float image of the loss : index)
 __device__ __forceinline__ void collect_body(State *st, int64_t n, const int32_t *__restrict__ size, unsigned long long *__restrict__ bestm,
@@ -544,7 +591,7 @@ struct SegArgs {
     double resolution;
     State *st;
     unsigned long long *edges_a, *edges_b, *table, *bestm, *prop_key;
-    int32_t *parent, *size, *bestu, *prop_u, *la, *lb;
+    int32_t *parent, *size, *bestu, *prop_u, *la, *lb, *offer_cnt;
     double *dis;
     unsigned char *d0, *d1;
     int first_round;  // fusion: lambda rounds first_round .. LAMBDA_ROUNDS - 1 (the launches did the others); < 0: the sweeps
@@ -601,9 +648,9 @@ __global__ __launch_bounds__(1024, 8) void segment_rest_kernel(SegArgs a) {
         unsigned long long *cur = (a.first_round & 1) ? a.edges_b : a.edges_a, *nxt = (a.first_round & 1) ? a.edges_a : a.edges_b;
         for (int r = a.first_round; r < LAMBDA_ROUNDS && fusing(st); ++r) {
             for (int s = 0; s < SUBROUNDS && fusing(st); ++s) {
-                cand_body<false>(a.xyz, a.nrm, a.resolution, st, cur, a.parent, a.size, a.bestm, a.bestu, s > 0);
+                cand_body(a.xyz, a.nrm, a.resolution, st, cur, a.parent, a.size, a.bestm, nxt, a.offer_cnt, s > 0);
                 grid.sync();
-                cand_body<true>(a.xyz, a.nrm, a.resolution, st, cur, a.parent, a.size, a.bestm, a.bestu, false);
+                cand2_body(a.xyz, a.nrm, a.resolution, st, a.bestm, a.bestu, nxt, a.offer_cnt);
                 grid.sync();
                 collect_body(st, a.n, a.size, a.bestm, a.bestu, a.prop_key, a.prop_u);
                 grid.sync();
@@ -644,8 +691,8 @@ static int segment_grid() {
         cached[dev] = -1;
         return 0;
     }
-    cached[dev] = cus * per_cu;
-    return cached[dev];
+    cached[dev] = (size_t)cus * per_cu * 16 <= OFFER_WAVES ? cus * per_cu : -1;  // (16 waves per workgroup: one offer count each)
+    return cached[dev] < 0 ? 0 : cached[dev];
 }
 
 static inline size_t align_up(size_t v) { return (v + 255) / 256 * 256; }
@@ -654,7 +701,7 @@ struct Ws {
     State *st;
     unsigned long long *keys_a, *keys_b, *edges_a, *edges_b, *table, *bestm, *prop_key;
     double *dis, *dis_sorted;
-    int32_t *parent, *size, *bestu, *prop_u, *la, *lb, *flag, *rank;
+    int32_t *parent, *size, *bestu, *prop_u, *la, *lb, *flag, *rank, *offer_cnt;
     unsigned char *d0, *d1;
     void *prim;
     size_t prim_bytes, total;
@@ -691,6 +738,7 @@ static int layout(int64_t n, int k, Ws &w, unsigned char *base) {
     w.lb = (int32_t *)carve((size_t)n * 4);
     w.flag = (int32_t *)carve((size_t)n * 4);
     w.rank = (int32_t *)carve((size_t)n * 4);
+    w.offer_cnt = (int32_t *)carve(OFFER_WAVES * 4);  // one count per wave of the candidate passes
     w.d0 = carve((size_t)n);
     w.d1 = carve((size_t)n);
     w.prim = carve(prim);
@@ -762,12 +810,12 @@ extern "C" int f4l_supervoxel_segment_device(const float *xyz, const double *nor
     sa.xyz = xyz; sa.nrm = normals; sa.knn = knn; sa.n = n; sa.k = k; sa.resolution = resolution; sa.st = w.st;
     sa.edges_a = w.edges_a; sa.edges_b = w.edges_b; sa.table = w.table; sa.bestm = w.bestm; sa.prop_key = w.prop_key;
     sa.parent = w.parent; sa.size = w.size; sa.bestu = w.bestu; sa.prop_u = w.prop_u; sa.la = w.la; sa.lb = w.lb;
-    sa.dis = w.dis; sa.d0 = w.d0; sa.d1 = w.d1;
+    sa.dis = w.dis; sa.d0 = w.d0; sa.d1 = w.d1; sa.offer_cnt = w.offer_cnt;
     unsigned long long *cur = w.edges_a, *nxt = w.edges_b;
     for (int r = 0; r < sched_rounds; ++r) {
         for (int s = 0; s < SUBROUNDS; ++s) {
-            hipLaunchKernelGGL(cand_kernel<false>, g, b, 0, st, xyz, normals, resolution, w.st, cur, w.parent, w.size, w.bestm, w.bestu, s > 0);
-            hipLaunchKernelGGL(cand_kernel<true>, g, b, 0, st, xyz, normals, resolution, w.st, cur, w.parent, w.size, w.bestm, w.bestu, false);
+            hipLaunchKernelGGL(cand_kernel, g, b, 0, st, xyz, normals, resolution, w.st, cur, w.parent, w.size, w.bestm, nxt, w.offer_cnt, s > 0);
+            hipLaunchKernelGGL(cand2_kernel, g, b, 0, st, xyz, normals, resolution, w.st, w.bestm, w.bestu, nxt, w.offer_cnt);
             hipLaunchKernelGGL(collect_kernel, g, dim3(1024), 0, st, w.st, n, w.size, w.bestm, w.bestu, w.prop_key, w.prop_u);
             hipLaunchKernelGGL(select_kernel, one, dim3(1024), 0, st, w.st, w.prop_key);
             hipLaunchKernelGGL(apply_kernel, g, b, 0, st, w.st, w.prop_key, w.prop_u, w.parent, w.size);
