@@ -35,6 +35,10 @@
 
 namespace f4l {
 
+// rocprim's radix sort switches to a merge sort at or below 2^20 items (147 us for the 1 M cell keys of a tile: ten merge
+// passes); with the cell keys' few significant bits the onesweep passes are three and take a third of that.
+using KeySortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 65536>;
+
 struct GridSpec {
     double minx, miny, minz;
     double inv_h, h;
@@ -939,12 +943,12 @@ static int knn_ws_layout(int64_t n, KnnWs &w, unsigned char *base) {
     size_t sort_b = 0, rle_b = 0, scan_b = 0;
     unsigned long long *k0 = nullptr;
     int32_t *i0 = nullptr;
-    if (rocprim::radix_sort_pairs(nullptr, sort_b, k0, k0, i0, i0, (size_t)n, 0, 64, 0, false) != hipSuccess) return F4L_EHIP;
+    if (rocprim::radix_sort_pairs<KeySortConfig>(nullptr, sort_b, k0, k0, i0, i0, (size_t)n, 0, 64, 0, false) != hipSuccess) return F4L_EHIP;
     if (rocprim::run_length_encode(nullptr, rle_b, k0, (unsigned int)n, k0, i0, i0, 0, false) != hipSuccess) return F4L_EHIP;
     {
         size_t s32 = 0, r32 = 0;
         unsigned int *q0 = nullptr;
-        if (rocprim::radix_sort_pairs(nullptr, s32, q0, q0, i0, i0, (size_t)n, 0, 32, 0, false) != hipSuccess) return F4L_EHIP;
+        if (rocprim::radix_sort_pairs<KeySortConfig>(nullptr, s32, q0, q0, i0, i0, (size_t)n, 0, 32, 0, false) != hipSuccess) return F4L_EHIP;
         if (rocprim::run_length_encode(nullptr, r32, q0, (unsigned int)n, q0, i0, i0, 0, false) != hipSuccess) return F4L_EHIP;
         sort_b = sort_b > s32 ? sort_b : s32;
         rle_b = rle_b > r32 ? rle_b : r32;
@@ -1057,7 +1061,7 @@ static int knn_build_grid(const float *xyz, int64_t n, int k, KnnWs &w, hipStrea
             unsigned int *u32 = k32b + n;  // (second half of the 64-bit buffer)
             hipLaunchKernelGGL(cell_key32_kernel, dim3(grid_for(n)), dim3(256), 0, st, xyz, n, g, k32a, w.ids_a);
             F4L_LAUNCH_CHECK();
-            F4L_HIP_CHECK(rocprim::radix_sort_pairs(w.prim_temp, tb, k32a, k32b, w.ids_a, w.ids_b, (size_t)n, 0, (unsigned)end_bit, st, false));
+            F4L_HIP_CHECK(rocprim::radix_sort_pairs<KeySortConfig>(w.prim_temp, tb, k32a, k32b, w.ids_a, w.ids_b, (size_t)n, 0, (unsigned)end_bit, st, false));
             tb = w.prim_bytes;
             F4L_HIP_CHECK(rocprim::run_length_encode(w.prim_temp, tb, k32b, (unsigned int)n, u32, w.cell_counts, w.n_cells, st, false));
             hipLaunchKernelGGL(widen_keys_kernel, dim3(256), dim3(256), 0, st, u32, w.n_cells, w.cell_keys);
@@ -1065,7 +1069,7 @@ static int knn_build_grid(const float *xyz, int64_t n, int k, KnnWs &w, hipStrea
         } else {
             hipLaunchKernelGGL(cell_key_kernel, dim3(grid_for(n)), dim3(256), 0, st, xyz, n, g, w.keys_a, w.ids_a);
             F4L_LAUNCH_CHECK();
-            F4L_HIP_CHECK(rocprim::radix_sort_pairs(w.prim_temp, tb, w.keys_a, w.keys_b, w.ids_a, w.ids_b, (size_t)n, 0,
+            F4L_HIP_CHECK(rocprim::radix_sort_pairs<KeySortConfig>(w.prim_temp, tb, w.keys_a, w.keys_b, w.ids_a, w.ids_b, (size_t)n, 0,
                                                     (unsigned)end_bit, st, false));
             tb = w.prim_bytes;
             F4L_HIP_CHECK(rocprim::run_length_encode(w.prim_temp, tb, w.keys_b, (unsigned int)n, w.cell_keys, w.cell_counts,
@@ -1245,7 +1249,7 @@ extern "C" int f4l_nn_query(const float *cloud, int64_t n, const float *queries,
     int end_bit = 1;
     while (end_bit < 63 && (double)(1ULL << end_bit) < ncell) ++end_bit;
     size_t tb = wq.prim_bytes;
-    F4L_HIP_CHECK(rocprim::radix_sort_pairs(wq.prim_temp, tb, wq.keys_a, wq.keys_b, wq.ids_a, wq.ids_b, (size_t)m, 0,
+    F4L_HIP_CHECK(rocprim::radix_sort_pairs<KeySortConfig>(wq.prim_temp, tb, wq.keys_a, wq.keys_b, wq.ids_a, wq.ids_b, (size_t)m, 0,
                                             (unsigned)end_bit, st, false));
     if (k <= KS_MAX_K && !getenv("F4L_KNN_WAVE_PER_QUERY") && !getenv("F4L_KNN_NO_SMALL")) {
         // a handful of neighbours: one lane per query (in cell order, for the locality of neighbouring lanes' reads); the
@@ -1407,7 +1411,7 @@ extern "C" int f4l_voxel_downsample(const float *xyz, int64_t n, double voxel, i
     int end_bit = 1;
     while (end_bit < 64 && std::ldexp(1.0, end_bit) < ncell) ++end_bit;
     size_t tb = w.prim_bytes;
-    F4L_HIP_CHECK(rocprim::radix_sort_pairs(w.prim_temp, tb, w.keys_a, w.keys_b, w.ids_a, w.ids_b, (size_t)n, 0,
+    F4L_HIP_CHECK(rocprim::radix_sort_pairs<KeySortConfig>(w.prim_temp, tb, w.keys_a, w.keys_b, w.ids_a, w.ids_b, (size_t)n, 0,
                                             (unsigned)end_bit, st, false));
     tb = w.prim_bytes;
     F4L_HIP_CHECK(rocprim::run_length_encode(w.prim_temp, tb, w.keys_b, (unsigned int)n, w.cell_keys, w.cell_counts,
@@ -1447,7 +1451,7 @@ static int csr_ws_layout(int64_t n, int64_t K, CsrWs &w, unsigned char *base) {
     size_t sort_b = 0, scan_b = 0;
     int32_t *i0 = nullptr;
     unsigned long long *u0 = nullptr;
-    if (rocprim::radix_sort_pairs(nullptr, sort_b, i0, i0, i0, i0, (size_t)n, 0, 32, 0, false) != hipSuccess) return F4L_EHIP;
+    if (rocprim::radix_sort_pairs<KeySortConfig>(nullptr, sort_b, i0, i0, i0, i0, (size_t)n, 0, 32, 0, false) != hipSuccess) return F4L_EHIP;
     if (rocprim::inclusive_scan(nullptr, scan_b, u0, u0, (size_t)K + 1, rocprim::plus<unsigned long long>(), 0, false) != hipSuccess)
         return F4L_EHIP;
     const size_t prim = sort_b > scan_b ? sort_b : scan_b;
@@ -1489,7 +1493,7 @@ extern "C" int f4l_labels_to_csr(const int32_t *labels, int64_t n, int64_t K, in
     int end_bit = 1;
     while (end_bit < 31 && (1LL << end_bit) < K) ++end_bit;
     size_t tb = w.prim_bytes;
-    F4L_HIP_CHECK(rocprim::radix_sort_pairs(w.prim_temp, tb, labels, w.keys_out, w.iota, order_out, (size_t)n, 0,
+    F4L_HIP_CHECK(rocprim::radix_sort_pairs<KeySortConfig>(w.prim_temp, tb, labels, w.keys_out, w.iota, order_out, (size_t)n, 0,
                                             (unsigned)end_bit, st, false));  // LSD radix sort is stable
     F4L_HIP_CHECK(hipMemsetAsync(w.hist, 0, ((size_t)K + 1) * 8, st));
     hipLaunchKernelGGL(label_hist_kernel, dim3(grid_for(n)), dim3(256), 0, st, labels, n, K, w.hist);
