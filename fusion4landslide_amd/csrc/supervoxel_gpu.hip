@@ -513,12 +513,17 @@ __device__ __forceinline__ void sweep_body(const float *__restrict__ xyz, const 
         din[i] = 0;
         if (look) {
             double best = dis[i];
+            // (several neighbours carry the same foreign label: the last two labels found no better are not measured again --
+            //  the best only decreases, so a label that lost once has lost for good)
+            int32_t r0 = a, r1 = a;
             for (int j = 0; j < k; ++j) {
                 const int32_t q = knn[i * k + j];
                 const int32_t b = q >= 0 ? lin[q] : a;
-                if (b == a || b == bl) continue;
+                if (b == a || b == bl || b == r0 || b == r1) continue;
                 const double d = sv_metric(xyz, nrm, i, (int64_t)b, resolution);
-                if (d < best) { best = d; bl = b; }
+                r1 = r0;
+                if (d < best) { r0 = bl; best = d; bl = b; }
+                else r0 = b;
             }
             if (bl != a) {
                 dis[i] = best;
