@@ -894,11 +894,18 @@ __device__ __forceinline__ void pca_normal_row(const float *__restrict__ xyz, co
     else { const double s = 1.0 / norm; nx *= s; ny *= s; nz *= s; }
     out[0] = nx; out[1] = ny; out[2] = nz;
 }
-__global__ void normals_kernel(const float *__restrict__ xyz, int64_t n, const int32_t *__restrict__ knn, int k,
-                               double *__restrict__ normals) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    pca_normal_row(xyz, knn + i * k, k, normals + 3 * i);
+// (one lane per point; the workgroup's 256 index rows are brought in with coalesced loads and read from LDS -- straight from
+//  the row-major lists the lanes of a wave would touch 64 cache lines per load, the same ones for each of the k steps.  Dynamic
+//  LDS: 256 * (k | 1) words.)
+__global__ __launch_bounds__(256) void normals_kernel(const float *__restrict__ xyz, int64_t n, const int32_t *__restrict__ knn, int k,
+                                                      double *__restrict__ normals) {
+    extern __shared__ int32_t nrm_rows[];
+    const int tid = (int)threadIdx.x, stride = k | 1;
+    const int64_t base = (int64_t)blockIdx.x * 256;
+    const int np = n - base < 256 ? (int)(n - base) : 256;
+    for (int t = tid; t < np * k; t += 256) nrm_rows[(t / k) * stride + t % k] = knn[base * k + t];
+    __syncthreads();
+    if (tid < np) pca_normal_row(xyz, nrm_rows + tid * stride, k, normals + 3 * (base + tid));
 }
 __global__ void normals_listed_kernel(const float *__restrict__ xyz, const float4 *__restrict__ q_sorted, const int32_t *__restrict__ list,
                                       const int32_t *__restrict__ count, const int32_t *__restrict__ knn, int k,
@@ -1145,7 +1152,11 @@ static int knn_self(const float *xyz, int64_t n, int k, int32_t *idx_out, double
         hipLaunchKernelGGL(knn_cells_kernel, dim3((unsigned)((M + KNN_NW - 1) / KNN_NW)), dim3(KNN_NW * 64), 0, st, a);
         F4L_LAUNCH_CHECK();
         if (normals_out) {
-            hipLaunchKernelGGL(normals_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, xyz, n, idx_out, k, normals_out);
+            {
+                const size_t lds = (size_t)256 * (k | 1) * 4;
+                if (lds > 48 * 1024) F4L_HIP_CHECK(hipFuncSetAttribute((const void *)normals_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                hipLaunchKernelGGL(normals_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), lds, st, xyz, n, idx_out, k, normals_out);
+            }
             F4L_LAUNCH_CHECK();
         }
         return F4L_OK;
@@ -1433,7 +1444,10 @@ extern "C" int f4l_voxel_downsample(const float *xyz, int64_t n, double voxel, i
 
 extern "C" int f4l_normals(const float *xyz, int64_t n, const int32_t *knn_idx, int k, double *normals_out, void *stream) {
     if (!xyz || n <= 0 || !knn_idx || k < 1 || !normals_out) return F4L_EINVAL;
-    hipLaunchKernelGGL(f4l::normals_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, xyz, n,
+    if (k > F4L_MAX_K) return F4L_EUNSUPPORTED;
+    const size_t lds = (size_t)256 * (k | 1) * 4;
+    if (lds > 48 * 1024) F4L_HIP_CHECK(hipFuncSetAttribute((const void *)f4l::normals_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(f4l::normals_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), lds, (hipStream_t)stream, xyz, n,
                        knn_idx, k, normals_out);
     F4L_LAUNCH_CHECK();
     return F4L_OK;
