@@ -66,6 +66,7 @@ struct State {
     int32_t stalled;              // the graph of representatives has no edges left but live > K
     int32_t sweeps_done, sweep_on, changed, full_sweep;
     int32_t n_labels;
+    int32_t hash_factor;          // parallel edges are merged through the hash set once there are more than this many edges per representative
     // grid barrier of segment_rest_kernel: BAR_GROUPS groups of workgroups, each with its own arrival counter and generation word
     // (a cache line apart), one more counter for the groups' last arrivals
     unsigned int bar_top, bar_pad[31];
@@ -114,7 +115,8 @@ __device__ __forceinline__ int32_t block_append(int32_t *counter, bool take, int
 
 // ---- K: occupied cells of the resolution grid ------------------------------------------------------------------------
 struct GridBox { int given; float mn[3], mx[3]; };
-__global__ void init_state_kernel(State *st, int32_t n, GridBox box) {
+__global__ void init_state_kernel(State *st, int32_t n, GridBox box, int32_t hash_factor) {
+    st->hash_factor = hash_factor;
     st->lambda = 0.0; st->tau_excl = 0ULL;
     for (int d = 0; d < 3; ++d) {  // the grid's anchor and extent: the cloud's own bounding box unless the caller gave one
         st->bb[d] = box.given ? f2ord(box.mn[d]) : 0xffffffffu;
@@ -437,7 +439,7 @@ __device__ __forceinline__ int64_t table_size(int32_t n_edges) { return n_edges 
 // Parallel edges are merged through the hash set only once they dominate the list (more than 40 edges per representative);
 // before that the pass just drops the self loops -- the list of a young forest holds few duplicates and 30 M random table
 // accesses cost more than they save.
-__device__ __forceinline__ bool use_hash(const State *st) { return (int64_t)st->n_edges > 40LL * (int64_t)st->live; }
+__device__ __forceinline__ bool use_hash(const State *st) { return (int64_t)st->n_edges > (int64_t)st->hash_factor * (int64_t)st->live; }
 __device__ __forceinline__ void table_clear_body(const State *st, unsigned long long *__restrict__ table) {
     if (!use_hash(st)) return;
     const int64_t ts = table_size(st->n_edges);
@@ -807,7 +809,9 @@ extern "C" int f4l_supervoxel_segment_device(const float *xyz, const double *nor
     hipStream_t st = (hipStream_t)stream;
     const dim3 g(GRID), b(BLOCK), one(1);
 
-    hipLaunchKernelGGL(init_state_kernel, one, one, 0, st, w.st, (int32_t)n, box);
+    int hash_factor = 40;
+    if (const char *e = getenv("F4L_SV_HASH_FACTOR")) { if (atoi(e) > 0) hash_factor = atoi(e); }
+    hipLaunchKernelGGL(init_state_kernel, one, one, 0, st, w.st, (int32_t)n, box, (int32_t)hash_factor);
     // K
     if (!box.given) hipLaunchKernelGGL(svg::bbox_kernel, dim3(256), b, 0, st, xyz, n, w.st);
     hipLaunchKernelGGL(grid_key_kernel, g, b, 0, st, xyz, n, resolution, w.st, w.keys_a);
