@@ -212,6 +212,14 @@ __global__ __launch_bounds__(256) void knn_transpose_kernel(const int32_t *__res
     }
 }
 
+// True when the distance term of metric(a, b) alone is at least `best` (with room for every rounding, and for a normal term
+// that rounds a hair below zero): the metric cannot be below `best`, and the normals need not be fetched to know it.
+__device__ __forceinline__ bool sv_metric_at_least(const float *__restrict__ xyz, int64_t a, int64_t b, double resolution, double best) {
+    const double t1 = (double)xyz[3 * a] - xyz[3 * b], t2 = (double)xyz[3 * a + 1] - xyz[3 * b + 1], t3 = (double)xyz[3 * a + 2] - xyz[3 * b + 2];
+    const double c = 0.4 / resolution, bound = best * 1.000001 + 1e-15;
+    return c * c * (t1 * t1 + t2 * t2 + t3 * t3) > bound * bound;
+}
+
 // ---- lambda0 -----------------------------------------------------------------------------------------------------
 #pragma clang fp contract(off)
 __global__ void min_metric_kernel(const float *__restrict__ xyz, const double *__restrict__ nrm, const int32_t *__restrict__ knnT,
@@ -220,7 +228,7 @@ __global__ void min_metric_kernel(const float *__restrict__ xyz, const double *_
         double best = DBL_MAX;
         for (int j = 0; j < k; ++j) {
             const int64_t q = knnT[(int64_t)j * n + i];
-            if (q != i && q >= 0) {  // (a negative entry = "no neighbour here": a point outside the caller's slab)
+            if (q != i && q >= 0 && !sv_metric_at_least(xyz, i, q, resolution, best)) {  // (a negative entry = "no neighbour here": a point outside the caller's slab)
                 const double m = sv_metric(xyz, nrm, i, q, resolution);
                 best = m < best ? m : best;
             }
@@ -294,11 +302,18 @@ __device__ __forceinline__ void cand_body(const float *__restrict__ xyz, const d
                     }
                 }
                 if (key != DEAD && heads(u, round) && !heads(v, round)) {
-                    const double m = sv_metric(xyz, nrm, u, v, resolution);
-                    const double loss = (double)size[v] * m;
-                    if (lambda - loss > 0.0) {  // :147-149 `improvement > 0.0`
-                        atomicMin(&bestm[v], d2ord(m));
-                        offer = true;
+                    const double sz = (double)size[v];
+                    // the distance term of the metric alone may already reach lambda (with room for every rounding, and for
+                    // a normal term that rounds a hair below zero): such an edge is rejected without fetching the normals
+                    const double t1 = (double)xyz[3 * u] - xyz[3 * v], t2 = (double)xyz[3 * u + 1] - xyz[3 * v + 1],
+                                 t3 = (double)xyz[3 * u + 2] - xyz[3 * v + 2];
+                    const double c = sz * 0.4 / resolution, bound = lambda * 1.000001 + sz * 1e-15;
+                    if (!(c * c * (t1 * t1 + t2 * t2 + t3 * t3) > bound * bound)) {
+                        const double m = sv_metric(xyz, nrm, u, v, resolution);
+                        if (lambda - sz * m > 0.0) {  // :147-149 `improvement > 0.0`
+                            atomicMin(&bestm[v], d2ord(m));
+                            offer = true;
+                        }
                     }
                 }
             }
@@ -543,8 +558,9 @@ __device__ __forceinline__ void sweep_body(const float *__restrict__ xyz, const 
                 const int32_t q = knnT[(int64_t)j * n + i];
                 const int32_t b = q >= 0 ? lin[q] : a;
                 if (b == a || b == bl || b == r0 || b == r1) continue;
-                const double d = sv_metric(xyz, nrm, i, (int64_t)b, resolution);
                 r1 = r0;
+                if (sv_metric_at_least(xyz, i, (int64_t)b, resolution, best)) { r0 = b; continue; }
+                const double d = sv_metric(xyz, nrm, i, (int64_t)b, resolution);
                 if (d < best) { r0 = bl; best = d; bl = b; }
                 else r0 = b;
             }
