@@ -107,11 +107,19 @@ def median_resolution(src, tgt=None):
     torch = require_gpu()
 
     def one(xyz):
+        """Device scalar: numpy's median (mean of the middle pair) of the nearest-neighbour distances."""
         _, d2 = knn(xyz, 2, return_d2=True)
-        return float(torch.quantile(torch.sqrt(d2[:, 1]), 0.5).item())  # numpy's median: mean of the middle pair
+        d = torch.sqrt(d2[:, 1])  # (the square root first: the mean of the middle pair is taken over distances)
+        out = torch.empty((1,), dtype=torch.float64, device=d.device)
+        nbytes = lib().f4l_median_f64_workspace_bytes(d.shape[0])
+        ws = torch.empty((max(int(nbytes), 1),), dtype=torch.uint8, device=d.device)
+        check(lib().f4l_median_f64(ptr(d), d.shape[0], 1, ptr(out), ptr(ws), C.c_size_t(nbytes), stream_ptr()), "f4l_median_f64")
+        return out
 
     r = one(src)
-    return r if tgt is None else max(r, one(tgt))
+    if tgt is None:
+        return float(r.item())
+    return float(torch.maximum(r, one(tgt)).item())  # one read-back for both clouds
 
 
 def kabsch_residuals(src, ref, off, R, t):

@@ -289,6 +289,13 @@ size_t f4l_labels_to_csr_workspace_bytes(int64_t n, int64_t K);
 int f4l_labels_to_csr(const int32_t *labels, int64_t n, int64_t K, int32_t *order_out, int64_t *off_out,
                       void *workspace, size_t workspace_bytes, void *stream);
 
+/* Median of n doubles values[i * stride] as numpy.median computes it (the middle element, or the mean of the middle pair) --
+ * the last step of `_compute_median_resolution` (src/coarse_to_fine_matching_base.py:2716-2754: median of the nearest-
+ * neighbour distances).  The values must not be NaN.  median_out: DEVICE double [1].  Device radix sort; no synchronisation. */
+size_t f4l_median_f64_workspace_bytes(int64_t n);
+int f4l_median_f64(const double *values, int64_t n, int64_t stride, double *median_out, void *workspace, size_t workspace_bytes,
+                   void *stream);
+
 /* Gather rows: out[i] = pts[order[i]] (float32 [n][3]); builds patch-contiguous clouds from a CSR order. */
 int f4l_gather_points(const float *pts, const int32_t *order, int64_t n, float *out, void *stream);
 
