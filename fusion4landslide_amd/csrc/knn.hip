@@ -4,24 +4,30 @@
 // sequential loop at supervoxel.cpp:105-107) and pca_estimate_normals.h:43-108.  The reference walks a
 // pointer-based KD-tree one query at a time on one CPU thread; here:
 //
-//   1. points are binned into a uniform grid: 64-bit linear cell key per point, LSD radix sort of
-//      (key, id) pairs (rocPRIM device primitive), run-length encode -> table of occupied cells;
+//   1. points are binned into a uniform grid: linear cell key per point (32-bit when the grid allows), radix sort of
+//      (key, id) pairs (rocPRIM onesweep passes), run-length encode -> table of occupied cells, plus ONE WORD PER CELL of
+//      the whole grid while that stays within two words per point (`dense`: a row of cells is two loads, else two binary
+//      searches over the occupied cells);
 //   2. sorted points are re-laid as float4 {x, y, z, id} so a wave's 64 lanes load 1 KiB contiguous;
-//   3. one wavefront per occupied cell: the 3x3 rows of neighbouring cells along x are contiguous runs of
-//      the sorted array, located with lane-parallel binary searches over the cell table (one row per
-//      lane); every query of the cell then streams those runs, 64 candidates per step, into the
-//      wave-resident top-k of topk.h;
-//   4. exactness: the k-th distance must not exceed the distance to the faces of the searched block,
-//      otherwise the block radius grows by one cell and the query is redone (rare).
+//   3. the search proper, one of three kernels:
+//        knn_lanes_kernel   k <= 36: one LANE per query; a wave takes 64 consecutive sorted points and streams their common
+//                           candidate set (the 3 x 3 rows of cells around them) through an LDS tile; per-lane d2 histogram,
+//                           survivors sorted on registers with exact d2, PCA normal fused (f4l_knn_normals);
+//        nn_small_kernel    k <= 4: one lane per query walking the rows of cells of its OWN block from the sorted array
+//                           (the 1-NN / 2-NN of the label transfer and of the median resolution);
+//        knn_cells_kernel / knn_listed_kernel   one WAVE per query with the wave-resident top-k of topk.h: k > 36, and
+//                           the queries the lane kernel could not certify;
+//   4. exactness: the k-th distance must lie inside the searched block of cells, otherwise the block grows (straight to
+//      the radius the k-th distance found so far asks for) and the query is redone.
 // Distances are double with separately rounded mul/add, so d2 and the neighbour order equal the reference's
 // except inside groups of exactly equal d2, which are ordered by point id here.
 //
-// The same kernel answers queries from ANOTHER cloud (f4l_nn_query: the queries are binned into the cloud's grid, outside
+// The same kernels answer queries from ANOTHER cloud (f4l_nn_query: the queries are binned into the cloud's grid, outside
 // points clamped into its border cells, blocks clipped to the grid and doubled while they hold fewer than k points),
 // and the binning machinery doubles as the voxel-grid filter (f4l_voxel_downsample: Open3D's and PCL's cell layouts).
 //
 // Roofline: algorithmic traffic is 12 B read + 4k B written per point (132 B/pt at k = 30).
-// The kernel is bounded by VALU/issue (top-k maintenance), not HBM; bench.py reports the achieved GB/s.
+// The kernels are bounded by VALU issue, not HBM; bench.py reports the achieved GB/s.
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
