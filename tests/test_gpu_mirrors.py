@@ -203,6 +203,23 @@ def test_median_resolution_vs_kdtree():
     assert abs(engine.median_resolution(torch.from_numpy(c["src"]).cuda()) - ref[0]) <= 1e-12
 
 
+def test_median_f64_is_numpys_median():
+    """f4l_median_f64 (the last step of _compute_median_resolution): numpy.median of strided doubles, odd and even counts,
+    duplicates, negative values, a single element -- bit for bit."""
+    import ctypes as C
+    from fusion4landslide_amd._lib import check, lib, ptr, stream_ptr
+    rng = np.random.default_rng(3)
+    for n, stride in ((1, 1), (2, 1), (7, 1), (10_000, 1), (9_999, 2), (250_001, 3)):
+        v = rng.normal(size=(n, stride)) * np.where(rng.uniform(size=(n, 1)) < 0.2, 0.0, 1.0)  # (a fifth exact zeros: ties)
+        d = torch.from_numpy(v).cuda()
+        out = torch.empty((1,), dtype=torch.float64, device="cuda")
+        nbytes = lib().f4l_median_f64_workspace_bytes(n)
+        ws = torch.empty((max(int(nbytes), 1),), dtype=torch.uint8, device="cuda")
+        col = stride - 1
+        check(lib().f4l_median_f64(d.data_ptr() + 8 * col, n, stride, ptr(out), ptr(ws), C.c_size_t(nbytes), stream_ptr()), "f4l_median_f64")
+        assert float(out.item()) == float(np.median(v[:, col])), (n, stride)
+
+
 def test_nn_query_vs_kdtree():
     """f4l_nn_query (the cKDTree(...).query of src/coarse_to_fine_matching_base.py:1042-1046): exact k nearest cloud
     points of queries that lie inside, at the border of and far outside the cloud's bounding box."""
