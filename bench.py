@@ -328,7 +328,7 @@ def extras(torch, engine, synthetic, prob, dev, args):
     # solution than the float64 arithmetic of the reference)
     s32 = _timed(torch, lambda: prob.step(search="f32"), max(2, args.steps // 5))
     out["fast_mode_f32"] = {"workload": args.config, "value": round(n / s32 / 1e6, 3), "unit": "Mpts/s", "ms_per_step": round(1e3 * s32, 4)}
-    for name in ("C2_1M_2k", "C2x16_16M_32k", "C3_10M_20k"):  # (C2x16: the C2 density at 32 400 patches, one rank's regime of an 8-GPU run)
+    for name in ("C1_50k_64", "C2_1M_2k", "C2x16_16M_32k", "C3_10M_20k"):  # (C2x16: the C2 density at 32 400 patches, one rank's regime of an 8-GPU run)
         if name == args.config:
             continue
         c = synthetic.CONFIGS[name]
