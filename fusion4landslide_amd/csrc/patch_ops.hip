@@ -12,6 +12,7 @@
 #include "f4l_device.h"
 #include "patch_grid.h"
 #include "topk.h"
+#include "lane_topk.h"
 
 namespace f4l {
 
@@ -137,13 +138,13 @@ __device__ __forceinline__ void smallest_eigvec3(const double *C, double *out) {
 // One workgroup per patch, one wave per query point (queries strided over the 4 waves).
 __global__ __launch_bounds__(PN_NT) void patch_normals_kernel(const float *__restrict__ pts,
                                                                const int64_t *__restrict__ off, int64_t P, int knn,
-                                                               int lds_cap, float *__restrict__ normals) {
+                                                               int lds_cap, int min_n, float *__restrict__ normals) {
     extern __shared__ __attribute__((aligned(16))) float pl[];  // packed xyz of the patch
     const int64_t p = blockIdx.x;
     if (p >= P) return;
     const int64_t o = off[p];
     const int n = (int)(off[p + 1] - o);
-    if (n == 0) return;
+    if (n == 0 || n <= min_n) return;  // (patches up to min_n points: patch_normals_lanes_kernel)
     const float *__restrict__ pg = pts + 3 * o;
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool in_lds = n <= lds_cap;
@@ -200,6 +201,223 @@ __global__ __launch_bounds__(PN_NT) void patch_normals_kernel(const float *__res
         if (lane == 0) {
             float *out = normals + 3 * (o + q);
             out[0] = (float)nv[0]; out[1] = (float)nv[1]; out[2] = (float)nv[2];
+        }
+    }
+}
+
+
+// ---- the same with one LANE per query (patches of up to PL_MAX_N points, k <= PL_MAX_K) ------------------------------------
+// The kernel above spends ~100 serial top-k insertions of a whole wave on every query (12 ms per 1 M points in patches of
+// 500).  Here a lane owns a query and all lanes of a wave walk the patch's points together (broadcast reads of the SoA copy
+// in LDS), the way knn_lanes_kernel walks a block's candidates: pass 1 bins the approximate d2 into a per-lane histogram
+// (32 quarter-octave bins below a top derived from the patch's point density), the bin at which the count reaches k gives
+// the threshold, pass 2 collects the candidates below it (widened far beyond the float32 error), the <= 43 survivors are
+// measured exactly and sorted on registers, the covariance of the first k is summed in neighbour order (the order of
+// Open3D's ComputeCovariance) and every lane solves its own 3 x 3 eigenproblem.  A query whose survivors overflow the
+// list is redone by the wave with the exact top-k of the kernel above.
+constexpr int PL_NW = 4, PL_NT = PL_NW * 64, PL_NB = 32, PL_CAP = 43, PL_MAX_K = 36, PL_MAX_N = 8192;
+__device__ __forceinline__ void pl_covariance_normal(const float *__restrict__ x, const float *__restrict__ y, const float *__restrict__ z,
+                                                     const int (&pay)[PL_CAP], int k, double (&nv)[3]) {
+    double cum[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < PL_MAX_K; ++j)
+        if (j < k) {
+            const int id = pay[j];
+            const double a = (double)x[id], b = (double)y[id], c = (double)z[id];
+            cum[0] += a; cum[1] += b; cum[2] += c;
+            cum[3] += a * a; cum[4] += a * b; cum[5] += a * c; cum[6] += b * b; cum[7] += b * c; cum[8] += c * c;
+        }
+    if (k < 3) { nv[0] = 0.0; nv[1] = 0.0; nv[2] = 1.0; return; }  // identity covariance -> no preferred axis -> (0,0,1)
+    const double ik = 1.0 / (double)k;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) cum[i] *= ik;
+    double Cm[6];
+    Cm[0] = cum[3] - cum[0] * cum[0];
+    Cm[1] = cum[4] - cum[0] * cum[1];
+    Cm[2] = cum[5] - cum[0] * cum[2];
+    Cm[3] = cum[6] - cum[1] * cum[1];
+    Cm[4] = cum[7] - cum[1] * cum[2];
+    Cm[5] = cum[8] - cum[2] * cum[2];
+    smallest_eigvec3(Cm, nv);
+    if (nv[0] * nv[0] + nv[1] * nv[1] + nv[2] * nv[2] == 0.0) { nv[0] = 0.0; nv[1] = 0.0; nv[2] = 1.0; }
+}
+__global__ __launch_bounds__(PL_NT, 2) void patch_normals_lanes_kernel(const float *__restrict__ pts, const int64_t *__restrict__ off,
+                                                                       int64_t P, int knn, int cap_pad, float *__restrict__ normals) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char pl_smem[];
+    float *xs = reinterpret_cast<float *>(pl_smem), *ys = xs + cap_pad, *zs = ys + cap_pad;  // the patch, SoA (original coordinates)
+    unsigned int *hist_all = reinterpret_cast<unsigned int *>(zs + cap_pad);                 // [PL_NW][PL_NB / 2][64]: two 16-bit bins per word
+    unsigned short *list_all = reinterpret_cast<unsigned short *>(hist_all + PL_NW * (PL_NB / 2) * 64);  // [PL_NW][PL_CAP + 1][64]
+    __shared__ float s_box[PL_NW][6];
+    const int64_t p = blockIdx.x;
+    if (p >= P) return;
+    const int64_t o = off[p];
+    const int n = (int)(off[p + 1] - o);
+    if (n == 0 || n > cap_pad - 8) return;  // (larger patches: patch_normals_kernel)
+    const float *__restrict__ pg = pts + 3 * o;
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    unsigned int *hist = hist_all + wave * (PL_NB / 2) * 64 + lane;
+    unsigned short *list = list_all + wave * (PL_CAP + 1) * 64 + lane;
+    float mn[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()}, mx[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+    const int n_pad = (n + 7) & ~7;
+    for (int i = tid; i < n_pad; i += PL_NT) {
+        const bool real = i < n;
+        const float a = real ? pg[3 * i] : 0.f, b = real ? pg[3 * i + 1] : 0.f, c = real ? pg[3 * i + 2] : 0.f;
+        xs[i] = a; ys[i] = b; zs[i] = c;
+        if (real) {
+            mn[0] = fminf(mn[0], a); mn[1] = fminf(mn[1], b); mn[2] = fminf(mn[2], c);
+            mx[0] = fmaxf(mx[0], a); mx[1] = fmaxf(mx[1], b); mx[2] = fmaxf(mx[2], c);
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            mn[d] = fminf(mn[d], __shfl_xor(mn[d], m, 64));
+            mx[d] = fmaxf(mx[d], __shfl_xor(mx[d], m, 64));
+        }
+    if (lane == 0) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) { s_box[wave][d] = mn[d]; s_box[wave][3 + d] = mx[d]; }
+    }
+    __syncthreads();
+    const int k = knn < n ? knn : n;
+    // top of the histogram's range: 16 x the squared radius that holds k points at the patch's mean density (surface: the two
+    // largest extents of the bounding box; a degenerate box: its diagonal)
+    int bin_base;
+    float slack;
+    {
+        float e[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            float lo = s_box[0][d], hi = s_box[0][3 + d];
+#pragma unroll
+            for (int w = 1; w < PL_NW; ++w) { lo = fminf(lo, s_box[w][d]); hi = fmaxf(hi, s_box[w][3 + d]); }
+            e[d] = hi - lo;
+        }
+        const float diag2 = e[0] * e[0] + e[1] * e[1] + e[2] * e[2];
+        const float e_min = fminf(e[0], fminf(e[1], e[2]));
+        const float area = e[0] * e[1] * e[2] > 0.f ? (e[0] * e[1] * e[2]) / e_min : 0.f;  // product of the two largest
+        float top = area > 0.f ? 16.f * (float)k * area / (3.14159265f * (float)n) : diag2;
+        top = top < diag2 ? top : diag2;
+        top = top > 1e-30f ? top : 1e-30f;
+        bin_base = (int)(__float_as_uint(top) >> 21) - (PL_NB - 1);
+        slack = 1e-6f * top;
+    }
+    for (int q0 = 0; q0 < n; q0 += PL_NT) {  // (whole waves iterate together)
+        const int q = q0 + tid;
+        const bool valid = q < n;
+        const float qx = xs[valid ? q : 0], qy = ys[valid ? q : 0], qz = zs[valid ? q : 0];
+#pragma unroll
+        for (int b = 0; b < PL_NB / 2; ++b) hist[b * 64] = 0u;
+        const unsigned int one = valid ? 1u : 0u;
+        // pass 1: per-lane histogram of the approximate d2 (differences of nearby float coordinates are exact or nearly so)
+        for (int c = 0; c < n_pad; c += 8) {
+            const float4 xa = *reinterpret_cast<const float4 *>(xs + c), xb = *reinterpret_cast<const float4 *>(xs + c + 4);
+            const float4 ya = *reinterpret_cast<const float4 *>(ys + c), yb = *reinterpret_cast<const float4 *>(ys + c + 4);
+            const float4 za = *reinterpret_cast<const float4 *>(zs + c), zb = *reinterpret_cast<const float4 *>(zs + c + 4);
+            const float cx[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w}, cy[8] = {ya.x, ya.y, ya.z, ya.w, yb.x, yb.y, yb.z, yb.w},
+                        cz[8] = {za.x, za.y, za.z, za.w, zb.x, zb.y, zb.z, zb.w};
+#pragma unroll
+            for (int w = 0; w < 8; ++w) {
+                const float dx = cx[w] - qx, dy = cy[w] - qy, dz = cz[w] - qz;
+                const float d2 = dx * dx + dy * dy + dz * dz;
+                int b = (int)(__float_as_uint(d2) >> 21) - bin_base;
+                b = b < 0 ? 0 : (b > PL_NB - 1 ? PL_NB - 1 : b);
+                atomicAdd(&hist[(b >> 1) * 64], (c + w < n ? one : 0u) << ((b & 1) * 16));
+            }
+        }
+        // the first bin at which the count reaches k
+        int T = PL_NB;
+        unsigned int cum = 0u;
+#pragma unroll
+        for (int b = 0; b < PL_NB; ++b) {
+            const unsigned int h = (hist[(b >> 1) * 64] >> ((b & 1) * 16)) & 0xffffu;
+            if (T == PL_NB && cum + h >= (unsigned int)k) T = b;
+            cum += h;
+        }
+        bool fb = valid && T == PL_NB;  // (cannot happen: every point of the patch lands in a bin)
+        float edge = T >= PL_NB - 1 ? __builtin_inff() : __uint_as_float((unsigned int)(T + bin_base + 1) << 21) * 1.0001f + slack;
+        edge = valid ? edge : -1.0f;
+        // pass 2: the candidates below the threshold go to the lane's list (a lane that does not take one writes the spare row)
+        int cnt = 0;
+        for (int c = 0; c < n_pad; c += 8) {
+            const float4 xa = *reinterpret_cast<const float4 *>(xs + c), xb = *reinterpret_cast<const float4 *>(xs + c + 4);
+            const float4 ya = *reinterpret_cast<const float4 *>(ys + c), yb = *reinterpret_cast<const float4 *>(ys + c + 4);
+            const float4 za = *reinterpret_cast<const float4 *>(zs + c), zb = *reinterpret_cast<const float4 *>(zs + c + 4);
+            const float cx[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w}, cy[8] = {ya.x, ya.y, ya.z, ya.w, yb.x, yb.y, yb.z, yb.w},
+                        cz[8] = {za.x, za.y, za.z, za.w, zb.x, zb.y, zb.z, zb.w};
+#pragma unroll
+            for (int w = 0; w < 8; ++w) {
+                const float dx = cx[w] - qx, dy = cy[w] - qy, dz = cz[w] - qz;
+                const float d2 = dx * dx + dy * dy + dz * dz;
+                const bool take = d2 < edge && c + w < n;
+                const int at = cnt < PL_CAP ? cnt : PL_CAP;
+                list[(take ? at : PL_CAP) * 64] = (unsigned short)(c + w);
+                cnt += take ? 1 : 0;
+            }
+        }
+        if (cnt > PL_CAP) { fb = true; cnt = PL_CAP; }
+        // the survivors, exact d2 from the float coordinates, sorted on registers
+        double key[PL_CAP];
+        int pay[PL_CAP];
+#pragma unroll
+        for (int j = 0; j < PL_CAP; ++j) {
+            const bool ok = j < cnt;
+            const int id = ok ? (int)list[j * 64] : 0;
+            key[j] = ok ? dist2_exact(xs[id], ys[id], zs[id], qx, qy, qz) : __builtin_inf();
+            pay[j] = ok ? id : 0x7fffffff;
+        }
+        lane_sort_ascending<PL_CAP>(key, pay);
+        lane_order_ties<PL_CAP>(key, pay);
+        double nv[3];
+        pl_covariance_normal(xs, ys, zs, pay, k, nv);
+        if (valid && !fb) {
+            float *out = normals + 3 * (o + q);
+            out[0] = (float)nv[0]; out[1] = (float)nv[1]; out[2] = (float)nv[2];
+        }
+        // the rare query whose survivors overflowed the list: the wave's exact top-k (patch_normals_kernel's arithmetic)
+        unsigned long long redo = __ballot(fb);
+        while (redo != 0ULL) {
+            const int src_lane = __ffsll((long long)redo) - 1;
+            redo &= redo - 1ULL;
+            const int rq = q0 + wave * 64 + src_lane;
+            const float rx = xs[rq], ry = ys[rq], rz = zs[rq];
+            WaveTopK best;
+            best.reset();
+            for (int c0 = 0; c0 < n; c0 += 64) {
+                const int c = c0 + lane;
+                double cd = __builtin_inf();
+                int ci = 0x7fffffff;
+                if (c < n) { cd = dist2_exact(xs[c], ys[c], zs[c], rx, ry, rz); ci = c; }
+                if (c0 == 0) best.fill_sorted(cd, ci);
+                else best.offer(cd, ci, k);
+            }
+            double cum[9];
+            {
+                const bool have = lane < k;
+                const int j = have ? best.i : rq;
+                const double a = have ? (double)xs[j] : 0.0, b = have ? (double)ys[j] : 0.0, c = have ? (double)zs[j] : 0.0;
+                cum[0] = a; cum[1] = b; cum[2] = c;
+                cum[3] = a * a; cum[4] = a * b; cum[5] = a * c; cum[6] = b * b; cum[7] = b * c; cum[8] = c * c;
+            }
+#pragma unroll
+            for (int i = 0; i < 9; ++i) cum[i] = wave_sum(cum[i]);
+            double rn[3];
+            if (k < 3) { rn[0] = 0.0; rn[1] = 0.0; rn[2] = 1.0; }
+            else {
+                const double ik = 1.0 / (double)k;
+#pragma unroll
+                for (int i = 0; i < 9; ++i) cum[i] *= ik;
+                double Cm[6];
+                Cm[0] = cum[3] - cum[0] * cum[0]; Cm[1] = cum[4] - cum[0] * cum[1]; Cm[2] = cum[5] - cum[0] * cum[2];
+                Cm[3] = cum[6] - cum[1] * cum[1]; Cm[4] = cum[7] - cum[1] * cum[2]; Cm[5] = cum[8] - cum[2] * cum[2];
+                smallest_eigvec3(Cm, rn);
+                if (rn[0] * rn[0] + rn[1] * rn[1] + rn[2] * rn[2] == 0.0) { rn[0] = 0.0; rn[1] = 0.0; rn[2] = 1.0; }
+            }
+            if (lane == 0) {
+                float *out = normals + 3 * (o + rq);
+                out[0] = (float)rn[0]; out[1] = (float)rn[1]; out[2] = (float)rn[2];
+            }
         }
     }
 }
@@ -293,12 +511,25 @@ extern "C" int f4l_patch_normals(const float *pts, const int64_t *off, int64_t P
     if (knn > F4L_MAX_K) return F4L_EUNSUPPORTED;
     if (P == 0 || max_patch_host == 0) return F4L_OK;
     if (P > 0x7fffffffLL || max_patch_host > 0x3fffffffLL) return F4L_EUNSUPPORTED;
+    // patches of up to PL_MAX_N points (k <= PL_MAX_K): one lane per query; larger ones: one wave per query
+    int min_n = 0;
+    if (knn <= PL_MAX_K && !getenv("F4L_PATCH_NORMALS_WAVES")) {
+        const int big = (int)(max_patch_host < PL_MAX_N ? max_patch_host : PL_MAX_N);
+        const int cap_pad = ((big + 7) & ~7) + 8;
+        const size_t lds = (size_t)cap_pad * 12 + (size_t)PL_NW * (PL_NB / 2) * 64 * 4 + (size_t)PL_NW * (PL_CAP + 1) * 64 * 2;
+        if (lds > 64 * 1024)
+            F4L_HIP_CHECK(hipFuncSetAttribute((const void *)patch_normals_lanes_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(patch_normals_lanes_kernel, dim3((unsigned)P), dim3(PL_NT), lds, (hipStream_t)stream, pts, off, P, knn, cap_pad, normals_out);
+        F4L_LAUNCH_CHECK();
+        min_n = big;
+        if (max_patch_host <= big) return F4L_OK;
+    }
     const int cap = (int)(max_patch_host < PN_LDS_MAX ? max_patch_host : PN_LDS_MAX);
     const size_t lds = (size_t)cap * 12;
     if (lds > 64 * 1024)
         F4L_HIP_CHECK(hipFuncSetAttribute((const void *)patch_normals_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(patch_normals_kernel, dim3((unsigned)P), dim3(PN_NT), lds, (hipStream_t)stream, pts, off, P, knn,
-                       cap, normals_out);
+                       cap, min_n, normals_out);
     F4L_LAUNCH_CHECK();
     return F4L_OK;
 }

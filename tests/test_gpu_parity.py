@@ -245,6 +245,39 @@ def test_icp_point2plane_vs_oracle(eng, search):
         eng.piecewise_icp(dev(d["src"]), dev(d["src_off"]), dev(d["tgt"]), dev(d["tgt_off"]), icp_type="generalized")
 
 
+def test_patch_normals_lane_per_query_equals_wave_per_query(eng):
+    """f4l_patch_normals: the lane-per-query kernel (patches up to 8192 points, k <= 36) against the wave-per-query kernel it
+    replaces there (F4L_PATCH_NORMALS_WAVES): the same neighbour sets, hence the same normals to rounding -- patches of every
+    size (fewer points than k, one point, empty, beyond the lane kernel's limit), a lattice (exact distance ties), duplicated
+    points, a collinear patch (degenerate bounding box), georeferenced coordinates."""
+    import os
+    rng = np.random.default_rng(9)
+    parts = []
+    for n in (0, 1, 2, 5, 29, 30, 31, 64, 257, 500, 1500, 9000):
+        xy = rng.uniform(0, 1, (n, 2)) * max(n, 1) ** 0.5 * 0.05
+        parts.append(np.c_[xy, 0.1 * np.sin(3 * xy[:, 0]) * np.cos(2 * xy[:, 1]) + rng.normal(0, 0.002, n)])
+    g = np.stack(np.meshgrid(np.arange(12), np.arange(12), np.arange(3), indexing="ij"), -1).reshape(-1, 3) * 0.05
+    parts.append(g)                                                        # lattice: ties
+    parts.append(np.repeat(parts[9][:120], 3, axis=0))                     # every point three times
+    parts.append(np.c_[np.linspace(0, 1, 200), np.zeros(200), np.zeros(200)])  # collinear
+    parts.append(parts[9] + np.array([2.6e6, 1.2e6, 1800.0]))              # georeferenced
+    pts = np.concatenate(parts).astype(np.float32)
+    off = np.concatenate([[0], np.cumsum([len(a) for a in parts])]).astype(np.int64)
+    for k in (30, 8, 36):
+        fast = eng.patch_normals(dev(pts), dev(off), k).cpu().numpy().astype(np.float64)
+        os.environ["F4L_PATCH_NORMALS_WAVES"] = "1"
+        try:
+            slow = eng.patch_normals(dev(pts), dev(off), k).cpu().numpy().astype(np.float64)
+        finally:
+            del os.environ["F4L_PATCH_NORMALS_WAVES"]
+        dots = np.abs(np.sum(fast * slow, axis=1))
+        # (degenerate neighbourhoods -- the collinear patch, duplicates -- have no unique smallest eigenvector)
+        well = np.ones(len(pts), dtype=bool)
+        well[off[13]:off[15]] = False
+        assert dots[well].min() >= 1 - 1e-6, (k, dots[well].min())
+        assert np.isfinite(fast).all() and np.abs(np.linalg.norm(fast, axis=1) - 1).max() < 1e-5
+
+
 def synthetic_patches(**kw):
     from fusion4landslide_amd import synthetic
     return synthetic.make_patches(kw.pop("n"), kw.pop("cells"), 1.386, **kw)
