@@ -234,7 +234,7 @@ class Problem:
                                  max_tgt_patch=d["max_tgt"], return_rows=False)
         self.cs, self.ct, self.coff = synthetic.correspondences_from_nn_device(d["src"], d["src_off"], d["tgt"], d["tgt_off"], nn)
 
-    def step(self, search="f64"):
+    def step(self, search="f64", icp_type="point2point", tgt_normals=None):
         d, torch = self.d, self.torch
         if self.dry:  # stub launch: identity transforms, fitness = GLOBAL patch id (checked after the gather)
             P = d["P"]
@@ -243,7 +243,7 @@ class Problem:
         # the whole loop body in one launch (f4l_patch_loop): Kabsch init -> ICP -> rows
         return self.engine.patch_loop(d["src"], d["src_off"], d["tgt"], d["tgt_off"], self.cs, self.ct, self.coff, None, 0.0, 1e-6,
                                       max_corr_dist=MAX_CORR, max_iter=MAX_ITER, fixed_iters=True, max_src_patch=d["max_src"],
-                                      max_tgt_patch=d["max_tgt"], search=search)
+                                      max_tgt_patch=d["max_tgt"], search=search, icp_type=icp_type, tgt_normals=tgt_normals)
 
     def host_prefix(self, p_hi):
         """The first p_hi patches as host numpy arrays (for the CPU baseline: the same bits the GPU worked on)."""
@@ -328,6 +328,17 @@ def extras(torch, engine, synthetic, prob, dev, args):
     # solution than the float64 arithmetic of the reference)
     s32 = _timed(torch, lambda: prob.step(search="f32"), max(2, args.steps // 5))
     out["fast_mode_f32"] = {"workload": args.config, "value": round(n / s32 / 1e6, 3), "unit": "Mpts/s", "ms_per_step": round(1e3 * s32, 4)}
+    # the other estimator of utils/o3d_tools.py:46-50: point-to-plane, with the target normals `estimate_normals()` gives every
+    # patch cloud (:29-30, f4l_patch_normals) -- the same step on the same cloud
+    def normals():
+        return engine.patch_normals(prob.d["tgt"], prob.d["tgt_off"], 30, max_patch=prob.d["max_tgt"])
+    normals()
+    s_n = _timed(torch, normals, 2)
+    nrm = normals()
+    s_pl = _timed(torch, lambda: prob.step(icp_type="point2plane", tgt_normals=nrm), max(2, args.steps // 10))
+    out["point2plane"] = {"workload": args.config, "value": round(n / s_pl / 1e6, 3), "unit": "Mpts/s", "ms_per_step": round(1e3 * s_pl, 4),
+                          "estimate_normals_ms": round(1e3 * s_n, 3)}
+    del nrm
     for name in ("C1_50k_64", "C2_1M_2k", "C2x16_16M_32k", "C3_10M_20k"):  # (C2x16: the C2 density at 32 400 patches, one rank's regime of an 8-GPU run)
         if name == args.config:
             continue
