@@ -603,9 +603,27 @@ __global__ void mutual_mask_kernel(const int64_t *__restrict__ src_ids, const in
 //   dist_mean    = sum over i < j / (n (n - 1) / 2)
 //   ratio_inlier = (#{(i, j), any order incl. i = j: diff <= thr} - n) / (n (n - 1))
 // One workgroup per patch match; distances in double (the reference's float32 torch.cdist is matched to ~1e-6).
+// Sets of up to RG_CAP pairs are staged in LDS as doubles and the n (n - 1) / 2 unordered pairs are dealt to the threads one
+// evenly -- pair (i, i + s mod n) for the shifts s = 1 .. (n - 1) / 2 (and half the rows of s = n / 2 when n is even), in units
+// of one point against eight consecutive shifts: every thread gets the same number of units whatever n is (a thread per ROW
+// of the triangle leaves half the lanes idle), the partner points come from LDS (neighbouring lanes, neighbouring words: 6.75
+// reads of 8 bytes per pair) and the square roots are v_rsq_f64 + two
+// Goldschmidt steps (<= 1 ulp; the distances here are far from the denormal and overflow ranges the IEEE sequence guards).
+constexpr int RG_CAP = 1024, RG_B = 8;
+__device__ __forceinline__ double rg_sqrt(double x) {
+    const double r = __builtin_amdgcn_rsq(x);
+    double g = x * r, h = 0.5 * r;
+    double e = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, e, g);
+    h = __builtin_fma(h, e, h);
+    e = __builtin_fma(-g, g, x);
+    g = __builtin_fma(e, h, g);
+    return x > 0.0 ? g : 0.0;
+}
 __global__ __launch_bounds__(256) void rigidity_kernel(const float *__restrict__ cs, const float *__restrict__ ct,
                                                       const int64_t *__restrict__ off, int64_t P, double thr,
                                                       double *__restrict__ dist_mean, double *__restrict__ ratio_inlier) {
+    __shared__ double pa[3][RG_CAP], pb[3][RG_CAP];
     __shared__ double s_sum[4];
     __shared__ long long s_in[4];
     for (int64_t p = blockIdx.x; p < P; p += gridDim.x) {
@@ -613,21 +631,56 @@ __global__ __launch_bounds__(256) void rigidity_kernel(const float *__restrict__
         const int n = (int)(off[p + 1] - o);
         const float *__restrict__ a = cs + 3 * o, *__restrict__ b = ct + 3 * o;
         double sum = 0.0;
-        long long inl = 0;
-        // pairs (i, j), i < j, dealt round-robin by row: thread t takes rows t, t + 256, ... (row i has n - 1 - i pairs)
-        for (int i = (int)threadIdx.x; i < n; i += 256) {
-            const double ax = a[3 * i], ay = a[3 * i + 1], az = a[3 * i + 2], bx = b[3 * i], by = b[3 * i + 1], bz = b[3 * i + 2];
-            for (int j = i + 1; j < n; ++j) {
-                const double dx = ax - (double)a[3 * j], dy = ay - (double)a[3 * j + 1], dz = az - (double)a[3 * j + 2];
-                const double ex = bx - (double)b[3 * j], ey = by - (double)b[3 * j + 1], ez = bz - (double)b[3 * j + 2];
-                const double diff = fabs(sqrt(dx * dx + dy * dy + dz * dz) - sqrt(ex * ex + ey * ey + ez * ez));
-                sum += diff;
-                inl += diff <= thr ? 1 : 0;
+        int inl = 0;  // (a thread sees < 2^31 pairs)
+        if (n <= RG_CAP) {
+            for (int t = (int)threadIdx.x; t < 3 * n; t += 256) {
+                pa[t % 3][t / 3] = (double)a[t];
+                pb[t % 3][t / 3] = (double)b[t];
+            }
+            __syncthreads();
+            // a unit of work = one point i against RG_B consecutive shifts (its coordinates are read once per unit): units are
+            // dealt round-robin, blk * n + i
+            const int h = (n - 1) / 2, nblk = (h + RG_B - 1) / RG_B;
+            int i = (int)threadIdx.x, blk = 0;
+            while (i >= n && blk < nblk) { i -= n; ++blk; }  // (n < 256: this thread's first unit lies in a later block)
+            while (blk < nblk) {
+                const double ax = pa[0][i], ay = pa[1][i], az = pa[2][i], bx = pb[0][i], by = pb[1][i], bz = pb[2][i];
+                const int s0 = 1 + blk * RG_B, s1 = s0 + RG_B - 1 < h ? s0 + RG_B - 1 : h;
+                for (int sft = s0; sft <= s1; ++sft) {
+                    const int j = i + sft < n ? i + sft : i + sft - n;
+                    const double dx = ax - pa[0][j], dy = ay - pa[1][j], dz = az - pa[2][j];
+                    const double ex = bx - pb[0][j], ey = by - pb[1][j], ez = bz - pb[2][j];
+                    const double diff = fabs(rg_sqrt(dx * dx + dy * dy + dz * dz) - rg_sqrt(ex * ex + ey * ey + ez * ez));
+                    sum += diff;
+                    inl += diff <= thr ? 1 : 0;
+                }
+                i += 256;
+                while (i >= n) { i -= n; ++blk; }
+            }
+            if ((n & 1) == 0)  // the opposite points of an even ring: each pair once
+                for (int r = (int)threadIdx.x; r < n / 2; r += 256) {
+                    const int j = r + n / 2;
+                    const double dx = pa[0][r] - pa[0][j], dy = pa[1][r] - pa[1][j], dz = pa[2][r] - pa[2][j];
+                    const double ex = pb[0][r] - pb[0][j], ey = pb[1][r] - pb[1][j], ez = pb[2][r] - pb[2][j];
+                    const double diff = fabs(rg_sqrt(dx * dx + dy * dy + dz * dz) - rg_sqrt(ex * ex + ey * ey + ez * ez));
+                    sum += diff;
+                    inl += diff <= thr ? 1 : 0;
+                }
+        } else {
+            // pairs (i, j), i < j, dealt round-robin by row: thread t takes rows t, t + 256, ... (row i has n - 1 - i pairs)
+            for (int i = (int)threadIdx.x; i < n; i += 256) {
+                const double ax = a[3 * i], ay = a[3 * i + 1], az = a[3 * i + 2], bx = b[3 * i], by = b[3 * i + 1], bz = b[3 * i + 2];
+                for (int j = i + 1; j < n; ++j) {
+                    const double dx = ax - (double)a[3 * j], dy = ay - (double)a[3 * j + 1], dz = az - (double)a[3 * j + 2];
+                    const double ex = bx - (double)b[3 * j], ey = by - (double)b[3 * j + 1], ez = bz - (double)b[3 * j + 2];
+                    const double diff = fabs(sqrt(dx * dx + dy * dy + dz * dz) - sqrt(ex * ex + ey * ey + ez * ez));
+                    sum += diff;
+                    inl += diff <= thr ? 1 : 0;
+                }
             }
         }
         sum = wave_sum(sum);
-        int in32 = (int)inl;  // (a row has < 2^31 pairs)
-        long long tot_in = (long long)wave_sum(in32);
+        long long tot_in = (long long)wave_sum(inl);
         if (lane_id() == 0) { s_sum[threadIdx.x >> 6] = sum; s_in[threadIdx.x >> 6] = tot_in; }
         __syncthreads();
         if (threadIdx.x == 0) {
