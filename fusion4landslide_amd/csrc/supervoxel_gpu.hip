@@ -9,18 +9,25 @@
 //   K        number of occupied cells of the resolution grid (grid_sample.h:48-68): bounding box by atomics, cell keys,
 //            device radix sort, count of distinct keys -- never leaves the device.
 //   lambda0  max(DBL_EPSILON, upper median of every point's smallest neighbour metric) (:105-113): device sort.
-//   fusion   for lambda = lambda0, 2 lambda0, 4 lambda0 ... (:117): SUB-ROUNDS of conflict-free fusion on the graph of
-//            representatives (directed edges u -> v: "v is a neighbour of a member of u", the reference's `adjacents`):
-//            every representative draws a coin per sub-round; a tails representative v may be absorbed by a heads
-//            neighbour u when the reference's own criterion holds, sizes[v] * metric(u, v) < lambda (:146-149), and
-//            proposes to the u of smallest metric (ties: smallest index).  Heads are never absorbed and tails never
-//            absorb in the same sub-round, so all proposals can be applied at once (Link(v, u), sizes[u] += sizes[v]).
+//   fusion   for lambda = lambda0, 2 lambda0, 4 lambda0 ... (:117), round r:
+//            BUILD   the round's list of directed edges u -> v between representatives ("v is a neighbour of a member of
+//                    u", the reference's `adjacents`): the previous round's list (round 1: the neighbour lists themselves)
+//                    re-pointed to the current representatives, self loops dropped, parallel edges merged by a direct-mapped
+//                    filter -- ONE pass over the list per round.  The same pass picks the round's ACTIVE edges, those the
+//                    criterion sizes[v] * metric(u, v) < lambda (:146-149) accepts with the size v has when the round starts
+//                    (sizes only grow): the only ones it can accept during the round -- a few per cent of the list (distance
+//                    term alone >= lambda / sizes[v]: rejected without fetching the normals).
+//            3 SUB-ROUNDS of conflict-free fusion over the active edges whose two ends are still representatives:
+//                    every representative draws a coin per sub-round (hash of index and sub-round number); a tails v may be
+//                    absorbed by a heads neighbour u when the criterion holds, and proposes to the u of smallest metric
+//                    (ties: smallest index).  Heads are never absorbed and tails never absorb in the same sub-round, so all
+//                    proposals apply at once (Link(v, u), sizes[u] += sizes[v]).  The adjacency of an absorbed
+//                    representative reaches its new representative with the NEXT round's list.
 //            Exactly like the reference's `if (--number_of_supervoxels == n_supervoxels) break` (:160), a sub-round never
-//            goes below K: when it holds more proposals than representatives to spare, only the best (smallest loss;
-//            ties by index) are applied -- an exact radix select on the device.
-//            Edges are re-pointed to the current representatives every sub-round, self loops dropped and parallel edges
-//            merged (hash set on the device) once per lambda.
-//   labels   label = Find (:179-182) by pointer jumping.
+//            goes below K: when it holds more proposals than representatives to spare, only the best (smallest loss; ties
+//            by index) are applied -- an exact radix select, which can happen once (it ends the fusion) and runs after the
+//            schedule.
+//   labels   label = Find (:179-182).
 //   exchange the boundary refinement (:186-237) as iterated relaxation: every sweep gives each point the label of the
 //            neighbour's representative that is strictly closer than its own (the minimum over its neighbour list,
 //            what the reference's scan over `neighbors[i]` ends with), double buffered; sweeps repeat until nothing
@@ -28,10 +35,12 @@
 //            strictly closer").
 //   relabel  0..K-1 in ascending order of the representative's index (:241-247).
 //
-// Nothing here synchronises the stream or copies to the host: loop bounds live in a device-side state block, every
-// kernel runs on a fixed grid and reads its trip counts from that block, and the host enqueues a fixed schedule of
-// launches (the rounds and sweeps clouds normally need; those past the target count return at once) followed by one
-// persistent kernel that loops over whatever is left (segment_rest_kernel).
+// Nothing here synchronises the stream or copies to the host.  Every kernel of the schedule knows its round / sub-round /
+// sweep NUMBER from the host (a kernel argument) and finds everything else -- list lengths, proposal counts, the sweeps'
+// on / full flags -- in per-round slots of a device-side state block that the kernels before it completed: no kernel
+// exists only to advance a counter.  The host enqueues the rounds and sweeps clouds normally need (those past the target
+// count return at once) followed by ONE-workgroup kernels that loop over whatever is left (segment_rest_kernel): same
+// device functions, workgroup barriers, no assumption about what else is resident on the device.
 // Results are deterministic (no result depends on the order atomics land in, nor on how the passes are split).
 #include <cfloat>
 #include <cstdio>
@@ -49,29 +58,35 @@ namespace svg {
 constexpr int LAMBDA_ROUNDS = 56;  // lambda0 * 2^55 exceeds any size * metric of a 2^31-point cloud
 constexpr int SUBROUNDS = 3;
 constexpr int SWEEPS = 96;
-// what the schedule of LAUNCHES covers when the rest can run in one persistent kernel (segment_rest_kernel): a 1 M-point
-// terrain tile at the reference's resolutions needs 11-14 rounds and 9-15 sweeps
+// what the schedule of LAUNCHES covers (the rest runs in segment_rest_kernel): a 1 M-point terrain tile at the reference's
+// resolutions needs 11-14 rounds and 5-15 sweeps
 constexpr int SCHED_ROUNDS = 16, SCHED_SWEEPS = 16;
-constexpr unsigned GRID = 2048, BLOCK = 256;
+constexpr unsigned GRID = 2048, BLOCK = 256, GRID_ACTIVE = 512, BUILD_BLOCK = 1024;
 constexpr unsigned long long DEAD = ~0ULL;
-constexpr size_t OFFER_WAVES = 65536;  // >= waves of any grid the candidate passes run on (2048 x 4; the rest kernel: <= 1024 x 16)
+// The first rounds work straight from the neighbour lists: while the representatives are a handful of points each, a list of
+// their edges would be nearly as long as the neighbour lists (18 M of 30 M edges after round 0 of a 1 M-point tile), and writing
+// it costs a filter access per edge.  Rounds 0 .. KNN_ROUNDS - 1 only pick their active edges (the neighbour lists re-pointed on
+// the fly); round KNN_ROUNDS builds the first list, when three quarters of a point's 30 edges have become parallel to one another
+// and fall to the filter a wave keeps in LDS.
+constexpr int KNN_ROUNDS = 3;
+constexpr int WAVE_FILTER = 256;  // slots of a wave's own filter (2 KB of LDS)
+constexpr int32_t NONE = 0x7fffffff;
 
 struct State {
-    double lambda;
-    unsigned long long tau_excl;  // proposals with key < tau_excl are applied
-    unsigned int bb[6];           // bounding box as order-preserving unsigned images of the floats (min x,y,z, max x,y,z)
-    int32_t live, K;              // representatives now / wanted
-    int32_t n_edges, n_edges_new;
-    int32_t n_prop, round;
-    int32_t stalled;              // the graph of representatives has no edges left but live > K
-    int32_t sweeps_done, sweep_on, changed, full_sweep;
-    int32_t n_labels;
-    int32_t hash_factor;          // parallel edges are merged through the hash set once there are more than this many edges per representative
-    // grid barrier of segment_rest_kernel: BAR_GROUPS groups of workgroups, each with its own arrival counter and generation word
-    // (a cache line apart), one more counter for the groups' last arrivals
-    unsigned int bar_top, bar_pad[31];
-    unsigned int bar[2 * 16][32];
-    int32_t bar_timeout;              // a workgroup gave up waiting at the barrier (never expected: status bit 3)
+    double lambda0;
+    unsigned long long tau_excl;                 // (overflow path) proposals with key < tau_excl are applied
+    unsigned long long ne[LAMBDA_ROUNDS + 1];    // ne[r]: edges of round r's list, r >= 1 (round 0's list is the neighbour lists)
+    unsigned long long na[LAMBDA_ROUNDS + 1];    // na[r]: active edges of round r
+    unsigned long long n_off[LAMBDA_ROUNDS * SUBROUNDS];  // offers of sub-round rho
+    unsigned long long n_list;                   // (overflow path) proposals collected
+    unsigned int bb[6];                          // bounding box as order-preserving unsigned images of the floats (min x,y,z, max x,y,z)
+    int32_t live, live_snap, K;                  // representatives now / when the current sub-round started / wanted
+    int32_t overflow;                            // 1 + the sub-round whose proposals exceeded the representatives to spare (0: none)
+    int32_t stalled;                             // the graph of representatives has no edges left but live > K
+    int32_t rounds;                              // lambda rounds entered
+    int32_t sweeps_done;
+    int32_t n_prop[LAMBDA_ROUNDS * SUBROUNDS];   // proposals of sub-round rho
+    int32_t sw_on[SWEEPS + 1], sw_full[SWEEPS + 1], sw_changed[SWEEPS + 1];  // per sweep: ran / looked at every point / changed a label
 };
 
 __device__ __forceinline__ unsigned int f2ord(float f) {
@@ -93,39 +108,73 @@ __device__ __forceinline__ bool heads(int32_t v, int32_t round) {
     h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12; h *= 0x297A2D39u; h ^= h >> 15;
     return (h & 1u) != 0u;
 }
-// One atomicAdd per WORKGROUP for all lanes with `take` (same-address atomics are slow: ~10 ns each): returns this lane's
-// slot (valid where take).  Every thread of the block must call it (two barriers inside).
-__device__ __forceinline__ int32_t block_append(int32_t *counter, bool take, int32_t *s_cnt /* [waves + 1] */) {
-    const unsigned long long m = __ballot(take);
+__device__ __forceinline__ unsigned int lanes_below(unsigned long long m) {
+    return __builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u));
+}
+// One atomicAdd per WORKGROUP and counter for all the workgroup's items with t0 / t1 (same-address atomics are slow: ~10 ns
+// each, and they serialise: a counter touched once per wave by 4096 waves costs 40 us whatever else the kernel does): the
+// slots of this lane's ITEMS items (valid where taken).  Every thread of the block must call it (three barriers inside).
+struct AppendScratch { int32_t c0[17], c1[17]; unsigned long long base[2]; };
+template <int ITEMS>
+__device__ __forceinline__ void block_append2(unsigned long long *counter0, const bool (&t0)[ITEMS], unsigned long long *counter1,
+                                              const bool (&t1)[ITEMS], unsigned long long (&at0)[ITEMS], unsigned long long (&at1)[ITEMS],
+                                              AppendScratch &s) {
+    unsigned long long m0[ITEMS], m1[ITEMS];
+    int n0 = 0, n1 = 0;
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        m0[j] = __ballot(t0[j]);
+        m1[j] = __ballot(t1[j]);
+        n0 += (int)__popcll(m0[j]);
+        n1 += (int)__popcll(m1[j]);
+    }
     const int wave = (int)(threadIdx.x >> 6), nw = (int)(blockDim.x >> 6);
-    if (lane_id() == 0) s_cnt[wave] = (int32_t)__popcll(m);
+    if (lane_id() == 0) { s.c0[wave] = n0; s.c1[wave] = n1; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        int32_t tot = 0;
-        for (int w = 0; w < nw; ++w) { const int32_t c = s_cnt[w]; s_cnt[w] = tot; tot += c; }
-        s_cnt[nw] = tot ? atomicAdd(counter, tot) : 0;
+        int32_t tot0 = 0, tot1 = 0;
+        for (int w = 0; w < nw; ++w) {
+            const int32_t a = s.c0[w], b = s.c1[w];
+            s.c0[w] = tot0; s.c1[w] = tot1;
+            tot0 += a; tot1 += b;
+        }
+        s.base[0] = tot0 ? atomicAdd(counter0, (unsigned long long)tot0) : 0ULL;
+        s.base[1] = tot1 ? atomicAdd(counter1, (unsigned long long)tot1) : 0ULL;
     }
     __syncthreads();
-    const int32_t base = s_cnt[nw] + s_cnt[wave];
-    __syncthreads();  // (s_cnt is reused by the next call)
-    const unsigned int below = __builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u));
-    return base + (int32_t)below;
+    unsigned long long b0 = s.base[0] + (unsigned long long)s.c0[wave], b1 = s.base[1] + (unsigned long long)s.c1[wave];
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        at0[j] = b0 + lanes_below(m0[j]);
+        at1[j] = b1 + lanes_below(m1[j]);
+        b0 += (unsigned long long)__popcll(m0[j]);
+        b1 += (unsigned long long)__popcll(m1[j]);
+    }
+    __syncthreads();  // (the scratch is reused by the next call)
+}
+// Sum of `v` over the workgroup added to *counter with ONE atomic (by thread 0; nothing when the sum is 0).  Every thread calls it.
+__device__ __forceinline__ void block_add(int32_t *counter, int v, bool subtract) {
+    __shared__ int part[16];
+    v = wave_sum(v);
+    if (lane_id() == 0) part[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int tot = 0;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) tot += part[w];
+        if (tot) { if (subtract) atomicSub(counter, tot); else atomicAdd(counter, tot); }
+    }
 }
 #define SV_FOR(i, n) for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (int64_t)(n); i += (int64_t)gridDim.x * blockDim.x)
 
 // ---- K: occupied cells of the resolution grid ------------------------------------------------------------------------
 struct GridBox { int given; float mn[3], mx[3]; };
-__global__ void init_state_kernel(State *st, int32_t n, GridBox box, int32_t hash_factor) {
-    st->hash_factor = hash_factor;
-    st->lambda = 0.0; st->tau_excl = 0ULL;
+__global__ void init_state_kernel(State *st, int32_t n, GridBox box) {  // (the block was zeroed by a memset before)
     for (int d = 0; d < 3; ++d) {  // the grid's anchor and extent: the cloud's own bounding box unless the caller gave one
         st->bb[d] = box.given ? f2ord(box.mn[d]) : 0xffffffffu;
         st->bb[3 + d] = box.given ? f2ord(box.mx[d]) : 0u;
     }
-    st->live = n; st->K = 0; st->n_edges = 0; st->n_edges_new = 0; st->n_prop = 0; st->round = 0; st->stalled = 0;
-    st->sweeps_done = 0; st->sweep_on = 1; st->changed = 0; st->full_sweep = 1; st->n_labels = 0;
-    st->bar_top = 0u; st->bar_timeout = 0;
-    for (int i = 0; i < 2 * 16; ++i) st->bar[i][0] = 0u;
+    st->live = n;
+    st->live_snap = n;
 }
 __global__ void bbox_kernel(const float *__restrict__ xyz, int64_t n, State *st) {
     unsigned int mn[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, mx[3] = {0u, 0u, 0u};
@@ -184,11 +233,18 @@ __global__ void grid_key_kernel(const float *__restrict__ xyz, int64_t n, double
                   (unsigned long long)c[2];
     }
 }
-__global__ void count_distinct_kernel(const unsigned long long *__restrict__ sorted, int64_t n, State *st) {
+__global__ void count_distinct_kernel(const unsigned long long *__restrict__ sorted, int64_t n, State *st) {  // (256 workgroups)
     int cnt = 0;
     SV_FOR(i, n) cnt += (i == 0 || sorted[i] != sorted[i - 1]) ? 1 : 0;
     cnt = wave_sum(cnt);
-    if (lane_id() == 0 && cnt) atomicAdd(&st->K, cnt);
+    __shared__ int part[16];
+    if (lane_id() == 0) part[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) {  // one atomic per workgroup
+        int tot = 0;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) tot += part[w];
+        if (tot) atomicAdd(&st->K, tot);
+    }
 }
 
 // ---- neighbour lists, transposed ----------------------------------------------------------------------------------------
@@ -220,6 +276,12 @@ __device__ __forceinline__ bool sv_metric_at_least(const float *__restrict__ xyz
     return c * c * (t1 * t1 + t2 * t2 + t3 * t3) > bound * bound;
 }
 
+__device__ __forceinline__ bool sv_distance_at_least(const float (&pa)[3], const float (&pb)[3], double resolution, double best) {
+    const double t1 = (double)pa[0] - pb[0], t2 = (double)pa[1] - pb[1], t3 = (double)pa[2] - pb[2];
+    const double c = 0.4 / resolution, bound = best * 1.000001 + 1e-15;
+    return c * c * (t1 * t1 + t2 * t2 + t3 * t3) > bound * bound;
+}
+
 // ---- lambda0 -----------------------------------------------------------------------------------------------------
 #pragma clang fp contract(off)
 __global__ void min_metric_kernel(const float *__restrict__ xyz, const double *__restrict__ nrm, const int32_t *__restrict__ knnT,
@@ -236,157 +298,374 @@ __global__ void min_metric_kernel(const float *__restrict__ xyz, const double *_
         dis0[i] = best;
     }
 }
-__global__ void start_kernel(State *st, const double *__restrict__ dis_sorted, int64_t n, int k) {
+__global__ void start_kernel(State *st, const double *__restrict__ dis_sorted, int64_t n) {
     const double med = dis_sorted[n / 2];  // median.h:27-30: nth_element at size / 2
-    st->lambda = med > DBL_EPSILON ? med : DBL_EPSILON;
-    st->n_edges = (int32_t)0;  // set by init_edges_kernel's grid
-    (void)k;
+    st->lambda0 = med > DBL_EPSILON ? med : DBL_EPSILON;
 }
 __global__ void init_points_kernel(int64_t n, int32_t *__restrict__ parent, int32_t *__restrict__ size,
                                    unsigned long long *__restrict__ bestm, int32_t *__restrict__ bestu) {
-    SV_FOR(i, n) { parent[i] = (int32_t)i; size[i] = 1; bestm[i] = ~0ULL; bestu[i] = 0x7fffffff; }
+    SV_FOR(i, n) { parent[i] = (int32_t)i; size[i] = 1; bestm[i] = ~0ULL; bestu[i] = NONE; }
 }
-__global__ void init_edges_kernel(const int32_t *__restrict__ knn, int64_t n, int k, unsigned long long *__restrict__ edges, State *st) {
-    const int64_t total = n * k;
-    SV_FOR(e, total) {
-        const int64_t i = e / k;
-        const int32_t q = knn[e];
-        edges[e] = (q == (int32_t)i || q < 0 || q >= n) ? DEAD : (((unsigned long long)i << 32) | (unsigned int)q);
+
+// What a pass over an edge list needs to know about an end point, in ONE 32-byte record: the pass is bound by the number of
+// scattered lanes it addresses (one cache line per lane and load), not by bytes -- representative, the representative's size and
+// position through parent[], size[] and xyz[] would be five loads of which three depend on the first.
+struct __attribute__((aligned(32))) Node { int32_t root, size; float x, y, z, pad0, pad1, pad2; };
+
+struct SegArgs {
+    const float *xyz;
+    const double *nrm;
+    const int32_t *knn, *knnT;  // neighbour lists, row major and transposed
+    int64_t n;
+    int k;
+    double resolution;
+    State *st;
+    unsigned long long *edges_a, *edges_b, *table, *akey, *bestm, *prop_key;
+    double *am, *dis;
+    int32_t *parent, *size, *bestu, *prop_u, *la, *lb;
+    Node *node;
+    unsigned char *d0, *d1;
+};
+
+__device__ __forceinline__ bool fusing(const State *st) { return st->live > st->K && !st->stalled && !st->overflow; }
+__device__ __forceinline__ double lambda_of(const State *st, int r) { return ldexp(st->lambda0, r); }  // :117 `lambda *= 2.0`, exact
+// the list of round r (r >= 1) alternates between the two edge buffers
+__device__ __forceinline__ unsigned long long *list_of(const SegArgs &a, int r) { return (r & 1) ? a.edges_a : a.edges_b; }
+__device__ __forceinline__ unsigned long long list_in_count(const SegArgs &a, int r) {
+    return r <= KNN_ROUNDS ? (unsigned long long)a.n * (unsigned long long)a.k : a.st->ne[r - 1];
+}
+// slots of the filter that merges the parallel edges of a list of n_edges
+__device__ __forceinline__ unsigned long long table_size(unsigned long long n_edges) {
+    return n_edges < 4096 ? 1024 : (n_edges / 4 < 0xffffffffULL ? n_edges / 4 : 0xffffffffULL);  // (indexed by the high word of a 32-bit product)
+}
+
+// ---- once per lambda round: the round's list and its active edges ------------------------------------------------------
+// Every point's record for the round: its representative (the forest is flattened on the way), and that one's size and position.
+__device__ __forceinline__ void node_body(const SegArgs &a) {
+    int32_t *__restrict__ parent = a.parent;
+    SV_FOR(i, a.n) {
+        int32_t r = parent[i];
+        while (parent[r] != r) r = parent[r];  // (roots are stable while this pass runs)
+        if (r != parent[i]) parent[i] = r;
+        Node nd;
+        nd.root = r;
+        nd.size = a.size[r];
+        nd.x = a.xyz[3 * (int64_t)r]; nd.y = a.xyz[3 * (int64_t)r + 1]; nd.z = a.xyz[3 * (int64_t)r + 2];
+        nd.pad0 = nd.pad1 = nd.pad2 = 0.f;
+        a.node[i] = nd;
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) st->n_edges = (int32_t)(total > 0x7fffffffLL ? 0x7fffffffLL : total);
 }
-
-__device__ __forceinline__ bool fusing(const State *st) { return st->live > st->K && !st->stalled; }
-
-// ---- one sub-round of conflict-free fusion -------------------------------------------------------------------------
-// cand:  re-point every edge to the current representatives; an edge u -> v with u heads, v tails and
-//        sizes[v] * metric(u, v) < lambda offers u to v: bestm[v] = min metric (atomicMin on the ordered image of the double).
-//        The offering edges are also written out -- every WAVE owns a contiguous chunk of the edge list and compacts its
-//        offers to the front of the same chunk of `offers` (the other edge buffer, idle until the lambda's merge), count in
-//        `offer_cnt`: no atomics, no barriers --
-// cand2: so that the tie pass (among the offers of smallest metric the smallest u wins: bestu[v] = min u) reads the offers only,
-//        a few per cent of the list, instead of walking all edges again and measuring a quarter of them a second time.
-// Both passes must run on the same grid (the chunks are derived from it).
-__device__ __forceinline__ void wave_chunk(int32_t ne, int64_t &start, int64_t &end, int &wave_id) {
-    const int waves = (int)(gridDim.x * (blockDim.x >> 6));
-    wave_id = (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
-    const int64_t chunk = (((int64_t)ne + waves - 1) / waves + 63) & ~(int64_t)63;
-    start = (int64_t)wave_id * chunk;
-    end = start + chunk < (int64_t)ne ? start + chunk : (int64_t)ne;
+__global__ void node_kernel(SegArgs a) {
+    if (!fusing(a.st)) return;
+    node_body(a);
 }
-__device__ __forceinline__ void cand_body(const float *__restrict__ xyz, const double *__restrict__ nrm, double resolution, State *st,
-                                          unsigned long long *__restrict__ edges, const int32_t *__restrict__ parent,
-                                          const int32_t *__restrict__ size, unsigned long long *__restrict__ bestm,
-                                          unsigned long long *__restrict__ offers, int32_t *__restrict__ offer_cnt, bool hop) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) st->n_prop = 0;  // (the previous sub-round's apply has finished)
-    const int32_t ne = st->n_edges, round = st->round;
-    const double lambda = st->lambda;
-    int64_t start, end;
-    int wave_id;
-    wave_chunk(ne, start, end, wave_id);
-    int cnt = 0;
-    for (int64_t base = start; base < end; base += 64) {  // (uniform per wave)
-        const int64_t e = base + lane_id();
-        bool offer = false;
-        unsigned long long key = DEAD;
-        if (e < end) {
-            key = edges[e];
-            if (key != DEAD) {
-                int32_t u = (int32_t)(key >> 32), v = (int32_t)(key & 0xffffffffULL);
-                if (hop) {  // (not in the first sub-round of a lambda: the list was re-pointed when it was merged)
-                    const int32_t pu = parent[u], pv = parent[v];  // both were representatives at the last re-pointing: one hop reaches the current ones
-                    if (pu != u || pv != v) {
-                        u = pu; v = pv;
-                        key = u == v ? DEAD : (((unsigned long long)(unsigned int)u << 32) | (unsigned int)v);
-                        edges[e] = key;
-                    }
-                }
-                if (key != DEAD && heads(u, round) && !heads(v, round)) {
-                    const double sz = (double)size[v];
-                    // the distance term of the metric alone may already reach lambda (with room for every rounding, and for
-                    // a normal term that rounds a hair below zero): such an edge is rejected without fetching the normals
-                    const double t1 = (double)xyz[3 * u] - xyz[3 * v], t2 = (double)xyz[3 * u + 1] - xyz[3 * v + 1],
-                                 t3 = (double)xyz[3 * u + 2] - xyz[3 * v + 2];
-                    const double c = sz * 0.4 / resolution, bound = lambda * 1.000001 + sz * 1e-15;
-                    if (!(c * c * (t1 * t1 + t2 * t2 + t3 * t3) > bound * bound)) {
-                        const double m = sv_metric(xyz, nrm, u, v, resolution);
-                        if (lambda - sz * m > 0.0) {  // :147-149 `improvement > 0.0`
-                            atomicMin(&bestm[v], d2ord(m));
-                            offer = true;
-                        }
-                    }
+__device__ __forceinline__ void table_clear_body(const SegArgs &a, int r) {
+    const unsigned long long ts = table_size(list_in_count(a, r));
+    SV_FOR(i, ts) a.table[i] = DEAD;
+}
+__global__ void table_clear_kernel(SegArgs a, int r) {
+    if (!fusing(a.st)) return;
+    table_clear_body(a, r);
+}
+// Round r's list from round r - 1's (FROM_KNN: from the neighbour lists themselves, rounds 0 and 1), and its active edges.
+// Round 0 has nothing to re-point or merge: only the active edges are picked.
+#ifndef SVX_ITEMS
+#define SVX_ITEMS 4
+#endif
+constexpr int BUILD_ITEMS = SVX_ITEMS;   // edges per thread and trip: four independent chains of dependent loads in flight, a quarter of the barriers and counter updates
+template <bool FROM_KNN>
+__device__ __forceinline__ void build_body(const SegArgs &a, int r) {
+    State *st = a.st;
+    const unsigned long long ne_in = list_in_count(a, r);
+    const unsigned long long ts = table_size(ne_in);
+    const double lambda = lambda_of(st, r), resolution = a.resolution;
+    const unsigned long long *__restrict__ lin = FROM_KNN ? nullptr : list_of(a, r - 1);
+    unsigned long long *__restrict__ lout = list_of(a, r);
+    const float *__restrict__ xyz = a.xyz;
+    const double inv_k = 1.0 / (double)a.k;
+    const unsigned int ts32 = (unsigned int)ts;
+    // the distance term of the metric alone against lambda, c * d * sizes[v] > lambda, first in float with a margin a thousand
+    // times the float error (the few edges inside the margin take the exact test in double)
+    const float cf = (float)(0.4 / resolution), lambda_hi = (float)(lambda * 1.001);
+    const double cd = 0.4 / resolution;
+    const bool emit = r >= KNN_ROUNDS;  // this round writes a list (and passes the device-wide filter)
+    const double lambda0 = st->lambda0;
+    __shared__ AppendScratch scratch;
+    __shared__ unsigned long long wave_filter[16 * WAVE_FILTER];
+    for (int t = (int)threadIdx.x; t < 16 * WAVE_FILTER; t += (int)blockDim.x) wave_filter[t] = DEAD;
+    __syncthreads();
+    unsigned long long *wf = wave_filter + (threadIdx.x >> 6) * WAVE_FILTER;
+    const unsigned long long step = (unsigned long long)blockDim.x * BUILD_ITEMS, stride = (unsigned long long)gridDim.x * step;
+    for (unsigned long long e0 = (unsigned long long)blockIdx.x * step; e0 < ne_in; e0 += stride) {  // whole workgroups iterate together
+        int32_t u[BUILD_ITEMS], v[BUILD_ITEMS];
+        bool live[BUILD_ITEMS], fresh[BUILD_ITEMS], act[BUILD_ITEMS], listed[BUILD_ITEMS];
+        unsigned long long key[BUILD_ITEMS];
+        double m[BUILD_ITEMS];
+        int32_t szv[BUILD_ITEMS];
+        unsigned int hsh[BUILD_ITEMS];
+        // the edges
+#pragma unroll
+        for (int j = 0; j < BUILD_ITEMS; ++j) {
+            const unsigned long long e = e0 + (unsigned long long)j * blockDim.x + threadIdx.x;
+            live[j] = e < ne_in;
+            fresh[j] = act[j] = false;
+            key[j] = DEAD;
+            m[j] = 0.0;
+            u[j] = v[j] = 0;
+            if (live[j]) {
+                if (FROM_KNN) {
+                    // e / k without the 64-bit integer division (~100 instructions): the double quotient is within one of it
+                    long long i = (long long)((double)e * inv_k);
+                    i -= (unsigned long long)i * (unsigned long long)a.k > e ? 1 : 0;
+                    i += ((unsigned long long)i + 1ULL) * (unsigned long long)a.k <= e ? 1 : 0;
+                    const int32_t q = a.knn[e];
+                    live[j] = q != (int32_t)i && q >= 0 && (int64_t)q < a.n;
+                    // (round 0: a point whose smallest metric is not below lambda0 has no active edge -- half of the points)
+                    if (r == 0 && !(a.dis[i] < lambda0)) live[j] = false;
+                    u[j] = (int32_t)i;
+                    v[j] = live[j] ? q : (int32_t)i;
+                } else {
+                    const unsigned long long old = lin[e];
+                    u[j] = (int32_t)(old >> 32);
+                    v[j] = (int32_t)(old & 0xffffffffULL);
                 }
             }
         }
-        const unsigned long long mask = __ballot(offer);
-        if (offer)
-            offers[start + cnt + (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)mask, 0u))] = key;
-        cnt += (int)__popcll(mask);
+        // ... re-pointed (the records of the round: one load per end gives representative, size and position)
+        int32_t szu[BUILD_ITEMS];
+        float pu[BUILD_ITEMS][3], pv[BUILD_ITEMS][3];
+        {
+            Node nu[BUILD_ITEMS], nv[BUILD_ITEMS];
+#pragma unroll
+            for (int j = 0; j < BUILD_ITEMS; ++j) { nu[j] = a.node[u[j]]; nv[j] = a.node[v[j]]; }
+#pragma unroll
+            for (int j = 0; j < BUILD_ITEMS; ++j) {
+                u[j] = nu[j].root; v[j] = nv[j].root;
+                szu[j] = nu[j].size; szv[j] = nv[j].size;
+                pu[j][0] = nu[j].x; pu[j][1] = nu[j].y; pu[j][2] = nu[j].z;
+                pv[j][0] = nv[j].x; pv[j][1] = nv[j].y; pv[j][2] = nv[j].z;
+            }
+        }
+        // ... merged.  First by the wave's own filter in LDS (direct mapped: an edge that finds itself in its slot is parallel to
+        // one this wave has already passed on): the neighbours of a point lie in a few supervoxels, so most of a row's edges are
+        // parallel to one another.  Then, for a list: an edge between two representatives without members cannot be any other
+        // edge of the list too; the others pass the device-wide filter, one exchange with the slot the edge hashes to.  Both
+        // filters forget an edge that another one displaced, so some parallel edges stay: nothing downstream counts edges (minimum
+        // metric, smallest index, proposals per absorbed representative), a parallel edge only costs its slot in the next pass.
+        // One access per edge and no probe chains instead of a hash set's two or more; the table is a quarter of the list's size
+        // and stays in the last-level cache.
+        {
+            unsigned long long old[BUILD_ITEMS];
+#pragma unroll
+            for (int j = 0; j < BUILD_ITEMS; ++j) {
+                live[j] = live[j] && u[j] != v[j];
+                key[j] = ((unsigned long long)(unsigned int)u[j] << 32) | (unsigned int)v[j];
+                unsigned int h = (unsigned int)u[j] * 0x9E3779B1u ^ ((unsigned int)v[j] * 0x85EBCA6Bu + 0x7F4A7C15u);
+                h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12; h *= 0x297A2D39u; h ^= h >> 15;
+                hsh[j] = h;
+                if (live[j] && r > 0)
+                    live[j] = __hip_atomic_exchange(&wf[h >> 24], key[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != key[j];
+                fresh[j] = live[j] && (!emit || (szu[j] == 1 && szv[j] == 1));
+                old[j] = DEAD;
+                if (live[j] && !fresh[j]) old[j] = atomicExch(&a.table[__umulhi(h * 0x9E3779B1u, ts32)], key[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < BUILD_ITEMS; ++j) fresh[j] = fresh[j] || (live[j] && old[j] != key[j]);
+        }
+        // ... and the active ones among the fresh: those the criterion `lambda - sizes[v] * metric(u, v) > 0` (:147-149) accepts
+        // with the size v has NOW -- sizes only grow, so no other edge can be accepted in this round.  The distance term of the
+        // metric alone may already reach lambda / sizes[v] (with room for every rounding, and for a normal term that rounds a
+        // hair below zero): such an edge is not active, and the normals stay unfetched
+        {
+            bool near[BUILD_ITEMS];
+#pragma unroll
+            for (int j = 0; j < BUILD_ITEMS; ++j) {
+                const float f1 = pu[j][0] - pv[j][0], f2 = pu[j][1] - pv[j][1], f3 = pu[j][2] - pv[j][2], fs = cf * (float)szv[j];
+                near[j] = fresh[j] && !(fs * fs * (f1 * f1 + f2 * f2 + f3 * f3) > lambda_hi * lambda_hi);
+                if (near[j]) {  // (exactly: sv_metric_at_least against lambda / sizes[v], without the division)
+                    const double t1 = (double)pu[j][0] - pv[j][0], t2 = (double)pu[j][1] - pv[j][1], t3 = (double)pu[j][2] - pv[j][2];
+                    const double c = cd * (double)szv[j], bound = lambda * 1.000001 + (double)szv[j] * 1e-15;
+                    near[j] = !(c * c * (t1 * t1 + t2 * t2 + t3 * t3) > bound * bound);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < BUILD_ITEMS; ++j) {
+                if (near[j]) {
+                    m[j] = sv_metric(xyz, a.nrm, u[j], v[j], resolution);
+                    act[j] = lambda - (double)szv[j] * m[j] > 0.0;
+                    // (a round without a list: its few active edges pass the device-wide filter here, or the active list of round 2
+                    //  would hold every edge four times over -- one per member pair of the two supervoxels)
+                    if (act[j] && !emit && r > 0) act[j] = atomicExch(&a.table[__umulhi(hsh[j] * 0x9E3779B1u, ts32)], key[j]) != key[j];
+                }
+                listed[j] = fresh[j] && r > 0;  // (counted from round 1 on: an empty list means a disconnected graph; written from round KNN_ROUNDS on)
+            }
+        }
+        unsigned long long at0[BUILD_ITEMS], at1[BUILD_ITEMS];
+#ifdef SVX_NO_APPEND  // (timing experiment only: nothing is listed)
+        bool any = false;
+        for (int j = 0; j < BUILD_ITEMS; ++j) { any = any || listed[j] || act[j]; listed[j] = act[j] = false; at0[j] = at1[j] = 0; }
+        if (__ballot(any) == 0x123456789ULL) st->tau_excl = 1;
+#else
+        block_append2<BUILD_ITEMS>(&st->ne[r], listed, &st->na[r], act, at0, at1, scratch);
+#endif
+#pragma unroll
+        for (int j = 0; j < BUILD_ITEMS; ++j) {
+            if (listed[j] && emit) lout[at0[j]] = key[j];
+            if (act[j]) { a.akey[at1[j]] = key[j]; a.am[at1[j]] = m[j]; }
+        }
     }
-    if (lane_id() == 0) offer_cnt[wave_id] = cnt;
 }
-__device__ __forceinline__ void cand2_body(const float *__restrict__ xyz, const double *__restrict__ nrm, double resolution, const State *st,
-                                           const unsigned long long *__restrict__ bestm, int32_t *__restrict__ bestu,
-                                           const unsigned long long *__restrict__ offers, const int32_t *__restrict__ offer_cnt) {
-    int64_t start, end;
-    int wave_id;
-    wave_chunk(st->n_edges, start, end, wave_id);
-    const int cnt = start < end ? offer_cnt[wave_id] : 0;
-    for (int j = lane_id(); j < cnt; j += 64) {
-        const unsigned long long key = offers[start + j];
+template <bool FROM_KNN>
+__global__ __launch_bounds__(1024) void build_kernel(SegArgs a, int r) {
+    if (!fusing(a.st)) return;
+    build_body<FROM_KNN>(a, r);
+}
+
+// ---- one sub-round (number rho = SUBROUNDS * r + s) of conflict-free fusion over the active edges of round r ----------------
+// cand:   an active edge u -> v whose ends are both still representatives, with u heads, v tails and
+//         sizes[v] * metric(u, v) < lambda, offers u to v: bestm[v] = min metric (atomicMin on the ordered image of the double);
+//         the offers are listed;
+// cand2:  among the offers of smallest metric the smallest u wins: bestu[v] = min u; the first to reach a v counts a proposal;
+// apply:  Link(v, bestu[v]) for every proposal -- unless there are more proposals than representatives to spare: then nothing
+//         is applied here, every later pass of the fusion returns at once, and the overflow passes after the schedule apply
+//         the best (the sub-round's bestm / bestu stay as they are until then).
+__device__ __forceinline__ bool offer_of(const SegArgs &a, unsigned long long e, int rho, double lambda, int32_t &u, int32_t &v, double &m) {
+    const unsigned long long key = a.akey[e];
+    u = (int32_t)(key >> 32);
+    v = (int32_t)(key & 0xffffffffULL);
+    if (!heads(u, rho) || heads(v, rho)) return false;
+    const int32_t pu = a.parent[u], pv = a.parent[v], sz = a.size[v];  // (loaded together, not one behind the other)
+    m = a.am[e];
+    return pu == u && pv == v && lambda - (double)sz * m > 0.0;  // :147-149 `improvement > 0.0`
+}
+__device__ __forceinline__ void cand_body(const SegArgs &a, int r, int s) {
+    State *st = a.st;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        st->live_snap = st->live;  // (the previous sub-round's apply has finished)
+        if (s == 0) {
+            if (r >= 1 && st->ne[r] == 0ULL) st->stalled = 1;  // disconnected graph of representatives: the reference would never return
+            else st->rounds = r + 1;
+        }
+    }
+    const int rho = SUBROUNDS * r + s;
+    const double lambda = lambda_of(st, r);
+    const unsigned long long na = st->na[r];
+    // the offers (their places in the active list) go to the edge buffer that is idle until the next round's list is built:
+    // the two passes after this one walk the sub-round's offers, a twentieth of the active edges, not the active edges again
+    unsigned long long *__restrict__ offers = list_of(a, r + 1);
+    __shared__ AppendScratch scratch;
+    constexpr int ITEMS = 4;
+    const unsigned long long step = (unsigned long long)blockDim.x * ITEMS, stride = (unsigned long long)gridDim.x * step;
+    for (unsigned long long e0 = (unsigned long long)blockIdx.x * step; e0 < na; e0 += stride) {  // whole workgroups iterate together
+        bool off[ITEMS], none[ITEMS];
+        unsigned long long e[ITEMS], at[ITEMS], unused[ITEMS];
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            e[j] = e0 + (unsigned long long)j * blockDim.x + threadIdx.x;
+            int32_t u = 0, v = 0;
+            double m = 0.0;
+            off[j] = e[j] < na && offer_of(a, e[j], rho, lambda, u, v, m);
+            none[j] = false;
+            if (off[j]) atomicMin(&a.bestm[v], d2ord(m));
+        }
+        block_append2<ITEMS>(&st->n_off[rho], off, &st->n_off[rho], none, at, unused, scratch);
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j)
+            if (off[j]) offers[at[j]] = e[j];
+    }
+}
+__device__ __forceinline__ void cand2_body(const SegArgs &a, int r, int s) {
+    State *st = a.st;
+    const int rho = SUBROUNDS * r + s;
+    const unsigned long long *__restrict__ offers = list_of(a, r + 1);
+    const unsigned long long n_off = st->n_off[rho];
+    int first = 0;
+    SV_FOR(i, n_off) {
+        const unsigned long long e = offers[i], key = a.akey[e];
         const int32_t u = (int32_t)(key >> 32), v = (int32_t)(key & 0xffffffffULL);
-        if (bestm[v] == d2ord(sv_metric(xyz, nrm, u, v, resolution))) atomicMin(&bestu[v], u);
+        if (a.bestm[v] == d2ord(a.am[e])) first += atomicMin(&a.bestu[v], u) == NONE ? 1 : 0;
+    }
+    block_add(&st->n_prop[rho], first, false);
+}
+__device__ __forceinline__ void apply_body(const SegArgs &a, int r, int s) {
+    State *st = a.st;
+    const int rho = SUBROUNDS * r + s;
+    if (st->n_prop[rho] > st->live_snap - st->K) {  // (both final since the kernels before: every thread takes the same branch)
+        if (blockIdx.x == 0 && threadIdx.x == 0) st->overflow = rho + 1;
+        return;
+    }
+    const unsigned long long *__restrict__ offers = list_of(a, r + 1);
+    const unsigned long long n_off = st->n_off[rho];
+    int dropped = 0;
+    SV_FOR(i, n_off) {
+        const unsigned long long e = offers[i], key = a.akey[e];
+        const int32_t u = (int32_t)(key >> 32), v = (int32_t)(key & 0xffffffffULL);
+        if (a.bestu[v] == u && a.bestm[v] == d2ord(a.am[e]) &&
+            atomicCAS(&a.bestu[v], u, NONE) == u) {  // (the claim lets one of several equal edges through, and leaves bestu clean for the next sub-round)
+            a.bestm[v] = ~0ULL;
+            a.parent[v] = u;                   // Link(v, u), disjoint_set.h:77-85
+            atomicAdd(&a.size[u], a.size[v]);  // sizes[i] += sizes[j], :153
+            ++dropped;
+        }
+    }
+    block_add(&st->live, dropped, true);
+}
+__global__ void cand_kernel(SegArgs a, int r, int s) {
+    if (!fusing(a.st)) return;
+    cand_body(a, r, s);
+}
+__global__ void cand2_kernel(SegArgs a, int r, int s) {
+    if (!fusing(a.st)) return;
+    cand2_body(a, r, s);
+}
+__global__ void apply_kernel(SegArgs a, int r, int s) {
+    if (!fusing(a.st)) return;
+    apply_body(a, r, s);
+}
+
+// ---- the sub-round that would go below K (at most one per segmentation; after the schedule) ---------------------------------
+// collect: its proposals (key = float image of the loss : index); select (one workgroup): exactly the (live - K) smallest keys --
+// radix select, 8 passes of 8 bits over the list; apply: those.
+__global__ __launch_bounds__(1024) void overflow_collect_kernel(SegArgs a) {
+    State *st = a.st;
+    if (!st->overflow) return;
+    const int rho = st->overflow - 1, r = rho / SUBROUNDS;
+    const unsigned long long *__restrict__ offers = list_of(a, r + 1);
+    const unsigned long long n_off = st->n_off[rho];
+    __shared__ AppendScratch scratch;
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+    for (unsigned long long i0 = (unsigned long long)blockIdx.x * blockDim.x; i0 < n_off; i0 += stride) {  // whole workgroups iterate together
+        const unsigned long long i = i0 + threadIdx.x;
+        int32_t u = 0, v = 0;
+        double m = 0.0;
+        bool has = false;
+        if (i < n_off) {
+            const unsigned long long e = offers[i], key = a.akey[e];
+            u = (int32_t)(key >> 32);
+            v = (int32_t)(key & 0xffffffffULL);
+            m = a.am[e];
+            // (the list may hold an edge twice: the claim lets one of them through)
+            has = a.bestu[v] == u && a.bestm[v] == d2ord(m) && atomicCAS(&a.bestu[v], u, NONE) == u;
+        }
+        const bool t0[1] = {has}, t1[1] = {false};
+        unsigned long long at_[1], unused[1];
+        block_append2<1>(&st->n_list, t0, &st->n_list, t1, at_, unused, scratch);
+        const unsigned long long at = at_[0];
+        if (has) {  // (one winning edge per proposing v: at most n entries)
+            const double loss = (double)a.size[v] * m;
+            a.prop_key[at] = ((unsigned long long)f2ord((float)loss) << 32) | (unsigned int)v;
+            a.prop_u[at] = u;
+        }
     }
 }
-__global__ void cand_kernel(const float *__restrict__ xyz, const double *__restrict__ nrm, double resolution, State *st,
-                            unsigned long long *__restrict__ edges, const int32_t *__restrict__ parent,
-                            const int32_t *__restrict__ size, unsigned long long *__restrict__ bestm,
-                            unsigned long long *__restrict__ offers, int32_t *__restrict__ offer_cnt, bool hop) {
-    if (!fusing(st)) return;
-    cand_body(xyz, nrm, resolution, st, edges, parent, size, bestm, offers, offer_cnt, hop);
-}
-__global__ void cand2_kernel(const float *__restrict__ xyz, const double *__restrict__ nrm, double resolution, const State *st,
-                             const unsigned long long *__restrict__ bestm, int32_t *__restrict__ bestu,
-                             const unsigned long long *__restrict__ offers, const int32_t *__restrict__ offer_cnt) {
-    if (!fusing(st)) return;
-    cand2_body(xyz, nrm, resolution, st, bestm, bestu, offers, offer_cnt);
-}
-// collect: every tails representative with an offer becomes a proposal (key = float image of the loss : index)
-__device__ __forceinline__ void collect_body(State *st, int64_t n, const int32_t *__restrict__ size, unsigned long long *__restrict__ bestm,
-                                             int32_t *__restrict__ bestu, unsigned long long *__restrict__ prop_key, int32_t *__restrict__ prop_u) {
-    __shared__ int32_t s_cnt[17];
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t v0 = (int64_t)blockIdx.x * blockDim.x; v0 < n; v0 += stride) {  // whole workgroups iterate together
-        const int64_t v = v0 + threadIdx.x;
-        const int32_t u = v < n ? bestu[v] : 0x7fffffff;
-        const bool has = u != 0x7fffffff;
-        const int32_t at = block_append(&st->n_prop, has, s_cnt);
-        if (!has) continue;
-        const double loss = (double)size[v] * ord2d(bestm[v]);
-        prop_key[at] = ((unsigned long long)f2ord((float)loss) << 32) | (unsigned int)v;
-        prop_u[at] = u;
-        bestm[v] = ~0ULL;
-        bestu[v] = 0x7fffffff;
-    }
-}
-__global__ __launch_bounds__(1024) void collect_kernel(State *st, int64_t n, const int32_t *__restrict__ size, unsigned long long *__restrict__ bestm,
-                               int32_t *__restrict__ bestu, unsigned long long *__restrict__ prop_key, int32_t *__restrict__ prop_u) {
-    if (!fusing(st)) return;
-    collect_body(st, n, size, bestm, bestu, prop_key, prop_u);
-}
-// select (one workgroup): all proposals when there are representatives to spare, else exactly the (live - K) smallest
-// keys -- radix select, 8 passes of 8 bits over the proposal list.
-__device__ __forceinline__ void select_body(State *st, const unsigned long long *__restrict__ prop_key) {  // (1024 threads)
+__global__ __launch_bounds__(1024) void overflow_select_kernel(State *st, const unsigned long long *__restrict__ prop_key) {  // (1024 threads)
+    if (!st->overflow) return;
     __shared__ unsigned int hist[256];
     __shared__ unsigned long long s_prefix;
     __shared__ int s_rank;
-    const int a = st->n_prop, budget = st->live - st->K;
+    const int a = (int)st->n_list, budget = st->live - st->K;
     const int tid = (int)threadIdx.x;
-    if (a <= budget) {
-        if (tid == 0) { st->tau_excl = ~0ULL; st->round += 1; }
-        return;
-    }
-    if (tid == 0) { s_prefix = 0ULL; s_rank = budget; }  // 1-based rank of the last key to keep
+    if (tid == 0) { s_prefix = 0ULL; s_rank = budget; }  // 1-based rank of the last key to keep (budget < a here)
     __syncthreads();
     for (int pass = 0; pass < 8; ++pass) {
         const int shift = 56 - 8 * pass;
@@ -410,114 +689,38 @@ __device__ __forceinline__ void select_body(State *st, const unsigned long long 
         }
         __syncthreads();
     }
-    if (tid == 0) { st->tau_excl = s_prefix + 1ULL; st->round += 1; }  // keys are unique (index in the low word)
+    if (tid == 0) st->tau_excl = s_prefix + 1ULL;  // keys are unique (index in the low word)
 }
-__global__ __launch_bounds__(1024) void select_kernel(State *st, const unsigned long long *__restrict__ prop_key) {
-    if (!fusing(st)) return;
-    select_body(st, prop_key);
-}
-__device__ __forceinline__ void apply_body(State *st, const unsigned long long *__restrict__ prop_key, const int32_t *__restrict__ prop_u,
-                                           int32_t *__restrict__ parent, int32_t *__restrict__ size) {
-    const int a = st->n_prop;
+__global__ void overflow_apply_kernel(State *st, const unsigned long long *__restrict__ prop_key, const int32_t *__restrict__ prop_u,
+                                      int32_t *__restrict__ parent, int32_t *__restrict__ size) {
+    if (!st->overflow) return;
+    const int a = (int)st->n_list;
     const unsigned long long tau = st->tau_excl;
     int dropped = 0;
     SV_FOR(i, a) {
         const unsigned long long key = prop_key[i];
         if (key >= tau) continue;
         const int32_t v = (int32_t)(key & 0xffffffffULL), u = prop_u[i];
-        parent[v] = u;                  // Link(v, u), disjoint_set.h:77-85
-        atomicAdd(&size[u], size[v]);   // sizes[i] += sizes[j], :153
+        parent[v] = u;
+        atomicAdd(&size[u], size[v]);
         ++dropped;
     }
     dropped = wave_sum(dropped);
     if (lane_id() == 0 && dropped) atomicSub(&st->live, dropped);
 }
-__global__ void apply_kernel(State *st, const unsigned long long *__restrict__ prop_key, const int32_t *__restrict__ prop_u,
-                             int32_t *__restrict__ parent, int32_t *__restrict__ size) {
-    if (!fusing(st)) return;
-    apply_body(st, prop_key, prop_u, parent, size);
-}
 
-// ---- once per lambda: flatten the forest, merge parallel edges, double lambda ---------------------------------------
-__device__ __forceinline__ void flatten_body(int64_t n, int32_t *__restrict__ parent) {
+// ---- labels, boundary exchange, relabel ------------------------------------------------------------------------------
+__global__ void flatten_kernel(int64_t n, int32_t *__restrict__ parent) {
     SV_FOR(i, n) {
         int32_t r = parent[i];
         while (parent[r] != r) r = parent[r];  // (roots are stable while this pass runs)
         if (r != parent[i]) parent[i] = r;
     }
 }
-__global__ void flatten_kernel(const State *st, int64_t n, int32_t *__restrict__ parent, bool always) {
-    if (!always && !fusing(st)) return;
-    flatten_body(n, parent);
-}
-__device__ __forceinline__ int64_t table_size(int32_t n_edges) { return n_edges < 512 ? 1024 : 2 * (int64_t)n_edges; }
-// Parallel edges are merged through the hash set only once they dominate the list (more than 40 edges per representative);
-// before that the pass just drops the self loops -- the list of a young forest holds few duplicates and 30 M random table
-// accesses cost more than they save.
-__device__ __forceinline__ bool use_hash(const State *st) { return (int64_t)st->n_edges > (int64_t)st->hash_factor * (int64_t)st->live; }
-__device__ __forceinline__ void table_clear_body(const State *st, unsigned long long *__restrict__ table) {
-    if (!use_hash(st)) return;
-    const int64_t ts = table_size(st->n_edges);
-    SV_FOR(i, ts) table[i] = DEAD;
-}
-__global__ void table_clear_kernel(const State *st, unsigned long long *__restrict__ table) {
-    if (!fusing(st)) return;
-    table_clear_body(st, table);
-}
-__device__ __forceinline__ void dedup_body(State *st, const unsigned long long *__restrict__ edges, const int32_t *__restrict__ parent,
-                                           unsigned long long *__restrict__ table, unsigned long long *__restrict__ edges_out) {
-    const int32_t ne = st->n_edges;
-    const unsigned long long ts = (unsigned long long)table_size(ne);
-    __shared__ int32_t s_cnt[17];
-    const bool hashed = use_hash(st);
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t e0 = (int64_t)blockIdx.x * blockDim.x; e0 < ne; e0 += stride) {  // whole workgroups iterate together
-        const int64_t e = e0 + threadIdx.x;
-        const unsigned long long old = e < ne ? edges[e] : DEAD;
-        bool fresh = false;
-        unsigned long long key = DEAD;
-        if (old != DEAD) {
-            const int32_t u = parent[(int32_t)(old >> 32)], v = parent[(int32_t)(old & 0xffffffffULL)];
-            if (u != v) {
-                key = ((unsigned long long)(unsigned int)u << 32) | (unsigned int)v;
-                fresh = !hashed;  // compaction only: every edge between two representatives is kept
-                unsigned long long h = key * 0x9E3779B97F4A7C15ULL;
-                h ^= h >> 29;
-                unsigned long long slot = h % ts;
-                while (hashed) {
-                    unsigned long long seen = __atomic_load_n(&table[slot], __ATOMIC_RELAXED);  // most parallel edges stop here
-                    if (seen == DEAD) seen = atomicCAS(&table[slot], DEAD, key);
-                    if (seen == DEAD) { fresh = true; break; }  // first of its kind
-                    if (seen == key) break;
-                    slot = slot + 1 == ts ? 0 : slot + 1;
-                }
-            }
-        }
-        const int32_t at = block_append(&st->n_edges_new, fresh, s_cnt);  // one counter update per workgroup, not per edge
-        if (fresh) edges_out[at] = key;
-    }
-}
-__global__ __launch_bounds__(1024) void dedup_kernel(State *st, const unsigned long long *__restrict__ edges, const int32_t *__restrict__ parent,
-                             unsigned long long *__restrict__ table, unsigned long long *__restrict__ edges_out) {
-    if (!fusing(st)) return;
-    dedup_body(st, edges, parent, table, edges_out);
-}
-__device__ __forceinline__ void next_lambda_body(State *st) {
-    st->n_edges = st->n_edges_new;
-    st->n_edges_new = 0;
-    st->lambda *= 2.0;  // :117
-    if (st->n_edges == 0) st->stalled = 1;  // disconnected graph of representatives: the reference would never return
-}
-__global__ void next_lambda_kernel(State *st) {
-    if (!fusing(st)) return;
-    next_lambda_body(st);
-}
-
-// ---- labels, boundary exchange, relabel ------------------------------------------------------------------------------
 #pragma clang fp contract(off)
-__device__ __forceinline__ void labels_init_body(const float *__restrict__ xyz, const double *__restrict__ nrm, double resolution, int64_t n,
-                                                 const int32_t *__restrict__ parent, int32_t *__restrict__ la, int32_t *__restrict__ lb,
-                                                 double *__restrict__ dis) {
+__global__ void labels_init_kernel(const float *__restrict__ xyz, const double *__restrict__ nrm, double resolution, int64_t n,
+                                   const int32_t *__restrict__ parent, int32_t *__restrict__ la, int32_t *__restrict__ lb,
+                                   double *__restrict__ dis) {
     SV_FOR(i, n) {
         const int32_t r = parent[i];
         la[i] = r;
@@ -525,46 +728,65 @@ __device__ __forceinline__ void labels_init_body(const float *__restrict__ xyz, 
         dis[i] = sv_metric(xyz, nrm, i, (int64_t)r, resolution);  // :186-189
     }
 }
-__global__ void labels_init_kernel(const float *__restrict__ xyz, const double *__restrict__ nrm, double resolution, int64_t n,
-                                   const int32_t *__restrict__ parent, int32_t *__restrict__ la, int32_t *__restrict__ lb,
-                                   double *__restrict__ dis) {
-    labels_init_body(xyz, nrm, resolution, n, parent, la, lb, dis);
+// What sweep number s does, from what sweep s - 1 did (s - 1's slots are final when s starts): a sweep that changed labels is
+// followed by one over the dirty points; a sweep over the dirty points that changed nothing by one over every point; a sweep over
+// every point that changed nothing ends the relaxation.
+__device__ __forceinline__ void sweep_state(const State *st, int s, bool &on, bool &full) {
+    if (s == 0) { on = true; full = true; return; }
+    const bool pon = st->sw_on[s - 1] != 0, pfull = st->sw_full[s - 1] != 0, pch = st->sw_changed[s - 1] != 0;
+    if (pch) { on = pon; full = false; }
+    else if (!pfull) { on = pon; full = true; }
+    else { on = false; full = true; }
 }
 // One sweep of the exchange (:214-226 for every point at once, reading the labels of the previous sweep).  A point is
-// looked at when it, or a point that lists it or that it lists, changed in the previous sweep (`dirty`); `full_sweep`
+// looked at when it, or a point that lists it or that it lists, changed in the previous sweep (`dirty`); a full sweep
 // looks at every point (the first sweep, and the verification sweep that ends the relaxation).
-__device__ __forceinline__ void sweep_body(const float *__restrict__ xyz, const double *__restrict__ nrm, const int32_t *__restrict__ knnT,
-                                           double resolution, int64_t n, int k, State *st, int32_t *__restrict__ l0, int32_t *__restrict__ l1,
-                                           double *__restrict__ dis, unsigned char *__restrict__ d0, unsigned char *__restrict__ d1) {
-    const bool odd = (st->sweeps_done & 1) != 0, full = st->full_sweep != 0;
-    const int32_t *__restrict__ lin = odd ? l1 : l0;
-    int32_t *__restrict__ lout = odd ? l0 : l1;
+__device__ __forceinline__ void sweep_body(const SegArgs &a, int s) {
+    State *st = a.st;
+    bool on, full;
+    sweep_state(st, s, on, full);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        st->sw_on[s] = on ? 1 : 0;
+        st->sw_full[s] = full ? 1 : 0;
+        if (on) st->sweeps_done = s + 1;
+    }
+    if (!on) return;
+    const float *__restrict__ xyz = a.xyz;
+    const double *__restrict__ nrm = a.nrm;
+    const int32_t *__restrict__ knnT = a.knnT;
+    const int64_t n = a.n;
+    const int k = a.k;
+    const double resolution = a.resolution;
+    const bool odd = (s & 1) != 0;
+    const int32_t *__restrict__ lin = odd ? a.lb : a.la;
+    int32_t *__restrict__ lout = odd ? a.la : a.lb;
     // (a point reads only its OWN flag of the previous sweep and clears it on the way: the buffer is clean again when the
     // next sweep writes its flags into it)
-    unsigned char *__restrict__ din = odd ? d1 : d0;
-    unsigned char *__restrict__ dout = odd ? d0 : d1;
+    unsigned char *__restrict__ din = odd ? a.d1 : a.d0;
+    unsigned char *__restrict__ dout = odd ? a.d0 : a.d1;
+    double *__restrict__ dis = a.dis;
     bool any = false;
     SV_FOR(i, n) {
-        const int32_t a = lin[i];
-        int32_t bl = a;
+        const int32_t own = lin[i];
+        int32_t bl = own;
         const bool look = full || din[i] != 0;
         din[i] = 0;
         if (look) {
             double best = dis[i];
             // (several neighbours carry the same foreign label: the last two labels found no better are not measured again --
             //  the best only decreases, so a label that lost once has lost for good)
-            int32_t r0 = a, r1 = a;
+            int32_t r0 = own, r1 = own;
             for (int j = 0; j < k; ++j) {
                 const int32_t q = knnT[(int64_t)j * n + i];
-                const int32_t b = q >= 0 ? lin[q] : a;
-                if (b == a || b == bl || b == r0 || b == r1) continue;
+                const int32_t b = q >= 0 ? lin[q] : own;
+                if (b == own || b == bl || b == r0 || b == r1) continue;
                 r1 = r0;
                 if (sv_metric_at_least(xyz, i, (int64_t)b, resolution, best)) { r0 = b; continue; }
                 const double d = sv_metric(xyz, nrm, i, (int64_t)b, resolution);
                 if (d < best) { r0 = bl; best = d; bl = b; }
                 else r0 = b;
             }
-            if (bl != a) {
+            if (bl != own) {
                 dis[i] = best;
                 any = true;
                 dout[i] = 1;  // looked at again next sweep, together with the points it lists (:228-236)
@@ -576,24 +798,9 @@ __device__ __forceinline__ void sweep_body(const float *__restrict__ xyz, const 
         }
         lout[i] = bl;
     }
-    if (__ballot(any) != 0ULL && lane_id() == 0) atomicOr(&st->changed, 1);
+    if (__ballot(any) != 0ULL && lane_id() == 0) atomicOr(&st->sw_changed[s], 1);
 }
-__global__ void sweep_kernel(const float *__restrict__ xyz, const double *__restrict__ nrm, const int32_t *__restrict__ knnT,
-                             double resolution, int64_t n, int k, State *st, int32_t *__restrict__ l0, int32_t *__restrict__ l1,
-                             double *__restrict__ dis, unsigned char *__restrict__ d0, unsigned char *__restrict__ d1) {
-    if (!st->sweep_on) return;
-    sweep_body(xyz, nrm, knnT, resolution, n, k, st, l0, l1, dis, d0, d1);
-}
-__device__ __forceinline__ void sweep_end_body(State *st) {
-    st->sweeps_done += 1;
-    if (st->changed) { st->changed = 0; st->full_sweep = 0; }
-    else if (!st->full_sweep) st->full_sweep = 1;                        // nothing left on the dirty lists: verify with a full sweep
-    else st->sweep_on = 0;                                               // a full sweep changed nothing: fixed point
-}
-__global__ void sweep_end_kernel(State *st) {
-    if (!st->sweep_on) return;
-    sweep_end_body(st);
-}
+__global__ void sweep_kernel(SegArgs a, int s) { sweep_body(a, s); }
 __global__ void root_flag_kernel(int64_t n, const int32_t *__restrict__ parent, int32_t *__restrict__ flag) {
     SV_FOR(i, n) flag[i] = parent[i] == (int32_t)i ? 1 : 0;
 }
@@ -606,146 +813,72 @@ __global__ void relabel_kernel(State *st, int64_t n, const int32_t *__restrict__
         if (reps_out && flag[i]) reps_out[rank[i]] = (int32_t)i;
     }
     if (blockIdx.x == 0 && threadIdx.x == 0 && info_out) {
+        bool on, full;
+        sweep_state(st, st->sweeps_done, on, full);  // would another sweep run? (only the budget can have stopped it)
         info_out[0] = rank[n - 1] + flag[n - 1];  // supervoxels produced
         info_out[1] = st->K;                      // occupied grid cells (the target)
-        info_out[2] = (st->stalled ? 1 : 0) | (st->live > st->K && !st->stalled ? 2 : 0) | (st->sweep_on ? 4 : 0) | (st->bar_timeout ? 8 : 0);
+        info_out[2] = (st->stalled ? 1 : 0) | (st->live > st->K && !st->stalled ? 2 : 0) | (on ? 4 : 0);
         info_out[3] = st->sweeps_done;
+        const unsigned long long lb = (unsigned long long)__double_as_longlong(st->lambda0);
+        info_out[4] = (int32_t)(unsigned int)(lb & 0xffffffffULL);  // the fusion's starting lambda (:105-113), the double's two words
+        info_out[5] = (int32_t)(unsigned int)(lb >> 32);
+        info_out[6] = st->rounds;                 // lambda rounds entered
+        info_out[7] = st->overflow;               // 1 + the sub-round that was cut to reach K exactly (0: none was)
     }
 }
 
-
-// ---- the rest of the fusion / of the exchange as ONE persistent launch ----------------------------------------------------
+// ---- whatever the schedule of launches did not cover, in ONE workgroup ------------------------------------------------------
 // The host cannot know how many lambda rounds and sweeps a cloud needs (no synchronisation), and a schedule long enough for
-// every cloud (56 rounds, 96 sweeps: ~1350 launches) is mostly launches that return at once -- 1.4 us each, 1.4 of the
-// 13.6 ms of a 1 M-point tile, which needs 14 rounds and 9 sweeps.  So the schedule of launches covers what clouds
-// normally need (SCHED_ROUNDS, SCHED_SWEEPS), and whatever is left after it runs inside ONE kernel of as many workgroups as
-// the chip holds at once: the same passes (the same device functions) separated by grid-wide barriers, in loops that END
-// when the state says so.  Every decision to leave a loop reads state that was last written before the preceding barrier:
-// all workgroups take the same branch and meet at the same barriers.  A barrier costs ~12 us against ~3 us for a kernel
-// boundary (measured: the whole segmentation inside this kernel takes 14.4 ms, as launches 13.6 ms), which is why the
-// passes that normally DO run stay launches.  The kernel is an ordinary launch on the caller's stream with the grid the
-// occupancy query allows (all workgroups resident at once on an otherwise idle device; the barrier's wait is bounded in any
-// case): hipLaunchCooperativeKernel goes through a queue of its own and cost 5 ms per call inside bench.py's process.
-struct SegArgs {
-    const float *xyz;
-    const double *nrm;
-    const int32_t *knnT;  // neighbour lists, transposed
-    int64_t n;
-    int k;
-    double resolution;
-    State *st;
-    unsigned long long *edges_a, *edges_b, *table, *bestm, *prop_key;
-    int32_t *parent, *size, *bestu, *prop_u, *la, *lb, *offer_cnt;
-    double *dis;
-    unsigned char *d0, *d1;
-    int first_round;  // fusion: lambda rounds first_round .. LAMBDA_ROUNDS - 1 (the launches did the others); < 0: the sweeps
-    int first_sweep;
-};
-// Grid-wide barrier between two passes.  Every wave first waits until its own stores have reached the L2 (vmcnt(0)); after
-// the workgroup barrier ONE thread per workgroup writes the L2 back (release at agent scope), arrives, waits for the
-// generation to change, and invalidates the caches (acquire at agent scope) -- 512 write-backs per barrier instead of one
-// per wave, and the workgroups poll 16 words a cache line apart instead of one (cooperative_groups' grid.sync(): 45 us per
-// barrier, 25 ms instead of 14 for the 1 M tile).  The wait is
-// bounded (about a second): a workgroup that gives up sets bar_timeout and everything after runs to its end without
-// waiting, so that the grid always drains.
-constexpr unsigned int BAR_GROUPS = 16;
-struct GridBarrier {
-    State *st;
-    unsigned int nblocks;
-    __device__ __forceinline__ void sync() const {
-        __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0) lgkmcnt(0)
-        __syncthreads();
-        if (threadIdx.x == 0 && !__hip_atomic_load(&st->bar_timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            const unsigned int g = blockIdx.x % BAR_GROUPS;
-            const unsigned int members = nblocks / BAR_GROUPS + (g < nblocks % BAR_GROUPS ? 1u : 0u);
-            const unsigned int groups = nblocks < BAR_GROUPS ? nblocks : BAR_GROUPS;
-            unsigned int *cnt = &st->bar[2 * g][0], *gen_w = &st->bar[2 * g + 1][0];
-            const unsigned int gen = __hip_atomic_load(gen_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            bool wait = true;
-            if (__hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == members - 1u) {
-                __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (__hip_atomic_fetch_add(&st->bar_top, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == groups - 1u) {
-                    __hip_atomic_store(&st->bar_top, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    for (unsigned int q = 0; q < groups; ++q)
-                        __hip_atomic_store(&st->bar[2 * q + 1][0], gen + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-                    wait = false;
-                }
-            }
-            if (wait) {
-                int spins = 0;
-                while (__hip_atomic_load(gen_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen) {
-                    __builtin_amdgcn_s_sleep(8);
-                    if (++spins > (1 << 22)) { __hip_atomic_store(&st->bar_timeout, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        }
-        __syncthreads();
-    }
-};
-__global__ __launch_bounds__(1024, 8) void segment_rest_kernel(SegArgs a) {
+// every cloud (56 rounds, 96 sweeps) is mostly launches that return at once.  So the schedule covers what clouds normally need
+// (SCHED_ROUNDS, SCHED_SWEEPS) and the rest -- normally nothing: the kernel returns -- runs here: the same device functions in
+// loops that END when the state says so, separated by workgroup barriers.  ONE workgroup: no assumption about co-residency, no
+// grid barrier that could wait for a workgroup the device never scheduled (round 2's persistent grid could), at the price of
+// one CU's speed for rounds that late -- by then the lists are short (they roughly halve per round) --, and for sweeps beyond
+// the scheduled ones (mostly a scan of the dirty flags).
+__device__ __forceinline__ void wg_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+__global__ __launch_bounds__(1024) void segment_rest_kernel(SegArgs a, int first_round, int first_sweep) {
     State *st = a.st;
-    const GridBarrier grid{st, gridDim.x};
-    if (a.first_round >= 0) {
-        // (an even number of rounds was scheduled: the edge list is back in edges_a)
-        unsigned long long *cur = (a.first_round & 1) ? a.edges_b : a.edges_a, *nxt = (a.first_round & 1) ? a.edges_a : a.edges_b;
-        for (int r = a.first_round; r < LAMBDA_ROUNDS && fusing(st); ++r) {
-            for (int s = 0; s < SUBROUNDS && fusing(st); ++s) {
-                cand_body(a.xyz, a.nrm, a.resolution, st, cur, a.parent, a.size, a.bestm, nxt, a.offer_cnt, s > 0);
-                grid.sync();
-                cand2_body(a.xyz, a.nrm, a.resolution, st, a.bestm, a.bestu, nxt, a.offer_cnt);
-                grid.sync();
-                collect_body(st, a.n, a.size, a.bestm, a.bestu, a.prop_key, a.prop_u);
-                grid.sync();
-                if (blockIdx.x == 0) select_body(st, a.prop_key);
-                grid.sync();
-                apply_body(st, a.prop_key, a.prop_u, a.parent, a.size);
-                grid.sync();
+    if (first_round >= 0) {
+        for (int r = first_round; r < LAMBDA_ROUNDS; ++r) {
+            if (!fusing(st)) break;  // (state written before the last barrier: the whole workgroup takes the same branch)
+            node_body(a);
+            if (r >= 1) table_clear_body(a, r);
+            wg_sync();
+            if (r <= KNN_ROUNDS) build_body<true>(a, r);
+            else build_body<false>(a, r);
+            wg_sync();
+            for (int s = 0; s < SUBROUNDS; ++s) {
+                if (!fusing(st)) break;
+                cand_body(a, r, s);
+                wg_sync();
+                if (!fusing(st)) break;  // (cand may have found the list empty)
+                cand2_body(a, r, s);
+                wg_sync();
+                apply_body(a, r, s);
+                wg_sync();
             }
-            if (!fusing(st)) break;
-            flatten_body(a.n, a.parent);
-            table_clear_body(st, a.table);  // (independent of the flattening: no barrier between them)
-            grid.sync();
-            dedup_body(st, cur, a.parent, a.table, nxt);
-            grid.sync();
-            if (blockIdx.x == 0 && threadIdx.x == 0) next_lambda_body(st);
-            grid.sync();
-            unsigned long long *t = cur; cur = nxt; nxt = t;
         }
     } else {
-        for (int s = a.first_sweep; s < SWEEPS && st->sweep_on; ++s) {
-            sweep_body(a.xyz, a.nrm, a.knnT, a.resolution, a.n, a.k, st, a.la, a.lb, a.dis, a.d0, a.d1);
-            grid.sync();
-            if (blockIdx.x == 0 && threadIdx.x == 0) sweep_end_body(st);
-            grid.sync();
+        for (int s = first_sweep; s < SWEEPS; ++s) {
+            if (s > 0 && !st->sw_on[s - 1]) break;
+            sweep_body(a, s);
+            wg_sync();
         }
     }
-}
-// Workgroups of segment_rest_kernel the device holds at once (0: unknown -> the whole schedule as launches).
-static int segment_grid() {
-    static int cached[16] = {};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 0;
-    if (cached[dev]) return cached[dev] < 0 ? 0 : cached[dev];
-    int cus = 0, per_cu = 0;
-    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, segment_rest_kernel, 1024, 0) != hipSuccess || per_cu < 1) {
-        (void)hipGetLastError();
-        cached[dev] = -1;
-        return 0;
-    }
-    cached[dev] = (size_t)cus * per_cu * 16 <= OFFER_WAVES ? cus * per_cu : -1;  // (16 waves per workgroup: one offer count each)
-    return cached[dev] < 0 ? 0 : cached[dev];
 }
 
 static inline size_t align_up(size_t v) { return (v + 255) / 256 * 256; }
 
 struct Ws {
     State *st;
-    unsigned long long *keys_a, *keys_b, *edges_a, *edges_b, *table, *bestm, *prop_key;
-    double *dis, *dis_sorted;
-    int32_t *parent, *size, *bestu, *prop_u, *la, *lb, *flag, *rank, *offer_cnt, *knnT;
+    unsigned long long *keys_a, *keys_b, *edges_a, *edges_b, *table, *akey, *bestm, *prop_key;
+    double *am, *dis, *dis_sorted;
+    int32_t *parent, *size, *bestu, *prop_u, *la, *lb, *flag, *rank, *knnT;
+    Node *node;
     unsigned char *d0, *d1;
     void *prim;
     size_t prim_bytes, total;
@@ -766,11 +899,13 @@ static int layout(int64_t n, int k, Ws &w, unsigned char *base) {
     w.st = (State *)carve(sizeof(State));
     w.edges_a = (unsigned long long *)carve(ne * 8);
     w.edges_b = (unsigned long long *)carve(ne * 8);
-    w.table = (unsigned long long *)carve((ne < 512 ? 1024 : 2 * ne) * 8);
+    w.table = (unsigned long long *)carve((ne / 4 > 2 * (size_t)n + 1024 ? ne / 4 : 2 * (size_t)n + 1024) * 8);  // (the filter; the grid keys and sorted metrics: 2 n words)
     // the grid keys and the sorted metrics are dead before the edge table is first used: they alias it
     w.keys_a = w.table;
     w.keys_b = w.table ? w.table + n : nullptr;
     w.dis_sorted = (double *)w.keys_a;
+    w.akey = (unsigned long long *)carve(ne * 8);
+    w.am = (double *)carve(ne * 8);
     w.bestm = (unsigned long long *)carve((size_t)n * 8);
     w.prop_key = (unsigned long long *)carve((size_t)n * 8);
     w.dis = (double *)carve((size_t)n * 8);
@@ -783,7 +918,7 @@ static int layout(int64_t n, int k, Ws &w, unsigned char *base) {
     w.flag = (int32_t *)carve((size_t)n * 4);
     w.rank = (int32_t *)carve((size_t)n * 4);
     w.knnT = (int32_t *)carve(ne * 4);
-    w.offer_cnt = (int32_t *)carve(OFFER_WAVES * 4);  // one count per wave of the candidate passes
+    w.node = (Node *)carve((size_t)n * sizeof(Node));
     w.d0 = carve((size_t)n);
     w.d1 = carve((size_t)n);
     w.prim = carve(prim);
@@ -817,82 +952,69 @@ extern "C" int f4l_supervoxel_segment_device(const float *xyz, const double *nor
         box.mx[d] = grid_bbox_host ? grid_bbox_host[3 + d] : 0.f;
         if (grid_bbox_host && !(box.mx[d] >= box.mn[d])) return F4L_EINVAL;
     }
-    if (n > 0x7fffffffLL || (double)n * (double)k > 2147483647.0) return F4L_EUNSUPPORTED;
     Ws w;
     int rc = layout(n, k, w, (unsigned char *)workspace);
     if (rc != F4L_OK) return rc;
     if (workspace_bytes < w.total) return F4L_EWORKSPACE;
     hipStream_t st = (hipStream_t)stream;
-    const dim3 g(GRID), b(BLOCK), one(1);
+    const dim3 g(GRID), ga(GRID_ACTIVE), b(BLOCK), one(1);
 
-    int hash_factor = 40;
-    if (const char *e = getenv("F4L_SV_HASH_FACTOR")) { if (atoi(e) > 0) hash_factor = atoi(e); }
-    hipLaunchKernelGGL(init_state_kernel, one, one, 0, st, w.st, (int32_t)n, box, (int32_t)hash_factor);
+    F4L_HIP_CHECK(hipMemsetAsync(w.st, 0, sizeof(State), st));
+    hipLaunchKernelGGL(init_state_kernel, one, one, 0, st, w.st, (int32_t)n, box);
     // K
     if (!box.given) hipLaunchKernelGGL(svg::bbox_kernel, dim3(256), b, 0, st, xyz, n, w.st);
     hipLaunchKernelGGL(grid_key_kernel, g, b, 0, st, xyz, n, resolution, w.st, w.keys_a);
     F4L_LAUNCH_CHECK();
     size_t tb = w.prim_bytes;
     F4L_HIP_CHECK(rocprim::radix_sort_keys(w.prim, tb, w.keys_a, w.keys_b, (size_t)n, 0, 64, st, false));
-    hipLaunchKernelGGL(count_distinct_kernel, g, b, 0, st, w.keys_b, n, w.st);
+    hipLaunchKernelGGL(count_distinct_kernel, dim3(256), b, 0, st, w.keys_b, n, w.st);
     // lambda0
     hipLaunchKernelGGL(knn_transpose_kernel, g, b, 0, st, knn, n, k, w.knnT);
     hipLaunchKernelGGL(min_metric_kernel, g, b, 0, st, xyz, normals, w.knnT, n, k, resolution, w.dis);
     F4L_LAUNCH_CHECK();
     tb = w.prim_bytes;
     F4L_HIP_CHECK(rocprim::radix_sort_keys(w.prim, tb, w.dis, w.dis_sorted, (size_t)n, 0, 64, st, false));
-    hipLaunchKernelGGL(start_kernel, one, one, 0, st, w.st, w.dis_sorted, n, k);
+    hipLaunchKernelGGL(start_kernel, one, one, 0, st, w.st, w.dis_sorted, n);
     hipLaunchKernelGGL(init_points_kernel, g, b, 0, st, n, w.parent, w.size, w.bestm, w.bestu);
-    hipLaunchKernelGGL(init_edges_kernel, g, b, 0, st, knn, n, k, w.edges_a, w.st);
     F4L_LAUNCH_CHECK();
-    // fusion, labels and the exchange: the schedule of launches clouds normally need, then one persistent kernel for
-    // whatever is left (see segment_rest_kernel).  F4L_SV_LAUNCHES=1: the whole
-    // schedule as launches, whose tail returns at once.  F4L_SV_SCHEDULED="rounds,sweeps" overrides the split (tests run
-    // "2,1": nearly everything inside the persistent kernel).
-    const int rest_grid = getenv("F4L_SV_LAUNCHES") ? 0 : segment_grid();
-    int sched_rounds = rest_grid > 0 ? SCHED_ROUNDS : LAMBDA_ROUNDS, sched_sweeps = rest_grid > 0 ? SCHED_SWEEPS : SWEEPS;
+    // fusion, labels and the exchange: the schedule of launches clouds normally need, then one-workgroup kernels for
+    // whatever is left (see segment_rest_kernel).  F4L_SV_LAUNCHES=1: the whole schedule as launches, whose tail returns at
+    // once.  F4L_SV_SCHEDULED="rounds,sweeps" overrides the split (tests run "2,1" and "0,0": nearly everything in the
+    // one-workgroup kernels).
+    int sched_rounds = SCHED_ROUNDS, sched_sweeps = SCHED_SWEEPS;
+    if (getenv("F4L_SV_LAUNCHES")) { sched_rounds = LAMBDA_ROUNDS; sched_sweeps = SWEEPS; }
     if (const char *e = getenv("F4L_SV_SCHEDULED")) {
         int a = 0, c = 0;
-        if (rest_grid > 0 && sscanf(e, "%d,%d", &a, &c) == 2 && a >= 0 && a <= LAMBDA_ROUNDS && c >= 0 && c <= SWEEPS) { sched_rounds = a; sched_sweeps = c; }
+        if (sscanf(e, "%d,%d", &a, &c) == 2 && a >= 0 && a <= LAMBDA_ROUNDS && c >= 0 && c <= SWEEPS) { sched_rounds = a; sched_sweeps = c; }
     }
     SegArgs sa;
-    sa.xyz = xyz; sa.nrm = normals; sa.knnT = w.knnT; sa.n = n; sa.k = k; sa.resolution = resolution; sa.st = w.st;
-    sa.edges_a = w.edges_a; sa.edges_b = w.edges_b; sa.table = w.table; sa.bestm = w.bestm; sa.prop_key = w.prop_key;
-    sa.parent = w.parent; sa.size = w.size; sa.bestu = w.bestu; sa.prop_u = w.prop_u; sa.la = w.la; sa.lb = w.lb;
-    sa.dis = w.dis; sa.d0 = w.d0; sa.d1 = w.d1; sa.offer_cnt = w.offer_cnt;
-    unsigned long long *cur = w.edges_a, *nxt = w.edges_b;
+    sa.xyz = xyz; sa.nrm = normals; sa.knn = knn; sa.knnT = w.knnT; sa.n = n; sa.k = k; sa.resolution = resolution; sa.st = w.st;
+    sa.edges_a = w.edges_a; sa.edges_b = w.edges_b; sa.table = w.table; sa.akey = w.akey; sa.am = w.am; sa.bestm = w.bestm;
+    sa.prop_key = w.prop_key; sa.parent = w.parent; sa.size = w.size; sa.bestu = w.bestu; sa.prop_u = w.prop_u; sa.la = w.la;
+    sa.lb = w.lb; sa.dis = w.dis; sa.d0 = w.d0; sa.d1 = w.d1; sa.node = w.node;
     for (int r = 0; r < sched_rounds; ++r) {
+        hipLaunchKernelGGL(node_kernel, g, b, 0, st, sa);
+        if (r >= 1) hipLaunchKernelGGL(table_clear_kernel, g, b, 0, st, sa, r);
+        if (r <= KNN_ROUNDS) hipLaunchKernelGGL(build_kernel<true>, g, dim3(BUILD_BLOCK), 0, st, sa, r);
+        else hipLaunchKernelGGL(build_kernel<false>, g, dim3(BUILD_BLOCK), 0, st, sa, r);
         for (int s = 0; s < SUBROUNDS; ++s) {
-            hipLaunchKernelGGL(cand_kernel, g, b, 0, st, xyz, normals, resolution, w.st, cur, w.parent, w.size, w.bestm, nxt, w.offer_cnt, s > 0);
-            hipLaunchKernelGGL(cand2_kernel, g, b, 0, st, xyz, normals, resolution, w.st, w.bestm, w.bestu, nxt, w.offer_cnt);
-            hipLaunchKernelGGL(collect_kernel, g, dim3(1024), 0, st, w.st, n, w.size, w.bestm, w.bestu, w.prop_key, w.prop_u);
-            hipLaunchKernelGGL(select_kernel, one, dim3(1024), 0, st, w.st, w.prop_key);
-            hipLaunchKernelGGL(apply_kernel, g, b, 0, st, w.st, w.prop_key, w.prop_u, w.parent, w.size);
+            hipLaunchKernelGGL(cand_kernel, ga, b, 0, st, sa, r, s);
+            hipLaunchKernelGGL(cand2_kernel, ga, b, 0, st, sa, r, s);
+            hipLaunchKernelGGL(apply_kernel, ga, b, 0, st, sa, r, s);
         }
-        hipLaunchKernelGGL(flatten_kernel, g, b, 0, st, w.st, n, w.parent, false);
-        hipLaunchKernelGGL(table_clear_kernel, g, b, 0, st, w.st, w.table);
-        hipLaunchKernelGGL(dedup_kernel, g, dim3(1024), 0, st, w.st, cur, w.parent, w.table, nxt);
-        hipLaunchKernelGGL(next_lambda_kernel, one, one, 0, st, w.st);
         F4L_LAUNCH_CHECK();
-        unsigned long long *t = cur; cur = nxt; nxt = t;
     }
-    if (sched_rounds < LAMBDA_ROUNDS) {
-        sa.first_round = sched_rounds; sa.first_sweep = 0;
-        hipLaunchKernelGGL(segment_rest_kernel, dim3((unsigned)rest_grid), dim3(1024), 0, st, sa);
-    }
+    if (sched_rounds < LAMBDA_ROUNDS) hipLaunchKernelGGL(segment_rest_kernel, one, dim3(1024), 0, st, sa, sched_rounds, 0);
+    hipLaunchKernelGGL(overflow_collect_kernel, dim3(256), dim3(1024), 0, st, sa);
+    hipLaunchKernelGGL(overflow_select_kernel, one, dim3(1024), 0, st, w.st, w.prop_key);
+    hipLaunchKernelGGL(overflow_apply_kernel, g, b, 0, st, w.st, w.prop_key, w.prop_u, w.parent, w.size);
     // labels and the boundary exchange
-    hipLaunchKernelGGL(flatten_kernel, g, b, 0, st, w.st, n, w.parent, true);
+    hipLaunchKernelGGL(flatten_kernel, g, b, 0, st, n, w.parent);
     hipLaunchKernelGGL(labels_init_kernel, g, b, 0, st, xyz, normals, resolution, n, w.parent, w.la, w.lb, w.dis);
     F4L_HIP_CHECK(hipMemsetAsync(w.d0, 0, (size_t)n, st));
     F4L_HIP_CHECK(hipMemsetAsync(w.d1, 0, (size_t)n, st));
-    for (int s = 0; s < sched_sweeps; ++s) {
-        hipLaunchKernelGGL(sweep_kernel, g, b, 0, st, xyz, normals, w.knnT, resolution, n, k, w.st, w.la, w.lb, w.dis, w.d0, w.d1);
-        hipLaunchKernelGGL(sweep_end_kernel, one, one, 0, st, w.st);
-    }
-    if (sched_sweeps < SWEEPS) {
-        sa.first_round = -1; sa.first_sweep = sched_sweeps;
-        hipLaunchKernelGGL(segment_rest_kernel, dim3((unsigned)rest_grid), dim3(1024), 0, st, sa);
-    }
+    for (int s = 0; s < sched_sweeps; ++s) hipLaunchKernelGGL(sweep_kernel, g, b, 0, st, sa, s);
+    if (sched_sweeps < SWEEPS) hipLaunchKernelGGL(segment_rest_kernel, one, dim3(1024), 0, st, sa, -1, sched_sweeps);
     F4L_LAUNCH_CHECK();
     // relabel 0..K-1 in ascending order of the representative's index
     hipLaunchKernelGGL(root_flag_kernel, g, b, 0, st, n, w.parent, w.flag);

@@ -472,8 +472,9 @@ def supervoxel(xyz, k, resolution, return_intermediates=False):
 def supervoxel_segment_device(xyz, normals, knn_idx, resolution, return_reps=False, grid_bbox=None):
     """The segmentation stage entirely on the device, asynchronously (f4l_supervoxel_segment_device: the parallel variant
     of supervoxel_segmentation.h:65-248; NOT label-identical to the sequential reference, same invariants).
-    Returns labels (n,) int32 and info (4,) int32 = [supervoxels, K wanted, status bits, sweeps], both ON THE DEVICE
-    (reading `info` is the caller's synchronisation point)[, reps (n,) int32: the first info[0] entries are the
+    Returns labels (n,) int32 and info (8,) int32 = [supervoxels, K wanted, status bits, sweeps, the starting lambda's two
+    32-bit words (`supervoxel_lambda0(info)`), lambda rounds, 1 + the sub-round that was cut to reach K (0: none)], both ON THE
+    DEVICE (reading `info` is the caller's synchronisation point)[, reps (n,) int32: the first info[0] entries are the
     representative point of every supervoxel].  `grid_bbox` (6 floats: min xyz, max xyz) anchors the resolution grid whose
     occupied cells set the count (default: the cloud's own box); knn entries < 0 or equal to their row are "no neighbour"."""
     torch = require_gpu()
@@ -484,7 +485,7 @@ def supervoxel_segment_device(xyz, normals, knn_idx, resolution, return_reps=Fal
     if xyz.shape[0] != n or normals.shape[0] != n:
         raise ValueError("xyz, normals and knn_idx must describe the same points")
     labels = torch.empty((n,), dtype=torch.int32, device=xyz.device)
-    info = torch.zeros((4,), dtype=torch.int32, device=xyz.device)
+    info = torch.zeros((8,), dtype=torch.int32, device=xyz.device)
     reps = torch.empty((n,), dtype=torch.int32, device=xyz.device) if return_reps else None
     nbytes = lib().f4l_supervoxel_segment_device_workspace_bytes(n, k)
     ws = torch.empty((max(int(nbytes), 1),), dtype=torch.uint8, device=xyz.device)
@@ -495,6 +496,13 @@ def supervoxel_segment_device(xyz, normals, knn_idx, resolution, return_reps=Fal
     return (labels, info, reps) if return_reps else (labels, info)
 
 
+def supervoxel_lambda0(info):
+    """The fusion's starting lambda (supervoxel_segmentation.h:105-113) out of the `info` words of the device segmentation."""
+    import struct
+    w = [int(v) & 0xffffffff for v in info[4:6]]
+    return struct.unpack("<d", struct.pack("<II", w[0], w[1]))[0]
+
+
 def supervoxel_parallel(xyz, k, resolution, return_intermediates=False):
     """Whole partition on the device (f4l_supervoxel_parallel: kNN + normals + the parallel segmentation).  Returns labels
     (n,) int32 on the GPU and K (reads the device-side count: the one synchronisation)[, knn, normals, reps, info]."""
@@ -502,7 +510,7 @@ def supervoxel_parallel(xyz, k, resolution, return_intermediates=False):
     xyz = _dev(xyz, torch.float32, "xyz", (3,))
     n = xyz.shape[0]
     labels = torch.empty((n,), dtype=torch.int32, device=xyz.device)
-    info = torch.zeros((4,), dtype=torch.int32, device=xyz.device)
+    info = torch.zeros((8,), dtype=torch.int32, device=xyz.device)
     knn_out = torch.empty((n, k), dtype=torch.int32, device=xyz.device) if return_intermediates else None
     nrm_out = torch.empty((n, 3), dtype=torch.float64, device=xyz.device) if return_intermediates else None
     reps = torch.empty((n,), dtype=torch.int32, device=xyz.device) if return_intermediates else None
@@ -512,9 +520,9 @@ def supervoxel_parallel(xyz, k, resolution, return_intermediates=False):
                                         ptr(nrm_out), ptr(ws), C.c_size_t(nbytes), stream_ptr()), "f4l_supervoxel_parallel")
     info_h = info.cpu()
     K = int(info_h[0])
-    if int(info_h[2]) & 8:  # (never expected: the persistent kernel's grid barrier gave up -- its workgroups were not all resident)
-        raise RuntimeError("f4l_supervoxel_parallel: the segmentation's grid barrier timed out (another kernel held the device?); "
-                           "rerun, or set F4L_SV_LAUNCHES=1 for the schedule of launches")
+    if int(info_h[2]) & 6:  # (bit 0, a disconnected neighbour graph that stops above its target, leaves a valid partition)
+        raise RuntimeError(f"f4l_supervoxel_parallel: the segmentation did not finish (status bits {int(info_h[2])}: 2 = lambda "
+                           "schedule exhausted above K, 4 = exchange stopped by its sweep budget)")
     if return_intermediates:
         return labels, K, knn_out, nrm_out, reps[:K], info_h
     return labels, K

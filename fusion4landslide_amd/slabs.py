@@ -78,6 +78,15 @@ def _a2a_v(dist, torch, payload, dest, world):
     return recv
 
 
+def _raise_together(dist, torch, dev, world, flag, what):
+    """Every rank raises when ANY rank reports `flag` != 0 (bitwise OR over the ranks, one small all_reduce)."""
+    f = torch.tensor([int(flag)], dtype=torch.int64, device=dev)
+    if world > 1:
+        _all_reduce(dist, f, dist.ReduceOp.BOR)
+    if int(f.item()):
+        raise RuntimeError(f"{what} [flags over all ranks: {int(f.item())}]")
+
+
 def plan_slabs(local_xyz, resolution, dist, world):
     """Steps 1-2.  local_xyz (n, 3) float32 torch tensor (any device).  Returns dict(grid_min, grid_max float32 (3,) numpy,
     bounds (world + 1,) int64 numpy: slab r owns the grid columns bounds[r] .. bounds[r + 1] - 1, n_total)."""
@@ -118,7 +127,13 @@ def slab_supervoxel(local_xyz, local_gid, k, resolution, dist, rank, world, halo
     x0 = float(plan["grid_min"][0])
     cuts = x0 + b.astype(np.float64) * resolution  # slab r = [cuts[r], cuts[r + 1]) in x (the last one closed by the clamp)
     width = np.diff(cuts)
-    if world > 1 and halo > width[(width > 0)].min():
+    # (decided from `bounds`, which every rank holds identically: all ranks raise together, nobody is left in a collective)
+    if world > 1 and (width <= 0).any():
+        empty = [int(r) for r in np.nonzero(width <= 0)[0]]
+        raise ValueError(f"slab(s) {empty} own no grid column (one column of the resolution grid holds more than 1/{world} of the points; "
+                         f"column bounds {b.tolist()}): halos only travel between adjacent ranks, so an empty slab would cut its "
+                         "neighbours off from each other -- use fewer ranks or tiles")
+    if world > 1 and halo > width.min():
         raise ValueError(f"halo {halo} m is wider than the thinnest slab ({width.min():.3f} m): use fewer ranks or tiles")
     col = torch.clamp(((local_xyz[:, 0].double() - x0) / resolution).to(torch.int64), 0, plan["ncol"] - 1)
     owner = torch.bucketize(col, torch.from_numpy(b[1:-1]).to(dev), right=True) if world > 1 else torch.zeros_like(col)
@@ -147,6 +162,9 @@ def slab_supervoxel(local_xyz, local_gid, k, resolution, dist, rank, world, halo
         def knn_normals_fn(p):
             idx, nrm, d2 = engine.knn_normals(p, k, return_d2=True)
             return idx, d2, nrm
+    # failures are decided TOGETHER: a rank that raised alone would leave the others waiting in the next collective
+    _raise_together(dist, torch, dev, world, 0 if xyz_all.shape[0] > k else 1,
+                    f"a slab holds {xyz_all.shape[0]} points (owned + halo), not more than k = {k}: use fewer ranks")
     idx, d2, nrm = knn_normals_fn(xyz_all)
     idx, d2, nrm = idx[:n_own].to(torch.int64), d2[:n_own], nrm[:n_own]
     # certified: the k-th neighbour lies inside slab + halo whatever lies beyond
@@ -169,11 +187,19 @@ def slab_supervoxel(local_xyz, local_gid, k, resolution, dist, rank, world, halo
 
         def segment_fn(p, normals, knn_, res, grid_bbox):
             labels, info = engine.supervoxel_segment_device(p, normals, knn_.to(torch.int32), res, grid_bbox=grid_bbox)
-            return labels, int(info.cpu()[0])
+            info = info.cpu()
+            return labels, int(info[0]), int(info[2])
+    status = 0
     if n_own:
-        labels, K_local = segment_fn(xyz_all[:n_own].contiguous(), nrm, knn_local, resolution, box)
+        seg = segment_fn(xyz_all[:n_own].contiguous(), nrm, knn_local, resolution, box)
+        labels, K_local = seg[0], seg[1]
+        status = int(seg[2]) if len(seg) > 2 else 0
     else:
         labels, K_local = torch.zeros(0, dtype=torch.int64, device=dev), 0
+    # status bits of f4l_supervoxel_segment_device other than 1 (a disconnected neighbour graph stopped above its target: a
+    # valid partition) mean the labels are not a finished segmentation: lambda schedule exhausted (2), sweep budget hit (4)
+    _raise_together(dist, torch, dev, world, status & ~1,
+                    "the device segmentation of a slab did not finish (status bits: 2 lambda schedule exhausted, 4 sweep budget hit)")
     counts = torch.zeros(world, dtype=torch.int64, device=dev)
     counts[rank] = K_local
     if world > 1:

@@ -255,11 +255,11 @@ int f4l_supervoxel(const float *xyz, int64_t n, int k, double resolution, int32_
  *   counted, or NULL for the cloud's own bounding box (grid_sample.h:48-51); a slab passes the WHOLE cloud's box so that the
  *   slabs' counts add up to the whole cloud's
  *   labels_out int32 [n];  reps_out int32 [n] or NULL: reps_out[l] = index of supervoxel l's representative point;
- *   info_out int32 [4] (device) or NULL: {supervoxels produced, K wanted, status bits, exchange sweeps run};
+ *   info_out int32 [8] (device) or NULL: {supervoxels produced, K wanted, status bits, exchange sweeps run, the fusion's
+ *   starting lambda (supervoxel_segmentation.h:105-113) as the low and the high word of the double, lambda rounds entered,
+ *   1 + the number of the sub-round whose proposals were cut to reach K exactly (0: none)};
  *   status bit 0: the graph of representatives ran out of edges above K (disconnected cloud; the reference would not
- *   return), bit 1: lambda schedule exhausted above K, bit 2: exchange stopped by the sweep budget before its fixed point,
- *   bit 3: the persistent kernel that runs the rounds beyond the scheduled launches gave up waiting at its grid barrier
- *   (its workgroups were not all resident: another kernel held the device for about a second) -- labels invalid, rerun.
+ *   return), bit 1: lambda schedule exhausted above K, bit 2: exchange stopped by the sweep budget before its fixed point.
  * f4l_supervoxel_parallel = f4l_knn + f4l_normals + this (f4l_knn synchronises once while it sizes its grid). */
 size_t f4l_supervoxel_segment_device_workspace_bytes(int64_t n, int k);
 int f4l_supervoxel_segment_device(const float *xyz, const double *normals, const int32_t *knn, int64_t n, int k,

@@ -12,6 +12,7 @@
 // Built by oracle/Makefile into oracle/_ref/libf4l_ref.so (git-ignored, travels with gpurun).
 #include <cstdint>
 #include <cfloat>
+#include <algorithm>
 #include <cmath>
 #include <random>
 #include <vector>
@@ -20,6 +21,7 @@
 #include "codelibrary/geometry/point_cloud/pca_estimate_normals.h"
 #include "codelibrary/geometry/point_cloud/supervoxel_segmentation.h"
 #include "codelibrary/geometry/util/distance_3d.h"
+#include "codelibrary/statistics/kernel/median.h"
 #include "codelibrary/util/tree/kd_tree.h"
 
 namespace {
@@ -136,6 +138,31 @@ int f4l_ref_segment(const float* xyz, const double* normals_in, const int32_t* k
     if (n_supervoxels_out) *n_supervoxels_out = supervoxels.size();
     if (labels_out)
         for (int i = 0; i < n_points; ++i) labels_out[i] = labels[i];
+    return 0;
+}
+
+// The starting lambda of the fusion (reference supervoxel_segmentation.h:105-113) -- a local variable there, so the five
+// lines are repeated here on caller-provided neighbours + normals: the per-point minimum of the metric over the neighbour
+// list (self skipped) and the reference's own cl::Median (statistics/kernel/median.h:22-31, nth_element at size / 2).
+int f4l_ref_lambda0(const float* xyz, const double* normals_in, const int32_t* knn_idx, int64_t n, int k,
+                    double resolution, double* lambda0_out) {
+    if (!xyz || !normals_in || !knn_idx || n <= 0 || k <= 0 || !lambda0_out) return -1;
+    int n_points = (int)n;
+    cl::Array<PointWithNormal> points(n_points);
+    for (int i = 0; i < n_points; ++i) {
+        points[i].x = xyz[3 * i];
+        points[i].y = xyz[3 * i + 1];
+        points[i].z = xyz[3 * i + 2];
+        points[i].normal = cl::RVector3D(normals_in[3 * i], normals_in[3 * i + 1], normals_in[3 * i + 2]);
+    }
+    VCCSMetric metric(resolution);
+    cl::Array<double> dis(n_points, DBL_MAX);
+    for (int i = 0; i < n_points; ++i)
+        for (int t = 0; t < k; ++t) {
+            int j = knn_idx[(int64_t)i * k + t];
+            if (i != j) dis[i] = std::min(dis[i], metric(points[i], points[j]));
+        }
+    *lambda0_out = std::max(DBL_EPSILON, cl::Median(dis.begin(), dis.end()));
     return 0;
 }
 

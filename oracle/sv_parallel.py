@@ -3,7 +3,9 @@ fusion4landslide_amd/csrc/supervoxel_gpu.hip (f4l_supervoxel_segment_device).
 
 The sequential algorithm of the reference (codelibrary/geometry/point_cloud/supervoxel_segmentation.h:65-248) is restated in
 oracle/f4l_oracle.c and pinned by the reference's own code.  The parallel variant keeps its structure and criteria but fuses
-the representatives of a round in conflict-free sub-rounds, so its labels differ from the reference's; it is deterministic,
+the representatives of a round in conflict-free sub-rounds over the graph of representatives as the round's start found it (the
+adjacency of absorbed representatives reaches their new representative with the next round's list), so its labels differ from
+the reference's; it is deterministic,
 and this independent restatement (vectorised numpy, written from the algorithm's description, not from the kernel code)
 must reproduce the device's labels EXACTLY.  What ties the variant to the reference are the invariants checked in
 tests/: K = occupied cells of the resolution grid, labels 0..K-1 all non-empty, the exchange's fixed point, and the
@@ -87,18 +89,20 @@ def segment(xyz, nrm, knn, resolution, grid_bbox=None):
     parent = np.arange(n, dtype=np.int64)
     size = np.ones(n, dtype=np.int64)
     eu, ev = idx[notself], flat[notself]
-    live, rnd, stalled = n, 0, False
+    live, rnd, stalled, rounds = n, 0, False, 0
     for _ in range(LAMBDA_ROUNDS):
         if live <= K or stalled:
             break
+        rounds += 1
         for _s in range(SUBROUNDS):
             if live <= K:
                 break
-            eu, ev = parent[eu], parent[ev]  # one hop reaches the current representatives
-            keep = eu != ev
-            eu, ev = eu[keep], ev[keep]
-            ok = _heads(eu, rnd) & ~_heads(ev, rnd)
-            u, v = eu[ok], ev[ok]
+            # (the list of a lambda round is the one its start built: an edge takes part while both its ends are still
+            #  representatives; edges of absorbed ones wait for the next round's list)
+            alive = (parent[eu] == eu) & (parent[ev] == ev)
+            cu, cv = eu[alive], ev[alive]
+            ok = _heads(cu, rnd) & ~_heads(cv, rnd)
+            u, v = cu[ok], cv[ok]
             m = metric(xyz, nrm, u, v, resolution)
             el = (lam - size[v].astype(np.float64) * m) > 0.0
             u, v, m = u[el], v[el], m[el]
@@ -173,7 +177,7 @@ def segment(xyz, nrm, knn, resolution, grid_bbox=None):
     rank[roots] = np.arange(len(roots))
     status = (1 if stalled else 0) | (2 if (live > K and not stalled) else 0) | (4 if on else 0)
     return dict(labels=rank[lab].astype(np.int32), reps=roots.astype(np.int32), n_supervoxels=len(roots), K_target=K,
-                status=status, sweeps=sweeps, lambda0=lambda0)
+                status=status, sweeps=sweeps, lambda0=lambda0, rounds=rounds)
 
 
 def check_invariants(xyz, nrm, knn, resolution, labels, reps):

@@ -49,3 +49,40 @@ def same_partition(la, lb):
     la, lb = np.asarray(la), np.asarray(lb)
     pairs = np.unique(np.stack([la, lb], axis=1), axis=0)
     return pairs.shape[0] == np.unique(la).shape[0] == np.unique(lb).shape[0]
+
+
+def partition_quality(xyz, nrm, lab):
+    """RMS distance of the points to their supervoxel's centroid, mean normal deviation inside a supervoxel (1 - |n . mean
+    normal|), coefficient of variation of the sizes."""
+    xyz, lab = xyz.astype(np.float64), lab.astype(np.int64)
+    K = lab.max() + 1
+    cnt = np.bincount(lab, minlength=K).astype(float)
+    c = np.stack([np.bincount(lab, weights=xyz[:, d], minlength=K) / cnt for d in range(3)], 1)
+    rms = float(np.sqrt((np.linalg.norm(xyz - c[lab], axis=1) ** 2).mean()))
+    first = np.zeros(K, dtype=np.int64)
+    first[lab[::-1]] = np.arange(len(lab))[::-1]
+    s = np.sign(np.sum(nrm * nrm[first][lab], axis=1))
+    s[s == 0] = 1
+    mn = np.stack([np.bincount(lab, weights=(nrm * s[:, None])[:, d], minlength=K) for d in range(3)], 1)
+    mn /= np.maximum(np.linalg.norm(mn, axis=1, keepdims=True), 1e-300)
+    return rms, float((1 - np.abs(np.sum(nrm * mn[lab], axis=1))).mean()), float(cnt.std() / cnt.mean())
+
+
+def piecewise_motion_scene(xyz, block=0.25, seed=11, tmax=0.004, noise=0.0005, extent=1.0):
+    """The second epoch of a golden cloud under a PIECEWISE rigid motion (SURVEY.md 8d's field at the cloud's scale): square
+    blocks of side `block`, each with its own rotation <= 0.5 deg about a random axis through the block centre and its own
+    translation U(-tmax, tmax), plus N(0, noise).  Returns (tgt (n, 3) float32, truth (n, 3) float64: the planted displacement
+    of every point).  A patch that straddles a block boundary cannot follow both blocks: how well a partition's per-patch
+    rigid fits recover `truth` depends on where the partition puts its boundaries."""
+    rng = np.random.default_rng(seed)
+    nb = int(np.ceil(extent / block))
+    bx = np.minimum((xyz[:, 0] / block).astype(int), nb - 1)
+    by = np.minimum((xyz[:, 1] / block).astype(int), nb - 1)
+    bid = by * nb + bx
+    B = nb * nb
+    R = np.stack([rot_from_axis_angle(rng.normal(size=3), np.deg2rad(rng.uniform(0, 0.5))) for _ in range(B)])
+    t = rng.uniform(-tmax, tmax, (B, 3))
+    c = np.c_[(bx + 0.5) * block, (by + 0.5) * block, np.zeros(len(xyz))]
+    p = xyz.astype(np.float64)
+    moved = np.einsum("nij,nj->ni", R[bid], p - c) + c + t[bid]
+    return (moved + rng.normal(0, noise, p.shape)).astype(np.float32), moved - p

@@ -1,7 +1,9 @@
 """GPU tests of the supervoxel segmentation on the device (f4l_supervoxel_segment_device / f4l_supervoxel_parallel, rows
 a5-a7 without the host).  The parallel variant is deterministic: the device's labels must equal those of its independent
-numpy restatement (oracle/sv_parallel.py) EXACTLY; what ties it to the reference are the invariants (K = occupied grid
-cells, labels 0..K-1 non-empty, fixed point of the boundary exchange) and the downstream displacements."""
+numpy restatement (oracle/sv_parallel.py) EXACTLY; what ties it to the REFERENCE are numbers the reference's own code produced
+(tests/golden/supervoxel_*.npz): K = its GridSample count and the starting lambda of its fusion, both bit-exact; the quality of
+the device's partition against its labels; the invariants (labels 0..K-1 non-empty, fixed point of the boundary exchange); and
+the per-patch displacements a piecewise motion yields on its partition and on the device's."""
 import glob
 import os
 
@@ -14,6 +16,7 @@ torch = pytest.importorskip("torch")
 
 from oracle import oracle as O  # noqa: E402
 from oracle import sv_parallel as M  # noqa: E402
+from tests._util import partition_quality, piecewise_motion_scene  # noqa: E402
 
 CASES = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "supervoxel_*.npz")))
 
@@ -37,17 +40,25 @@ def test_device_segmentation_equals_its_numpy_model(eng, path):
     info = info.cpu().numpy()
     ref = M.segment(xyz, nrm, knn, res)
     assert info[0] == ref["n_supervoxels"] == int(g["n_grid_cells"]) and info[1] == ref["K_target"] and info[2] == 0
-    assert info[3] == ref["sweeps"]
+    # K and the fusion's starting lambda are REFERENCE-held numbers: the count of the reference's own GridSample and the value its
+    # own Median gives over its own metric (supervoxel_segmentation.h:105-113, 254-265; tools/make_golden_supervoxel.py): bit-exact
+    assert info[1] == int(g["n_grid_cells"]) == int(g["n_supervoxels"])
+    assert eng.supervoxel_lambda0(info) == float(g["lambda0"]) == ref["lambda0"]
+    assert info[3] == ref["sweeps"] and info[6] == ref["rounds"]
     assert np.array_equal(labels.cpu().numpy(), ref["labels"])
     assert np.array_equal(reps.cpu().numpy()[:info[0]], ref["reps"])
+    # the quality of the DEVICE's partition against the labels the reference's own code produced on this cloud
+    rms_ref, dev_ref, cv_ref = partition_quality(xyz, nrm, g["labels"])
+    rms, dvn, cv = partition_quality(xyz, nrm, labels.cpu().numpy())
+    assert rms <= 1.10 * rms_ref and dvn <= 1.15 * dev_ref + 1e-4 and cv <= 1.3 * cv_ref, ((rms, dvn, cv), (rms_ref, dev_ref, cv_ref))
     inv = M.check_invariants(xyz, nrm, knn.astype(np.int64), res, labels.cpu().numpy(), reps.cpu().numpy()[:info[0]])
     assert inv["K_equals_cells"] and inv["labels_contiguous"] and inv["all_non_empty"] and inv["fixed_point_violations"] == 0
     # run-to-run identical
     again, _ = eng.supervoxel_segment_device(dev(xyz), dev(nrm), dev(knn.astype(np.int32)), res)
     assert torch.equal(again, labels)
-    # ... and the same however the passes are split between the schedule of launches and the persistent kernel that runs
-    # what the schedule did not cover: everything as launches (devices without a known occupancy), and two rounds and one
-    # sweep as launches with all the rest inside the persistent kernel
+    # ... and the same however the passes are split between the schedule of launches and the kernels that run what the
+    # schedule did not cover: everything as launches, none of it, and two rounds and one
+    # sweep as launches with all the rest inside the one-workgroup kernels
     for name, value in (("F4L_SV_LAUNCHES", "1"), ("F4L_SV_SCHEDULED", "2,1"), ("F4L_SV_SCHEDULED", "0,0")):
         os.environ[name] = value
         try:
@@ -77,34 +88,32 @@ def test_whole_partition_on_the_device_and_edge_cases(eng):
     assert not set(labels.cpu().numpy()[:200]) & set(labels.cpu().numpy()[200:])
 
 
-def test_parallel_partition_gives_the_reference_partitions_displacements(eng):
-    """Downstream agreement: the golden cloud moved by ONE rigid motion, cut into patches by the reference's labels and by
-    the device's parallel labels; per-patch ICP on both partitions -> the two displacement fields agree to 1e-4 m
-    (the tolerance that ties a non-identical partition to the reference's)."""
+def test_parallel_partition_recovers_a_piecewise_motion_like_the_reference_partition(eng):
+    """Downstream tie of the device partition to the reference: the golden cloud's second epoch under
+    a PIECEWISE rigid motion (tests/_util.piecewise_motion_scene: 16 blocks, each its own rotation <= 0.5 deg and translation
+    <= 4 mm), cut into patches by the reference's own labels and by the DEVICE's parallel labels; the same per-patch ICP
+    (f4l_piecewise_icp) on both, against the planted field.  Patches that straddle a block boundary cannot follow both blocks,
+    so the error depends on where a partition puts its boundaries (p95 is millimetres where the median is 0.16 mm); the two
+    error distributions must agree: median within 15 % + 0.02 mm, p95 within 15 %."""
     g = np.load([c for c in CASES if "surf_s4_n20000" in c][0])
     xyz, res = g["xyz"], float(g["resolution"])
-    rng = np.random.default_rng(2)
-    ax = rng.normal(size=3)
-    ax /= np.linalg.norm(ax)
-    ang = np.deg2rad(0.4)
-    Kx = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
-    R = np.eye(3) + np.sin(ang) * Kx + (1 - np.cos(ang)) * Kx @ Kx
-    c = xyz.mean(axis=0).astype(np.float64)
-    tgt = ((xyz.astype(np.float64) - c) @ R.T + c + np.array([0.004, -0.003, 0.002])).astype(np.float32)
+    tgt, truth = piecewise_motion_scene(xyz)
     par, K = eng.supervoxel_parallel(dev(xyz), int(g["k"]), res)
-    fields = []
+    stats = []
     for lab, nsv in ((g["labels"], int(g["n_supervoxels"])), (par.cpu().numpy(), K)):
         order, off = eng.labels_to_csr(dev(lab.astype(np.int32)), nsv)
         s = eng.gather_points(dev(xyz), order)
         t = eng.gather_points(dev(tgt), order)  # the same points one epoch later: the same partition of the target
-        out = eng.piecewise_icp(s, off, t, off, max_corr_dist=0.05, max_iter=30)
+        out = eng.piecewise_icp(s, off, t, off, max_corr_dist=0.02, max_iter=30)
         rows = eng.apply_transform(s, off, out["T"]).cpu().numpy()
-        disp = np.empty((len(xyz), 3))
-        disp[order.cpu().numpy()] = rows[:, 3:].astype(np.float64) - rows[:, :3].astype(np.float64)
-        fields.append(disp)
-    assert np.abs(fields[0] - fields[1]).max() <= 1e-4, np.abs(fields[0] - fields[1]).max()
-    truth = tgt.astype(np.float64) - xyz.astype(np.float64)
-    assert np.abs(fields[1] - truth).max() <= 1e-4
+        est = rows[:, 3:].astype(np.float64) - rows[:, :3].astype(np.float64)
+        err = np.linalg.norm(est - truth[order.cpu().numpy()], axis=1)
+        stats.append((float(np.median(err)), float(np.quantile(err, 0.95))))
+    (med_ref, p95_ref), (med_par, p95_par) = stats
+    assert p95_ref > 5 * med_ref, stats  # the scene does depend on the partition
+    assert med_par <= 1.15 * med_ref + 2e-5 and p95_par <= 1.15 * p95_ref, stats
+    print(f"piecewise-motion scene: reference partition median {1e3 * med_ref:.3f} mm p95 {1e3 * p95_ref:.3f} mm; device partition "
+          f"median {1e3 * med_par:.3f} mm p95 {1e3 * p95_par:.3f} mm")
 
 
 def test_device_segmentation_1M_invariants_and_no_host_round_trip(eng):

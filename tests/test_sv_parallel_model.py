@@ -11,25 +11,9 @@ import numpy as np
 import pytest
 
 from oracle import sv_parallel as M
+from tests._util import partition_quality, piecewise_motion_scene
 
 CASES = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "supervoxel_*.npz")))
-
-
-def partition_quality(xyz, nrm, lab):
-    """RMS distance of the points to their supervoxel's centroid, mean normal deviation inside a supervoxel (1 - |n . mean
-    normal|), coefficient of variation of the sizes."""
-    xyz, lab = xyz.astype(np.float64), lab.astype(np.int64)
-    K = lab.max() + 1
-    cnt = np.bincount(lab, minlength=K).astype(float)
-    c = np.stack([np.bincount(lab, weights=xyz[:, d], minlength=K) / cnt for d in range(3)], 1)
-    rms = float(np.sqrt((np.linalg.norm(xyz - c[lab], axis=1) ** 2).mean()))
-    first = np.zeros(K, dtype=np.int64)
-    first[lab[::-1]] = np.arange(len(lab))[::-1]
-    s = np.sign(np.sum(nrm * nrm[first][lab], axis=1))
-    s[s == 0] = 1
-    mn = np.stack([np.bincount(lab, weights=(nrm * s[:, None])[:, d], minlength=K) for d in range(3)], 1)
-    mn /= np.maximum(np.linalg.norm(mn, axis=1, keepdims=True), 1e-300)
-    return rms, float((1 - np.abs(np.sum(nrm * mn[lab], axis=1))).mean()), float(cnt.std() / cnt.mean())
 
 
 @pytest.mark.parametrize("path", CASES, ids=[os.path.basename(p)[11:-4] for p in CASES])
@@ -39,6 +23,7 @@ def test_parallel_model_invariants_and_quality(path):
     r = M.segment(xyz, nrm, knn, res)
     assert r["status"] == 0
     assert r["n_supervoxels"] == r["K_target"] == int(g["n_grid_cells"]) == int(g["n_supervoxels"])  # K exactly, as the reference
+    assert r["lambda0"] == float(g["lambda0"])  # the starting lambda, bit for bit the value the reference's own Median gives (:105-113)
     inv = M.check_invariants(xyz, nrm, knn, res, r["labels"], r["reps"])
     assert inv["K_equals_cells"] and inv["labels_contiguous"] and inv["all_non_empty"]
     assert inv["reps_carry_own_label"] and inv["reps_ascending"] and inv["fixed_point_violations"] == 0
@@ -71,3 +56,30 @@ def test_parallel_model_edge_cases():
     # loop for ever, supervoxel_segmentation.h:117); the variant stops and says so
     r = M.segment(xyz, nrm, knn, 100.0)
     assert r["K_target"] == 1 and r["n_supervoxels"] == 2 and r["status"] & 1
+
+
+def test_parallel_partition_recovers_a_piecewise_motion_like_the_reference_partition():
+    """Downstream tie of the variant to the reference: the golden cloud's second epoch under a PIECEWISE
+    rigid motion, cut into patches by the reference's own labels and by the variant's; per-patch ICP (the oracle's) against
+    the planted field.  Patches that straddle a block boundary make the error depend on the partition (p95 is millimetres
+    where the median is 0.16 mm); the two partitions' error distributions must agree: median within 15 % + 0.02 mm, p95 within
+    15 %.  The same test runs on the DEVICE's labels and ICP under -m gpu (tests/test_gpu_supervoxel_parallel.py)."""
+    from oracle import oracle as O
+    g = np.load([c for c in CASES if "surf_s4_n20000" in c][0])
+    xyz, res = g["xyz"], float(g["resolution"])
+    tgt, truth = piecewise_motion_scene(xyz)
+    model = M.segment(xyz, g["normals"], g["knn_idx"].astype(np.int64), res)
+    stats = []
+    for lab, K in ((g["labels"].astype(np.int64), int(g["n_supervoxels"])), (model["labels"].astype(np.int64), model["n_supervoxels"])):
+        order = np.argsort(lab, kind="stable")
+        off = np.zeros(K + 1, np.int64)
+        off[1:] = np.cumsum(np.bincount(lab, minlength=K))
+        s, t = np.ascontiguousarray(xyz[order]), np.ascontiguousarray(tgt[order])
+        out = O.piecewise_icp(s, off, t, off, max_corr_dist=0.02, max_iter=30)
+        pid = np.repeat(np.arange(K), np.diff(off))
+        est = np.einsum("nij,nj->ni", out["T"][pid, :3, :3], s.astype(np.float64)) + out["T"][pid, :3, 3] - s
+        err = np.linalg.norm(est - truth[order], axis=1)
+        stats.append((float(np.median(err)), float(np.quantile(err, 0.95))))
+    (med_ref, p95_ref), (med_par, p95_par) = stats
+    assert p95_ref > 5 * med_ref  # the scene does depend on the partition
+    assert med_par <= 1.15 * med_ref + 2e-5 and p95_par <= 1.15 * p95_ref, stats

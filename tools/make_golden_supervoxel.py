@@ -4,7 +4,7 @@
 Runs only in the build container: needs oracle/_ref/libf4l_ref.so, which oracle/Makefile compiles from
 the headers where they lie under /root/reference/cpp_core/supervoxel_segmentation (see
 oracle/ref_harness.cpp).  Output is data only: the float32 input cloud and what the reference computed
-for it (kNN indices / squared distances, PCA normals, #grid cells, #supervoxels, labels).
+for it (kNN indices / squared distances, PCA normals, #grid cells, the fusion's starting lambda, #supervoxels, labels).
 """
 import os
 import sys
@@ -51,12 +51,13 @@ def main():
         r = O.ref_supervoxel(xyz, k, res)
         arrays = dict(xyz=xyz, k=np.int32(k), resolution=np.float64(res), knn_idx=r["knn_idx"],
                       normals=r["normals"], labels=r["labels"], n_supervoxels=np.int32(r["n_supervoxels"]),
-                      n_grid_cells=np.int32(r["n_grid_cells"]))
+                      n_grid_cells=np.int32(r["n_grid_cells"]),
+                      lambda0=np.float64(O.ref_lambda0(xyz, r["normals"], r["knn_idx"], res)))
         if with_d2:
             arrays["knn_d2"] = r["knn_d2"]
         path = os.path.join(out_dir, f"supervoxel_{name}.npz")
         np.savez_compressed(path, **arrays)
-        print(f"{name}: n={xyz.shape[0]} k={k} res={res} K={r['n_supervoxels']} cells={r['n_grid_cells']} "
+        print(f"{name}: n={xyz.shape[0]} k={k} res={res} K={r['n_supervoxels']} cells={r['n_grid_cells']} lambda0={float(arrays['lambda0'])!r} "
               f"-> {os.path.getsize(path)} bytes")
 
 
