@@ -68,7 +68,10 @@ constexpr unsigned long long DEAD = ~0ULL;
 // it costs a filter access per edge.  Rounds 0 .. KNN_ROUNDS - 1 only pick their active edges (the neighbour lists re-pointed on
 // the fly); round KNN_ROUNDS builds the first list, when three quarters of a point's 30 edges have become parallel to one another
 // and fall to the filter a wave keeps in LDS.
-constexpr int KNN_ROUNDS = 3;
+#ifndef SVX_KNN_ROUNDS
+#define SVX_KNN_ROUNDS 3
+#endif
+constexpr int KNN_ROUNDS = SVX_KNN_ROUNDS;
 constexpr int WAVE_FILTER = 256;  // slots of a wave's own filter (2 KB of LDS)
 constexpr int32_t NONE = 0x7fffffff;
 
@@ -79,7 +82,8 @@ struct State {
     unsigned long long na[LAMBDA_ROUNDS + 1];    // na[r]: active edges of round r
     unsigned long long n_off[LAMBDA_ROUNDS * SUBROUNDS];  // offers of sub-round rho
     unsigned long long n_list;                   // (overflow path) proposals collected
-    unsigned int bb[6];                          // bounding box as order-preserving unsigned images of the floats (min x,y,z, max x,y,z)
+    unsigned int bb[6];                          // the box of the resolution grid as order-preserving unsigned images of the floats (min x,y,z, max x,y,z)
+    unsigned int pb[6];                          // the points' own bounding box (the frame of the quantised positions)
     int32_t live, live_snap, K;                  // representatives now / when the current sub-round started / wanted
     int32_t overflow;                            // 1 + the sub-round whose proposals exceeded the representatives to spare (0: none)
     int32_t stalled;                             // the graph of representatives has no edges left but live > K
@@ -172,11 +176,13 @@ __global__ void init_state_kernel(State *st, int32_t n, GridBox box) {  // (the 
     for (int d = 0; d < 3; ++d) {  // the grid's anchor and extent: the cloud's own bounding box unless the caller gave one
         st->bb[d] = box.given ? f2ord(box.mn[d]) : 0xffffffffu;
         st->bb[3 + d] = box.given ? f2ord(box.mx[d]) : 0u;
+        st->pb[d] = 0xffffffffu;
+        st->pb[3 + d] = 0u;
     }
     st->live = n;
     st->live_snap = n;
 }
-__global__ void bbox_kernel(const float *__restrict__ xyz, int64_t n, State *st) {
+__global__ void bbox_kernel(const float *__restrict__ xyz, int64_t n, State *st, int grid_box_given) {
     unsigned int mn[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, mx[3] = {0u, 0u, 0u};
     SV_FOR(i, n) {
 #pragma unroll
@@ -207,8 +213,8 @@ __global__ void bbox_kernel(const float *__restrict__ xyz, int64_t n, State *st)
         const int d = (int)threadIdx.x;
         unsigned int v = part[0][d];
         for (int w = 1; w < nw; ++w) v = d < 3 ? (part[w][d] < v ? part[w][d] : v) : (part[w][d] > v ? part[w][d] : v);
-        if (d < 3) atomicMin(&st->bb[d], v);
-        else atomicMax(&st->bb[d], v);
+        if (d < 3) { atomicMin(&st->pb[d], v); if (!grid_box_given) atomicMin(&st->bb[d], v); }
+        else { atomicMax(&st->pb[d], v); if (!grid_box_given) atomicMax(&st->bb[d], v); }
     }
 }
 // grid_sample.h:48-68: size = int(len / res + 1), cell = clamp(int((p - min) / res)), all in double
@@ -276,6 +282,11 @@ __device__ __forceinline__ bool sv_metric_at_least(const float *__restrict__ xyz
     return c * c * (t1 * t1 + t2 * t2 + t3 * t3) > bound * bound;
 }
 
+// c * |p_a - p_b| > bound, exactly as sv_metric_at_least evaluates it
+__device__ __forceinline__ bool sv_metric_at_least_sized(const float *__restrict__ xyz, int64_t a, int64_t b, double c, double bound) {
+    const double t1 = (double)xyz[3 * a] - xyz[3 * b], t2 = (double)xyz[3 * a + 1] - xyz[3 * b + 1], t3 = (double)xyz[3 * a + 2] - xyz[3 * b + 2];
+    return c * c * (t1 * t1 + t2 * t2 + t3 * t3) > bound * bound;
+}
 __device__ __forceinline__ bool sv_distance_at_least(const float (&pa)[3], const float (&pb)[3], double resolution, double best) {
     const double t1 = (double)pa[0] - pb[0], t2 = (double)pa[1] - pb[1], t3 = (double)pa[2] - pb[2];
     const double c = 0.4 / resolution, bound = best * 1.000001 + 1e-15;
@@ -286,12 +297,28 @@ __device__ __forceinline__ bool sv_distance_at_least(const float (&pa)[3], const
 #pragma clang fp contract(off)
 __global__ void min_metric_kernel(const float *__restrict__ xyz, const double *__restrict__ nrm, const int32_t *__restrict__ knnT,
                                   int64_t n, int k, double resolution, double *__restrict__ dis0) {
+    constexpr int CH = 6;  // neighbours whose indices and coordinates are loaded together (see rows_body)
     SV_FOR(i, n) {
         double best = DBL_MAX;
-        for (int j = 0; j < k; ++j) {
-            const int64_t q = knnT[(int64_t)j * n + i];
-            if (q != i && q >= 0 && !sv_metric_at_least(xyz, i, q, resolution, best)) {  // (a negative entry = "no neighbour here": a point outside the caller's slab)
-                const double m = sv_metric(xyz, nrm, i, q, resolution);
+        const double xi = xyz[3 * i], yi = xyz[3 * i + 1], zi = xyz[3 * i + 2];
+        const double c = 0.4 / resolution;
+        for (int j0 = 0; j0 < k; j0 += CH) {
+            int64_t q[CH];
+            float p[CH][3];
+#pragma unroll
+            for (int t = 0; t < CH; ++t) {
+                q[t] = j0 + t < k ? knnT[(int64_t)(j0 + t) * n + i] : -1;
+                if (q[t] < 0) q[t] = i;  // (a negative entry = "no neighbour here": a point outside the caller's slab)
+            }
+#pragma unroll
+            for (int t = 0; t < CH; ++t) { p[t][0] = xyz[3 * q[t]]; p[t][1] = xyz[3 * q[t] + 1]; p[t][2] = xyz[3 * q[t] + 2]; }
+#pragma unroll
+            for (int t = 0; t < CH; ++t) {
+                if (q[t] == i) continue;
+                // sv_metric_at_least(xyz, i, q, resolution, best) on the coordinates already here
+                const double t1 = xi - p[t][0], t2 = yi - p[t][1], t3 = zi - p[t][2], bound = best * 1.000001 + 1e-15;
+                if (c * c * (t1 * t1 + t2 * t2 + t3 * t3) > bound * bound) continue;
+                const double m = sv_metric(xyz, nrm, i, q[t], resolution);
                 best = m < best ? m : best;
             }
         }
@@ -307,10 +334,54 @@ __global__ void init_points_kernel(int64_t n, int32_t *__restrict__ parent, int3
     SV_FOR(i, n) { parent[i] = (int32_t)i; size[i] = 1; bestm[i] = ~0ULL; bestu[i] = NONE; }
 }
 
-// What a pass over an edge list needs to know about an end point, in ONE 32-byte record: the pass is bound by the number of
-// scattered lanes it addresses (one cache line per lane and load), not by bytes -- representative, the representative's size and
-// position through parent[], size[] and xyz[] would be five loads of which three depend on the first.
-struct __attribute__((aligned(32))) Node { int32_t root, size; float x, y, z, pad0, pad1, pad2; };
+// What a pass over an edge list needs to know about an end point, in ONE 16-byte record (one load instruction): the pass is bound
+// by the scattered lanes it addresses and the cache lines they touch, not by bytes -- representative, the representative's size
+// and position through parent[], size[] and xyz[] would be five loads of which three depend on the first.  The position is
+// quantised (21 bits per axis of the cloud's bounding cube: a third of a millimetre on a 600 m tile): it only serves the test
+// "the distance term alone rules the edge out", taken with three steps of slack per axis, i.e. on a LOWER bound of the distance; the
+// edges it cannot rule out (a tenth) take the exact test on the float coordinates.
+struct __attribute__((aligned(16))) Node { int32_t root, size; unsigned int qlo, qhi; };
+struct Quant { float mn[3]; float inv_step, step; };
+__device__ __forceinline__ Quant quant_of(const State *st);
+__device__ __forceinline__ void node_pack(Node &nd, const Quant &q, float x, float y, float z) {
+    const float f[3] = {x, y, z};
+    unsigned long long w = 0ULL;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        float t = (f[d] - q.mn[d]) * q.inv_step;
+        t = t < 0.f ? 0.f : (t > 2097151.f ? 2097151.f : t);
+        w |= (unsigned long long)(unsigned int)t << (21 * d);
+    }
+    nd.qlo = (unsigned int)w;
+    nd.qhi = (unsigned int)(w >> 32);
+}
+// a lower bound of the squared distance between two records' positions, in units of the quantisation step squared
+__device__ __forceinline__ float node_dist2_low(const Node &a, const Node &b) {
+    const unsigned long long wa = ((unsigned long long)a.qhi << 32) | a.qlo, wb = ((unsigned long long)b.qhi << 32) | b.qlo;
+    float s = 0.f;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const int da = (int)((wa >> (21 * d)) & 0x1fffffULL), db = (int)((wb >> (21 * d)) & 0x1fffffULL);
+        int g = da > db ? da - db : db - da;
+        g = g > 3 ? g - 3 : 0;  // (a quantised coordinate lies within a step and a half of the true one, float rounding at 2^21 included: three steps of slack per axis)
+        s += (float)g * (float)g;
+    }
+    return s;
+}
+
+__device__ __forceinline__ Quant quant_of(const State *st) {
+    Quant q;
+    float ext = 0.f;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        q.mn[d] = ord2f(st->pb[d]);
+        const float e = ord2f(st->pb[3 + d]) - q.mn[d];
+        ext = e > ext ? e : ext;
+    }
+    q.step = ext > 0.f ? ext / 2097150.f : 1.f;
+    q.inv_step = 1.f / q.step;
+    return q;
+}
 
 struct SegArgs {
     const float *xyz;
@@ -341,23 +412,27 @@ __device__ __forceinline__ unsigned long long table_size(unsigned long long n_ed
 
 // ---- once per lambda round: the round's list and its active edges ------------------------------------------------------
 // Every point's record for the round: its representative (the forest is flattened on the way), and that one's size and position.
-__device__ __forceinline__ void node_body(const SegArgs &a) {
+__device__ __forceinline__ void node_body(const SegArgs &a, int r) {
     int32_t *__restrict__ parent = a.parent;
+    // a round that reads a LIST only meets the representatives of the round before as end points: a point that was absorbed
+    // earlier (its record of the last pass names another point) is never looked up again
+    const bool reps_only = r > KNN_ROUNDS;
+    const Quant qt = quant_of(a.st);
     SV_FOR(i, a.n) {
-        int32_t r = parent[i];
-        while (parent[r] != r) r = parent[r];  // (roots are stable while this pass runs)
-        if (r != parent[i]) parent[i] = r;
+        if (reps_only && a.node[i].root != (int32_t)i) continue;
+        int32_t q = parent[i];
+        while (parent[q] != q) q = parent[q];  // (roots are stable while this pass runs)
+        if (q != parent[i]) parent[i] = q;
         Node nd;
-        nd.root = r;
-        nd.size = a.size[r];
-        nd.x = a.xyz[3 * (int64_t)r]; nd.y = a.xyz[3 * (int64_t)r + 1]; nd.z = a.xyz[3 * (int64_t)r + 2];
-        nd.pad0 = nd.pad1 = nd.pad2 = 0.f;
+        nd.root = q;
+        nd.size = a.size[q];
+        node_pack(nd, qt, a.xyz[3 * (int64_t)q], a.xyz[3 * (int64_t)q + 1], a.xyz[3 * (int64_t)q + 2]);
         a.node[i] = nd;
     }
 }
-__global__ void node_kernel(SegArgs a) {
+__global__ void node_kernel(SegArgs a, int r) {
     if (!fusing(a.st)) return;
-    node_body(a);
+    node_body(a, r);
 }
 __device__ __forceinline__ void table_clear_body(const SegArgs &a, int r) {
     const unsigned long long ts = table_size(list_in_count(a, r));
@@ -386,7 +461,7 @@ __device__ __forceinline__ void build_body(const SegArgs &a, int r) {
     const unsigned int ts32 = (unsigned int)ts;
     // the distance term of the metric alone against lambda, c * d * sizes[v] > lambda, first in float with a margin a thousand
     // times the float error (the few edges inside the margin take the exact test in double)
-    const float cf = (float)(0.4 / resolution), lambda_hi = (float)(lambda * 1.001);
+    const float cfs = (float)(0.4 / resolution) * quant_of(st).step, lambda_hi = (float)(lambda * 1.001);  // (cfs: c times the quantisation step)
     const double cd = 0.4 / resolution;
     const bool emit = r >= KNN_ROUNDS;  // this round writes a list (and passes the device-wide filter)
     const double lambda0 = st->lambda0;
@@ -433,7 +508,7 @@ __device__ __forceinline__ void build_body(const SegArgs &a, int r) {
         }
         // ... re-pointed (the records of the round: one load per end gives representative, size and position)
         int32_t szu[BUILD_ITEMS];
-        float pu[BUILD_ITEMS][3], pv[BUILD_ITEMS][3];
+        float d2low[BUILD_ITEMS];
         {
             Node nu[BUILD_ITEMS], nv[BUILD_ITEMS];
 #pragma unroll
@@ -442,8 +517,7 @@ __device__ __forceinline__ void build_body(const SegArgs &a, int r) {
             for (int j = 0; j < BUILD_ITEMS; ++j) {
                 u[j] = nu[j].root; v[j] = nv[j].root;
                 szu[j] = nu[j].size; szv[j] = nv[j].size;
-                pu[j][0] = nu[j].x; pu[j][1] = nu[j].y; pu[j][2] = nu[j].z;
-                pv[j][0] = nv[j].x; pv[j][1] = nv[j].y; pv[j][2] = nv[j].z;
+                d2low[j] = node_dist2_low(nu[j], nv[j]);
             }
         }
         // ... merged.  First by the wave's own filter in LDS (direct mapped: an edge that finds itself in its slot is parallel to
@@ -480,13 +554,10 @@ __device__ __forceinline__ void build_body(const SegArgs &a, int r) {
             bool near[BUILD_ITEMS];
 #pragma unroll
             for (int j = 0; j < BUILD_ITEMS; ++j) {
-                const float f1 = pu[j][0] - pv[j][0], f2 = pu[j][1] - pv[j][1], f3 = pu[j][2] - pv[j][2], fs = cf * (float)szv[j];
-                near[j] = fresh[j] && !(fs * fs * (f1 * f1 + f2 * f2 + f3 * f3) > lambda_hi * lambda_hi);
-                if (near[j]) {  // (exactly: sv_metric_at_least against lambda / sizes[v], without the division)
-                    const double t1 = (double)pu[j][0] - pv[j][0], t2 = (double)pu[j][1] - pv[j][1], t3 = (double)pu[j][2] - pv[j][2];
-                    const double c = cd * (double)szv[j], bound = lambda * 1.000001 + (double)szv[j] * 1e-15;
-                    near[j] = !(c * c * (t1 * t1 + t2 * t2 + t3 * t3) > bound * bound);
-                }
+                const float fs = cfs * (float)szv[j];
+                near[j] = fresh[j] && !(fs * fs * d2low[j] > lambda_hi * lambda_hi);
+                // (exactly: the distance term against lambda / sizes[v], without the division)
+                if (near[j]) near[j] = !sv_metric_at_least_sized(xyz, u[j], v[j], cd * (double)szv[j], lambda * 1.000001 + (double)szv[j] * 1e-15);
             }
 #pragma unroll
             for (int j = 0; j < BUILD_ITEMS; ++j) {
@@ -519,6 +590,165 @@ template <bool FROM_KNN>
 __global__ __launch_bounds__(1024) void build_kernel(SegArgs a, int r) {
     if (!fusing(a.st)) return;
     build_body<FROM_KNN>(a, r);
+}
+
+// ---- rounds 0 .. KNN_ROUNDS: straight from the neighbour lists, one lane per point ------------------------------------------------
+// The point's record is one coalesced load, its neighbours come from the transposed lists (coalesced), and the one scattered
+// load per edge is the neighbour's record.  A lane notes which of its row's edges are listed / active in two bit masks, the
+// workgroup turns the lanes' counts into places in the lists (one counter update per workgroup), and the lanes write.
+// Per-lane inclusive scan over the wave + the workgroup's one update of each counter: this lane's first places.
+struct CountScratch { int32_t c0[17], c1[17]; unsigned long long base[2]; };
+__device__ __forceinline__ void block_reserve2(unsigned long long *counter0, int n0, unsigned long long *counter1, int n1,
+                                               unsigned long long &at0, unsigned long long &at1, CountScratch &s) {
+    int x0 = n0, x1 = n1;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int y0 = __shfl_up(x0, d, 64), y1 = __shfl_up(x1, d, 64);
+        if (lane_id() >= d) { x0 += y0; x1 += y1; }
+    }
+    const int wave = (int)(threadIdx.x >> 6), nw = (int)(blockDim.x >> 6);
+    if (lane_id() == 63) { s.c0[wave] = x0; s.c1[wave] = x1; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int32_t tot0 = 0, tot1 = 0;
+        for (int w = 0; w < nw; ++w) {
+            const int32_t a = s.c0[w], b = s.c1[w];
+            s.c0[w] = tot0; s.c1[w] = tot1;
+            tot0 += a; tot1 += b;
+        }
+        s.base[0] = tot0 ? atomicAdd(counter0, (unsigned long long)tot0) : 0ULL;
+        s.base[1] = tot1 ? atomicAdd(counter1, (unsigned long long)tot1) : 0ULL;
+    }
+    __syncthreads();
+    at0 = s.base[0] + (unsigned long long)(s.c0[wave] + x0 - n0);
+    at1 = s.base[1] + (unsigned long long)(s.c1[wave] + x1 - n1);
+    __syncthreads();  // (the scratch is reused by the next call)
+}
+__device__ __forceinline__ unsigned int edge_slot(int32_t u, int32_t v, unsigned int ts32) {
+    unsigned int h = (unsigned int)u * 0x9E3779B1u ^ ((unsigned int)v * 0x85EBCA6Bu + 0x7F4A7C15u);
+    h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12; h *= 0x297A2D39u; h ^= h >> 15;
+    return __umulhi(h * 0x9E3779B1u, ts32);
+}
+constexpr int ROW_SEEN = 8;
+constexpr int ROW_CHUNK = 10;
+constexpr int SWEEP_CHUNK = 10;  // representatives a lane remembers having met in its row (most of a row's edges lead to a few supervoxels)
+__device__ __forceinline__ void rows_body(const SegArgs &a, int r) {
+    State *st = a.st;
+    const int64_t n = a.n;
+    const int k = a.k;
+    const bool emit = r >= KNN_ROUNDS;  // this round writes a list (and passes the device-wide filter)
+    const double lambda = lambda_of(st, r), lambda0 = st->lambda0, resolution = a.resolution;
+    const unsigned int ts32 = (unsigned int)table_size((unsigned long long)n * (unsigned long long)k);
+    // the distance term of the metric alone against lambda, c * d * sizes[v] > lambda, first in float with a margin a thousand
+    // times the float error (the few edges inside the margin take the exact test in double)
+    const float cfs = (float)(0.4 / resolution) * quant_of(st).step, lambda_hi = (float)(lambda * 1.001);  // (cfs: c times the quantisation step)
+    const double cd = 0.4 / resolution;
+    unsigned long long *__restrict__ lout = list_of(a, r);
+    const float *__restrict__ xyz = a.xyz;
+    const int32_t *__restrict__ knnT = a.knnT;
+    __shared__ CountScratch scratch;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x; i0 < n; i0 += stride) {  // whole workgroups iterate together
+        const int64_t i = i0 + threadIdx.x;
+        unsigned long long listmask = 0ULL, actmask = 0ULL;
+        int n_fresh = 0;
+        int32_t u = 0;
+        // (round 0: a point whose smallest metric is not below lambda0 has no active edge -- half of the points)
+        const bool row = i < n && !(r == 0 && !(a.dis[i] < lambda0));
+        if (row) {
+            const Node nu = a.node[i];
+            u = nu.root;
+            // pass 1, every neighbour, cheap: the edges that are new to this row, pass the filter, and that the quantised
+            // positions cannot rule out ("near").  Pass 2 takes the exact test and the metric for the near ones only: in one
+            // loop every step would pay for them -- some lane of the wave always has a near edge -- although a row has one or two.
+            unsigned long long nearmask = 0ULL;
+            int32_t seen[ROW_SEEN];
+#pragma unroll
+            for (int t = 0; t < ROW_SEEN; ++t) seen[t] = u;
+            int at_seen = 0;
+            // (the neighbours ROW_CHUNK at a time: their indices, then their records, are loaded together -- one after the other
+            //  a row would wait for sixty memory round trips in turn, and the pass is bound by exactly that wait)
+            for (int j0 = 0; j0 < k; j0 += ROW_CHUNK) {
+                int32_t q[ROW_CHUNK];
+                Node nq[ROW_CHUNK];
+#pragma unroll
+                for (int c = 0; c < ROW_CHUNK; ++c) {
+                    q[c] = j0 + c < k ? knnT[(int64_t)(j0 + c) * n + i] : -1;
+                    if (q[c] < 0 || (int64_t)q[c] >= n) q[c] = (int32_t)i;  // (its own record: the edge is dropped as a self loop)
+                }
+#pragma unroll
+                for (int c = 0; c < ROW_CHUNK; ++c) nq[c] = a.node[q[c]];
+                // new to this row?  (its own supervoxel, or one this row has just met, is not)
+                bool fresh[ROW_CHUNK], asked[ROW_CHUNK];
+#pragma unroll
+                for (int c = 0; c < ROW_CHUNK; ++c) {
+                    const int32_t v = nq[c].root;
+                    bool dup = q[c] == (int32_t)i;
+#pragma unroll
+                    for (int t = 0; t < ROW_SEEN; ++t) dup = dup || seen[t] == v;
+                    if (!dup) {
+#pragma unroll
+                        for (int t = 0; t < ROW_SEEN; ++t) seen[t] = t == at_seen ? v : seen[t];  // (a ring: the oldest entry goes)
+                        at_seen = at_seen + 1 == ROW_SEEN ? 0 : at_seen + 1;
+                    }
+                    fresh[c] = !dup;
+                    // a list: an edge between two representatives without members cannot be any other edge of the list too; the
+                    // others pass the device-wide filter (see build_body) -- the chunk's exchanges are issued together
+                    asked[c] = fresh[c] && emit && !(nu.size == 1 && nq[c].size == 1);
+                }
+                unsigned long long found[ROW_CHUNK];
+#pragma unroll
+                for (int c = 0; c < ROW_CHUNK; ++c) {
+                    const unsigned long long key = ((unsigned long long)(unsigned int)u << 32) | (unsigned int)nq[c].root;
+                    found[c] = asked[c] ? atomicExch(&a.table[edge_slot(u, nq[c].root, ts32)], key) : DEAD;
+                }
+#pragma unroll
+                for (int c = 0; c < ROW_CHUNK; ++c) {
+                    const int j = j0 + c;
+                    const unsigned long long key = ((unsigned long long)(unsigned int)u << 32) | (unsigned int)nq[c].root;
+                    if (fresh[c] && found[c] != key) {
+                        ++n_fresh;
+                        if (emit) listmask |= 1ULL << j;
+                        const float fs = cfs * (float)nq[c].size;
+                        if (!(fs * fs * node_dist2_low(nu, nq[c]) > lambda_hi * lambda_hi)) nearmask |= 1ULL << j;
+                    }
+                }
+            }
+            while (nearmask) {
+                const int j = __ffsll((long long)nearmask) - 1;
+                nearmask &= nearmask - 1ULL;
+                const Node nv = a.node[knnT[(int64_t)j * n + i]];
+                const int32_t v = nv.root;
+                if (sv_metric_at_least_sized(xyz, u, v, cd * (double)nv.size, lambda * 1.000001 + (double)nv.size * 1e-15)) continue;
+                const double m = sv_metric(xyz, a.nrm, u, v, resolution);
+                if (!(lambda - (double)nv.size * m > 0.0)) continue;
+                // (a round without a list: its few active edges pass the device-wide filter here)
+                const unsigned long long key = ((unsigned long long)(unsigned int)u << 32) | (unsigned int)v;
+                if (!emit && r > 0 && atomicExch(&a.table[edge_slot(u, v, ts32)], key) == key) continue;
+                actmask |= 1ULL << j;
+            }
+        }
+        // (the list's length is counted from round 1 on -- an empty list means a disconnected graph -- and written from round KNN_ROUNDS on)
+        unsigned long long at0, at1;
+        block_reserve2(&st->ne[r], r > 0 ? n_fresh : 0, &st->na[r], (int)__popcll(actmask), at0, at1, scratch);
+        while (listmask) {
+            const int j = __ffsll((long long)listmask) - 1;
+            listmask &= listmask - 1ULL;
+            const int32_t v = a.node[knnT[(int64_t)j * n + i]].root;
+            lout[at0++] = ((unsigned long long)(unsigned int)u << 32) | (unsigned int)v;
+        }
+        while (actmask) {
+            const int j = __ffsll((long long)actmask) - 1;
+            actmask &= actmask - 1ULL;
+            const int32_t v = a.node[knnT[(int64_t)j * n + i]].root;
+            a.akey[at1] = ((unsigned long long)(unsigned int)u << 32) | (unsigned int)v;
+            a.am[at1++] = sv_metric(xyz, a.nrm, u, v, resolution);
+        }
+    }
+}
+__global__ __launch_bounds__(256) void rows_kernel(SegArgs a, int r) {
+    if (!fusing(a.st)) return;
+    rows_body(a, r);
 }
 
 // ---- one sub-round (number rho = SUBROUNDS * r + s) of conflict-free fusion over the active edges of round r ----------------
@@ -776,15 +1006,24 @@ __device__ __forceinline__ void sweep_body(const SegArgs &a, int s) {
             // (several neighbours carry the same foreign label: the last two labels found no better are not measured again --
             //  the best only decreases, so a label that lost once has lost for good)
             int32_t r0 = own, r1 = own;
-            for (int j = 0; j < k; ++j) {
-                const int32_t q = knnT[(int64_t)j * n + i];
-                const int32_t b = q >= 0 ? lin[q] : own;
-                if (b == own || b == bl || b == r0 || b == r1) continue;
-                r1 = r0;
-                if (sv_metric_at_least(xyz, i, (int64_t)b, resolution, best)) { r0 = b; continue; }
-                const double d = sv_metric(xyz, nrm, i, (int64_t)b, resolution);
-                if (d < best) { r0 = bl; best = d; bl = b; }
-                else r0 = b;
+            // (the neighbours SWEEP_CHUNK at a time: their indices, then their labels, are loaded together -- the pass is bound by
+            //  the wait for these loads, see rows_body)
+            for (int j0 = 0; j0 < k; j0 += SWEEP_CHUNK) {
+                int32_t q[SWEEP_CHUNK], lab[SWEEP_CHUNK];
+#pragma unroll
+                for (int c = 0; c < SWEEP_CHUNK; ++c) q[c] = j0 + c < k ? knnT[(int64_t)(j0 + c) * n + i] : -1;
+#pragma unroll
+                for (int c = 0; c < SWEEP_CHUNK; ++c) lab[c] = lin[q[c] >= 0 ? q[c] : (int32_t)i];
+#pragma unroll
+                for (int c = 0; c < SWEEP_CHUNK; ++c) {
+                    const int32_t b = lab[c];
+                    if (b == own || b == bl || b == r0 || b == r1) continue;
+                    r1 = r0;
+                    if (sv_metric_at_least(xyz, i, (int64_t)b, resolution, best)) { r0 = b; continue; }
+                    const double d = sv_metric(xyz, nrm, i, (int64_t)b, resolution);
+                    if (d < best) { r0 = bl; best = d; bl = b; }
+                    else r0 = b;
+                }
             }
             if (bl != own) {
                 dis[i] = best;
@@ -845,10 +1084,10 @@ __global__ __launch_bounds__(1024) void segment_rest_kernel(SegArgs a, int first
     if (first_round >= 0) {
         for (int r = first_round; r < LAMBDA_ROUNDS; ++r) {
             if (!fusing(st)) break;  // (state written before the last barrier: the whole workgroup takes the same branch)
-            node_body(a);
+            node_body(a, r);
             if (r >= 1) table_clear_body(a, r);
             wg_sync();
-            if (r <= KNN_ROUNDS) build_body<true>(a, r);
+            if (r <= KNN_ROUNDS) rows_body(a, r);
             else build_body<false>(a, r);
             wg_sync();
             for (int s = 0; s < SUBROUNDS; ++s) {
@@ -962,7 +1201,7 @@ extern "C" int f4l_supervoxel_segment_device(const float *xyz, const double *nor
     F4L_HIP_CHECK(hipMemsetAsync(w.st, 0, sizeof(State), st));
     hipLaunchKernelGGL(init_state_kernel, one, one, 0, st, w.st, (int32_t)n, box);
     // K
-    if (!box.given) hipLaunchKernelGGL(svg::bbox_kernel, dim3(256), b, 0, st, xyz, n, w.st);
+    hipLaunchKernelGGL(svg::bbox_kernel, dim3(256), b, 0, st, xyz, n, w.st, box.given);
     hipLaunchKernelGGL(grid_key_kernel, g, b, 0, st, xyz, n, resolution, w.st, w.keys_a);
     F4L_LAUNCH_CHECK();
     size_t tb = w.prim_bytes;
@@ -993,9 +1232,9 @@ extern "C" int f4l_supervoxel_segment_device(const float *xyz, const double *nor
     sa.prop_key = w.prop_key; sa.parent = w.parent; sa.size = w.size; sa.bestu = w.bestu; sa.prop_u = w.prop_u; sa.la = w.la;
     sa.lb = w.lb; sa.dis = w.dis; sa.d0 = w.d0; sa.d1 = w.d1; sa.node = w.node;
     for (int r = 0; r < sched_rounds; ++r) {
-        hipLaunchKernelGGL(node_kernel, g, b, 0, st, sa);
+        hipLaunchKernelGGL(node_kernel, g, b, 0, st, sa, r);
         if (r >= 1) hipLaunchKernelGGL(table_clear_kernel, g, b, 0, st, sa, r);
-        if (r <= KNN_ROUNDS) hipLaunchKernelGGL(build_kernel<true>, g, dim3(BUILD_BLOCK), 0, st, sa, r);
+        if (r <= KNN_ROUNDS) hipLaunchKernelGGL(rows_kernel, g, b, 0, st, sa, r);
         else hipLaunchKernelGGL(build_kernel<false>, g, dim3(BUILD_BLOCK), 0, st, sa, r);
         for (int s = 0; s < SUBROUNDS; ++s) {
             hipLaunchKernelGGL(cand_kernel, ga, b, 0, st, sa, r, s);
