@@ -23,8 +23,11 @@ Extra objects on the JSON line:
                  (20 iters x 24 B + 24 B Kabsch read + 24 B row written = 528 B per source point) / its mean
                  duration measured with events on the launch stream; peak = 8 TB/s; traffic = HBM bytes per launch from
                  the committed rocprofv3 --pmc passes of this command (null when the kernel source changed since).
+                 `bound` and the `valu` sub-object (vector-issue cycles per launch against 256 CUs x 4 SIMDs x 2.4 GHz) come from
+                 the same committed passes: the kernel is LDS resident, HBM is not what bounds it.
   roofline_knn   the same for the exact kNN-30 kernel of the supervoxel stage (132 B per point), the kernel north_star
                  asks HBM numbers for (N = 1 only).
+  roofline_supervoxel  the same for the whole partition stage, f4l_supervoxel_parallel on 10 M points (160 B per point).
   extras         the other single-GPU BASELINE configs (C2 1 M, C3 10 M dense) and the float32 fast mode (N = 1 only).
   cpu_baseline   the C oracle (oracle/f4l_oracle.c, "port") timed on a bounded prefix of the same patches, 1 thread, and
                  with its patch loop on all host cores (rank 0, N = 1 only).
@@ -50,7 +53,11 @@ FIXED_BYTES_PER_PT = 48      # ... + Kabsch init read (24 B/pt) + displacement r
 KNN_BYTES_PER_PT = 132       # 12 B read + 30 x 4 B neighbour indices written
 MAX_ITER = 20
 MAX_CORR = 0.1
-KERNEL_SOURCES = ("icp.hip", "patch_grid.h", "f4l_device.h")
+SV_BYTES_PER_PT = 160        # kNN 132 B + normals 24 B + labels 4 B per point
+VALU_PEAK_GCYC = 256 * 4 * 2.4  # G SIMD-cycles of vector issue per second: 256 CUs x 4 SIMD-32 x 2.4 GHz (MI355X_MICROARCH.md); a wave64
+                                # float32 / integer instruction takes 2 of them, a float64 one 4
+KERNEL_SOURCES = {"icp": ("icp.hip", "patch_grid.h", "f4l_device.h"), "knn": ("knn.hip", "lane_topk.h", "topk.h", "f4l_device.h"),
+                  "supervoxel": ("supervoxel_gpu.hip", "sv_metric.h", "knn.hip", "lane_topk.h", "topk.h", "f4l_device.h")}
 
 
 def parse_args(argv=None):
@@ -197,14 +204,17 @@ def run_rank(args, world):
                                 "kernel_ms": round(icp_ms, 4), "algorithmic_bytes": alg_bytes,
                                 "note": "achieved = algorithmic bytes / kernel time (contract: events on the launch stream around one "
                                         "f4l_patch_loop = the icp_kernel launch of the bulk of the patches with the few large border patches' "
-                                        "launch beside it); the patch pair is LDS resident, so the kernel is bound by VALU issue (70 % busy), not by HBM"}
-            attach_traffic(line["roofline"], "icp_kernel_traffic.json", args.config if world == 1 else None, icp_ms)
+                                        "launch beside it); `bound` is what the committed counter passes show (profiles/README.md): the patch "
+                                        "pair is LDS resident, the measured HBM traffic is a fraction of the algorithmic bytes, and the "
+                                        "vector-issue share under `valu` is the larger of the two"}
+            attach_counters(line["roofline"], "icp_kernel_counters.json", "icp", args.config if world == 1 else None, icp_ms)
             if world == 1:
                 copy_gbs = measured_copy_gbs(torch, dev)
                 line["roofline"]["peak_copy_measured"] = round(copy_gbs, 1)
                 line["roofline"]["frac_of_copy_measured"] = round(achieved / copy_gbs, 5)
                 if args.extras:
                     line["roofline_knn"] = knn_roofline(torch, engine, d["src"][:10_000_000])
+                    line["roofline_supervoxel"] = supervoxel_roofline(torch, engine, d["src"][:10_000_000])
                     line["extras"] = extras(torch, engine, synthetic, prob, dev, args)
                 if args.cpu_seconds > 0:  # rank 0 at N = 1 only
                     line["cpu_baseline"] = cpu_baseline(prob, args.cpu_seconds)
@@ -254,29 +264,39 @@ class Problem:
                     cs=h(self.cs[:c1]), ct=h(self.ct[:c1]), coff=h(self.coff[:p_hi + 1]))
 
 
-def kernel_source_hash():
+def kernel_source_hash(which):
     h = hashlib.sha256()
-    for f in KERNEL_SOURCES:
+    for f in KERNEL_SOURCES[which]:
         h.update(open(os.path.join(ROOT, "fusion4landslide_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 
 
-def attach_traffic(roof, fname, workload, kernel_ms):
-    """HBM bytes per launch from the PMC counters cannot be collected from inside this process; they come from the committed
-    rocprofv3 --pmc passes of this same command (profiles/README.md).  Used only when the workload AND the kernel sources
-    are the ones the passes were taken on -- otherwise `traffic` stays null rather than going stale."""
+def attach_counters(roof, fname, which, workload, kernel_ms, units=None):
+    """HBM bytes and instruction counts cannot be collected from inside this process; they come from the committed rocprofv3
+    --pmc passes of the same call (profiles/README.md, tools/gpu/pmc_passes.py -> tools/make_roofline_profiles.py).  Used only when
+    the workload AND the kernel sources are the ones the passes were taken on -- otherwise `traffic` stays null rather than going
+    stale.  `units`: the file's figures are per `units_in_profile` points; this run processed `units` (same code path, other size)."""
     path = os.path.join(ROOT, "profiles", fname)
     if workload is None or not os.path.exists(path):
         return
     t = json.load(open(path))
     if t.get("workload") != workload:
         return
-    if t.get("kernel_source_sha256_16") != kernel_source_hash():
+    if t.get("kernel_source_sha256_16") != kernel_source_hash(which):
         roof["traffic_note"] = "profiles/%s was taken on other kernel sources; not reported" % fname
         return
-    roof["traffic"] = t["hbm_bytes_per_launch"]
+    scale = 1.0 if units is None else units / float(t["units_in_profile"])
+    roof["traffic"] = int(t["hbm_bytes_per_launch"] * scale)
     roof["traffic_source"] = t["source"]
-    roof["achieved_measured_traffic"] = round(t["hbm_bytes_per_launch"] / (kernel_ms * 1e-3) / 1e9, 2)
+    roof["achieved_measured_traffic"] = round(roof["traffic"] / (kernel_ms * 1e-3) / 1e9, 2)
+    roof["frac_measured_traffic"] = round(roof["achieved_measured_traffic"] / HBM_PEAK_GBS, 5)
+    v = t.get("valu")
+    if v:
+        cyc = v["issue_cycles_per_launch"] * scale
+        ach = cyc / (kernel_ms * 1e-3) / 1e9
+        roof["valu"] = {"achieved": round(ach, 1), "peak": VALU_PEAK_GCYC, "unit": "G SIMD-cycles/s of vector issue", "frac": round(ach / VALU_PEAK_GCYC, 4),
+                        "wave_insts_per_launch": int(v["insts_per_launch"] * scale), "f64_share": v["f64_share"], "weights": v["weights"]}
+        roof["bound"] = "valu" if roof["valu"]["frac"] > roof["frac_measured_traffic"] else "hbm"
 
 
 def measured_copy_gbs(torch, dev, gib=1.0, reps=10):
@@ -316,6 +336,31 @@ def knn_roofline(torch, engine, xyz, k=30):
     roof = {"bound": "hbm", "kernel": "knn_lanes_kernel (f4l_knn end to end: binning + search)", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None, "kernel_ms": round(1e3 * s, 4),
             "algorithmic_bytes": KNN_BYTES_PER_PT * n, "points": n, "k": k, "Mpts_per_s": round(n / s / 1e6, 2)}
+    attach_counters(roof, "knn_counters.json", "knn", "f4l_knn k=30", 1e3 * s, units=n)
+    return roof
+
+
+def supervoxel_roofline(torch, engine, xyz, k=30):
+    """The partition stage of the full path on (up to 10 M points of) the source epoch: f4l_supervoxel_parallel end to end -- exact
+    kNN-30 + PCA normals + the device segmentation -- at the path's own resolution rule (sqrt(3) x 10 x median point spacing,
+    src/coarse_to_fine_matching_base.py:2668-2671), timed with events on the launch stream; SURVEY.md 8(d) prices the stage at
+    132 + 24 + 4 = 160 B per point."""
+    import numpy as np
+    n = xyz.shape[0]
+    res = float(np.sqrt(3.0) * 10.0 * engine.median_resolution(xyz))
+    K = [0]
+
+    def run():
+        K[0] = engine.supervoxel_parallel(xyz, k, res)[1]
+    s = _timed(torch, run, 3)
+    ach = SV_BYTES_PER_PT * n / s / 1e9
+    roof = {"bound": "hbm", "kernel": "f4l_supervoxel_parallel (knn_lanes_kernel + the svg:: kernels of the segmentation, ~270 launches)",
+            "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None,
+            "kernel_ms": round(1e3 * s, 4), "algorithmic_bytes": SV_BYTES_PER_PT * n, "points": n, "k": k, "resolution_m": round(res, 4),
+            "supervoxels": int(K[0]), "Mpts_per_s": round(n / s / 1e6, 2),
+            "note": "a graph contraction: ~14 passes over edge lists that shrink from 30 edges per point; its passes wait for dependent "
+                    "scattered loads (profiles/README.md: TA 50 % busy, HBM 30 %, VALU 30 % in the largest of them)"}
+    attach_counters(roof, "supervoxel_counters.json", "supervoxel", "f4l_supervoxel_parallel k=30", 1e3 * s, units=n)
     return roof
 
 
@@ -355,7 +400,7 @@ def extras(torch, engine, synthetic, prob, dev, args):
     # configs[4] on one GPU: the whole hot path of a tile -- supervoxel partition (all on the device), patches, point matches,
     # Kabsch + 20-iteration ICP + rows, nearest-neighbour refinement -- end to end, stage by stage
     from fusion4landslide_amd import pipeline
-    for n_pts, cells in ((1_000_000, 45), (10_000_000, 142)):
+    for n_pts, cells in ((1_000_000, 45), (10_000_000, 142), (100_000_000, 450)):  # (the last one: BASELINE.json configs[4], C5_100M_full)
         c = synthetic.make_patches_device(n_pts, cells, 1.386, dev, seed=0)
         src, tgt = c["src"], c["tgt"]
         del c

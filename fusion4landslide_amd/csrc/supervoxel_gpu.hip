@@ -253,18 +253,62 @@ __global__ void count_distinct_kernel(const unsigned long long *__restrict__ sor
     }
 }
 
+// ---- the segmentation's own order of the points ----------------------------------------------------------------------------
+// Every pass gathers records of a point's neighbours; with the points in the caller's order (a scanner's, or no order at all)
+// each gather is a cache line of its own from HBM: 10 KB of traffic per point in all.  The segmentation therefore works on a copy
+// sorted along a Z-curve of (x, y) cells of half the resolution: neighbours share lines.  Everything that DECIDES by index --
+// the coin of a sub-round, the smallest index among equal offers, the order of the labels -- uses the caller's index of a point
+// (`orig`), so the result is the one the caller's order gives.
+__device__ __forceinline__ unsigned int spread16(unsigned int v) {
+    v &= 0xffffu;
+    v = (v | (v << 8)) & 0x00ff00ffu;
+    v = (v | (v << 4)) & 0x0f0f0f0fu;
+    v = (v | (v << 2)) & 0x33333333u;
+    v = (v | (v << 1)) & 0x55555555u;
+    return v;
+}
+__global__ void order_key_kernel(const float *__restrict__ xyz, int64_t n, double resolution, const State *st, int identity,
+                                 unsigned int *__restrict__ keys, int32_t *__restrict__ ids) {
+    const float x0 = ord2f(st->pb[0]), y0 = ord2f(st->pb[1]);
+    const float ex = ord2f(st->pb[3]) - x0, ey = ord2f(st->pb[4]) - y0, e = ex > ey ? ex : ey;
+    float cell = (float)(0.5 * resolution);
+    if (e / cell > 65535.f) cell = e / 65535.f;
+    const float inv = 1.f / cell;
+    SV_FOR(i, n) {
+        float cx = (xyz[3 * i] - x0) * inv, cy = (xyz[3 * i + 1] - y0) * inv;
+        cx = cx < 0.f ? 0.f : (cx > 65535.f ? 65535.f : cx);
+        cy = cy < 0.f ? 0.f : (cy > 65535.f ? 65535.f : cy);
+        keys[i] = identity ? (unsigned int)i : (spread16((unsigned int)cx) | (spread16((unsigned int)cy) << 1));
+        ids[i] = (int32_t)i;
+    }
+}
+__global__ void order_apply_kernel(const float *__restrict__ xyz, const double *__restrict__ nrm, const int32_t *__restrict__ orig, int64_t n,
+                                   float *__restrict__ xyz_p, double *__restrict__ nrm_p, int32_t *__restrict__ pos_of) {
+    SV_FOR(i, n) {
+        const int64_t o = orig[i];
+        pos_of[o] = (int32_t)i;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) { xyz_p[3 * i + d] = xyz[3 * o + d]; nrm_p[3 * i + d] = nrm[3 * o + d]; }
+    }
+}
 // ---- neighbour lists, transposed ----------------------------------------------------------------------------------------
 // The passes that walk a point's neighbour list with one lane per point (lambda0's minimum metric, every sweep of the
 // exchange) would read the row-major lists [n][k] with a stride of k words between lanes: 64 cache lines per load
 // instruction, the same lines again for each of the k steps, and an L1 that 32 waves thrash.  They read knnT[j * n + i]
 // instead: neighbour j of 64 consecutive points is 256 contiguous bytes.  One tiled transpose through LDS, 0.08 ms per 1 M
 // points (lambda0's pass 0.83 -> 0.4 ms, a full sweep 0.5 -> 0.3 ms).
-__global__ __launch_bounds__(256) void knn_transpose_kernel(const int32_t *__restrict__ knn, int64_t n, int k, int32_t *__restrict__ knnT) {
+__global__ __launch_bounds__(256) void knn_transpose_kernel(const int32_t *__restrict__ knn, const int32_t *__restrict__ orig,
+                                                            const int32_t *__restrict__ pos_of, int64_t n, int k, int32_t *__restrict__ knnT) {
     __shared__ int32_t tile[64 * 65];
     const int tid = (int)threadIdx.x;
     for (int64_t base = (int64_t)blockIdx.x * 64; base < n; base += (int64_t)gridDim.x * 64) {
         const int np = n - base < 64 ? (int)(n - base) : 64;
-        for (int t = tid; t < np * k; t += 256) tile[(t / k) * 65 + t % k] = knn[base * k + t];  // (rows padded to 65 words)
+        // the row of the point at place base + p is the caller's row orig[base + p]; its entries become places
+        for (int t = tid; t < np * k; t += 256) {
+            const int p = t / k, j = t % k;
+            const int32_t q = knn[(int64_t)orig[base + p] * k + j];
+            tile[p * 65 + j] = (q < 0 || (int64_t)q >= n) ? -1 : pos_of[q];  // (rows padded to 65 words)
+        }
         __syncthreads();
         for (int t = tid; t < 64 * k; t += 256) {
             const int j = t >> 6, p = t & 63;
@@ -386,14 +430,15 @@ __device__ __forceinline__ Quant quant_of(const State *st) {
 struct SegArgs {
     const float *xyz;
     const double *nrm;
-    const int32_t *knn, *knnT;  // neighbour lists, row major and transposed
+    const int32_t *knnT;        // neighbour lists, transposed
+    const int32_t *orig;        // the caller's index of the point at every place (the segmentation works on a spatially sorted copy)
     int64_t n;
     int k;
     double resolution;
     State *st;
     unsigned long long *edges_a, *edges_b, *table, *akey, *bestm, *prop_key;
     double *am, *dis;
-    int32_t *parent, *size, *bestu, *prop_u, *la, *lb;
+    int32_t *parent, *size, *bestu, *prop_u, *prop_v, *la, *lb;
     Node *node;
     unsigned char *d0, *d1;
 };
@@ -448,23 +493,20 @@ __global__ void table_clear_kernel(SegArgs a, int r) {
 #define SVX_ITEMS 4
 #endif
 constexpr int BUILD_ITEMS = SVX_ITEMS;   // edges per thread and trip: four independent chains of dependent loads in flight, a quarter of the barriers and counter updates
-template <bool FROM_KNN>
 __device__ __forceinline__ void build_body(const SegArgs &a, int r) {
     State *st = a.st;
     const unsigned long long ne_in = list_in_count(a, r);
     const unsigned long long ts = table_size(ne_in);
     const double lambda = lambda_of(st, r), resolution = a.resolution;
-    const unsigned long long *__restrict__ lin = FROM_KNN ? nullptr : list_of(a, r - 1);
+    const unsigned long long *__restrict__ lin = list_of(a, r - 1);
     unsigned long long *__restrict__ lout = list_of(a, r);
     const float *__restrict__ xyz = a.xyz;
-    const double inv_k = 1.0 / (double)a.k;
     const unsigned int ts32 = (unsigned int)ts;
     // the distance term of the metric alone against lambda, c * d * sizes[v] > lambda, first in float with a margin a thousand
     // times the float error (the few edges inside the margin take the exact test in double)
     const float cfs = (float)(0.4 / resolution) * quant_of(st).step, lambda_hi = (float)(lambda * 1.001);  // (cfs: c times the quantisation step)
     const double cd = 0.4 / resolution;
     const bool emit = r >= KNN_ROUNDS;  // this round writes a list (and passes the device-wide filter)
-    const double lambda0 = st->lambda0;
     __shared__ AppendScratch scratch;
     __shared__ unsigned long long wave_filter[16 * WAVE_FILTER];
     for (int t = (int)threadIdx.x; t < 16 * WAVE_FILTER; t += (int)blockDim.x) wave_filter[t] = DEAD;
@@ -488,22 +530,9 @@ __device__ __forceinline__ void build_body(const SegArgs &a, int r) {
             m[j] = 0.0;
             u[j] = v[j] = 0;
             if (live[j]) {
-                if (FROM_KNN) {
-                    // e / k without the 64-bit integer division (~100 instructions): the double quotient is within one of it
-                    long long i = (long long)((double)e * inv_k);
-                    i -= (unsigned long long)i * (unsigned long long)a.k > e ? 1 : 0;
-                    i += ((unsigned long long)i + 1ULL) * (unsigned long long)a.k <= e ? 1 : 0;
-                    const int32_t q = a.knn[e];
-                    live[j] = q != (int32_t)i && q >= 0 && (int64_t)q < a.n;
-                    // (round 0: a point whose smallest metric is not below lambda0 has no active edge -- half of the points)
-                    if (r == 0 && !(a.dis[i] < lambda0)) live[j] = false;
-                    u[j] = (int32_t)i;
-                    v[j] = live[j] ? q : (int32_t)i;
-                } else {
-                    const unsigned long long old = lin[e];
-                    u[j] = (int32_t)(old >> 32);
-                    v[j] = (int32_t)(old & 0xffffffffULL);
-                }
+                const unsigned long long old = lin[e];
+                u[j] = (int32_t)(old >> 32);
+                v[j] = (int32_t)(old & 0xffffffffULL);
             }
         }
         // ... re-pointed (the records of the round: one load per end gives representative, size and position)
@@ -586,10 +615,9 @@ __device__ __forceinline__ void build_body(const SegArgs &a, int r) {
         }
     }
 }
-template <bool FROM_KNN>
 __global__ __launch_bounds__(1024) void build_kernel(SegArgs a, int r) {
     if (!fusing(a.st)) return;
-    build_body<FROM_KNN>(a, r);
+    build_body(a, r);
 }
 
 // ---- rounds 0 .. KNN_ROUNDS: straight from the neighbour lists, one lane per point ------------------------------------------------
@@ -763,7 +791,7 @@ __device__ __forceinline__ bool offer_of(const SegArgs &a, unsigned long long e,
     const unsigned long long key = a.akey[e];
     u = (int32_t)(key >> 32);
     v = (int32_t)(key & 0xffffffffULL);
-    if (!heads(u, rho) || heads(v, rho)) return false;
+    if (!heads(a.orig[u], rho) || heads(a.orig[v], rho)) return false;  // (the coins are drawn on the CALLER's indices)
     const int32_t pu = a.parent[u], pv = a.parent[v], sz = a.size[v];  // (loaded together, not one behind the other)
     m = a.am[e];
     return pu == u && pv == v && lambda - (double)sz * m > 0.0;  // :147-149 `improvement > 0.0`
@@ -813,7 +841,7 @@ __device__ __forceinline__ void cand2_body(const SegArgs &a, int r, int s) {
     SV_FOR(i, n_off) {
         const unsigned long long e = offers[i], key = a.akey[e];
         const int32_t u = (int32_t)(key >> 32), v = (int32_t)(key & 0xffffffffULL);
-        if (a.bestm[v] == d2ord(a.am[e])) first += atomicMin(&a.bestu[v], u) == NONE ? 1 : 0;
+        if (a.bestm[v] == d2ord(a.am[e])) first += atomicMin(&a.bestu[v], a.orig[u]) == NONE ? 1 : 0;  // (ties: the smallest index of the caller's)
     }
     block_add(&st->n_prop[rho], first, false);
 }
@@ -830,8 +858,9 @@ __device__ __forceinline__ void apply_body(const SegArgs &a, int r, int s) {
     SV_FOR(i, n_off) {
         const unsigned long long e = offers[i], key = a.akey[e];
         const int32_t u = (int32_t)(key >> 32), v = (int32_t)(key & 0xffffffffULL);
-        if (a.bestu[v] == u && a.bestm[v] == d2ord(a.am[e]) &&
-            atomicCAS(&a.bestu[v], u, NONE) == u) {  // (the claim lets one of several equal edges through, and leaves bestu clean for the next sub-round)
+        const int32_t ou = a.orig[u];
+        if (a.bestu[v] == ou && a.bestm[v] == d2ord(a.am[e]) &&
+            atomicCAS(&a.bestu[v], ou, NONE) == ou) {  // (the claim lets one of several equal edges through, and leaves bestu clean for the next sub-round)
             a.bestm[v] = ~0ULL;
             a.parent[v] = u;                   // Link(v, u), disjoint_set.h:77-85
             atomicAdd(&a.size[u], a.size[v]);  // sizes[i] += sizes[j], :153
@@ -875,7 +904,8 @@ __global__ __launch_bounds__(1024) void overflow_collect_kernel(SegArgs a) {
             v = (int32_t)(key & 0xffffffffULL);
             m = a.am[e];
             // (the list may hold an edge twice: the claim lets one of them through)
-            has = a.bestu[v] == u && a.bestm[v] == d2ord(m) && atomicCAS(&a.bestu[v], u, NONE) == u;
+            const int32_t ou = a.orig[u];
+            has = a.bestu[v] == ou && a.bestm[v] == d2ord(m) && atomicCAS(&a.bestu[v], ou, NONE) == ou;
         }
         const bool t0[1] = {has}, t1[1] = {false};
         unsigned long long at_[1], unused[1];
@@ -883,8 +913,9 @@ __global__ __launch_bounds__(1024) void overflow_collect_kernel(SegArgs a) {
         const unsigned long long at = at_[0];
         if (has) {  // (one winning edge per proposing v: at most n entries)
             const double loss = (double)a.size[v] * m;
-            a.prop_key[at] = ((unsigned long long)f2ord((float)loss) << 32) | (unsigned int)v;
+            a.prop_key[at] = ((unsigned long long)f2ord((float)loss) << 32) | (unsigned int)a.orig[v];  // (ties by the caller's index)
             a.prop_u[at] = u;
+            a.prop_v[at] = v;
         }
     }
 }
@@ -922,7 +953,7 @@ __global__ __launch_bounds__(1024) void overflow_select_kernel(State *st, const 
     if (tid == 0) st->tau_excl = s_prefix + 1ULL;  // keys are unique (index in the low word)
 }
 __global__ void overflow_apply_kernel(State *st, const unsigned long long *__restrict__ prop_key, const int32_t *__restrict__ prop_u,
-                                      int32_t *__restrict__ parent, int32_t *__restrict__ size) {
+                                      const int32_t *__restrict__ prop_v, int32_t *__restrict__ parent, int32_t *__restrict__ size) {
     if (!st->overflow) return;
     const int a = (int)st->n_list;
     const unsigned long long tau = st->tau_excl;
@@ -930,7 +961,7 @@ __global__ void overflow_apply_kernel(State *st, const unsigned long long *__res
     SV_FOR(i, a) {
         const unsigned long long key = prop_key[i];
         if (key >= tau) continue;
-        const int32_t v = (int32_t)(key & 0xffffffffULL), u = prop_u[i];
+        const int32_t v = prop_v[i], u = prop_u[i];
         parent[v] = u;
         atomicAdd(&size[u], size[v]);
         ++dropped;
@@ -1040,16 +1071,17 @@ __device__ __forceinline__ void sweep_body(const SegArgs &a, int s) {
     if (__ballot(any) != 0ULL && lane_id() == 0) atomicOr(&st->sw_changed[s], 1);
 }
 __global__ void sweep_kernel(SegArgs a, int s) { sweep_body(a, s); }
-__global__ void root_flag_kernel(int64_t n, const int32_t *__restrict__ parent, int32_t *__restrict__ flag) {
-    SV_FOR(i, n) flag[i] = parent[i] == (int32_t)i ? 1 : 0;
+__global__ void root_flag_kernel(int64_t n, const int32_t *__restrict__ parent, const int32_t *__restrict__ orig, int32_t *__restrict__ flag) {
+    SV_FOR(i, n) flag[orig[i]] = parent[i] == (int32_t)i ? 1 : 0;  // (flag and rank live in the caller's index space)
 }
-__global__ void relabel_kernel(State *st, int64_t n, const int32_t *__restrict__ l0, const int32_t *__restrict__ l1,
+__global__ void relabel_kernel(State *st, int64_t n, const int32_t *__restrict__ l0, const int32_t *__restrict__ l1, const int32_t *__restrict__ orig,
                                const int32_t *__restrict__ flag, const int32_t *__restrict__ rank, int32_t *__restrict__ labels_out,
                                int32_t *__restrict__ reps_out, int32_t *__restrict__ info_out) {
     const int32_t *__restrict__ lab = (st->sweeps_done & 1) ? l1 : l0;
     SV_FOR(i, n) {
-        labels_out[i] = rank[lab[i]];  // :241-247: position of the representative in ascending index order
-        if (reps_out && flag[i]) reps_out[rank[i]] = (int32_t)i;
+        const int32_t oi = orig[i];
+        labels_out[oi] = rank[orig[lab[i]]];  // :241-247: position of the representative in ascending index order
+        if (reps_out && flag[oi]) reps_out[rank[oi]] = oi;
     }
     if (blockIdx.x == 0 && threadIdx.x == 0 && info_out) {
         bool on, full;
@@ -1088,7 +1120,7 @@ __global__ __launch_bounds__(1024) void segment_rest_kernel(SegArgs a, int first
             if (r >= 1) table_clear_body(a, r);
             wg_sync();
             if (r <= KNN_ROUNDS) rows_body(a, r);
-            else build_body<false>(a, r);
+            else build_body(a, r);
             wg_sync();
             for (int s = 0; s < SUBROUNDS; ++s) {
                 if (!fusing(st)) break;
@@ -1116,7 +1148,10 @@ struct Ws {
     State *st;
     unsigned long long *keys_a, *keys_b, *edges_a, *edges_b, *table, *akey, *bestm, *prop_key;
     double *am, *dis, *dis_sorted;
-    int32_t *parent, *size, *bestu, *prop_u, *la, *lb, *flag, *rank, *knnT;
+    int32_t *parent, *size, *bestu, *prop_u, *la, *lb, *flag, *rank, *knnT, *orig, *pos_of, *ids_in;
+    unsigned int *okey_a, *okey_b;
+    float *xyz_p;
+    double *nrm_p;
     Node *node;
     unsigned char *d0, *d1;
     void *prim;
@@ -1130,8 +1165,12 @@ static int layout(int64_t n, int k, Ws &w, unsigned char *base) {
     if (rocprim::radix_sort_keys(nullptr, sort_u, u0, u0, (size_t)n, 0, 64, 0, false) != hipSuccess) return F4L_EHIP;
     if (rocprim::radix_sort_keys(nullptr, sort_d, f0, f0, (size_t)n, 0, 64, 0, false) != hipSuccess) return F4L_EHIP;
     if (rocprim::exclusive_scan(nullptr, scan_b, i0, i0, 0, (size_t)n, rocprim::plus<int32_t>(), 0, false) != hipSuccess) return F4L_EHIP;
+    size_t sort_p = 0;
+    unsigned int *k0 = nullptr;
+    if (rocprim::radix_sort_pairs(nullptr, sort_p, k0, k0, i0, i0, (size_t)n, 0, 32, 0, false) != hipSuccess) return F4L_EHIP;
     size_t prim = sort_u > sort_d ? sort_u : sort_d;
     prim = prim > scan_b ? prim : scan_b;
+    prim = prim > sort_p ? prim : sort_p;
     size_t o = 0;
     auto carve = [&](size_t bytes) { size_t at = o; o += align_up(bytes); return base ? base + at : (unsigned char *)nullptr; };
     const size_t ne = (size_t)n * (size_t)k;
@@ -1158,6 +1197,14 @@ static int layout(int64_t n, int k, Ws &w, unsigned char *base) {
     w.rank = (int32_t *)carve((size_t)n * 4);
     w.knnT = (int32_t *)carve(ne * 4);
     w.node = (Node *)carve((size_t)n * sizeof(Node));
+    w.orig = (int32_t *)carve((size_t)n * 4);
+    w.pos_of = (int32_t *)carve((size_t)n * 4);
+    w.xyz_p = (float *)carve((size_t)n * 12);
+    w.nrm_p = (double *)carve((size_t)n * 24);
+    // (sort keys and unsorted ids of the ordering: dead before the label buffers are first used)
+    w.okey_a = (unsigned int *)w.la;
+    w.okey_b = (unsigned int *)w.lb;
+    w.ids_in = w.rank;
     w.d0 = carve((size_t)n);
     w.d1 = carve((size_t)n);
     w.prim = carve(prim);
@@ -1202,13 +1249,21 @@ extern "C" int f4l_supervoxel_segment_device(const float *xyz, const double *nor
     hipLaunchKernelGGL(init_state_kernel, one, one, 0, st, w.st, (int32_t)n, box);
     // K
     hipLaunchKernelGGL(svg::bbox_kernel, dim3(256), b, 0, st, xyz, n, w.st, box.given);
-    hipLaunchKernelGGL(grid_key_kernel, g, b, 0, st, xyz, n, resolution, w.st, w.keys_a);
+    // the segmentation's own order of the points (F4L_SV_NO_REORDER: the caller's, for measurements)
+    hipLaunchKernelGGL(order_key_kernel, g, b, 0, st, xyz, n, resolution, w.st, getenv("F4L_SV_NO_REORDER") ? 1 : 0, w.okey_a, w.ids_in);
     F4L_LAUNCH_CHECK();
     size_t tb = w.prim_bytes;
+    F4L_HIP_CHECK(rocprim::radix_sort_pairs(w.prim, tb, w.okey_a, w.okey_b, w.ids_in, w.orig, (size_t)n, 0, 32, st, false));
+    hipLaunchKernelGGL(order_apply_kernel, g, b, 0, st, xyz, normals, w.orig, n, w.xyz_p, w.nrm_p, w.pos_of);
+    xyz = w.xyz_p;  // (from here on: the sorted copies)
+    normals = w.nrm_p;
+    hipLaunchKernelGGL(grid_key_kernel, g, b, 0, st, xyz, n, resolution, w.st, w.keys_a);
+    F4L_LAUNCH_CHECK();
+    tb = w.prim_bytes;
     F4L_HIP_CHECK(rocprim::radix_sort_keys(w.prim, tb, w.keys_a, w.keys_b, (size_t)n, 0, 64, st, false));
     hipLaunchKernelGGL(count_distinct_kernel, dim3(256), b, 0, st, w.keys_b, n, w.st);
     // lambda0
-    hipLaunchKernelGGL(knn_transpose_kernel, g, b, 0, st, knn, n, k, w.knnT);
+    hipLaunchKernelGGL(knn_transpose_kernel, g, b, 0, st, knn, w.orig, w.pos_of, n, k, w.knnT);
     hipLaunchKernelGGL(min_metric_kernel, g, b, 0, st, xyz, normals, w.knnT, n, k, resolution, w.dis);
     F4L_LAUNCH_CHECK();
     tb = w.prim_bytes;
@@ -1227,15 +1282,15 @@ extern "C" int f4l_supervoxel_segment_device(const float *xyz, const double *nor
         if (sscanf(e, "%d,%d", &a, &c) == 2 && a >= 0 && a <= LAMBDA_ROUNDS && c >= 0 && c <= SWEEPS) { sched_rounds = a; sched_sweeps = c; }
     }
     SegArgs sa;
-    sa.xyz = xyz; sa.nrm = normals; sa.knn = knn; sa.knnT = w.knnT; sa.n = n; sa.k = k; sa.resolution = resolution; sa.st = w.st;
+    sa.xyz = xyz; sa.nrm = normals; sa.orig = w.orig; sa.knnT = w.knnT; sa.n = n; sa.k = k; sa.resolution = resolution; sa.st = w.st;
     sa.edges_a = w.edges_a; sa.edges_b = w.edges_b; sa.table = w.table; sa.akey = w.akey; sa.am = w.am; sa.bestm = w.bestm;
-    sa.prop_key = w.prop_key; sa.parent = w.parent; sa.size = w.size; sa.bestu = w.bestu; sa.prop_u = w.prop_u; sa.la = w.la;
+    sa.prop_key = w.prop_key; sa.parent = w.parent; sa.size = w.size; sa.bestu = w.bestu; sa.prop_u = w.prop_u; sa.prop_v = w.flag; sa.la = w.la;
     sa.lb = w.lb; sa.dis = w.dis; sa.d0 = w.d0; sa.d1 = w.d1; sa.node = w.node;
     for (int r = 0; r < sched_rounds; ++r) {
         hipLaunchKernelGGL(node_kernel, g, b, 0, st, sa, r);
         if (r >= 1) hipLaunchKernelGGL(table_clear_kernel, g, b, 0, st, sa, r);
         if (r <= KNN_ROUNDS) hipLaunchKernelGGL(rows_kernel, g, b, 0, st, sa, r);
-        else hipLaunchKernelGGL(build_kernel<false>, g, dim3(BUILD_BLOCK), 0, st, sa, r);
+        else hipLaunchKernelGGL(build_kernel, g, dim3(BUILD_BLOCK), 0, st, sa, r);
         for (int s = 0; s < SUBROUNDS; ++s) {
             hipLaunchKernelGGL(cand_kernel, ga, b, 0, st, sa, r, s);
             hipLaunchKernelGGL(cand2_kernel, ga, b, 0, st, sa, r, s);
@@ -1246,7 +1301,7 @@ extern "C" int f4l_supervoxel_segment_device(const float *xyz, const double *nor
     if (sched_rounds < LAMBDA_ROUNDS) hipLaunchKernelGGL(segment_rest_kernel, one, dim3(1024), 0, st, sa, sched_rounds, 0);
     hipLaunchKernelGGL(overflow_collect_kernel, dim3(256), dim3(1024), 0, st, sa);
     hipLaunchKernelGGL(overflow_select_kernel, one, dim3(1024), 0, st, w.st, w.prop_key);
-    hipLaunchKernelGGL(overflow_apply_kernel, g, b, 0, st, w.st, w.prop_key, w.prop_u, w.parent, w.size);
+    hipLaunchKernelGGL(overflow_apply_kernel, g, b, 0, st, w.st, w.prop_key, w.prop_u, w.flag, w.parent, w.size);  // (prop_v lives in `flag`, idle until the relabelling)
     // labels and the boundary exchange
     hipLaunchKernelGGL(flatten_kernel, g, b, 0, st, n, w.parent);
     hipLaunchKernelGGL(labels_init_kernel, g, b, 0, st, xyz, normals, resolution, n, w.parent, w.la, w.lb, w.dis);
@@ -1256,11 +1311,11 @@ extern "C" int f4l_supervoxel_segment_device(const float *xyz, const double *nor
     if (sched_sweeps < SWEEPS) hipLaunchKernelGGL(segment_rest_kernel, one, dim3(1024), 0, st, sa, -1, sched_sweeps);
     F4L_LAUNCH_CHECK();
     // relabel 0..K-1 in ascending order of the representative's index
-    hipLaunchKernelGGL(root_flag_kernel, g, b, 0, st, n, w.parent, w.flag);
+    hipLaunchKernelGGL(root_flag_kernel, g, b, 0, st, n, w.parent, w.orig, w.flag);
     F4L_LAUNCH_CHECK();
     tb = w.prim_bytes;
     F4L_HIP_CHECK(rocprim::exclusive_scan(w.prim, tb, w.flag, w.rank, 0, (size_t)n, rocprim::plus<int32_t>(), st, false));
-    hipLaunchKernelGGL(relabel_kernel, g, b, 0, st, w.st, n, w.la, w.lb, w.flag, w.rank, labels_out, reps_out, info_out);
+    hipLaunchKernelGGL(relabel_kernel, g, b, 0, st, w.st, n, w.la, w.lb, w.orig, w.flag, w.rank, labels_out, reps_out, info_out);
     F4L_LAUNCH_CHECK();
     return F4L_OK;
 }

@@ -21,10 +21,11 @@ from . import engine
 
 
 def full_path(src, tgt, k=30, icp_threshold=0.1, voxel_size=0.0, partition="parallel", max_iter=30, fixed_iters=False,
-              search="f64", resolution=None):
+              search="f64", resolution=None, keep_inputs=False):
     """src, tgt: (n, 3) float32 CUDA tensors (two epochs of one tile).  Returns dict(rows (n_src, 6) dense displacement
     rows in patch order, sparse (m, 6), labels, K, T, fitness, rmse, iters, order (patch-contiguous source order),
-    resolution, stage_ms {name: milliseconds})."""
+    resolution, stage_ms {name: milliseconds}[, with keep_inputs: what the per-patch loop was given -- patch_src, patch_tgt (the
+    two epochs in patch order), corr_src, corr_ref, corr_off (the point matches of every patch)])."""
     torch = engine.require_gpu()
     stages, marks = [], []
 
@@ -43,14 +44,14 @@ def full_path(src, tgt, k=30, icp_threshold=0.1, voxel_size=0.0, partition="para
     mark("median_resolution")
     labels, K = (engine.supervoxel_parallel if partition == "parallel" else engine.supervoxel)(src, k, float(resolution))
     mark("supervoxel_partition")
-    st = _patches_and_registration(torch, src, tgt, labels, None, K, med, icp_threshold, max_iter, fixed_iters, search, mark)
+    st = _patches_and_registration(torch, src, tgt, labels, None, K, med, icp_threshold, max_iter, fixed_iters, search, mark, keep_inputs)
     torch.cuda.synchronize()
     ms = {stages[i]: marks[i - 1].elapsed_time(marks[i]) for i in range(1, len(stages))}
     ms["total"] = marks[0].elapsed_time(marks[-1])
     return dict(labels=labels, K=K, resolution=float(resolution), stage_ms=ms, **st)
 
 
-def _patches_and_registration(torch, src, tgt, labels, tgt_nn, K, med, icp_threshold, max_iter, fixed_iters, search, mark):
+def _patches_and_registration(torch, src, tgt, labels, tgt_nn, K, med, icp_threshold, max_iter, fixed_iters, search, mark, keep_inputs=False):
     """The stages after the partition, on one device: patches of both epochs (a target point joins the patch of its nearest
     source point: `tgt_nn` (m,) int64 indices into `src` when the caller has them already, else f4l_nn_query), point matches,
     the per-patch loop, the refinement.  Returns dict(rows, sparse, T, fitness, rmse, iters, order, src_off, tgt_off)."""
@@ -82,8 +83,11 @@ def _patches_and_registration(torch, src, tgt, labels, tgt_nn, K, med, icp_thres
     nn2, sparse = engine.nn_refine(ps, off_s, pt, off_t, out["T"], thr, max_tgt_patch=max_t)
     sparse = sparse[nn2 >= 0]
     mark("nn_refine")
-    return dict(rows=out["rows"], sparse=sparse, T=out["T"], fitness=out["fitness"], rmse=out["rmse"], iters=out["iters"],
-                order=order_s, src_off=off_s, tgt_off=off_t)
+    res = dict(rows=out["rows"], sparse=sparse, T=out["T"], fitness=out["fitness"], rmse=out["rmse"], iters=out["iters"],
+               order=order_s, src_off=off_s, tgt_off=off_t)
+    if keep_inputs:
+        res.update(patch_src=ps, patch_tgt=pt, corr_src=cs, corr_ref=ct, corr_off=coff)
+    return res
 
 
 def full_path_slabs(local_src, local_gid, local_tgt, dist, rank, world, halo, resolution, k=30, icp_threshold=0.1, max_iter=30,

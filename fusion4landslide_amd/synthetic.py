@@ -23,6 +23,9 @@ CONFIGS = {
     "C2x16_16M_32k": dict(n=16_000_000, cells=180, resolution=1.386),
     "C3_10M_20k": dict(n=10_000_000, cells=141, resolution=0.1),
     "C4_50M_100k": dict(n=50_000_000, cells=316, resolution=1.386),
+    # BASELINE.json configs[4]: the full hot path (supervoxel partition + per-patch loop) on 100 M points per epoch, C2's density;
+    # `cells` only sizes the cloud and its block motion field here -- the patches are the supervoxels the path itself cuts
+    "C5_100M_full": dict(n=100_000_000, cells=450, resolution=1.386),
 }
 
 

@@ -1,4 +1,4 @@
-"""GPU tests at BASELINE.json's full sizes (configs[2] "C3_10M_20k", configs[3] "C4_50M_100k"): the oracle cannot run whole
+"""GPU tests at BASELINE.json's full sizes (configs[2] "C3_10M_20k", configs[3] "C4_50M_100k", configs[4] "C5_100M_full"): the oracle cannot run whole
 clouds of that size in seconds, so each test checks size-independent properties of the whole result and a bounded sample
 of patches (>= 24, the largest patch among them) against the CPU oracle in float64 mode, through the same fused launch
 `bench.py` times (f4l_patch_loop: Kabsch init -> 20 fixed ICP iterations -> displacement rows).
@@ -166,3 +166,88 @@ def test_full_size_C3_10M_20k_dense(eng):
     big = np.argsort(-np.maximum(size_s, size_t))[:3]  # the largest patches (targets beyond 4096)
     pick = np.unique(np.r_[np.linspace(0, d["P"] - 1, 24).astype(int), big, rng.integers(0, d["P"], 5)])
     _check_sample_against_oracle(d, cs, ct, coff, out, pick)
+
+
+def _occupied_cells_device(xyz, res):
+    """grid_sample.h:48-68 on the device (double arithmetic like the reference): the number of occupied cells of the resolution
+    grid anchored at the cloud's bounding-box minimum."""
+    mn = xyz.min(dim=0).values.double()
+    mx = xyz.max(dim=0).values.double()
+    size = ((mx - mn) / res + 1).to(torch.int64)
+    key = torch.zeros(xyz.shape[0], dtype=torch.int64, device=xyz.device)
+    for d in range(3):
+        c = torch.clamp(((xyz[:, d].double() - mn[d]) / res).to(torch.int64), min=0)
+        c = torch.minimum(c, size[d] - 1)
+        key = key * size[d] + c
+    return int(torch.unique(key).shape[0])
+
+
+def test_full_size_C5_100M_full_path(eng):
+    """BASELINE.json configs[4] on ONE GPU: the whole hot path -- median resolution, supervoxel partition on the device,
+    patches, point matches, per-patch Kabsch + 20-iteration ICP + rows, nearest-neighbour refinement -- on 100 M points per
+    epoch (pipeline.full_path, what bench.py's `full_path_100M` extra times).  Size-independent properties of the whole result,
+    and >= 30 sampled patches of its per-patch stage against the CPU oracle to 1e-9 m."""
+    from fusion4landslide_amd import pipeline, synthetic
+    c = synthetic.CONFIGS["C5_100M_full"]
+    n = c["n"]
+    dev = torch.device("cuda")
+    d = synthetic.make_patches_device(n, c["cells"], c["resolution"], dev, seed=0)
+    src, tgt = d["src"], d["tgt"]
+    del d
+    torch.cuda.empty_cache()
+    r = pipeline.full_path(src, tgt, max_iter=MAX_ITER, fixed_iters=True, keep_inputs=True)
+    K, labels = r["K"], r["labels"]
+    # the partition: K = occupied cells of the resolution grid exactly (grid_sample.h:48-68), labels 0 .. K-1 all non-empty
+    assert K == _occupied_cells_device(src, r["resolution"])
+    cnt = torch.bincount(labels.to(torch.int64), minlength=K)
+    assert cnt.shape[0] == K and int(cnt.min()) > 0 and int(labels.min()) == 0 and int(cnt.sum()) == n
+    off = r["src_off"]
+    assert off.shape[0] == K + 1 and int(off[-1]) == n and torch.equal(off[1:] - off[:-1], cnt)
+    # the per-patch stage: every patch ran its 20 iterations; rotations orthonormal; fitness / rmse in range; rows = T s
+    T = r["T"]
+    assert bool((r["iters"] == MAX_ITER).all())
+    R = T[:, :3, :3]
+    fit, rmse = r["fitness"], r["rmse"]
+    ncorr = r["corr_off"][1:] - r["corr_off"][:-1]
+    ortho = (R @ R.transpose(1, 2) - torch.eye(3, dtype=torch.float64, device=dev)).abs().amax(dim=(1, 2))
+    # (of 1.67 M supervoxels a handful start from a degenerate fit -- e.g. seven matches that all name the same target point:
+    #  cross-covariance zero, any rotation is "the" Kabsch answer -- and keep 1e-8 of non-orthonormality; everything well posed is
+    #  orthonormal to rounding)
+    posed = (fit >= 0.5) & (ncorr >= 10)
+    assert float(ortho[posed].max()) < 1e-12 and float(ortho.max()) < 1e-6 and float((ortho > 1e-12).double().mean()) < 1e-4
+    assert float((torch.linalg.det(R) - 1.0).abs().max()) < 1e-6
+    assert bool(((fit >= 0) & (fit <= 1)).all()) and bool((rmse <= MAX_CORR).all()) and bool(torch.isfinite(T).all())
+    assert float(fit.mean()) > 0.5
+    rows, ps = r["rows"], r["patch_src"]
+    assert rows.shape == (n, 6) and torch.equal(rows[:, :3], ps) and torch.equal(ps, src[r["order"].to(torch.int64)])
+    pid = torch.repeat_interleave(torch.arange(K, device=dev), cnt, output_size=n)
+    worst, lo = 0.0, 0
+    while lo < n:
+        hi = min(n, lo + 5_000_000)
+        Tp = T[pid[lo:hi]]
+        q = torch.einsum("nij,nj->ni", Tp[:, :3, :3], ps[lo:hi].to(torch.float64)) + Tp[:, :3, 3]
+        worst = max(worst, float((q - rows[lo:hi, 3:].to(torch.float64)).abs().max()))
+        lo = hi
+    assert worst <= 5e-5, worst  # float32 rounding of coordinates up to ~620 m; the arithmetic is double
+    del pid
+    # >= 30 sampled patches (the largest and the smallest among them) against the oracle: Kabsch init -> 20 ICP iterations
+    # (supervoxels of ~60 points: the sample is drawn from the well-posed ones -- >= 30 points in both epochs, fitness >= 0.5 --;
+    #  a patch of a dozen points, or one whose epochs barely overlap, may settle in another local solution after the first
+    #  rounding difference, on the device and on the host alike)
+    rng = np.random.default_rng(5)
+    size = cnt.cpu().numpy()
+    size_t = (r["tgt_off"][1:] - r["tgt_off"][:-1]).cpu().numpy()
+    ok = np.nonzero((size >= 30) & (size_t >= 30) & (fit.cpu().numpy() >= 0.5) & (ncorr.cpu().numpy() >= 10))[0]
+    assert len(ok) > K // 2
+    pick = np.unique(np.r_[ok[np.linspace(0, len(ok) - 1, 28).astype(int)], ok[int(size[ok].argmax())], ok[int(size[ok].argmin())],
+                           ok[rng.integers(0, len(ok), 8)]])
+    dd = dict(src=ps, tgt=r["patch_tgt"], src_off=off, tgt_off=r["tgt_off"])
+    assert len(pick) >= 30
+    _check_sample_against_oracle(dd, r["corr_src"], r["corr_ref"], r["corr_off"], dict(T=T, fitness=fit, rmse=rmse), pick)
+    # bit reproducible at full size: the partition and the transforms of a second run
+    keep = dict(labels=labels.clone(), T=T.clone(), K=K)
+    del r, rows, ps, dd, T, R
+    torch.cuda.empty_cache()
+    r2 = pipeline.full_path(src, tgt, max_iter=MAX_ITER, fixed_iters=True)
+    assert r2["K"] == keep["K"] and torch.equal(r2["labels"], keep["labels"]) and torch.equal(r2["T"], keep["T"])
+    print(f"C5 100 M points: K = {K}, stages (ms) " + ", ".join(f"{k_} {v:.1f}" for k_, v in r2["stage_ms"].items()))
