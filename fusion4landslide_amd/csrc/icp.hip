@@ -71,6 +71,7 @@ struct IcpArgs {
     const float *rows_src;
     const int64_t *rows_off;
     int64_t min_corr;  // patch matches with fewer correspondences are skipped (:3338, `num_min_fine_match`)
+    int init_round_f32;  // the Kabsch transform reaches ICP as float32 values (scripts/weighted_svd.py:148-151: a float32 4 x 4)
     const float *tgt_normals;
     double r, r2;
     int max_iter;
@@ -389,6 +390,10 @@ __global__ __launch_bounds__(NW * 64, WIDE ? 3 : (sizeof(F) == 8 ? ICP_WAVES_PER
             Tk[3] = l0 - (R[0] * k0 + R[1] * k1 + R[2] * k2);
             Tk[7] = l1 - (R[3] * k0 + R[4] * k1 + R[5] * k2);
             Tk[11] = l2 - (R[6] * k0 + R[7] * k1 + R[8] * k2);
+            if (a.init_round_f32) {
+#pragma unroll
+                for (int i = 0; i < 12; ++i) Tk[i] = (double)(float)Tk[i];
+            }
         }
         __syncthreads();
     }
@@ -994,6 +999,7 @@ struct IcpFusedExtra {
     const float *rows_src = nullptr;
     const int64_t *rows_off = nullptr;
     int64_t min_corr = 0;
+    int init_round_f32 = 0;
 };
 static int icp_launch_host(const float *src, const int64_t *src_off, const float *tgt, const int64_t *tgt_off,
                            int64_t P, const double *init_T, const float *tgt_normals, double max_corr_dist,
@@ -1029,6 +1035,8 @@ extern "C" int f4l_patch_loop(const float *src, const int64_t *src_off, const fl
     fx.corr_src = corr_src; fx.corr_ref = corr_ref; fx.corr_w = corr_w; fx.corr_off = corr_off;
     fx.w_thresh = kabsch_w_thresh; fx.eps = kabsch_eps; fx.rows_out = rows_out;
     fx.rows_src = rows_src; fx.rows_off = rows_off; fx.min_corr = min_corr;
+    fx.init_round_f32 = (mode & F4L_ICP_INIT_ROUND_F32) ? 1 : 0;
+    mode &= ~F4L_ICP_INIT_ROUND_F32;
     return f4l::icp_launch_host(src, src_off, tgt, tgt_off, P, nullptr, tgt_normals, max_corr_dist, max_iter, rel_fitness,
                                 rel_rmse, mode, fixed_iters, search_precision, max_src_patch_host, max_tgt_patch_host,
                                 n_src_host, T_out, fitness_out, rmse_out, iters_out, corr_out, fx, stream);
@@ -1058,7 +1066,7 @@ static int f4l::icp_launch_host(const float *src, const int64_t *src_off, const 
     a.init_T = init_T; a.tgt_normals = tgt_normals;
     a.corr_src = fx.corr_src; a.corr_ref = fx.corr_ref; a.corr_w = fx.corr_w; a.corr_off = fx.corr_off;
     a.kabsch_w_thresh = fx.w_thresh; a.kabsch_eps = fx.eps; a.rows_out = fx.rows_out;
-    a.rows_src = fx.rows_src; a.rows_off = fx.rows_off; a.min_corr = fx.min_corr;
+    a.rows_src = fx.rows_src; a.rows_off = fx.rows_off; a.min_corr = fx.min_corr; a.init_round_f32 = fx.init_round_f32;
     a.r = max_corr_dist > 0.0 ? max_corr_dist : 0.0;
     a.r2 = a.r * a.r;
     a.max_iter = max_iter; a.rel_fitness = rel_fitness; a.rel_rmse = rel_rmse; a.fixed_iters = fixed_iters;

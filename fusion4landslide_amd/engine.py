@@ -207,7 +207,7 @@ def piecewise_icp(src, src_off, tgt, tgt_off, init_T=None, max_corr_dist=0.1, ma
 def patch_loop(src, src_off, tgt, tgt_off, corr_src, corr_ref, corr_off, corr_weights=None, weight_thresh=0.0, eps=1e-6,
                max_corr_dist=0.1, max_iter=30, rel_fitness=1e-6, rel_rmse=1e-6, icp_type="point2point", fixed_iters=False,
                tgt_normals=None, return_corr=False, return_rows=True, max_src_patch=None, max_tgt_patch=None, search="f64",
-               rows_src=None, rows_off=None, min_corr=0):
+               rows_src=None, rows_off=None, min_corr=0, init_round_f32=False):
     """The per-patch loop body of src/coarse_to_fine_matching_base.py:3338-3408 in one launch (f4l_patch_loop):
     weighted Kabsch of each patch match's correspondences -> ICP from that on (src, tgt) -> displacement rows [s, T s].
 
@@ -215,6 +215,8 @@ def patch_loop(src, src_off, tgt, tgt_off, corr_src, corr_ref, corr_off, corr_we
     corr_off``; :3352-3353) and ``rows_src / rows_off`` all points of the source patch (:3348, 3371-3374); without
     ``rows_src`` the rows are those of ``src``.  Matches with fewer than ``min_corr`` correspondences are skipped as the
     reference skips them (:3338): ``iters == -1``, identity transform, rows left unwritten (zero here).
+    ``init_round_f32``: ICP starts from the float32 values of the Kabsch transform, like the reference's float32 4 x 4
+    (scripts/weighted_svd.py:148-151, :3360).
 
     Equivalent to ``T0 = kabsch_transforms(...); out = piecewise_icp(..., init_T=T0); rows = apply_transform(rows_src,
     rows_off, out["T"])``.  Returns the dict of :func:`piecewise_icp` plus ``rows`` (n_rows, 6) float32 when ``return_rows``."""
@@ -261,7 +263,8 @@ def patch_loop(src, src_off, tgt, tgt_off, corr_src, corr_ref, corr_off, corr_we
     rows = (torch.zeros if min_corr > 0 else torch.empty)((n_rows, 6), dtype=torch.float32, device=dev) if return_rows else None
     check(lib().f4l_patch_loop(ptr(src), ptr(src_off), ptr(tgt), ptr(tgt_off), P, ptr(corr_src), ptr(corr_ref), ptr(cw),
                                ptr(corr_off), int(min_corr), float(weight_thresh), float(eps), ptr(tn), float(max_corr_dist),
-                               int(max_iter), float(rel_fitness), float(rel_rmse), mode, int(bool(fixed_iters)),
+                               int(max_iter), float(rel_fitness), float(rel_rmse), mode | (0x100 if init_round_f32 else 0),
+                               int(bool(fixed_iters)),
                                {"f32": _lib.SEARCH_F32, "f64": _lib.SEARCH_F64}[search], int(max_src_patch),
                                int(max_tgt_patch), int(src.shape[0]), ptr(T), ptr(fit), ptr(rmse), ptr(iters), ptr(corr),
                                ptr(rows_src), ptr(rows_off), ptr(rows), stream_ptr()), "f4l_patch_loop")

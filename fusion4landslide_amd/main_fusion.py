@@ -1,0 +1,74 @@
+"""Counterpart of the reference's main_fusion.py for the 3D hot path: `--config` (nested yaml, main_fusion.py:63) -> cfg -> tiling
+once -> per tile `Coarse2Fine(cfg).implement_c2f_matching()` (:134-148) -> `results/c2f_*_tile_<id>.txt`.
+
+    python -m fusion4landslide_amd.main_fusion --config configs/landslide/fusion_3d_brienz.yaml [--partition parallel]
+
+The config keys are the reference's (path_name / data / method / parameter_setting / misc).  What the reference computes with
+its learned models -- point matches, patch matches, the 2D matches lifted to 3D -- enters through hooks on the cfg
+(src/coarse_to_fine_matching.py of this package); without them the 3D stand-ins run (nearest neighbours), and
+`fine_matching_fusion` / `_only_2d` need `cfg.point_matches_from_2d`.  `method.partition_type` must be `supervoxel`.
+"""
+import argparse
+import copy
+import os
+import os.path as osp
+import time
+
+from .src.coarse_to_fine_matching import Coarse2Fine
+from .utils.common import AttrDict, access_device, get_logger, load_yaml, setup_seed
+from .utils.tiles import for_each_tile, prepare_tiles
+
+
+def build_config(path, log_prefix='coarse2fine_matching'):
+    cfg = load_yaml(path, keep_sub_directory=True)
+    cfg['path_name']['output_root'] = osp.join(cfg['path_name']['output_dir'], cfg['path_name']['output_folder'])
+    log_dir = osp.join(cfg['path_name']['output_root'], 'logs')
+    os.makedirs(log_dir, exist_ok=True)
+    log_path = osp.join(log_dir, '{}_{}.log'.format(log_prefix, time.strftime('%Y%m%d_%H%M%S')))
+    cfg['logging'] = get_logger(log_path)
+    cfg = AttrDict(cfg)
+    cfg.verbose = cfg.misc.verbose
+    cfg.save_interim = cfg.misc.save_interim
+    cfg.device = access_device()
+    return cfg, log_path
+
+
+def run(cfg, first_tile=0):
+    """main_fusion.py:106-148 on a prepared cfg (also the entry for callers that attach the matching hooks)."""
+    import torch
+    tile_dir = cfg.path_name.tile_dir = osp.join(cfg.path_name.output_root, 'tiled_data')
+
+    def tiling_config():  # main_fusion.py:113-123
+        c = copy.copy(cfg)
+        c.data_dir, c.src_name, c.tgt_name = cfg.path_name.input_root, cfg.data.src_pcd, cfg.data.tgt_pcd
+        c.tiling_type, c.max_pts_per_tile, c.min_pts_per_tile = cfg.method.tiling_type, cfg.method.max_pts_per_tile, cfg.method.min_pts_per_tile
+        c.voxel_size, c.tile_dir = cfg.method.voxel_size_init, tile_dir
+        return c
+
+    with torch.no_grad():
+        tiles = prepare_tiles(tile_dir, tiling_config, cfg.logging)
+        for_each_tile(cfg, tiles, lambda c: Coarse2Fine(c).implement_c2f_matching(), cfg.logging, first=first_tile)
+    return tiles
+
+
+def main(argv=None):
+    parser = argparse.ArgumentParser()
+    parser.add_argument('--config', type=str, default='./configs/landslide/fusion_3d_brienz.yaml', help='Path to config file.')
+    parser.add_argument('--partition', type=str, default=None, choices=['identical', 'parallel'],
+                        help="supervoxel segmentation: the reference's labels (host replay) or the device segmentation")
+    parser.add_argument('--first-tile', type=int, default=0)
+    args = parser.parse_args(argv)
+    setup_seed(0)
+    cfg, log_path = build_config(args.config)
+    if args.partition:
+        from .cpp_core.supervoxel_segmentation.build import supervoxel
+        supervoxel.SEGMENTATION = args.partition
+    start = time.time()
+    run(cfg, args.first_tile)
+    if cfg.verbose:
+        cfg.logging.info(f"Displacement estimation is done! Save log information to: '{log_path}'.")
+        cfg.logging.info(f"Save results to: '{cfg.path_name.output_root}'. Total time taken: {time.time() - start:.1f} seconds.")
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,34 @@
+"""The part the reference's entry scripts share (main_piecewise_icp.py:60-94, main_fusion.py:106-148): fill
+`<output_root>/tiled_data` through `point_cloud_tiling` when it is empty, then visit the overlap tiles in numeric order, setting
+`tile_id`, `src_tile_overlap_path` and `tgt_tile_overlap_path` on the config before each tile is processed."""
+import glob
+import os
+import os.path as osp
+import re
+
+from .common import dir_exist
+
+
+def prepare_tiles(tile_dir, tiling_config, log):
+    """Runs the tiler into an empty `tile_dir` (src/functions.py:147-177; tiles already there are used as they are) and returns the
+    source overlap tiles sorted by tile number."""
+    from ..src.functions import point_cloud_tiling
+    dir_exist(tile_dir)
+    if not any(os.listdir(tile_dir)):
+        point_cloud_tiling(tiling_config())
+    else:
+        log.info('Skip point cloud tiling. Tiles will be loaded from %s.', tile_dir)
+    tiles = sorted(glob.glob(osp.join(tile_dir, 'overlap', 'source_tile_*')), key=lambda x: int(re.search(r'\d+', osp.basename(x)).group()))
+    log.info(f'Num. of tile(s) from source/target point cloud: {len(tiles)}')
+    return tiles
+
+
+def for_each_tile(cfg, tiles, process, log, first=0):
+    """`process(cfg)` per tile, `first` being the reference's hand-edited `continue_tile`."""
+    for tile_i, src_path in enumerate(tiles[first:]):
+        log.info(f'Current tile {tile_i + first} of total {len(tiles)} tiles')
+        tgt_path = src_path.replace('source_tile_', 'target_tile_')
+        assert osp.exists(tgt_path), tgt_path
+        cfg.tile_id = re.findall(r'\d+', osp.basename(src_path))[0]
+        cfg.src_tile_overlap_path, cfg.tgt_tile_overlap_path = src_path, tgt_path
+        process(cfg)

@@ -1,0 +1,105 @@
+"""The fusion-path entry (fusion4landslide_amd/main_fusion.py + src/coarse_to_fine_matching.py, the counterparts of the
+reference's main_fusion.py:134-148 and Coarse2Fine.implement_c2f_matching) and its result writer `save_process_dvf`
+(src/coarse_to_fine_matching_base.py:3459-3600).  The writer is host code (CPU test); the entry runs on the GPU."""
+import os
+
+import numpy as np
+import pytest
+
+
+def test_save_process_dvf_writes_the_reference_files(tmp_path):
+    """File names, column layout, '%.6f', and the two planted rows of the *_visualize files (base:3477-3516): the files read back to
+    the rows they were given."""
+    from fusion4landslide_amd.src.coarse_to_fine_matching import save_process_dvf
+    rng = np.random.default_rng(0)
+    src = rng.uniform(0, 50, (400, 3))
+    dense = np.c_[src, src + rng.normal(0, 0.05, (400, 3))].astype(np.float32)
+    sparse = dense[::3]
+    files = save_process_dvf(str(tmp_path), "7", "brienz_tls", dense, sparse)
+    names = sorted(os.path.basename(f) for f in files)
+    assert names == ["c2f_dense_dvfms_src2tgt_tile_7.txt", "c2f_dense_dvfms_src2tgt_visualize_tile_7.txt",
+                     "c2f_dense_dvfs_src2tgt_tile_7.txt", "c2f_sparse_dvfms_src2tgt_visualize_tile_7.txt"]
+    res = tmp_path / "results"
+    rows = np.loadtxt(res / "c2f_dense_dvfs_src2tgt_tile_7.txt")
+    assert rows.shape == (400, 6) and np.abs(rows - dense).max() <= 5.1e-7  # '%.6f'
+    first = open(res / "c2f_dense_dvfs_src2tgt_tile_7.txt").readline().split()
+    assert len(first) == 6 and all(len(v.split(".")[1]) == 6 for v in first)
+    mag = np.linalg.norm(dense[:, 3:] - dense[:, :3], axis=1)
+    dvfms = np.loadtxt(res / "c2f_dense_dvfms_src2tgt_tile_7.txt")
+    assert dvfms.shape == (400, 4) and np.abs(dvfms[:, :3] - dense[:, :3]).max() <= 5.1e-7 and np.abs(dvfms[:, 3] - mag).max() <= 1e-6
+    vis = np.loadtxt(res / "c2f_dense_dvfms_src2tgt_visualize_tile_7.txt")
+    assert vis[0, 3] == 0 and vis[1, 3] == 5 and np.abs(vis[2:, 3] - mag[2:]).max() <= 1e-6  # max_mag_visualize of brienz_tls (:3482-3483)
+    svis = np.loadtxt(res / "c2f_sparse_dvfms_src2tgt_visualize_tile_7.txt")
+    assert svis.shape == (len(sparse), 4) and svis[0, 3] == 0 and svis[1, 3] == 5
+    # the other data sets' colour scale, and the single-case file names (:3570-3600)
+    files = save_process_dvf(str(tmp_path / "rock"), "0", "rockfall_simulator", dense, sparse, multiple_case=False)
+    assert sorted(os.path.basename(f) for f in files) == ["c2f_dvfms_src2tgt.txt", "c2f_dvfms_src2tgt_discrete_visualize_0_5.txt",
+                                                          "c2f_dvfms_src2tgt_visualize_0_5.txt", "c2f_dvfs_src2tgt.txt"]
+    assert np.loadtxt(tmp_path / "rock" / "results" / "c2f_dvfms_src2tgt_visualize_0_5.txt")[1, 3] == pytest.approx(0.06)
+
+
+@pytest.mark.gpu
+def test_main_fusion_entry_runs_the_tiles_and_writes_the_dvf_files(tmp_path):
+    """`python -m fusion4landslide_amd.main_fusion --config <yaml>` on a synthetic two-tile data set already tiled (the tiler
+    is skipped like in the reference when tiled_data/ is not empty): the reference's nested yaml keys, both tiles visited in
+    numeric order, the c2f_* files of save_process_dvf per tile; the dense rows are [s, T s] of the registered patches and
+    recover the planted motion of the stable blocks.  Then the fusion branch through `run()` with a second set of point matches
+    in the role of the lifted 2D matches."""
+    import torch
+    import yaml
+    from fusion4landslide_amd import main_fusion, synthetic
+    from fusion4landslide_amd.utils.ply import write_ply
+    out_root = tmp_path / "out" / "demo_run"
+    tiles = out_root / "tiled_data" / "overlap"
+    os.makedirs(tiles)
+    clouds = {}
+    for t, seed in ((0, 0), (1, 5)):
+        c = synthetic.two_epoch_cloud(60_000, 9, 1.386, seed=seed, roughness=0.05)
+        write_ply(str(tiles / f"source_tile_{t}_overlap.ply"), c["src"])
+        write_ply(str(tiles / f"target_tile_{t}_overlap.ply"), c["tgt"])
+        clouds[t] = c
+    cfg = dict(
+        misc=dict(verbose=True, save_interim=False),
+        path_name=dict(input_root=str(tmp_path), output_dir=str(tmp_path / "out"), output_folder="demo_run"),
+        data=dict(dataset="brienz_tls", src_pcd="a.ply", tgt_pcd="b.ply", multiple_case=True),
+        method=dict(tiling_type="xy_tiling", max_pts_per_tile=1000000, min_pts_per_tile=5000, voxel_size_init=0.1, partition=True,
+                    partition_type="supervoxel", fine_matching_fusion=False, fine_matching_only_3d=True, fine_matching_only_2d=False,
+                    remove_low_quality_patch_matches=True, num_min_matches_for_quality_check=10, thres_dist_diff=0.5, thres_inlier_ratio=0.15,
+                    num_min_fine_match=10, weighting_svd=False, icp_refine=True, output_tgt2src=False, assign_type="assign_then_nn"),
+        parameter_setting=dict(n_normals=30, icp_threshold=0.1, max_magnitude=5))
+    path = tmp_path / "fusion_3d.yaml"
+    yaml.safe_dump(cfg, open(path, "w"))
+    main_fusion.main(["--config", str(path), "--partition", "parallel"])
+    res = out_root / "results"
+    for t in (0, 1):
+        dvfs = np.loadtxt(res / f"c2f_dense_dvfs_src2tgt_tile_{t}.txt")
+        dvfms = np.loadtxt(res / f"c2f_dense_dvfms_src2tgt_tile_{t}.txt")
+        vis = np.loadtxt(res / f"c2f_dense_dvfms_src2tgt_visualize_tile_{t}.txt")
+        sparse = np.loadtxt(res / f"c2f_sparse_dvfms_src2tgt_visualize_tile_{t}.txt")
+        assert dvfs.shape[1] == 6 and dvfms.shape == (len(dvfs), 4) and vis.shape == dvfms.shape and sparse.shape[1] == 4
+        assert 30_000 < len(dvfs) <= 60_000 and vis[0, 3] == 0 and vis[1, 3] == 5
+        assert np.allclose(dvfms[:, 3], np.linalg.norm(dvfs[:, 3:] - dvfs[:, :3], axis=1), atol=2e-6)
+        # every row starts at a point of the tile's source epoch; the field of the stable blocks is a few centimetres
+        from scipy.spatial import cKDTree
+        assert cKDTree(clouds[t]["src"].astype(np.float64)).query(dvfs[:, :3], k=1)[0].max() < 2e-6  # ('%.6f' of float32 coordinates)
+        assert np.median(dvfms[:, 3]) < 0.12
+        assert os.path.exists(out_root / "supervoxel_partition" / f"partition_of_input_src_tile_{t}.txt")
+    # the fusion branch: the same tile with lifted "2D" matches attached to the cfg
+    from scipy.spatial import cKDTree
+    cfg2, _ = main_fusion.build_config(str(path))
+    cfg2.method.fine_matching_only_3d, cfg2.method.fine_matching_fusion, cfg2.method.weighting_svd = False, True, True
+    cfg2.path_name.output_root = str(tmp_path / "out" / "fusion_run")
+    os.makedirs(tmp_path / "out" / "fusion_run" / "tiled_data" / "overlap")
+    for name in ("source_tile_0_overlap.ply", "target_tile_0_overlap.ply"):
+        os.link(tiles / name, tmp_path / "out" / "fusion_run" / "tiled_data" / "overlap" / name)
+    c = clouds[0]
+    d, j = cKDTree(c["tgt"].astype(np.float64)).query(c["src"].astype(np.float64), k=2, distance_upper_bound=0.3)
+    cfg2.point_matches_from_2d = np.where(np.isfinite(d[:, 1]) & (np.arange(len(d)) % 3 == 0), j[:, 1], -1)
+    from fusion4landslide_amd.cpp_core.supervoxel_segmentation.build import supervoxel
+    supervoxel.SEGMENTATION = "parallel"
+    try:
+        main_fusion.run(cfg2)
+    finally:
+        supervoxel.SEGMENTATION = "identical"
+    fus = np.loadtxt(tmp_path / "out" / "fusion_run" / "results" / "c2f_dense_dvfs_src2tgt_tile_0.txt")
+    assert fus.shape[1] == 6 and len(fus) > 30_000 and np.median(np.linalg.norm(fus[:, 3:] - fus[:, :3], axis=1)) < 0.12
