@@ -7,10 +7,11 @@ Contract (driver):  python bench.py --gpus N --steps K --warmup W   prints ONE J
   anything in this process touches the GPU) and relays rank 0's line.  WORLD_SIZE != N is an error (exit code 2).
 
 Workload at every N: BASELINE.json's metric config "C4_50M_100k" (50 M points per epoch, 316 x 316 = 99 856 patches), which
-fits one MI355X (2.4 GB of inputs and outputs out of 288 GB).  The cloud is generated ON THE DEVICE by every rank
-(fusion4landslide_amd.synthetic.make_patches_device: counter-based, identical on every rank, < 1 s), its patches are
-assigned to the ranks by LPT on |src| x |tgt| (fusion4landslide_amd.sharding) and every rank keeps only its own share in
-HBM: total work is fixed as N grows ("scaling": "strong"), `value` = the cloud's 50 M source points / max-over-ranks time.
+fits one MI355X (2.4 GB of inputs and outputs out of 288 GB).  The cloud comes from a counter-based generator ON THE DEVICE
+(fusion4landslide_amd.synthetic: any rank can produce any part of it); its patches are assigned to the ranks by LPT on
+|src| x |tgt| (fusion4landslide_amd.sharding) and every rank generates and keeps only its own share
+(synthetic.make_rank_share_device): total work is fixed as N grows ("scaling": "strong"), `value` = the cloud's 50 M source
+points / max-over-ranks time.
 
 A "step" is one pass of the hot path over the rank's share, inputs resident in HBM when the clock starts:
     per-patch weighted Kabsch init from the 1-NN correspondences
@@ -131,10 +132,16 @@ def run_rank(args, world):
     cfg = synthetic.CONFIGS[args.config]
     n, cells, res = cfg["n"], cfg["cells"], cfg["resolution"]
     t_setup = time.perf_counter()
-    cloud = synthetic.make_patches_device(n, cells, res, dev, seed=0)  # the same cloud on every rank
-    P_total = cloud["P"]
-    d, ids_per_rank = sharding.shard_cloud(cloud, rank, world)          # ... of which this rank keeps its LPT share
-    del cloud
+    if world == 1:
+        cloud = synthetic.make_patches_device(n, cells, res, dev, seed=0)
+        P_total = cloud["P"]
+        d, ids_per_rank = sharding.shard_cloud(cloud, rank, world)
+        del cloud
+    else:
+        # every rank produces ITS share of the one cloud straight from the counter-based generator (a counting pass for the LPT
+        # assignment, a keeping pass): no rank ever holds the whole 50 M-point cloud, and nothing is scattered between ranks
+        d, ids_per_rank = synthetic.make_rank_share_device(n, cells, res, dev, rank, world, seed=0)
+        P_total = cells * cells
     if not dry:
         torch.cuda.empty_cache()
     P, n_mine = d["P"], d["n_src"]
@@ -397,6 +404,35 @@ def extras(torch, engine, synthetic, prob, dev, args):
                      "algorithmic_GBs": round(528.0 * c["n"] / s / 1e9, 1), "frac_of_hbm_peak": round(528.0 * c["n"] / s / 1e9 / HBM_PEAK_GBS, 5)}
         del p, d
         torch.cuda.empty_cache()
+    # the reference's real unit of work is a tile of <= 1 M points (main_fusion.py:134, fusion_brienz.yaml:25-26): eight C2 tiles,
+    # tile by tile, and as ONE launch over their concatenated patches (engine.patch_loop_tiles; the concatenation is inside the clock)
+    c = synthetic.CONFIGS["C2_1M_2k"]
+    tiles = []
+    for seed in range(8):
+        d = synthetic.make_patches_device(c["n"], c["cells"], c["resolution"], dev, seed=seed)
+        p = Problem(torch, engine, synthetic, d, dev)
+        tiles.append(dict(src=d["src"], src_off=d["src_off"], tgt=d["tgt"], tgt_off=d["tgt_off"], corr_src=p.cs, corr_ref=p.ct, corr_off=p.coff,
+                          max_src=d["max_src"], max_tgt=d["max_tgt"]))
+    kw = dict(max_corr_dist=MAX_CORR, max_iter=MAX_ITER, fixed_iters=True)
+
+    def one_by_one():
+        for t in tiles:
+            engine.patch_loop(t["src"], t["src_off"], t["tgt"], t["tgt_off"], t["corr_src"], t["corr_ref"], t["corr_off"],
+                              max_src_patch=t["max_src"], max_tgt_patch=t["max_tgt"], **kw)
+    s_each = _timed(torch, one_by_one, 5)
+    s_all = _timed(torch, lambda: engine.patch_loop_tiles(tiles, **kw), 5)
+    m = engine.merge_tiles(tiles)
+    m.pop("split")
+    margs = [m.pop(k) for k in ("src", "src_off", "tgt", "tgt_off", "corr_src", "corr_ref", "corr_off", "corr_weights")]
+    s_merged = _timed(torch, lambda: engine.patch_loop(*margs, **m, **kw), 5)
+    out["C2x8_tiles"] = {"workload": "8 tiles of C2_1M_2k (8 M points, 16 200 patches), float64 mode", "unit": "Mpts/s",
+                         "tile_by_tile": round(8 * c["n"] / s_each / 1e6, 3), "ms_tile_by_tile": round(1e3 * s_each, 4),
+                         "one_launch": round(8 * c["n"] / s_merged / 1e6, 3), "ms_one_launch": round(1e3 * s_merged, 4),
+                         "one_launch_incl_concatenation": round(8 * c["n"] / s_all / 1e6, 3), "ms_incl_concatenation": round(1e3 * s_all, 4),
+                         "note": "one_launch: the tiles' patch arrays already in one buffer (engine.merge_tiles once, then engine.patch_loop); "
+                                 "incl_concatenation: engine.patch_loop_tiles on separate per-tile arrays, the copies inside the clock"}
+    del tiles, m, margs
+    torch.cuda.empty_cache()
     # configs[4] on one GPU: the whole hot path of a tile -- supervoxel partition (all on the device), patches, point matches,
     # Kabsch + 20-iteration ICP + rows, nearest-neighbour refinement -- end to end, stage by stage
     from fusion4landslide_amd import pipeline

@@ -276,6 +276,67 @@ def patch_loop(src, src_off, tgt, tgt_off, corr_src, corr_ref, corr_off, corr_we
     return out
 
 
+def merge_tiles(tiles):
+    """The CSR arrays of several tiles' patch matches concatenated (offsets shifted) into the arguments of ONE :func:`patch_loop`:
+    dict(src, src_off, tgt, tgt_off, corr_src, corr_ref, corr_off[, corr_weights, rows_src, rows_off][, max_src_patch,
+    max_tgt_patch]) plus `split`, the per-tile (patches, rows, source points) counts :func:`split_tiles` cuts the results by.
+    tiles: list of dicts with those keys (all tiles with or all without the optional ones; `max_src` / `max_tgt`, the tile's largest
+    patch sizes, spare the launch its read-back)."""
+    torch = require_gpu()
+
+    def cat_pts(key):
+        return torch.cat([t[key] for t in tiles]) if tiles[0].get(key) is not None else None
+
+    def cat_off(key, pts_key):
+        if tiles[0].get(key) is None:
+            return None
+        parts, base = [], 0
+        for i, t in enumerate(tiles):
+            parts.append((t[key] if i == 0 else t[key][1:]) + base)
+            base += t[pts_key].shape[0]  # (= the tile's last offset, known without asking the device)
+        return torch.cat(parts)
+    m = {k: cat_pts(k) for k in ("src", "tgt", "corr_src", "corr_ref", "corr_weights", "rows_src")}
+    m.update({k: cat_off(k, v) for k, v in (("src_off", "src"), ("tgt_off", "tgt"), ("corr_off", "corr_src"), ("rows_off", "rows_src"))})
+    for key, name in (("max_src", "max_src_patch"), ("max_tgt", "max_tgt_patch")):
+        if all(key in t for t in tiles):
+            m[name] = max(int(t[key]) for t in tiles)
+    m["split"] = [(t["src_off"].shape[0] - 1, (t["rows_src"] if t.get("rows_src") is not None else t["src"]).shape[0], t["src"].shape[0]) for t in tiles]
+    return m
+
+
+def split_tiles(out, split):
+    """The result of a merged launch cut back into one dict per tile (views)."""
+    res, p0, r0, s0 = [], 0, 0, 0
+    for P, n_rows, n_src in split:
+        one = {k: out[k][p0:p0 + P] for k in ("T", "fitness", "rmse", "iters")}
+        if "rows" in out:
+            one["rows"] = out["rows"][r0:r0 + n_rows]
+        if "corr" in out:
+            one["corr"] = out["corr"][s0:s0 + n_src]
+        res.append(one)
+        p0, r0, s0 = p0 + P, r0 + n_rows, s0 + n_src
+    return res
+
+
+def patch_loop_tiles(tiles, **kw):
+    """The loop body of SEVERAL tiles in one launch.  The reference works tile by tile (main_fusion.py:134: <= 1 M points each,
+    configs/landslide/fusion_brienz.yaml:25-26), and one tile's ~2000 patch matches are only two rounds of workgroups on this
+    chip -- a launch of that size runs at two thirds of the rate of a large one.  Patches are independent and
+    f4l_patch_loop does not care which tile a patch came from: the tiles' CSR arrays are concatenated (:func:`merge_tiles`),
+    launched once, and the per-patch results and rows handed back per tile as views (:func:`split_tiles`).  A pipeline that
+    produces its tiles' arrays into one buffer in the first place calls :func:`patch_loop` on that directly.
+    `kw`: the keyword arguments of :func:`patch_loop`.  Returns a list of result dicts, one per tile."""
+    if not tiles:
+        return []
+    m = merge_tiles(tiles)
+    split = m.pop("split")
+    args = [m.pop(k) for k in ("src", "src_off", "tgt", "tgt_off", "corr_src", "corr_ref", "corr_off", "corr_weights")]
+    for name in ("max_src_patch", "max_tgt_patch"):
+        if name in kw:
+            m.pop(name, None)
+    return split_tiles(patch_loop(*args, **m, **kw), split)
+
+
 def mutual_correspondences(src_ids, src_off, tgt_ids, tgt_off, corr_tgt):
     """`torch.isin(corr[src patch][:, 1], tgt patch)` for all patch matches at once (src/coarse_to_fine_matching_base.py:
     3259-3274; f4l_mutual_correspondences).  src_ids / tgt_ids: int64 point ids grouped by match (CSR offsets src_off /

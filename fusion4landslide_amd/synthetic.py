@@ -177,53 +177,72 @@ def _surface_t(torch, x, y, phases):
     return z
 
 
+class _DeviceCloud:
+    """The two-epoch cloud of `make_patches_device`, chunk by chunk: `chunk(lo, hi)` -> (src (m, 3), tgt (m, 3)) float32 of the points
+    with generation indices lo .. hi - 1 (a pure function of the indices: any rank can produce any part)."""
+
+    def __init__(self, cells, resolution, device, seed, noise):
+        import torch
+        self.torch, self.device, self.seed, self.noise = torch, device, seed, noise
+        self.cells, self.resolution, self.L = cells, resolution, cells * resolution
+        self.phases = np.random.Generator(np.random.PCG64(seed)).uniform(0, 2 * np.pi, (4, 2))
+        r2 = np.random.Generator(np.random.PCG64(seed + 2))
+        self.nb = nb = int(np.ceil(cells / 4.0))
+        B = nb * nb
+        ang = np.deg2rad(r2.uniform(0, 0.5, B))
+        Rb = _rodrigues(r2.normal(size=(B, 3)), ang)
+        stable = r2.uniform(size=B) < 0.7
+        t_small = r2.uniform(-0.05, 0.05, (B, 3))
+        t_big = r2.uniform(0.2, 0.5, (B, 3)) * np.where(r2.uniform(size=(B, 3)) < 0.5, -1.0, 1.0)
+        tb = np.where(stable[:, None], t_small, t_big)
+        self.Rb = torch.from_numpy(Rb.reshape(B, 9)).to(device)
+        self.tb = torch.from_numpy(tb).to(device)
+
+    def chunk(self, lo, hi):
+        torch, seed, noise, L, nb = self.torch, self.seed, self.noise, self.L, self.nb
+        bs = 4.0 * self.resolution
+        idx = torch.arange(lo, hi, dtype=torch.int64, device=self.device)
+        src = torch.empty((hi - lo, 3), dtype=torch.float32, device=self.device)
+        tgt = torch.empty((hi - lo, 3), dtype=torch.float32, device=self.device)
+        x, y = L * _uniform01(torch, seed, 0, idx), L * _uniform01(torch, seed, 1, idx)
+        src[:, 0], src[:, 1] = x.to(torch.float32), y.to(torch.float32)
+        src[:, 2] = (_surface_t(torch, x, y, self.phases) + noise * _normal(torch, seed, 1, idx)).to(torch.float32)
+        x, y = L * _uniform01(torch, seed, 6, idx), L * _uniform01(torch, seed, 7, idx)
+        z = _surface_t(torch, x, y, self.phases)
+        bx = torch.clamp((x / bs).to(torch.int64), max=nb - 1)
+        by = torch.clamp((y / bs).to(torch.int64), max=nb - 1)
+        bid = by * nb + bx
+        px, py, pz = x - (bx.to(torch.float64) + 0.5) * bs, y - (by.to(torch.float64) + 0.5) * bs, z
+        R = self.Rb[bid]
+        t = self.tb[bid]
+        qx = R[:, 0] * px + R[:, 1] * py + R[:, 2] * pz + (bx.to(torch.float64) + 0.5) * bs + t[:, 0]
+        qy = R[:, 3] * px + R[:, 4] * py + R[:, 5] * pz + (by.to(torch.float64) + 0.5) * bs + t[:, 1]
+        qz = R[:, 6] * px + R[:, 7] * py + R[:, 8] * pz + t[:, 2] + noise * _normal(torch, seed, 4, idx)
+        tgt[:, 0], tgt[:, 1], tgt[:, 2] = qx.to(torch.float32), qy.to(torch.float32), qz.to(torch.float32)
+        return src, tgt
+
+    def cell_of(self, p):
+        torch = self.torch
+        cx = torch.clamp((p[:, 0].to(torch.float64) / self.resolution).to(torch.int64), 0, self.cells - 1)
+        cy = torch.clamp((p[:, 1].to(torch.float64) / self.resolution).to(torch.int64), 0, self.cells - 1)
+        return cy * self.cells + cx
+
+
 def make_patches_device(n, cells, resolution, device, seed=0, noise=0.005, chunk=8_000_000):
     """`make_patches` on the device: dict(src, src_off, tgt, tgt_off (torch tensors on `device`), P, max_src, max_tgt, L).
     src/tgt are float32 (n, 3) patch-contiguous, offsets int64; patch = (x, y) grid cell at `resolution`, points inside a
     patch in ascending generation index."""
     import torch
 
-    L = cells * resolution
-    phases = np.random.Generator(np.random.PCG64(seed)).uniform(0, 2 * np.pi, (4, 2))
-    r2 = np.random.Generator(np.random.PCG64(seed + 2))
-    nb = int(np.ceil(cells / 4.0))
-    B = nb * nb
-    ang = np.deg2rad(r2.uniform(0, 0.5, B))
-    Rb = _rodrigues(r2.normal(size=(B, 3)), ang)
-    stable = r2.uniform(size=B) < 0.7
-    t_small = r2.uniform(-0.05, 0.05, (B, 3))
-    t_big = r2.uniform(0.2, 0.5, (B, 3)) * np.where(r2.uniform(size=(B, 3)) < 0.5, -1.0, 1.0)
-    tb = np.where(stable[:, None], t_small, t_big)
-    Rb_d = torch.from_numpy(Rb.reshape(B, 9)).to(device)
-    tb_d = torch.from_numpy(tb).to(device)
-    bs = 4.0 * resolution
+    gen = _DeviceCloud(cells, resolution, device, seed, noise)
     src = torch.empty((n, 3), dtype=torch.float32, device=device)
     tgt = torch.empty((n, 3), dtype=torch.float32, device=device)
     for lo in range(0, n, chunk):
         hi = min(n, lo + chunk)
-        idx = torch.arange(lo, hi, dtype=torch.int64, device=device)
-        x, y = L * _uniform01(torch, seed, 0, idx), L * _uniform01(torch, seed, 1, idx)
-        src[lo:hi, 0], src[lo:hi, 1] = x.to(torch.float32), y.to(torch.float32)
-        src[lo:hi, 2] = (_surface_t(torch, x, y, phases) + noise * _normal(torch, seed, 1, idx)).to(torch.float32)
-        x, y = L * _uniform01(torch, seed, 6, idx), L * _uniform01(torch, seed, 7, idx)
-        z = _surface_t(torch, x, y, phases)
-        bx = torch.clamp((x / bs).to(torch.int64), max=nb - 1)
-        by = torch.clamp((y / bs).to(torch.int64), max=nb - 1)
-        bid = by * nb + bx
-        px, py, pz = x - (bx.to(torch.float64) + 0.5) * bs, y - (by.to(torch.float64) + 0.5) * bs, z
-        R = Rb_d[bid]
-        t = tb_d[bid]
-        qx = R[:, 0] * px + R[:, 1] * py + R[:, 2] * pz + (bx.to(torch.float64) + 0.5) * bs + t[:, 0]
-        qy = R[:, 3] * px + R[:, 4] * py + R[:, 5] * pz + (by.to(torch.float64) + 0.5) * bs + t[:, 1]
-        qz = R[:, 6] * px + R[:, 7] * py + R[:, 8] * pz + t[:, 2] + noise * _normal(torch, seed, 4, idx)
-        tgt[lo:hi, 0], tgt[lo:hi, 1], tgt[lo:hi, 2] = qx.to(torch.float32), qy.to(torch.float32), qz.to(torch.float32)
-        del idx, x, y, z, bx, by, bid, px, py, pz, R, t, qx, qy, qz
+        src[lo:hi], tgt[lo:hi] = gen.chunk(lo, hi)
 
     def partition(p):
-        cx = torch.clamp((p[:, 0].to(torch.float64) / resolution).to(torch.int64), 0, cells - 1)
-        cy = torch.clamp((p[:, 1].to(torch.float64) / resolution).to(torch.int64), 0, cells - 1)
-        cid = cy * cells + cx
-        del cx, cy
+        cid = gen.cell_of(p)
         _, order = torch.sort(cid, stable=True)
         off = torch.zeros(cells * cells + 1, dtype=torch.int64, device=device)
         off[1:] = torch.cumsum(torch.bincount(cid, minlength=cells * cells), 0)
@@ -231,8 +250,53 @@ def make_patches_device(n, cells, resolution, device, seed=0, noise=0.005, chunk
 
     src, soff = partition(src)
     tgt, toff = partition(tgt)
-    return dict(src=src, src_off=soff, tgt=tgt, tgt_off=toff, P=cells * cells, L=L,
+    return dict(src=src, src_off=soff, tgt=tgt, tgt_off=toff, P=cells * cells, L=gen.L,
                 max_src=int((soff[1:] - soff[:-1]).max().item()), max_tgt=int((toff[1:] - toff[:-1]).max().item()))
+
+
+def make_rank_share_device(n, cells, resolution, device, rank, world, seed=0, noise=0.005, chunk=8_000_000):
+    """The share of `make_patches_device`'s cloud that rank `rank` of `world` owns under the LPT assignment of
+    sharding.shard_cloud -- the same dict, bit for bit, as `shard_cloud(make_patches_device(...), rank, world)` -- WITHOUT any rank
+    ever holding the whole cloud: a first pass over the generator counts the points per patch (both epochs; the assignment needs
+    nothing else), a second pass keeps the rank's own points.  Returns (share dict, ids_per_rank)."""
+    import torch
+
+    from .sharding import lpt_assign
+    gen = _DeviceCloud(cells, resolution, device, seed, noise)
+    P = cells * cells
+    cnt_s = torch.zeros(P, dtype=torch.int64, device=device)
+    cnt_t = torch.zeros(P, dtype=torch.int64, device=device)
+    for lo in range(0, n, chunk):
+        s, t = gen.chunk(lo, min(n, lo + chunk))
+        cnt_s += torch.bincount(gen.cell_of(s), minlength=P)
+        cnt_t += torch.bincount(gen.cell_of(t), minlength=P)
+    cs, ct = cnt_s.cpu().numpy(), cnt_t.cpu().numpy()
+    ids_per_rank = lpt_assign(cs.astype(np.float64) * np.maximum(ct, 1), world)  # (sharding.patch_costs on the counts)
+    mine = ids_per_rank[rank]
+    own = torch.zeros(P, dtype=torch.bool, device=device)
+    own[torch.from_numpy(mine).to(device)] = True
+    kept = {"s": ([], []), "t": ([], [])}
+    for lo in range(0, n, chunk):
+        s, t = gen.chunk(lo, min(n, lo + chunk))
+        for key, p in (("s", s), ("t", t)):
+            cid = gen.cell_of(p)
+            m = own[cid]
+            kept[key][0].append(p[m])
+            kept[key][1].append(cid[m])
+    local = torch.full((P,), -1, dtype=torch.int64, device=device)  # patch id -> place among the rank's patches (ascending ids)
+    local[torch.from_numpy(mine).to(device)] = torch.arange(len(mine), device=device)
+
+    def pack(pts, cids):
+        pts, lid = torch.cat(pts), local[torch.cat(cids)]
+        _, order = torch.sort(lid, stable=True)  # (stable: generation order inside a patch, as in the whole cloud)
+        off = torch.zeros(len(mine) + 1, dtype=torch.int64, device=device)
+        off[1:] = torch.cumsum(torch.bincount(lid, minlength=len(mine)), 0)
+        return pts[order].contiguous(), off
+
+    src, soff = pack(*kept["s"])
+    tgt, toff = pack(*kept["t"])
+    mx = lambda o: int((o[1:] - o[:-1]).max().item()) if len(mine) else 0  # noqa: E731
+    return dict(src=src, src_off=soff, tgt=tgt, tgt_off=toff, P=len(mine), max_src=mx(soff), max_tgt=mx(toff), n_src=int(soff[-1].item())), ids_per_rank
 
 
 def correspondences_from_nn_device(src, src_off, tgt, tgt_off, nn):

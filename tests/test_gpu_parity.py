@@ -829,3 +829,28 @@ def test_icp_launch_is_capturable_into_a_hip_graph(eng):
             g.replay()
             torch.cuda.synchronize()
             assert torch.equal(out["T"], ref["T"]) and torch.equal(out["iters"], ref["iters"])
+
+
+def test_patch_loop_over_several_tiles_in_one_launch(eng):
+    """engine.patch_loop_tiles: the loop body of several tiles (the reference's unit of work, main_fusion.py:134) concatenated into
+    one launch gives every tile the results of its own launch -- to rounding when the merged batch crosses into the throughput
+    launch shape (sums in another order), bit for bit otherwise -- and its own rows."""
+    from fusion4landslide_amd import synthetic
+    tiles = []
+    for seed in (0, 1, 2):
+        d = synthetic.make_patches(30_000, 7, 1.386, seed=seed, roughness=0.05)
+        t = {k: dev(d[k]) for k in ("src", "src_off", "tgt", "tgt_off")}
+        eye = torch.eye(4, dtype=torch.float64, device="cuda").repeat(d["P"], 1, 1)
+        nn, _ = eng.nn_refine(t["src"], t["src_off"], t["tgt"], t["tgt_off"], eye, torch.full((d["P"],), 0.2, dtype=torch.float64, device="cuda"),
+                              return_rows=False)
+        cs, ct, coff = synthetic.correspondences_from_nn(d["src"], d["src_off"], d["tgt"], d["tgt_off"], nn.cpu().numpy())
+        t.update(corr_src=dev(cs), corr_ref=dev(ct), corr_off=dev(coff), max_src=d["max_src"], max_tgt=d["max_tgt"])
+        tiles.append(t)
+    kw = dict(max_corr_dist=0.1, max_iter=20, fixed_iters=True)
+    merged = eng.patch_loop_tiles(tiles, **kw)
+    assert len(merged) == 3
+    for t, m in zip(tiles, merged):
+        one = eng.patch_loop(t["src"], t["src_off"], t["tgt"], t["tgt_off"], t["corr_src"], t["corr_ref"], t["corr_off"], **kw)
+        assert m["T"].shape == one["T"].shape and m["rows"].shape == one["rows"].shape == (t["src"].shape[0], 6)
+        assert torch.equal(m["iters"], one["iters"]) and torch.equal(m["rows"][:, :3], t["src"])
+        assert float((m["T"] - one["T"]).abs().max()) < 1e-9 and float((m["rows"] - one["rows"]).abs().max()) < 1e-5

@@ -164,3 +164,42 @@ def test_bench_gpus2_dry_run_starts_two_ranks():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], capture_output=True, text=True,
                        env=dict(env, WORLD_SIZE="4"), timeout=60)
     assert r.returncode == 2 and "WORLD_SIZE=4" in r.stderr
+
+
+def test_rank_share_generated_alone_equals_the_share_of_the_whole_cloud():
+    """synthetic.make_rank_share_device: a rank's share of the bench cloud produced WITHOUT holding the whole cloud (counting pass,
+    LPT on the counts, keeping pass) is bit for bit `shard_cloud(make_patches_device(...), rank, world)` -- points, offsets, patch
+    ids --, for chunk sizes that do not divide the cloud."""
+    import torch
+    from fusion4landslide_amd import sharding, synthetic
+    dev = torch.device("cpu")
+    whole = synthetic.make_patches_device(120_000, 11, 1.386, dev, seed=3, chunk=50_000)
+    for world in (1, 3, 8):
+        seen = np.zeros(whole["P"], dtype=np.int64)
+        for rank in range(world):
+            a, ids_a = sharding.shard_cloud(whole, rank, world)
+            b, ids_b = synthetic.make_rank_share_device(120_000, 11, 1.386, dev, rank, world, seed=3, chunk=47_000)
+            assert all(np.array_equal(x, y) for x, y in zip(ids_a, ids_b))
+            for k in ("src", "src_off", "tgt", "tgt_off"):
+                assert torch.equal(a[k], b[k]), (world, rank, k)
+            assert (a["P"], a["max_src"], a["max_tgt"], a["n_src"]) == (b["P"], b["max_src"], b["max_tgt"], b["n_src"])
+            seen[ids_b[rank]] += 1
+        assert (seen == 1).all()
+
+
+@pytest.mark.timeout(600)
+def test_bench_gpus8_dry_run_is_one_line_of_eight_ranks():
+    """The orchestration of an 8-GPU node (`--gpus 8 --dry-run`: eight gloo ranks on CPU tensors, every rank generating only its own
+    share, the per-patch results of all of them arriving in global patch order on rank 0)."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["OMP_NUM_THREADS"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--dry-run", "--config", "C1_50k_64",
+                        "--steps", "2", "--warmup", "1"], capture_output=True, text=True, env=env, timeout=540)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 8 and line["dry_run"] and line["dry_run_gather_ok"] and line["value"] is None
+    assert line["config"]["patches"] == 64 and line["config"]["patches_on_rank0"] == 8
