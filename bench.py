@@ -132,6 +132,12 @@ def run_rank(args, world):
     cfg = synthetic.CONFIGS[args.config]
     n, cells, res = cfg["n"], cfg["cells"], cfg["resolution"]
     t_setup = time.perf_counter()
+    setup_parts = {}
+    if not dry:  # the first device call of the process: context, code objects of torch and of libf4l_hip.so
+        torch.zeros(1, device=dev).add_(1)
+        engine.lib()
+        sync()
+    setup_parts["device_and_library_start"] = time.perf_counter() - t_setup
     if world == 1:
         cloud = synthetic.make_patches_device(n, cells, res, dev, seed=0)
         P_total = cloud["P"]
@@ -144,12 +150,15 @@ def run_rank(args, world):
         P_total = cells * cells
     if not dry:
         torch.cuda.empty_cache()
+    sync()
+    setup_parts["generate_cloud"] = time.perf_counter() - t_setup - setup_parts["device_and_library_start"]
     P, n_mine = d["P"], d["n_src"]
     mine = torch.from_numpy(ids_per_rank[rank]).to(dev)
     prob = Problem(torch, engine, synthetic, d, dev, dry, mine)
     gather = sharding.PatchResultGather(dist, torch, ids_per_rank, rank, dev)
     sync()
     t_setup = time.perf_counter() - t_setup
+    setup_parts["point_matches"] = t_setup - setup_parts["generate_cloud"] - setup_parts["device_and_library_start"]
 
     ev = [] if dry else [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
 
@@ -195,7 +204,10 @@ def run_rank(args, world):
                        "points_on_rank0": n_mine, "patches_on_rank0": P,
                        "icp": "point2point, 20 fixed iters, max_corr_dist 0.1 m, float64 search (parity mode)",
                        "parallelism": f"one cloud, patches LPT-sharded x{world}, all-gather of per-patch results",
-                       "setup_seconds": round(t_setup, 2)},
+                       "setup_seconds": round(t_setup, 2),
+                       # (on a fresh box most of it is the first device call -- context, code objects paged in from a cold image --
+                       #  and the allocator's first gigabytes; untimed, outside the metric)
+                       "setup_breakdown_s": {k: round(v, 2) for k, v in setup_parts.items()}},
         }
         if dry:
             line["dry_run"] = True

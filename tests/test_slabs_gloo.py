@@ -136,3 +136,43 @@ def test_slab_split_matches_the_whole_cloud(world):
     assert all(r[1]["tgt_uncertified"] == 0 for r in res) and sum(r[1]["tgt_forwarded"] for r in res) > 0
     for rank, out, _ in res:
         assert (owner[out["tgt_src_gid"]] == rank).all()
+
+
+def _worker_heavy_column(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from fusion4landslide_amd import slabs
+    rng = np.random.default_rng(3)
+    n = 6000
+    x = np.where(rng.uniform(size=n) < 0.7, rng.uniform(2.0, 2.0 + RES * 0.9, n), rng.uniform(0, 5, n))  # 70 % of the points in ONE grid column
+    xyz = np.c_[x, rng.uniform(0, 3, n), rng.normal(0, 0.01, n)].astype(np.float32)
+    mine = np.arange(rank, n, world)
+    try:
+        slabs.slab_supervoxel(torch.from_numpy(xyz[mine]), torch.from_numpy(mine.astype(np.int64)), K_NN, RES, dist, rank, world, 0.2,
+                              knn_normals_fn=_knn_normals, segment_fn=_segment)
+        q.put((rank, "no error"))
+    except ValueError as e:
+        q.put((rank, str(e)))
+    dist.barrier()  # (every rank raised at the same point: nobody is left inside a collective)
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_a_slab_without_columns_is_refused_on_every_rank():
+    """with 70 % of the points in one column of the resolution grid and three ranks, the balanced cuts leave one rank no
+    column.  Halos only travel between adjacent ranks, so its neighbours would certify neighbour lists that miss the points on the
+    other side: `slab_supervoxel` must refuse, on every rank together (decided from the bounds all ranks hold)."""
+    world = 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_heavy_column, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=240) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert len(res) == world and all("own no grid column" in msg for msg in res.values()), res
