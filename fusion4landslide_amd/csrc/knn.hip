@@ -52,6 +52,14 @@ struct GridSpec {
     int nx, ny, nz;
 };
 
+// The grid as the DEVICE sized it (f4l_knn's no-host-round-trip path): kernels that are handed one take the grid and the number
+// of occupied cells from it instead of from their launch arguments.
+struct DevGrid {
+    GridSpec g;
+    int M;         // occupied cells
+    int dense_ok;  // the grid is small enough for the one-word-per-cell table
+};
+
 __device__ __forceinline__ void cell_of(const GridSpec &g, float x, float y, float z, int &cx, int &cy, int &cz) {
     cx = (int)(((double)x - g.minx) * g.inv_h);
     cy = (int)(((double)y - g.miny) * g.inv_h);
@@ -113,7 +121,8 @@ __global__ void cell_key_kernel(const float *__restrict__ xyz, int64_t n, GridSp
 
 // the same keys as 32-bit words (grids of fewer than 2^32 cells: nearly all): half the bytes through the radix sort
 __global__ void cell_key32_kernel(const float *__restrict__ xyz, int64_t n, GridSpec g, unsigned int *__restrict__ keys,
-                                  int32_t *__restrict__ ids) {
+                                  int32_t *__restrict__ ids, const DevGrid *__restrict__ dg = nullptr) {
+    if (dg) g = dg->g;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         int cx, cy, cz;
         cell_of(g, xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], cx, cy, cz);
@@ -160,7 +169,11 @@ __device__ __forceinline__ void cell_range(const int32_t *__restrict__ dense, co
     else { lo = cell_start[lower_bound_u64(cell_keys, M, k0)]; hi = cell_start[lower_bound_u64(cell_keys, M, k1 + 1ULL)]; }
 }
 __global__ void dense_scatter_kernel(const unsigned long long *__restrict__ cell_keys, const int32_t *__restrict__ cell_counts, int M,
-                                     int32_t *__restrict__ dense) {
+                                     int32_t *__restrict__ dense, const DevGrid *__restrict__ dg = nullptr) {
+    if (dg) {
+        if (!dg->dense_ok) return;
+        M = dg->M;
+    }
     const int j = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     if (j < M) dense[cell_keys[j] + 1ULL] = cell_counts[j];
 }
@@ -172,9 +185,15 @@ constexpr int KNN_NW = 4;
 __global__ void cell_runs_kernel(const unsigned long long *__restrict__ q_keys, const int32_t *__restrict__ q_start, int Mq,
                                  const unsigned long long *__restrict__ cell_keys, const int32_t *__restrict__ cell_start, int M,
                                  const int32_t *__restrict__ dense, GridSpec g, int32_t *__restrict__ run_lo, int32_t *__restrict__ run_hi,
-                                 int32_t *__restrict__ pcell) {
-    const int t = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-    if (t >= 9 * Mq) return;
+                                 int32_t *__restrict__ pcell, const DevGrid *__restrict__ dg = nullptr) {
+    if (dg) {
+        g = dg->g;
+        M = Mq = dg->M;
+        if (!dg->dense_ok) dense = nullptr;
+    }
+    const int64_t t64 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t64 >= 9 * (int64_t)Mq) return;
+    const int t = (int)t64;
     const int c = t / 9, r = t % 9;
     const unsigned long long key = q_keys[c];
     const int cx = (int)(key % (unsigned long long)g.nx);
@@ -209,7 +228,14 @@ struct KnnArgs {
     GridSpec g;
     int32_t *idx_out;
     double *d2_out;
+    const DevGrid *dg;                // non-null: grid, cell counts and the dense-table switch come from the device (see DevGrid)
 };
+__device__ __forceinline__ void adopt_device_grid(KnnArgs &a) {
+    if (!a.dg) return;
+    a.g = a.dg->g;
+    a.M = a.Mq = a.dg->M;
+    if (!a.dg->dense_ok) a.dense = nullptr;
+}
 
 // Rows of the R = 1 block of cell (cx, cy, cz), one per lane (lanes 0..8): [lo, hi) of the sorted array.
 __device__ __forceinline__ void block1_rows(const KnnArgs &a, int cx, int cy, int cz, int &row_lo1, int &row_hi1) {
@@ -339,6 +365,7 @@ __global__ __launch_bounds__(KNN_NW * 64) void knn_cells_kernel(KnnArgs a) {
 // one wavefront per query, the search above.
 __global__ __launch_bounds__(KNN_NW * 64) void knn_listed_kernel(KnnArgs a, const int32_t *__restrict__ list,
                                                                 const int32_t *__restrict__ count) {
+    adopt_device_grid(a);
     const int lane = lane_id();
     const int n_list = *count;
     const int k = a.k;
@@ -371,6 +398,7 @@ __global__ __launch_bounds__(KNN_NW * 64) void knn_listed_kernel(KnnArgs a, cons
 // `list` = nullptr: all nq queries of q_sorted; else the listed ones.
 constexpr int KS_MAX_K = 4;
 __global__ __launch_bounds__(256) void nn_small_kernel(KnnArgs a, int nq, const int32_t *__restrict__ list, const int32_t *__restrict__ count) {
+    adopt_device_grid(a);
     const int n_q = list ? *count : nq;
     const GridSpec g = a.g;
     const int k = a.k;
@@ -622,7 +650,14 @@ __global__ __launch_bounds__(KR_NW * 64, 2) void knn_lanes_kernel(KnnLanesArgs r
     __shared__ unsigned int s_hist[KR_NW][KR_NB * 64];
     __shared__ unsigned int s_list[KR_NW][(KR_CAP + 1) * 64];  // (+ 1: the row predicated-off writes of pass 2 land in)
     __shared__ __attribute__((aligned(16))) float s_tile[KR_NW][3 * 68];
-    const KnnArgs &a = ra.a;
+    KnnArgs a = ra.a;
+    int bin_base = ra.bin_base;
+    float edge_slack = ra.edge_slack;
+    if (a.dg) {  // (the host did not know the cell size when it launched)
+        adopt_device_grid(a);
+        edge_slack = (float)(1e-6 * a.g.h * a.g.h);
+        bin_base = (int)(__float_as_uint((float)(4.0 * a.g.h * a.g.h)) >> 21) - (KR_NB - 1);
+    }
     const GridSpec g = a.g;
     const int lane = lane_id(), wave = (int)(threadIdx.x >> 6);
     unsigned int *hist = s_hist[wave] + lane, *list = s_list[wave] + lane;
@@ -678,7 +713,7 @@ __global__ __launch_bounds__(KR_NW * 64, 2) void knn_lanes_kernel(KnnLanesArgs r
                     for (int w = 0; w < 4; ++w) {
                         const float dx = xs[w] - rx, dy = ys[w] - ry_, dz = zs[w] - rz_;
                         const float d2 = dx * dx + dy * dy + dz * dz;
-                        int b = (int)(__float_as_uint(d2) >> 21) - ra.bin_base;
+                        int b = (int)(__float_as_uint(d2) >> 21) - bin_base;
                         b = b < 0 ? 0 : (b > KR_NB - 1 ? KR_NB - 1 : b);
                         o.addr[4 * v + w] = b * 64;
                         o.inc[4 * v + w] = 4 * v + w < real ? one : 0u;
@@ -703,7 +738,7 @@ __global__ __launch_bounds__(KR_NW * 64, 2) void knn_lanes_kernel(KnnLanesArgs r
         }
         if (mine && T == KR_NB) fb = true;  // fewer than k points in the block
         // upper edge of bin T, widened far beyond the float32 error of the wave-relative arithmetic; lanes of other rows: nothing
-        float edge = T >= KR_NB - 1 ? __builtin_inff() : __uint_as_float((unsigned int)(T + ra.bin_base + 1) << 21) * 1.0001f + ra.edge_slack;
+        float edge = T >= KR_NB - 1 ? __builtin_inff() : __uint_as_float((unsigned int)(T + bin_base + 1) << 21) * 1.0001f + edge_slack;
         edge = mine ? edge : -1.0f;
         KR_TICK(2);
         // pass 2: the candidates below it go to the lane's list (branch free: a lane that does not take a candidate writes
@@ -1030,6 +1065,82 @@ static int bbox_to_host(const float *xyz, int64_t n, float *partial, hipStream_t
     return F4L_OK;
 }
 
+// ---- the same sizing without the host: f4l_knn on a stream that must not be synchronised (a HIP graph capture; F4L_KNN_ASYNC) ----
+// One thread finishes the bounding box and sets the cell size from the surface-density guess of knn_build_grid -- without the
+// correction from the measured occupancy, which would need the count on the host: exact for any cell size, tuned for terrain (where
+// the guess is within the accepted band); the grid is kept below 2^32 cells so that the keys sort as 32-bit words.
+__global__ void grid_init_kernel(const float *__restrict__ partial, int nb, int64_t n, int k, DevGrid *dg) {
+    double mn[3] = {1e300, 1e300, 1e300}, mx[3] = {-1e300, -1e300, -1e300};
+    for (int b = 0; b < nb; ++b)
+        for (int d = 0; d < 3; ++d) {
+            if (partial[6 * b + d] < mn[d]) mn[d] = partial[6 * b + d];
+            if (partial[6 * b + 3 + d] > mx[d]) mx[d] = partial[6 * b + 3 + d];
+        }
+    bool ok = true;
+    for (int d = 0; d < 3; ++d) ok = ok && mx[d] >= mn[d] && isfinite(mn[d]) && isfinite(mx[d]);
+    if (!ok) { for (int d = 0; d < 3; ++d) { mn[d] = 0.0; mx[d] = 0.0; } }  // (NaN / inf coordinates: one cell; the sizing with the host refuses them)
+    const double ext[3] = {mx[0] - mn[0], mx[1] - mn[1], mx[2] - mn[2]};
+    double e0 = ext[0], e1 = ext[1], e2 = ext[2], t;
+    if (e0 > e1) { t = e0; e0 = e1; e1 = t; }
+    if (e1 > e2) { t = e1; e1 = e2; e2 = t; }
+    if (e0 > e1) { t = e0; e0 = e1; e1 = t; }
+    const double diag = sqrt(ext[0] * ext[0] + ext[1] * ext[1] + ext[2] * ext[2]);
+    const double target = k / 2.0 < 4.0 ? 4.0 : k / 2.0;
+    double h;
+    if (diag == 0.0) h = 1.0;
+    else {
+        const double area = (e2 > 0 ? e2 : diag) * (e1 > 0 ? e1 : (e2 > 0 ? e2 : diag) * 1e-3);
+        h = sqrt(target * area / (double)n);
+        if (!(h > 0.0)) h = diag;
+    }
+    GridSpec g;
+    for (int iter = 0; iter < 64; ++iter) {
+        const double hmin = (e2 > 0 ? e2 : 1.0) / 1048000.0;
+        if (h < hmin) h = hmin;
+        g.minx = mn[0]; g.miny = mn[1]; g.minz = mn[2];
+        g.h = h; g.inv_h = 1.0 / h; g.inv_hz = g.inv_h;
+        g.nx = (int)(ext[0] / h) + 1; g.ny = (int)(ext[1] / h) + 1; g.nz = (int)(ext[2] / h) + 1;
+        if (g.nz > 1 && 5 * g.nz < (g.nx < g.ny ? g.nx : g.ny)) { g.nz = 1; g.inv_hz = 0.0; }
+        if ((double)g.nx * (double)g.ny * (double)g.nz < 4294967295.0) break;
+        h *= 1.26;  // (a volume with so many cells of this size: larger cells until the keys fit 32 bits)
+    }
+    dg->g = g;
+    dg->M = 0;
+    dg->dense_ok = (double)g.nx * (double)g.ny * (double)g.nz <= 2.0 * (double)n + 2.0 ? 1 : 0;
+}
+__global__ void grid_finish_kernel(DevGrid *dg, const int32_t *__restrict__ n_cells) { dg->M = *n_cells; }
+
+static int knn_build_grid_async(const float *xyz, int64_t n, int k, KnnWs &w, hipStream_t st, DevGrid *dg) {
+    const unsigned bb_grid = grid_for(n, 256, 256);
+    hipLaunchKernelGGL(bbox_kernel, dim3(bb_grid), dim3(256), 0, st, xyz, n, w.bbox_partial);
+    hipLaunchKernelGGL(grid_init_kernel, dim3(1), dim3(1), 0, st, w.bbox_partial, (int)bb_grid, n, k, dg);
+    F4L_LAUNCH_CHECK();
+    unsigned int *k32a = reinterpret_cast<unsigned int *>(w.keys_a), *k32b = reinterpret_cast<unsigned int *>(w.keys_b);
+    unsigned int *u32 = k32b + n;  // (second half of the 64-bit buffer)
+    hipLaunchKernelGGL(cell_key32_kernel, dim3(grid_for(n)), dim3(256), 0, st, xyz, n, GridSpec(), k32a, w.ids_a, (const DevGrid *)dg);
+    F4L_LAUNCH_CHECK();
+    size_t tb = w.prim_bytes;
+    F4L_HIP_CHECK(rocprim::radix_sort_pairs<KeySortConfig>(w.prim_temp, tb, k32a, k32b, w.ids_a, w.ids_b, (size_t)n, 0, 32u, st, false));
+    // (the scans below run over the arrays' whole capacity -- the host does not know how many cells are occupied: zeros behind them)
+    F4L_HIP_CHECK(hipMemsetAsync(w.cell_counts, 0, ((size_t)n + 1) * 4, st));
+    tb = w.prim_bytes;
+    F4L_HIP_CHECK(rocprim::run_length_encode(w.prim_temp, tb, k32b, (unsigned int)n, u32, w.cell_counts, w.n_cells, st, false));
+    hipLaunchKernelGGL(widen_keys_kernel, dim3(256), dim3(256), 0, st, u32, w.n_cells, w.cell_keys);
+    hipLaunchKernelGGL(grid_finish_kernel, dim3(1), dim3(1), 0, st, dg, (const int32_t *)w.n_cells);
+    F4L_LAUNCH_CHECK();
+    tb = w.prim_bytes;
+    F4L_HIP_CHECK(rocprim::exclusive_scan(w.prim_temp, tb, w.cell_counts, w.cell_start, 0, (size_t)n + 1, rocprim::plus<int32_t>(), st, false));
+    hipLaunchKernelGGL(relayout_kernel, dim3(grid_for(n)), dim3(256), 0, st, xyz, w.ids_b, n, w.sorted);
+    F4L_LAUNCH_CHECK();
+    F4L_HIP_CHECK(hipMemsetAsync(w.dense, 0, (2 * (size_t)n + 4) * 4, st));
+    hipLaunchKernelGGL(dense_scatter_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w.cell_keys, w.cell_counts, 0, w.dense, (const DevGrid *)dg);
+    F4L_LAUNCH_CHECK();
+    tb = w.prim_bytes;
+    F4L_HIP_CHECK(rocprim::inclusive_scan(w.prim_temp, tb, w.dense, w.dense, 2 * (size_t)n + 4, rocprim::plus<int32_t>(), st, false));
+    w.has_dense = true;
+    return F4L_OK;
+}
+
 static int knn_build_grid(const float *xyz, int64_t n, int k, KnnWs &w, hipStream_t st, GridSpec &g, int &M) {
     // 1. bounding box
     double mn[3], mx[3];
@@ -1138,15 +1249,33 @@ static int knn_self(const float *xyz, int64_t n, int k, int32_t *idx_out, double
     int rc = knn_ws_layout(n, w, (unsigned char *)workspace);
     if (rc != F4L_OK) return rc;
     if (workspace_bytes < w.total) return F4L_EWORKSPACE;
-    GridSpec g;
+    GridSpec g = GridSpec();
     int M = 0;
-    rc = knn_build_grid(xyz, n, k, w, st, g, M);
+    // The grid is sized with the host in the loop (two read-backs: bounding box, occupied cells -- and a cell size corrected by
+    // the measured occupancy) unless the stream must not be synchronised: while it is being captured into a HIP graph, or on
+    // request (F4L_KNN_ASYNC); then the device sizes it (knn_build_grid_async) and the kernels read grid and counts there.
+    DevGrid *dg = nullptr;
+    {
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(st, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
+        const bool lanes_or_small = !getenv("F4L_KNN_WAVE_PER_QUERY") && k <= KR_MAX_K;
+        if ((cap != hipStreamCaptureStatusNone || getenv("F4L_KNN_ASYNC")) && lanes_or_small)
+            dg = reinterpret_cast<DevGrid *>(reinterpret_cast<unsigned char *>(w.n_cells) + 64);
+        else if (cap != hipStreamCaptureStatusNone)
+            return F4L_EUNSUPPORTED;  // (the wave-per-query search sizes its launch by the occupied cells)
+    }
+    if (dg) {
+        rc = knn_build_grid_async(xyz, n, k, w, st, dg);
+        M = (int)n;  // (an upper bound, to size launches by: the kernels take the count from the device)
+    } else {
+        rc = knn_build_grid(xyz, n, k, w, st, g, M);
+    }
     if (rc != F4L_OK) return rc;
     KnnArgs a;
     a.sorted = w.sorted; a.cell_keys = w.cell_keys; a.cell_start = w.cell_start; a.M = M; a.n = n; a.k = k; a.g = g;
     a.dense = w.has_dense ? w.dense : nullptr;
     a.q_sorted = w.sorted; a.q_cell_keys = w.cell_keys; a.q_cell_start = w.cell_start; a.Mq = M;
-    a.idx_out = idx_out; a.d2_out = d2_out;
+    a.idx_out = idx_out; a.d2_out = d2_out; a.dg = dg;
     if (k <= KS_MAX_K && !normals_out && !getenv("F4L_KNN_WAVE_PER_QUERY") && !getenv("F4L_KNN_NO_SMALL")) {
         hipLaunchKernelGGL(nn_small_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a, (int)n, (const int32_t *)nullptr, (const int32_t *)nullptr);
         F4L_LAUNCH_CHECK();
@@ -1170,7 +1299,7 @@ static int knn_self(const float *xyz, int64_t n, int k, int32_t *idx_out, double
     // one lane per query; the queries it cannot certify are listed and redone one wave each
     F4L_HIP_CHECK(hipMemsetAsync(w.fb_count, 0, 4, st));
     hipLaunchKernelGGL(cell_runs_kernel, dim3((unsigned)((9 * (int64_t)M + 255) / 256)), dim3(256), 0, st, w.cell_keys, w.cell_start, M,
-                       w.cell_keys, w.cell_start, M, a.dense, g, w.run_lo, w.run_hi, w.pcell);
+                       w.cell_keys, w.cell_start, M, a.dense, g, w.run_lo, w.run_hi, w.pcell, (const DevGrid *)dg);
     F4L_LAUNCH_CHECK();
     KnnLanesArgs ra;
     ra.run_lo = w.run_lo; ra.run_hi = w.run_hi; ra.pcell = w.pcell;
@@ -1277,7 +1406,7 @@ extern "C" int f4l_nn_query(const float *cloud, int64_t n, const float *queries,
         a.sorted = w.sorted; a.cell_keys = w.cell_keys; a.cell_start = w.cell_start; a.M = M; a.n = n; a.k = k; a.g = g;
         a.dense = w.has_dense ? w.dense : nullptr;
         a.q_sorted = wq.sorted; a.q_cell_keys = nullptr; a.q_cell_start = nullptr; a.Mq = 0;
-        a.idx_out = idx_out; a.d2_out = d2_out;
+        a.idx_out = idx_out; a.d2_out = d2_out; a.dg = nullptr;
         hipLaunchKernelGGL(nn_small_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, a, (int)m, (const int32_t *)nullptr, (const int32_t *)nullptr);
         F4L_LAUNCH_CHECK();
         return F4L_OK;
@@ -1298,7 +1427,7 @@ extern "C" int f4l_nn_query(const float *cloud, int64_t n, const float *queries,
     a.sorted = w.sorted; a.cell_keys = w.cell_keys; a.cell_start = w.cell_start; a.M = M; a.n = n; a.k = k; a.g = g;
     a.dense = w.has_dense ? w.dense : nullptr;
     a.q_sorted = wq.sorted; a.q_cell_keys = wq.cell_keys; a.q_cell_start = wq.cell_start; a.Mq = Mq;
-    a.idx_out = idx_out; a.d2_out = d2_out;
+    a.idx_out = idx_out; a.d2_out = d2_out; a.dg = nullptr;
     if (k > KR_MAX_K || getenv("F4L_KNN_WAVE_PER_QUERY")) {
         hipLaunchKernelGGL(knn_cells_kernel, dim3((unsigned)((Mq + KNN_NW - 1) / KNN_NW)), dim3(KNN_NW * 64), 0, st, a);
         F4L_LAUNCH_CHECK();

@@ -567,9 +567,12 @@ def supervoxel_lambda0(info):
     return struct.unpack("<d", struct.pack("<II", w[0], w[1]))[0]
 
 
-def supervoxel_parallel(xyz, k, resolution, return_intermediates=False):
+def supervoxel_parallel(xyz, k, resolution, return_intermediates=False, read_count=True):
     """Whole partition on the device (f4l_supervoxel_parallel: kNN + normals + the parallel segmentation).  Returns labels
-    (n,) int32 on the GPU and K (reads the device-side count: the one synchronisation)[, knn, normals, reps, info]."""
+    (n,) int32 on the GPU and K (reads the device-side count: the one synchronisation)[, knn, normals, reps, info].
+    read_count=False: nothing is read back -- returns (labels, info (8,) int32 ON THE DEVICE[, knn, normals, reps]); with the
+    stream under capture (or F4L_KNN_ASYNC set) f4l_knn sizes its grid on the device too, and the whole partition is one
+    enqueue-only call that a HIP graph can hold (tests/test_gpu_supervoxel_parallel.py)."""
     torch = require_gpu()
     xyz = _dev(xyz, torch.float32, "xyz", (3,))
     n = xyz.shape[0]
@@ -582,6 +585,8 @@ def supervoxel_parallel(xyz, k, resolution, return_intermediates=False):
     ws = torch.empty((max(int(nbytes), 1),), dtype=torch.uint8, device=xyz.device)
     check(lib().f4l_supervoxel_parallel(ptr(xyz), n, int(k), float(resolution), ptr(labels), ptr(reps), ptr(info), ptr(knn_out),
                                         ptr(nrm_out), ptr(ws), C.c_size_t(nbytes), stream_ptr()), "f4l_supervoxel_parallel")
+    if not read_count:
+        return (labels, info, knn_out, nrm_out, reps) if return_intermediates else (labels, info)
     info_h = info.cpu()
     K = int(info_h[0])
     if int(info_h[2]) & 6:  # (bit 0, a disconnected neighbour graph that stops above its target, leaves a valid partition)

@@ -264,7 +264,8 @@ int f4l_supervoxel(const float *xyz, int64_t n, int k, double resolution, int32_
  *   1 + the number of the sub-round whose proposals were cut to reach K exactly (0: none)};
  *   status bit 0: the graph of representatives ran out of edges above K (disconnected cloud; the reference would not
  *   return), bit 1: lambda schedule exhausted above K, bit 2: exchange stopped by the sweep budget before its fixed point.
- * f4l_supervoxel_parallel = f4l_knn + f4l_normals + this (f4l_knn synchronises once while it sizes its grid). */
+ * f4l_supervoxel_parallel = f4l_knn + f4l_normals + this (f4l_knn synchronises while it sizes its grid -- unless the stream is
+ * being captured into a HIP graph or F4L_KNN_ASYNC is set: then the grid is sized on the device and the call only enqueues). */
 size_t f4l_supervoxel_segment_device_workspace_bytes(int64_t n, int k);
 int f4l_supervoxel_segment_device(const float *xyz, const double *normals, const int32_t *knn, int64_t n, int k,
                                   double resolution, const float *grid_bbox_host, int32_t *labels_out, int32_t *reps_out,

@@ -184,3 +184,36 @@ def test_full_path_over_slabs_single_rank_equals_the_tile_path(eng):
     for key in ("T", "fitness", "rmse", "iters", "rows", "src_off", "tgt_off"):
         assert torch.equal(part[key], whole[key]), key
     assert part["stage_ms"]["total"] > 0 and "target_exchange" in part["stage_ms"]
+
+
+def test_whole_partition_is_capturable_into_a_hip_graph(eng):
+    """f4l_supervoxel_parallel -- kNN, normals, segmentation -- only enqueues when its stream is under capture (f4l_knn then sizes
+    its grid on the device instead of reading the bounding box and the cell count back): captured once, replayed, the labels
+    of the eager call every time.  The same path on request (F4L_KNN_ASYNC) gives the eager path's neighbours exactly: the
+    search is exact for any cell size."""
+    rng = np.random.default_rng(9)
+    xyz = np.c_[rng.uniform(0, 8, (60_000, 2)), np.zeros(60_000)]
+    xyz[:, 2] = 0.3 * np.sin(xyz[:, 0]) * np.cos(1.3 * xyz[:, 1]) + rng.normal(0, 0.003, 60_000)
+    x = dev(xyz.astype(np.float32))
+    ref_labels, K = eng.supervoxel_parallel(x, 30, 0.5)
+    idx_ref, d2_ref = eng.knn(x, 30, return_d2=True)
+    os.environ["F4L_KNN_ASYNC"] = "1"
+    try:
+        idx, d2 = eng.knn(x, 30, return_d2=True)
+        idx2 = eng.knn(x, 2)
+    finally:
+        del os.environ["F4L_KNN_ASYNC"]
+    assert torch.equal(d2, d2_ref) and torch.equal(idx, idx_ref) and torch.equal(idx2, eng.knn(x, 2))
+    torch.cuda.synchronize()
+    g, s = torch.cuda.CUDAGraph(), torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        eng.supervoxel_parallel(x, 30, 0.5, read_count=False)
+        torch.cuda.synchronize()
+        with torch.cuda.graph(g, stream=s):
+            labels, info = eng.supervoxel_parallel(x, 30, 0.5, read_count=False)
+    for _ in range(3):
+        labels.zero_()
+        info.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(labels, ref_labels) and int(info[0]) == K and int(info[2]) == 0
