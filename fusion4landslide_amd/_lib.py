@@ -41,6 +41,7 @@ SIGNATURES = {
     "f4l_knn_workspace_bytes": (_SZ, [_I64, _I]),
     "f4l_knn": (C.c_int, [_P, _I64, _I, _P, _P, _P, _SZ, _P]),
     "f4l_knn_normals": (C.c_int, [_P, _I64, _I, _P, _P, _P, _P, _SZ, _P]),
+    "f4l_knn_normals_nn1": (C.c_int, [_P, _I64, _I, _P, _P, _P, _P, _P, _SZ, _P]),
     "f4l_normals": (C.c_int, [_P, _I64, _P, _I, _P, _P]),
     "f4l_voxel_downsample_workspace_bytes": (_SZ, [_I64]),
     "f4l_voxel_downsample": (C.c_int, [_P, _I64, _D, _I, _P, _P, _P, _P, _P, _SZ, _P]),

@@ -86,7 +86,8 @@ struct IcpArgs {
     int32_t *iters_out, *corr_out;
     int subdiv;     // cells per radius the grid may use (patch_grid.h: grid_build)
     float dens;     // points per bounding-box cell a subdivided grid keeps on average
-    double mu_frac; // certificate margin as a fraction of the correspondence radius
+    double mu_frac; // certificate margin as a fraction of the correspondence radius ...
+    double mu_cell; // ... and of the cell edge (the smaller of the two counts: fine grids, i.e. dense patches, get less)
     int debug;  // F4L_ICP_DEBUG env, bit switches for A/B measurements and tests: 4 = no certificates, 8 = no bound from
                 // the previous correspondence, 16 = no narrow look-up before pass 0 on fine grids, 128 = always the Jacobi
                 // SVD (no Newton), 64 = search counters (profiling build)
@@ -338,7 +339,7 @@ __global__ __launch_bounds__(NW * 64, WIDE ? 3 : (sizeof(F) == 8 ? ICP_WAVES_PER
     __syncthreads();  // scratch is free again
     // margin of the certificates beyond the re-measured correspondence: a fraction of the radius, less on grids
     // finer than the radius (dense patches), where a wide margin would pull many points into every search
-    const F mu = rF * (F)a.mu_frac < g.h * (F)0.25 ? rF * (F)a.mu_frac : g.h * (F)0.25;
+    const F mu = rF * (F)a.mu_frac < g.h * (F)a.mu_cell ? rF * (F)a.mu_frac : g.h * (F)a.mu_cell;
 
     // Fused initialisation: weighted Kabsch of this patch's correspondences (scripts/weighted_svd.py:58-129, the same
     // arithmetic as kabsch_kernel<float, NW, false>): two streaming passes, block reductions, SVD on one thread.
@@ -1075,6 +1076,10 @@ static int f4l::icp_launch_host(const float *src, const int64_t *src_off, const 
     { const char *e = getenv("F4L_ICP_DENS"); if (e && atof(e) > 0.0) a.dens = (float)atof(e); }
     { const char *e = getenv("F4L_ICP_SUBDIV"); if (e && atoi(e) >= 1) a.subdiv = atoi(e); }
     { const char *e = getenv("F4L_ICP_MU"); if (e && atof(e) > 0.0) a.mu_frac = atof(e); }
+    // (an eighth of a cell: C3 20.3 ms against 22.3 with a quarter -- a search scans everything within the previous
+    //  correspondence's distance plus this margin, and on a fine grid the runner-up limits the certificate long before it)
+    a.mu_cell = 0.125;
+    { const char *e = getenv("F4L_ICP_MU_CELL"); if (e && atof(e) > 0.0) a.mu_cell = atof(e); }
     a.T_out = T_out; a.fitness_out = fitness_out; a.rmse_out = rmse_out; a.iters_out = iters_out; a.corr_out = corr_out;
 
     // throughput regime: six and more rounds of workgroups (1024 slots of four waves on the chip), where patches per second

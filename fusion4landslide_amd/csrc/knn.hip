@@ -228,6 +228,7 @@ struct KnnArgs {
     GridSpec g;
     int32_t *idx_out;
     double *d2_out;
+    double *nn1_out = nullptr;        // [n] squared distance to the nearest OTHER point (slot 1 of the row), or null
     const DevGrid *dg;                // non-null: grid, cell counts and the dense-table switch come from the device (see DevGrid)
 };
 __device__ __forceinline__ void adopt_device_grid(KnnArgs &a) {
@@ -357,6 +358,7 @@ __global__ __launch_bounds__(KNN_NW * 64) void knn_cells_kernel(KnnArgs a) {
         if (lane < k) {
             a.idx_out[(int64_t)qid * k + lane] = best.i;
             if (a.d2_out) a.d2_out[(int64_t)qid * k + lane] = best.d;
+            if (a.nn1_out && lane == 1) a.nn1_out[qid] = best.d;
         }
     }
 }
@@ -382,6 +384,7 @@ __global__ __launch_bounds__(KNN_NW * 64) void knn_listed_kernel(KnnArgs a, cons
         if (lane < k) {
             a.idx_out[(int64_t)qid * k + lane] = best.i;
             if (a.d2_out) a.d2_out[(int64_t)qid * k + lane] = best.d;
+            if (a.nn1_out && lane == 1) a.nn1_out[qid] = best.d;
         }
     }
 }
@@ -879,6 +882,7 @@ __global__ __launch_bounds__(KR_NW * 64, 2) void knn_lanes_kernel(KnnLanesArgs r
         for (int j = 0; j < KR_MAX_K; ++j)
             if (j < k) a.d2_out[row + j] = key[j];
     }
+    if (a.nn1_out && k > 1) a.nn1_out[__float_as_int(qp.w)] = key[1];
     if (ra.normals_out) {
         float px[KR_MAX_K], py[KR_MAX_K], pz[KR_MAX_K];
 #pragma unroll
@@ -961,10 +965,16 @@ __global__ void normals_listed_kernel(const float *__restrict__ xyz, const float
 __global__ void iota_kernel(int32_t *v, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) v[i] = (int32_t)i;
 }
-__global__ void label_hist_kernel(const int32_t *__restrict__ labels, int64_t n, int64_t K, unsigned long long *__restrict__ hist) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const int32_t l = labels[i];
-        if (l >= 0 && l < K) atomicAdd(&hist[l + 1], 1ULL);
+// CSR offsets straight from the SORTED labels: off[l] = first position whose label is >= l.  Position i (0 .. n) writes the
+// offsets of the labels that begin there: those above its left neighbour's label up to its own (one, unless labels are
+// skipped); position n those above the last label up to K.  No histogram, no atomics, no scan.
+__global__ void label_bounds_kernel(const int32_t *__restrict__ sorted, int64_t n, int64_t K, int64_t *__restrict__ off) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= n; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t a = i == 0 ? -1 : (int64_t)sorted[i - 1];
+        int64_t b = i == n ? K : (int64_t)sorted[i];
+        a = a < -1 ? -1 : a;
+        b = b > K ? K : b;
+        for (int64_t l = a + 1; l <= b; ++l) off[l] = i;
     }
 }
 
@@ -1242,7 +1252,7 @@ __global__ void normals_listed_kernel(const float *__restrict__ xyz, const float
                                       double *__restrict__ normals);
 
 static int knn_self(const float *xyz, int64_t n, int k, int32_t *idx_out, double *d2_out, double *normals_out, void *workspace,
-                    size_t workspace_bytes, hipStream_t st) {
+                    size_t workspace_bytes, hipStream_t st, double *nn1_out = nullptr) {
     if (!xyz || n <= 0 || k < 1 || k > n || !idx_out || !workspace) return F4L_EINVAL;
     if (k > F4L_MAX_K || n > 0x7fffffffLL) return F4L_EUNSUPPORTED;
     KnnWs w;
@@ -1275,8 +1285,8 @@ static int knn_self(const float *xyz, int64_t n, int k, int32_t *idx_out, double
     a.sorted = w.sorted; a.cell_keys = w.cell_keys; a.cell_start = w.cell_start; a.M = M; a.n = n; a.k = k; a.g = g;
     a.dense = w.has_dense ? w.dense : nullptr;
     a.q_sorted = w.sorted; a.q_cell_keys = w.cell_keys; a.q_cell_start = w.cell_start; a.Mq = M;
-    a.idx_out = idx_out; a.d2_out = d2_out; a.dg = dg;
-    if (k <= KS_MAX_K && !normals_out && !getenv("F4L_KNN_WAVE_PER_QUERY") && !getenv("F4L_KNN_NO_SMALL")) {
+    a.idx_out = idx_out; a.d2_out = d2_out; a.dg = dg; a.nn1_out = nn1_out;
+    if (k <= KS_MAX_K && !normals_out && !nn1_out && !getenv("F4L_KNN_WAVE_PER_QUERY") && !getenv("F4L_KNN_NO_SMALL")) {
         hipLaunchKernelGGL(nn_small_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a, (int)n, (const int32_t *)nullptr, (const int32_t *)nullptr);
         F4L_LAUNCH_CHECK();
         return F4L_OK;
@@ -1351,6 +1361,15 @@ extern "C" int f4l_knn_normals(const float *xyz, int64_t n, int k, int32_t *idx_
                                void *workspace, size_t workspace_bytes, void *stream) {
     if (!normals_out) return F4L_EINVAL;
     return f4l::knn_self(xyz, n, k, idx_out, d2_out, normals_out, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+// f4l_knn_normals that also hands out the squared distance of every point to its nearest other point (slot 1 of its
+// row): what `_compute_median_resolution` (src/coarse_to_fine_matching_base.py:2716-2754) takes the median of -- the
+// neighbour search of the partition then serves the resolution estimate too, and the 2-NN pass over the same cloud goes.
+extern "C" int f4l_knn_normals_nn1(const float *xyz, int64_t n, int k, int32_t *idx_out, double *d2_out, double *normals_out,
+                                   double *nn1_d2_out, void *workspace, size_t workspace_bytes, void *stream) {
+    if (!normals_out || !nn1_d2_out || k < 2) return F4L_EINVAL;
+    return f4l::knn_self(xyz, n, k, idx_out, d2_out, normals_out, workspace, workspace_bytes, (hipStream_t)stream, nn1_d2_out);
 }
 
 // ---- k nearest points of ANOTHER cloud --------------------------------------------------------------------------
@@ -1683,11 +1702,7 @@ extern "C" int f4l_labels_to_csr(const int32_t *labels, int64_t n, int64_t K, in
     size_t tb = w.prim_bytes;
     F4L_HIP_CHECK(rocprim::radix_sort_pairs<KeySortConfig>(w.prim_temp, tb, labels, w.keys_out, w.iota, order_out, (size_t)n, 0,
                                             (unsigned)end_bit, st, false));  // LSD radix sort is stable
-    F4L_HIP_CHECK(hipMemsetAsync(w.hist, 0, ((size_t)K + 1) * 8, st));
-    hipLaunchKernelGGL(label_hist_kernel, dim3(grid_for(n)), dim3(256), 0, st, labels, n, K, w.hist);
+    hipLaunchKernelGGL(label_bounds_kernel, dim3(grid_for(n + 1)), dim3(256), 0, st, (const int32_t *)w.keys_out, n, K, off_out);
     F4L_LAUNCH_CHECK();
-    tb = w.prim_bytes;
-    F4L_HIP_CHECK(rocprim::inclusive_scan(w.prim_temp, tb, w.hist, reinterpret_cast<unsigned long long *>(off_out),
-                                          (size_t)K + 1, rocprim::plus<unsigned long long>(), st, false));
     return F4L_OK;
 }

@@ -100,23 +100,30 @@ def kabsch2_batched(src, ref, off, weights=None, normalize_w=True, w_threshold=0
     return R, t
 
 
-def median_resolution(src, tgt=None):
+def _median_of_sqrt(d2):
+    """Device scalar: numpy's median (mean of the middle pair) of sqrt(d2) -- the square root first: the mean of the middle pair
+    is taken over distances."""
+    torch = require_gpu()
+    d = torch.sqrt(d2).contiguous()
+    out = torch.empty((1,), dtype=torch.float64, device=d.device)
+    nbytes = lib().f4l_median_f64_workspace_bytes(d.shape[0])
+    ws = torch.empty((max(int(nbytes), 1),), dtype=torch.uint8, device=d.device)
+    check(lib().f4l_median_f64(ptr(d), d.shape[0], 1, ptr(out), ptr(ws), C.c_size_t(nbytes), stream_ptr()), "f4l_median_f64")
+    return out
+
+
+def median_resolution(src, tgt=None, src_nn1_d2=None):
     """`_compute_median_resolution` (src/coarse_to_fine_matching_base.py:2716-2754): median distance of every point to
     its nearest other point (exact 2-NN on the GPU, f4l_knn), the larger of the two clouds' medians when `tgt` is given.
-    Returns a Python float."""
+    `src_nn1_d2`: the squared nearest-neighbour distances of `src` when a neighbour search of it has run already
+    (`knn_normals(..., return_nn1=True)`): its 2-NN pass is skipped.  Returns a Python float."""
     torch = require_gpu()
 
     def one(xyz):
-        """Device scalar: numpy's median (mean of the middle pair) of the nearest-neighbour distances."""
         _, d2 = knn(xyz, 2, return_d2=True)
-        d = torch.sqrt(d2[:, 1])  # (the square root first: the mean of the middle pair is taken over distances)
-        out = torch.empty((1,), dtype=torch.float64, device=d.device)
-        nbytes = lib().f4l_median_f64_workspace_bytes(d.shape[0])
-        ws = torch.empty((max(int(nbytes), 1),), dtype=torch.uint8, device=d.device)
-        check(lib().f4l_median_f64(ptr(d), d.shape[0], 1, ptr(out), ptr(ws), C.c_size_t(nbytes), stream_ptr()), "f4l_median_f64")
-        return out
+        return _median_of_sqrt(d2[:, 1])
 
-    r = one(src)
+    r = one(src) if src_nn1_d2 is None else _median_of_sqrt(_dev(src_nn1_d2, torch.float64, "src_nn1_d2"))
     if tgt is None:
         return float(r.item())
     return float(torch.maximum(r, one(tgt)).item())  # one read-back for both clouds
@@ -421,9 +428,10 @@ def knn(xyz, k, return_d2=False):
     return (idx, d2) if return_d2 else idx
 
 
-def knn_normals(xyz, k, return_d2=False):
+def knn_normals(xyz, k, return_d2=False, return_nn1=False):
     """Exact kNN and the PCA normal of every neighbour list in ONE launch (f4l_knn_normals; supervoxel.cpp:105-113)
-    -> (n, k) int32, (n, 3) float64[, (n, k) f64]."""
+    -> (n, k) int32, (n, 3) float64[, (n, k) f64][, (n,) f64: squared distance to the nearest other point
+    (f4l_knn_normals_nn1; equal to `knn(xyz, 2, return_d2=True)[1][:, 1]`)]."""
     torch = require_gpu()
     xyz = _dev(xyz, torch.float32, "xyz", (3,))
     n = xyz.shape[0]
@@ -432,6 +440,11 @@ def knn_normals(xyz, k, return_d2=False):
     d2 = torch.empty((n, k), dtype=torch.float64, device=xyz.device) if return_d2 else None
     nbytes = lib().f4l_knn_workspace_bytes(n, k)
     ws = torch.empty((max(int(nbytes), 1),), dtype=torch.uint8, device=xyz.device)
+    if return_nn1:
+        nn1 = torch.empty((n,), dtype=torch.float64, device=xyz.device)
+        check(lib().f4l_knn_normals_nn1(ptr(xyz), n, int(k), ptr(idx), ptr(d2), ptr(nrm), ptr(nn1), ptr(ws), C.c_size_t(nbytes),
+                                        stream_ptr()), "f4l_knn_normals_nn1")
+        return (idx, nrm, d2, nn1) if return_d2 else (idx, nrm, nn1)
     check(lib().f4l_knn_normals(ptr(xyz), n, int(k), ptr(idx), ptr(d2), ptr(nrm), ptr(ws), C.c_size_t(nbytes), stream_ptr()),
           "f4l_knn_normals")
     return (idx, nrm, d2) if return_d2 else (idx, nrm)

@@ -36,14 +36,30 @@ def full_path(src, tgt, k=30, icp_threshold=0.1, voxel_size=0.0, partition="para
         stages.append(name)
 
     mark("start")
-    if resolution is None:
-        med = engine.median_resolution(src, tgt)
+    if resolution is None and partition == "parallel" and k >= 2:
+        # the partition's neighbour search does not depend on the resolution: run it first and let it serve the median point
+        # spacing of the source epoch too (slot 1 of every row), instead of a 2-NN pass of its own over the same cloud
+        knn_idx, nrm, nn1 = engine.knn_normals(src, k, return_nn1=True)
+        mark("neighbours")
+        med = engine.median_resolution(src, tgt, src_nn1_d2=nn1)
         resolution = max(np.sqrt(3.0) * 10.0 * med, float(voxel_size), 1e-6)  # base:2668-2671
+        mark("median_resolution")
+        labels, info = engine.supervoxel_segment_device(src, nrm, knn_idx, float(resolution))
+        info_h = info.cpu()
+        K = int(info_h[0])
+        if int(info_h[2]) & 6:
+            raise RuntimeError(f"f4l_supervoxel_segment_device: the segmentation did not finish (status bits {int(info_h[2])})")
+        del knn_idx, nrm, nn1
+        mark("supervoxel_partition")
     else:
-        med = float(resolution) / (np.sqrt(3.0) * 10.0)
-    mark("median_resolution")
-    labels, K = (engine.supervoxel_parallel if partition == "parallel" else engine.supervoxel)(src, k, float(resolution))
-    mark("supervoxel_partition")
+        if resolution is None:
+            med = engine.median_resolution(src, tgt)
+            resolution = max(np.sqrt(3.0) * 10.0 * med, float(voxel_size), 1e-6)  # base:2668-2671
+        else:
+            med = float(resolution) / (np.sqrt(3.0) * 10.0)
+        mark("median_resolution")
+        labels, K = (engine.supervoxel_parallel if partition == "parallel" else engine.supervoxel)(src, k, float(resolution))
+        mark("supervoxel_partition")
     st = _patches_and_registration(torch, src, tgt, labels, None, K, med, icp_threshold, max_iter, fixed_iters, search, mark, keep_inputs)
     torch.cuda.synchronize()
     ms = {stages[i]: marks[i - 1].elapsed_time(marks[i]) for i in range(1, len(stages))}
@@ -67,13 +83,18 @@ def _patches_and_registration(torch, src, tgt, labels, tgt_nn, K, med, icp_thres
     max_s = int((off_s[1:] - off_s[:-1]).max().item()) if P else 0
     m, _ = engine.nn_refine(ps, off_s, pt, off_t, eye, torch.full((P,), 2.0 * icp_threshold, dtype=torch.float64, device=dev),
                             max_tgt_patch=max_t, return_rows=False)
+    # rows that found a match, their targets and the matches' CSR offsets: one compaction (`nonzero`), one running count --
+    # rows are in patch order, so the count of kept rows before a patch's first row is that patch's offset
     cnt = off_s[1:] - off_s[:-1]
-    pid = torch.repeat_interleave(torch.arange(P, device=dev), cnt, output_size=ps.shape[0])
     keep = m >= 0
-    cs = ps[keep]
-    ct = pt[off_t[pid[keep]] + m[keep].to(torch.int64)]
-    coff = torch.zeros(P + 1, dtype=torch.int64, device=dev)
-    coff[1:] = torch.cumsum(torch.bincount(pid[keep], minlength=P), 0)
+    kept = torch.nonzero(keep).squeeze(1)
+    tbase = torch.repeat_interleave(off_t[:-1], cnt, output_size=ps.shape[0])  # first target row of every source row's patch
+    cs = ps[kept]
+    ct = pt[tbase[kept] + m[kept].to(torch.int64)]
+    running = torch.zeros(ps.shape[0] + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(keep, 0, out=running[1:])
+    coff = running[off_s]
+    del tbase, running
     mark("point_matches")
     out = engine.patch_loop(ps, off_s, pt, off_t, cs.contiguous(), ct.contiguous(), coff, None, 0.0, 1e-6, max_corr_dist=icp_threshold,
                             max_iter=max_iter, fixed_iters=fixed_iters, max_src_patch=max_s, max_tgt_patch=max_t, search=search)

@@ -238,6 +238,11 @@ int f4l_normals(const float *xyz, int64_t n, const int32_t *knn_idx, int k, doub
  * (grid sizing, like f4l_knn). */
 int f4l_knn_normals(const float *xyz, int64_t n, int k, int32_t *idx_out, double *d2_out, double *normals_out,
                     void *workspace, size_t workspace_bytes, void *stream);
+/* ... and with the squared distance of every point to its nearest OTHER point (slot 1 of its row; double [n], k >= 2): the
+ * quantity `_compute_median_resolution` (src/coarse_to_fine_matching_base.py:2716-2754) takes the median of, so that the
+ * partition's neighbour search serves the resolution estimate too (same values as f4l_knn with k = 2). */
+int f4l_knn_normals_nn1(const float *xyz, int64_t n, int k, int32_t *idx_out, double *d2_out, double *normals_out,
+                        double *nn1_d2_out, void *workspace, size_t workspace_bytes, void *stream);
 size_t f4l_supervoxel_workspace_bytes(int64_t n, int k);
 int f4l_supervoxel(const float *xyz, int64_t n, int k, double resolution, int32_t *labels_out,
                    int32_t *n_supervoxels_host, int32_t *knn_out, double *normals_out, void *workspace,

@@ -201,6 +201,19 @@ def test_median_resolution_vs_kdtree():
     got = engine.median_resolution(torch.from_numpy(c["src"]).cuda(), torch.from_numpy(c["tgt"][:30_001]).cuda())
     assert abs(got - max(ref)) <= 1e-12 * max(ref) + 1e-15
     assert abs(engine.median_resolution(torch.from_numpy(c["src"]).cuda()) - ref[0]) <= 1e-12
+    # the partition's own neighbour search hands out the same nearest-neighbour distances (f4l_knn_normals_nn1): bit-equal to
+    # the 2-NN pass, the same rows and normals as without that output, and the same median when it stands in for the 2-NN pass
+    s_dev, t_dev = torch.from_numpy(c["src"]).cuda(), torch.from_numpy(c["tgt"][:30_001]).cuda()
+    idx, nrm, nn1 = engine.knn_normals(s_dev, 30, return_nn1=True)
+    idx0, nrm0 = engine.knn_normals(s_dev, 30)
+    assert torch.equal(idx, idx0) and torch.equal(nrm, nrm0)
+    assert torch.equal(nn1, engine.knn(s_dev, 2, return_d2=True)[1][:, 1])
+    assert engine.median_resolution(s_dev, t_dev, src_nn1_d2=nn1) == got
+    # ... also where the lane-per-query kernel hands queries to the wave-per-query search (sparse outliers, duplicates)
+    rng = np.random.default_rng(3)
+    odd = np.concatenate([c["src"][:5000], c["src"][:40], rng.uniform(-50, 80, (60, 3)).astype(np.float32)])
+    odd_dev = torch.from_numpy(odd).cuda()
+    assert torch.equal(engine.knn_normals(odd_dev, 30, return_nn1=True)[2], engine.knn(odd_dev, 2, return_d2=True)[1][:, 1])
 
 
 def test_median_f64_is_numpys_median():
@@ -365,6 +378,11 @@ def test_full_path_of_a_tile_end_to_end():
     for partition in ("parallel", "identical"):
         r = pipeline.full_path(src, tgt, partition=partition)
         K = r["K"]
+        if partition == "parallel":  # (the path shares one neighbour search between the resolution estimate and the partition)
+            from fusion4landslide_amd import engine
+            assert abs(r["resolution"] - np.sqrt(3.0) * 10.0 * engine.median_resolution(src, tgt)) <= 1e-12
+            lab, K2 = engine.supervoxel_parallel(src, 30, r["resolution"])
+            assert K2 == K and torch.equal(lab, r["labels"])
         assert r["labels"].shape == (200_000,) and int(r["labels"].max()) == K - 1 and 500 < K < 50_000
         assert r["rows"].shape == (200_000, 6) and r["T"].shape == (K, 4, 4) and set(r["stage_ms"]) >= {"supervoxel_partition", "patch_loop", "total"}
         order, so, to = r["order"].cpu().numpy(), r["src_off"].cpu().numpy(), r["tgt_off"].cpu().numpy()

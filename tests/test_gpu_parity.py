@@ -743,6 +743,12 @@ def test_labels_to_csr_and_gather(eng):
     assert np.array_equal(order, np.argsort(labels, kind="stable"))
     pts = rng.uniform(0, 1, (n, 3)).astype(np.float32)
     assert np.array_equal(eng.gather_points(dev(pts), dev(order.astype(np.int32))).cpu().numpy(), pts[order])
+    # empty supervoxels at both ends and in a row, a single label, a single point
+    for lab, k in ((np.where((labels < 3) | (labels > 30), 17, labels), K), (np.zeros(100, np.int32), 1), (np.full(7, 4, np.int32), 9),
+                   (np.array([2], np.int32), 5)):
+        o, f = eng.labels_to_csr(dev(lab.astype(np.int32)), k)
+        assert np.array_equal(np.diff(f.cpu().numpy()), np.bincount(lab, minlength=k)) and int(f[0]) == 0
+        assert np.array_equal(o.cpu().numpy(), np.argsort(lab, kind="stable"))
 
 
 # --------------------------------------------------------------- size-independent properties, full size
