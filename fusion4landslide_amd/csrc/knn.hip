@@ -578,70 +578,108 @@ __device__ __forceinline__ void pca_normal_regs(const float (&px)[MAXK], const f
 // per step, coordinates relative to the wave origin.  The tile is three arrays (x, y, z) so that one broadcast ds_read_b128
 // brings the same coordinate of four candidates and packed float32 instructions work on them in pairs.  Every step is split
 // in two so that LDS latency stays off the critical path at two waves per SIMD:
-//     R = measure(index of the first, x[KR_U], y[KR_U], z[KR_U], how many are real)      registers only
+//     R = measure(index of the first, x[KR_U], y[KR_U], z[KR_U], how many are real)      registers only (places past the
+//                                                                                        run hold points at infinity)
 //     <the NEXT step's tile reads are issued here>
 //     commit(R)                                                                           the step's LDS writes / atomics
 // (LDS operations of a wave complete in order: reads issued before the commit's writes are not held up by them.)
 // The next 64 candidates are requested from global memory before the current 64 are used.
 constexpr int KR_U = 8;
+// Lanes of a wave that share a candidate set: the wave's 64 queries are KR_G groups of KR_L consecutive points, every group
+// with the nine runs of ITS OWN block -- the cells its queries span, plus one on either side -- streamed through its own
+// segment of the tile.  The union block of all 64 queries holds 324 candidates per lane at 1 M points; the larger of two
+// half-wave blocks 242, of four quarter-wave blocks 201 (simulated on the C2 cloud: tools/knn_block_sim.py): a wave walks
+// as many steps as its longest group.
+#ifndef F4L_KNN_GROUPS
+#define F4L_KNN_GROUPS 4
+#endif
+// KR_T: candidates a group stages per tile; a lane loads KR_T / KR_L of them.  One per lane is what works: two loads in flight
+// per lane (tiles of 32 for four groups, 64 for two) cost 50 % -- the prefetched registers are copied, i.e. waited for,
+// right behind the loads -- and so measured: per 10 M points 4.96 ms one group (round 2), 4.54 with padded tiles, 4.22 two
+// groups, 4.17 four groups of 16; 6.2 - 6.6 ms with the longer tiles.
+#ifndef F4L_KNN_TILE
+#define F4L_KNN_TILE 16
+#endif
+constexpr int KR_G = F4L_KNN_GROUPS, KR_L = 64 / KR_G, KR_T = KR_L < F4L_KNN_TILE ? F4L_KNN_TILE : KR_L, KR_PL = KR_T / KR_L;
+constexpr int KR_TS = 3 * (KR_T + 4);  // tile segment of a group: x[], y[], z[] of KR_T + 4
 struct KrStep { float4 x[KR_U / 4], y[KR_U / 4], z[KR_U / 4]; };
-__device__ __forceinline__ void kr_read(const float *tile, int u, KrStep &t) {
+__device__ __forceinline__ void kr_read(const float *gt, int u, KrStep &t) {
 #pragma unroll
     for (int v = 0; v < KR_U / 4; ++v) {
-        t.x[v] = *reinterpret_cast<const float4 *>(tile + u + 4 * v);
-        t.y[v] = *reinterpret_cast<const float4 *>(tile + 68 + u + 4 * v);
-        t.z[v] = *reinterpret_cast<const float4 *>(tile + 136 + u + 4 * v);
+        t.x[v] = *reinterpret_cast<const float4 *>(gt + u + 4 * v);
+        t.y[v] = *reinterpret_cast<const float4 *>(gt + (KR_T + 4) + u + 4 * v);
+        t.z[v] = *reinterpret_cast<const float4 *>(gt + 2 * (KR_T + 4) + u + 4 * v);
     }
 }
+// lo / hi: lane (first lane of its group) + r holds run r of the group's block as [lo, hi); groups without a block hold
+// empty runs.  Everything that is uniform inside a group lives in vector registers (the groups differ); the wave iterates
+// until its last group is through, groups that are done measure points at infinity.
 template <class R, class F1, class F2>
-__device__ __forceinline__ void kr_walk(const float4 *__restrict__ sorted, float *tile /* [3][64 + 4] */, int lo, int hi, double ox,
+__device__ __forceinline__ void kr_walk(const float4 *__restrict__ sorted, float *tile /* [KR_G][KR_TS] */, int lo, int hi, double ox,
                                         double oy, double oz, F1 &&measure, F2 &&commit) {
-    const int lane = lane_id();
-    // tiles of <= 64 candidates, run after run; the load of the NEXT tile (of this run or of the next non-empty one) is in
-    // flight while the current tile is consumed: nothing waits for global memory except the very first tile
-    int r = 0, s = 0, e = 0;
-    for (; r < 9; ++r) {
-        s = __builtin_amdgcn_readlane(lo, r);
-        e = __builtin_amdgcn_readlane(hi, r);
-        if (s < e) break;
+    const int lane = lane_id(), l = lane & (KR_L - 1), gb = lane & ~(KR_L - 1);
+    float *gt = tile + (lane / KR_L) * KR_TS;
+    // tiles of <= KR_T candidates per group, run after run; the load of the NEXT tile (of this run or of the next non-empty
+    // one) is in flight while the current tile is consumed: nothing waits for global memory except the very first tile
+    unsigned int runs = (unsigned int)(__ballot(lo < hi) >> gb) & 0x1ffu;  // the group's non-empty runs
+    int r = runs ? __builtin_ctz(runs) : 9;
+    int base = __shfl(lo, gb + (r < 9 ? r : 0), 64), e = __shfl(hi, gb + (r < 9 ? r : 0), 64);
+    if (!__any(r < 9)) return;
+    float4 nxt[KR_PL];
+    bool nxt_real[KR_PL];
+#pragma unroll
+    for (int c = 0; c < KR_PL; ++c) {
+        const int j = base + l + c * KR_L;
+        nxt[c] = sorted[r < 9 ? (j < e ? j : e - 1) : 0];
+        nxt_real[c] = r < 9 && j < e;
     }
-    if (r == 9) return;
-    int base = s;
-    float4 nxt = sorted[base + lane < e ? base + lane : e - 1];
-    while (r < 9) {
-        tile[lane] = (float)((double)nxt.x - ox);
-        tile[68 + lane] = (float)((double)nxt.y - oy);
-        tile[136 + lane] = (float)((double)nxt.z - oz);
-        const int cbase = base, m = e - base < 64 ? e - base : 64;
-        base += 64;
-        if (base >= e) {
-            for (++r; r < 9; ++r) {
-                s = __builtin_amdgcn_readlane(lo, r);
-                e = __builtin_amdgcn_readlane(hi, r);
-                if (s < e) break;
-            }
-            base = s;
+    while (__any(r < 9)) {
+        // places of the tile beyond the run hold a point at infinity (d2 = +inf: last bin of pass 1, below no edge in pass 2),
+        // so that neither pass has to ask which of a step's candidates are real
+#pragma unroll
+        for (int c = 0; c < KR_PL; ++c) {
+            gt[l + c * KR_L] = nxt_real[c] ? (float)((double)nxt[c].x - ox) : 1e30f;
+            gt[KR_T + 4 + l + c * KR_L] = nxt_real[c] ? (float)((double)nxt[c].y - oy) : 1e30f;
+            gt[2 * (KR_T + 4) + l + c * KR_L] = nxt_real[c] ? (float)((double)nxt[c].z - oz) : 1e30f;
         }
-        {   // (unconditional on purpose: a load under `if (r < 9)` makes the compiler copy the loaded registers into the loop's
-            //  own right behind the load, i.e. wait for it at once, and the tile's latency is back on the critical path)
-            const int at = r < 9 ? (base + lane < e ? base + lane : e - 1) : 0;
-            nxt = sorted[at];
+        const int cbase = base, m = r < 9 ? (e - base < KR_T ? e - base : KR_T) : 0;
+        base += KR_T;
+        const bool next_run = r < 9 && base >= e;
+        if (next_run) {
+            runs &= ~((2u << r) - 1u);
+            r = runs ? __builtin_ctz(runs) : 9;
+        }
+        {
+            const int s2 = __shfl(lo, gb + (r < 9 ? r : 0), 64), e2 = __shfl(hi, gb + (r < 9 ? r : 0), 64);
+            base = next_run ? s2 : base;
+            e = next_run ? e2 : e;
+        }
+        // (unconditional on purpose: a load under `if (r < 9)` makes the compiler copy the loaded registers into the loop's own
+        //  right behind the load, i.e. wait for it at once, and the tile's latency is back on the critical path)
+#pragma unroll
+        for (int c = 0; c < KR_PL; ++c) {
+            const int j = base + l + c * KR_L;
+            nxt[c] = sorted[r < 9 ? (j < e ? j : e - 1) : 0];
+            nxt_real[c] = r < 9 && j < e;
         }
         // two register sets used in turn (a single set would be copied from the prefetched one every step)
         KrStep t0, t1;
-        kr_read(tile, 0, t0);
-        for (int u = 0; u < m; u += 2 * KR_U) {
+        kr_read(gt, 0, t0);
+        int mw = 0;  // the longest group's count: the wave's trip count, in a scalar register
+#pragma unroll
+        for (int g = 0; g < KR_G; ++g) { const int mg = __builtin_amdgcn_readlane(m, g * KR_L); mw = mg > mw ? mg : mw; }
+        for (int u = 0; u < mw; u += 2 * KR_U) {
             {
                 const R res = measure(cbase + u, t0, m - u);
                 __builtin_amdgcn_sched_barrier(0);
-                if (u + KR_U < m) kr_read(tile, u + KR_U, t1);
+                if (KR_U < KR_T && u + KR_U < mw) kr_read(gt, u + KR_U, t1);
                 __builtin_amdgcn_sched_barrier(0);
                 commit(res);
             }
-            if (u + KR_U < m) {
+            if (KR_U < KR_T && u + KR_U < mw) {
                 const R res = measure(cbase + u + KR_U, t1, m - u - KR_U);
                 __builtin_amdgcn_sched_barrier(0);
-                if (u + 2 * KR_U < m) kr_read(tile, u + 2 * KR_U, t0);
+                if (2 * KR_U < KR_T && u + 2 * KR_U < mw) kr_read(gt, u + 2 * KR_U, t0);
                 __builtin_amdgcn_sched_barrier(0);
                 commit(res);
             }
@@ -652,7 +690,7 @@ __device__ __forceinline__ void kr_walk(const float4 *__restrict__ sorted, float
 __global__ __launch_bounds__(KR_NW * 64, 2) void knn_lanes_kernel(KnnLanesArgs ra) {
     __shared__ unsigned int s_hist[KR_NW][KR_NB * 64];
     __shared__ unsigned int s_list[KR_NW][(KR_CAP + 1) * 64];  // (+ 1: the row predicated-off writes of pass 2 land in)
-    __shared__ __attribute__((aligned(16))) float s_tile[KR_NW][3 * 68];
+    __shared__ __attribute__((aligned(16))) float s_tile[KR_NW][KR_G * KR_TS];
     KnnArgs a = ra.a;
     int bin_base = ra.bin_base;
     float edge_slack = ra.edge_slack;
@@ -686,27 +724,32 @@ __global__ __launch_bounds__(KR_NW * 64, 2) void knn_lanes_kernel(KnnLanesArgs r
     int cnt = 0;
     bool fb = false;
     unsigned long long remaining = __ballot(valid);
-    while (remaining != 0ULL) {  // one turn per (y, z) row of cells among the wave's queries: nearly always one
-        const int leader = __ffsll((long long)remaining) - 1;
-        const int ry = __builtin_amdgcn_readlane(cy, leader), rz = __builtin_amdgcn_readlane(cz, leader);
-        const bool mine = valid && cy == ry && cz == rz;
+    const int gl = lane & (KR_L - 1), gb = lane & ~(KR_L - 1);
+    const unsigned long long gmask = KR_L == 64 ? ~0ULL : ((1ULL << (KR_L & 63)) - 1ULL);
+    while (remaining != 0ULL) {  // one turn per (y, z) row of cells among a group's queries: nearly always one
+        // every group takes the row of its first query that is still waiting (a group that is through sits the turn out)
+        const unsigned long long grem = (remaining >> gb) & gmask;
+        const int leader = gb + (grem ? __ffsll((long long)grem) - 1 : 0);
+        const int ry = __shfl(cy, leader, 64), rz = __shfl(cz, leader, 64);
+        const bool mine = valid && grem != 0ULL && cy == ry && cz == rz;
         const unsigned long long act = __ballot(mine);
         remaining &= ~act;
         // the sorted order is x-fastest: the first / last lane of the row sit in its first / last cell; the runs come from
         // the per-cell table (cell_runs_kernel)
-        const int c_first = __builtin_amdgcn_readlane(pc, __ffsll((long long)act) - 1);
-        const int c_last = __builtin_amdgcn_readlane(pc, 63 - __clzll((long long)act));
+        const unsigned long long gact = (act >> gb) & gmask;
+        const int c_first = __shfl(pc, gb + (gact ? __ffsll((long long)gact) - 1 : 0), 64);
+        const int c_last = __shfl(pc, gb + (gact ? 63 - __clzll((long long)gact) : 0), 64);
         int lo = 0, hi = 0;
-        if (lane < 9) {
-            lo = ra.run_lo[9 * c_first + lane];
-            hi = ra.run_hi[9 * c_last + lane];
+        if (gl < 9 && gact != 0ULL) {
+            lo = ra.run_lo[9 * c_first + gl];
+            hi = ra.run_hi[9 * c_last + gl];
         }
         const unsigned int one = mine ? 1u : 0u;
         KR_TICK(0);
         // pass 1: per-lane histogram of the approximate d2 over the block's candidates
-        struct Bins { int addr[KR_U]; unsigned int inc[KR_U]; };
+        struct Bins { int addr[KR_U]; };
         kr_walk<Bins>(a.sorted, tile, lo, hi, ox, oy, oz,
-            [&](int, const KrStep &t, int real) {
+            [&](int, const KrStep &t, int) {
                 Bins o;
 #pragma unroll
                 for (int v = 0; v < KR_U / 4; ++v) {
@@ -719,14 +762,13 @@ __global__ __launch_bounds__(KR_NW * 64, 2) void knn_lanes_kernel(KnnLanesArgs r
                         int b = (int)(__float_as_uint(d2) >> 21) - bin_base;
                         b = b < 0 ? 0 : (b > KR_NB - 1 ? KR_NB - 1 : b);
                         o.addr[4 * v + w] = b * 64;
-                        o.inc[4 * v + w] = 4 * v + w < real ? one : 0u;
                     }
                 }
                 return o;
             },
             [&](const Bins &o) {
 #pragma unroll
-                for (int w = 0; w < KR_U; ++w) atomicAdd(&hist[o.addr[w]], o.inc[w]);
+                for (int w = 0; w < KR_U; ++w) atomicAdd(&hist[o.addr[w]], one);
             });
         KR_TICK(1);
         // the first bin at which the count reaches k
@@ -748,7 +790,7 @@ __global__ __launch_bounds__(KR_NW * 64, 2) void knn_lanes_kernel(KnnLanesArgs r
         // it to the spare row)
         struct Takes { int row[KR_U]; unsigned int index; };
         kr_walk<Takes>(a.sorted, tile, lo, hi, ox, oy, oz,
-            [&](int c_index, const KrStep &t, int real) {
+            [&](int c_index, const KrStep &t, int) {
                 Takes o;
                 o.index = (unsigned int)c_index;
 #pragma unroll
@@ -759,7 +801,7 @@ __global__ __launch_bounds__(KR_NW * 64, 2) void knn_lanes_kernel(KnnLanesArgs r
                     for (int w = 0; w < 4; ++w) {
                         const float dx = xs[w] - rx, dy = ys[w] - ry_, dz = zs[w] - rz_;
                         const float d2 = dx * dx + dy * dy + dz * dz;
-                        const bool take = d2 < edge && 4 * v + w < real;
+                        const bool take = d2 < edge;
                         const int at = cnt < KR_CAP ? cnt : KR_CAP;
                         o.row[4 * v + w] = (take ? at : KR_CAP) * 64;
                         cnt += take ? 1 : 0;
