@@ -37,6 +37,7 @@
 #include <rocprim/rocprim.hpp>
 
 #include "f4l_device.h"
+#include "select.h"
 #include "topk.h"
 
 namespace f4l {
@@ -1679,39 +1680,28 @@ static int csr_ws_layout(int64_t n, int64_t K, CsrWs &w, unsigned char *base) {
 
 // ---- median (the last step of `_compute_median_resolution`) ---------------------------------------------------------------
 namespace f4l {
-__global__ void strided_copy_kernel(const double *__restrict__ v, int64_t n, int64_t stride, double *__restrict__ out) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = v[i * stride];
-}
-__global__ void median_pick_kernel(const double *__restrict__ sorted, int64_t n, double *__restrict__ out) {
-    // numpy.median: mean of the two middle elements (they coincide for odd n)
-    const double a = sorted[(n - 1) / 2], b = sorted[n / 2];
-    out[0] = (n & 1) ? a : (a + b) * 0.5;
-}
-static size_t median_sort_bytes(int64_t n) {
-    size_t b = 0;
-    double *d0 = nullptr;
-    if (rocprim::radix_sort_keys<KeySortConfig>(nullptr, b, d0, d0, (size_t)n, 0, 64, 0, false) != hipSuccess) return 0;
-    return b;
+__global__ void median_pick_kernel(const double *__restrict__ middle, int64_t n, double *__restrict__ out) {
+    // numpy.median: mean of the two middle elements (they coincide for odd n); middle = the elements of rank (n - 1) / 2, n / 2
+    out[0] = (n & 1) ? middle[0] : (middle[0] + middle[1]) * 0.5;
 }
 }  // namespace f4l
 
 extern "C" size_t f4l_median_f64_workspace_bytes(int64_t n) {
     if (n <= 0) return 0;
-    return 2 * f4l::align_up((size_t)n * 8) + f4l::align_up(f4l::median_sort_bytes(n));
+    return f4l::select_workspace_bytes() + 256;
 }
+// The two middle order statistics by radix select (select.hip): six passes that read the values, no sort.
 extern "C" int f4l_median_f64(const double *values, int64_t n, int64_t stride, double *median_out, void *workspace, size_t workspace_bytes,
                               void *stream) {
     using namespace f4l;
     if (!values || n <= 0 || stride < 1 || !median_out || !workspace) return F4L_EINVAL;
     if (workspace_bytes < f4l_median_f64_workspace_bytes(n)) return F4L_EWORKSPACE;
     hipStream_t st = (hipStream_t)stream;
-    double *a = (double *)workspace, *b = (double *)((unsigned char *)workspace + align_up((size_t)n * 8));
-    void *tmp = (unsigned char *)workspace + 2 * align_up((size_t)n * 8);
-    size_t tb = median_sort_bytes(n);
-    hipLaunchKernelGGL(strided_copy_kernel, dim3(grid_for(n)), dim3(256), 0, st, values, n, stride, a);
-    F4L_LAUNCH_CHECK();
-    F4L_HIP_CHECK(rocprim::radix_sort_keys<KeySortConfig>(tmp, tb, a, b, (size_t)n, 0, 64, st, false));
-    hipLaunchKernelGGL(median_pick_kernel, dim3(1), dim3(1), 0, st, (const double *)b, n, median_out);
+    double *middle = (double *)((unsigned char *)workspace + select_workspace_bytes());
+    const int64_t ranks[2] = {(n - 1) / 2, n / 2};
+    const int rc = select_ranks_f64(values, n, stride, 2, ranks, middle, workspace, st);
+    if (rc != F4L_OK) return rc;
+    hipLaunchKernelGGL(median_pick_kernel, dim3(1), dim3(1), 0, st, (const double *)middle, n, median_out);
     F4L_LAUNCH_CHECK();
     return F4L_OK;
 }

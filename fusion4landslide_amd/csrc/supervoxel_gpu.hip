@@ -50,6 +50,7 @@
 #include <rocprim/rocprim.hpp>
 
 #include "f4l_device.h"
+#include "select.h"
 #include "sv_metric.h"
 
 namespace f4l {
@@ -369,8 +370,8 @@ __global__ void min_metric_kernel(const float *__restrict__ xyz, const double *_
         dis0[i] = best;
     }
 }
-__global__ void start_kernel(State *st, const double *__restrict__ dis_sorted, int64_t n) {
-    const double med = dis_sorted[n / 2];  // median.h:27-30: nth_element at size / 2
+__global__ void start_kernel(State *st, const double *__restrict__ median) {
+    const double med = median[0];  // median.h:27-30: nth_element at size / 2 (the element of that rank: select.hip)
     st->lambda0 = med > DBL_EPSILON ? med : DBL_EPSILON;
 }
 __global__ void init_points_kernel(int64_t n, int32_t *__restrict__ parent, int32_t *__restrict__ size,
@@ -1147,7 +1148,8 @@ static inline size_t align_up(size_t v) { return (v + 255) / 256 * 256; }
 struct Ws {
     State *st;
     unsigned long long *keys_a, *keys_b, *edges_a, *edges_b, *table, *akey, *bestm, *prop_key;
-    double *am, *dis, *dis_sorted;
+    double *am, *dis, *median;
+    void *sel;  // select_ranks_f64's workspace
     int32_t *parent, *size, *bestu, *prop_u, *la, *lb, *flag, *rank, *knnT, *orig, *pos_of, *ids_in;
     unsigned int *okey_a, *okey_b;
     float *xyz_p;
@@ -1158,17 +1160,15 @@ struct Ws {
     size_t prim_bytes, total;
 };
 static int layout(int64_t n, int k, Ws &w, unsigned char *base) {
-    size_t sort_u = 0, sort_d = 0, scan_b = 0;
+    size_t sort_u = 0, scan_b = 0;
     unsigned long long *u0 = nullptr;
-    double *f0 = nullptr;
     int32_t *i0 = nullptr;
     if (rocprim::radix_sort_keys(nullptr, sort_u, u0, u0, (size_t)n, 0, 64, 0, false) != hipSuccess) return F4L_EHIP;
-    if (rocprim::radix_sort_keys(nullptr, sort_d, f0, f0, (size_t)n, 0, 64, 0, false) != hipSuccess) return F4L_EHIP;
     if (rocprim::exclusive_scan(nullptr, scan_b, i0, i0, 0, (size_t)n, rocprim::plus<int32_t>(), 0, false) != hipSuccess) return F4L_EHIP;
     size_t sort_p = 0;
     unsigned int *k0 = nullptr;
     if (rocprim::radix_sort_pairs(nullptr, sort_p, k0, k0, i0, i0, (size_t)n, 0, 32, 0, false) != hipSuccess) return F4L_EHIP;
-    size_t prim = sort_u > sort_d ? sort_u : sort_d;
+    size_t prim = sort_u;
     prim = prim > scan_b ? prim : scan_b;
     prim = prim > sort_p ? prim : sort_p;
     size_t o = 0;
@@ -1181,7 +1181,6 @@ static int layout(int64_t n, int k, Ws &w, unsigned char *base) {
     // the grid keys and the sorted metrics are dead before the edge table is first used: they alias it
     w.keys_a = w.table;
     w.keys_b = w.table ? w.table + n : nullptr;
-    w.dis_sorted = (double *)w.keys_a;
     w.akey = (unsigned long long *)carve(ne * 8);
     w.am = (double *)carve(ne * 8);
     w.bestm = (unsigned long long *)carve((size_t)n * 8);
@@ -1207,6 +1206,8 @@ static int layout(int64_t n, int k, Ws &w, unsigned char *base) {
     w.ids_in = w.rank;
     w.d0 = carve((size_t)n);
     w.d1 = carve((size_t)n);
+    w.sel = carve(select_workspace_bytes());
+    w.median = (double *)carve(16);
     w.prim = carve(prim);
     w.prim_bytes = prim;
     w.total = o;
@@ -1266,9 +1267,12 @@ extern "C" int f4l_supervoxel_segment_device(const float *xyz, const double *nor
     hipLaunchKernelGGL(knn_transpose_kernel, g, b, 0, st, knn, w.orig, w.pos_of, n, k, w.knnT);
     hipLaunchKernelGGL(min_metric_kernel, g, b, 0, st, xyz, normals, w.knnT, n, k, resolution, w.dis);
     F4L_LAUNCH_CHECK();
-    tb = w.prim_bytes;
-    F4L_HIP_CHECK(rocprim::radix_sort_keys(w.prim, tb, w.dis, w.dis_sorted, (size_t)n, 0, 64, st, false));
-    hipLaunchKernelGGL(start_kernel, one, one, 0, st, w.st, w.dis_sorted, n);
+    {   // the median of the smallest neighbour metrics: one order statistic, no sort
+        const int64_t rank = n / 2;
+        rc = select_ranks_f64(w.dis, n, 1, 1, &rank, w.median, w.sel, st);
+        if (rc != F4L_OK) return rc;
+    }
+    hipLaunchKernelGGL(start_kernel, one, one, 0, st, w.st, (const double *)w.median);
     hipLaunchKernelGGL(init_points_kernel, g, b, 0, st, n, w.parent, w.size, w.bestm, w.bestu);
     F4L_LAUNCH_CHECK();
     // fusion, labels and the exchange: the schedule of launches clouds normally need, then one-workgroup kernels for

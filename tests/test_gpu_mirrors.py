@@ -231,6 +231,16 @@ def test_median_f64_is_numpys_median():
         col = stride - 1
         check(lib().f4l_median_f64(d.data_ptr() + 8 * col, n, stride, ptr(out), ptr(ws), C.c_size_t(nbytes), stream_ptr()), "f4l_median_f64")
         assert float(out.item()) == float(np.median(v[:, col])), (n, stride)
+    # what the path feeds it: millions of positive values within a few octaves (all but the last digits of the select shared)
+    for n in (3_000_001, 2_000_000):
+        v = 0.03 + 0.02 * np.abs(rng.normal(size=n))
+        v[: n // 3] = v[0]  # (a third of them one value: the median may sit in the run)
+        d = torch.from_numpy(v).cuda()
+        out = torch.empty((1,), dtype=torch.float64, device="cuda")
+        nbytes = lib().f4l_median_f64_workspace_bytes(n)
+        ws = torch.empty((max(int(nbytes), 1),), dtype=torch.uint8, device="cuda")
+        check(lib().f4l_median_f64(ptr(d), n, 1, ptr(out), ptr(ws), C.c_size_t(nbytes), stream_ptr()), "f4l_median_f64")
+        assert float(out.item()) == float(np.median(v)), n
 
 
 def test_nn_query_vs_kdtree():
