@@ -54,8 +54,11 @@ for case in range(n_cases):
                                fixed_iters=fixed, search="f64")
     T = out["T"].cpu().numpy()
     fit = ref["fitness"]
-    tol = 1e-9 if icp_type == "point2point" else 1e-6  # (point-to-plane: the normals' eigen-solvers differ in the last bits)
-    worst, worst_posed, n_bad, n_bad_posed, detail = 0.0, 0.0, 0, 0, []
+    # (point-to-plane: the normals reach the kernel as float32, the oracle keeps its own in double -- 6e-8 relative on every normal,
+    #  times what the patch's conditioning makes of it: 1.6e-6 m was seen on a 47-point patch whose radius exceeds its size;
+    #  the contract's tolerance is 1e-4 m)
+    tol = 1e-9 if icp_type == "point2point" else 5e-6
+    worst, worst_posed, n_bad, n_bad_posed, n_unstable, detail = 0.0, 0.0, 0, 0, 0, []
     for p in range(P):
         s = src[soff[p]:soff[p + 1]].astype(np.float64)
         if not len(s):
@@ -65,6 +68,19 @@ for case in range(n_cases):
         # sides may settle differently after the first rounding difference (that is chaos, not a defect)
         posed = len(s) >= 40 and fit[p] >= 0.5 and (toff[p + 1] - toff[p]) >= 40
         worst = max(worst, e)
+        if e > tol and posed:
+            # ... or with a trajectory that amplifies rounding by itself: the ORACLE, started 1e-13 m away from the identity,
+            # must land where it landed before -- if it does not, no second implementation can be held to it on this patch
+            one = lambda a, off: np.ascontiguousarray(a[off[p]:off[p + 1]])
+            z2 = np.array([0, len(s)], np.int64), np.array([0, int(toff[p + 1] - toff[p])], np.int64)
+            Tp = np.eye(4)[None].copy()
+            Tp[0, :3, 3] = (1e-13, -1e-13, 1e-13)
+            again = O.piecewise_icp(one(src, soff), z2[0], one(tgt, toff), z2[1], init_T=Tp, max_corr_dist=r, max_iter=30, icp_type=icp_type,
+                                    fixed_iters=fixed)
+            e_self = float(np.abs((s @ again["T"][0, :3, :3].T + again["T"][0, :3, 3]) - (s @ ref["T"][p, :3, :3].T + ref["T"][p, :3, 3])).max())
+            if e_self > tol:
+                posed = False
+                n_unstable += 1
         if e > tol:
             n_bad += 1
             if posed:
@@ -76,5 +92,6 @@ for case in range(n_cases):
     bad += not ok
     print(f"case {seed0 + case:3d} P={P:4d} {kind:8s} n={len(src):6d} max_src={int(np.diff(soff).max()):5d} r={r} dens={density:6.0f} "
           f"{'geo' if origin[0] else 'loc'} {icp_type:11s} fixed={int(fixed)}  worst {worst:.1e} (well-posed patches {worst_posed:.1e}), "
-          f"{n_bad} patches differ, {n_bad_posed} of them well-posed  {'ok' if ok else 'MISMATCH ' + str(detail[:4])}", flush=True)
+          f"{n_bad} patches differ, {n_bad_posed} of them well-posed{f' ({n_unstable} more where the oracle itself moves by more than the tolerance when started 1e-13 m off)' if n_unstable else ''}  "
+          f"{'ok' if ok else 'MISMATCH ' + str(detail[:4])}", flush=True)
 print("FUZZ", "CLEAN" if bad == 0 else f"{bad} MISMATCHES")
