@@ -58,7 +58,7 @@ namespace svg {
 
 constexpr int LAMBDA_ROUNDS = 56;  // lambda0 * 2^55 exceeds any size * metric of a 2^31-point cloud
 constexpr int SUBROUNDS = 3;
-constexpr int SWEEPS = 96;
+constexpr int SWEEPS = 1024;  // (the reference sweeps until nothing changes; a k = 8 graph over supervoxels of 1600 points needed more than 96)
 // what the schedule of LAUNCHES covers (the rest runs in segment_rest_kernel): a 1 M-point terrain tile at the reference's
 // resolutions needs 11-14 rounds and 5-15 sweeps
 constexpr int SCHED_ROUNDS = 16, SCHED_SWEEPS = 16;
@@ -1101,7 +1101,7 @@ __global__ void relabel_kernel(State *st, int64_t n, const int32_t *__restrict__
 
 // ---- whatever the schedule of launches did not cover, in ONE workgroup ------------------------------------------------------
 // The host cannot know how many lambda rounds and sweeps a cloud needs (no synchronisation), and a schedule long enough for
-// every cloud (56 rounds, 96 sweeps) is mostly launches that return at once.  So the schedule covers what clouds normally need
+// every cloud (56 rounds, 1024 sweeps) is mostly launches that return at once.  So the schedule covers what clouds normally need
 // (SCHED_ROUNDS, SCHED_SWEEPS) and the rest -- normally nothing: the kernel returns -- runs here: the same device functions in
 // loops that END when the state says so, separated by workgroup barriers.  ONE workgroup: no assumption about co-residency, no
 // grid barrier that could wait for a workgroup the device never scheduled (round 2's persistent grid could), at the price of

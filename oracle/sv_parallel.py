@@ -15,7 +15,7 @@ Only tests/ may import this module.
 """
 import numpy as np
 
-LAMBDA_ROUNDS, SUBROUNDS, SWEEPS = 56, 3, 96
+LAMBDA_ROUNDS, SUBROUNDS, SWEEPS = 56, 3, 1024
 
 
 def metric(xyz, nrm, a, b, resolution):
