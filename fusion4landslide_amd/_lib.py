@@ -102,9 +102,22 @@ def require_gpu():
     return torch
 
 
+_EMPTY = {}  # device index -> a few bytes of device memory that stand for "an array of no elements"
+
+
 def ptr(t):
-    """Device pointer of a torch tensor (None -> NULL)."""
-    return None if t is None else C.c_void_p(t.data_ptr())
+    """Device pointer of a torch tensor (None -> NULL).  An EMPTY tensor is still an array: torch hands out a null data pointer for
+    it, which the C ABI reads as "argument missing" (a tile in which no patch has a single correspondence would be refused), so
+    an empty CUDA tensor gets the address of a small buffer nobody reads."""
+    if t is None:
+        return None
+    if t.numel() == 0 and t.is_cuda:
+        buf = _EMPTY.get(t.device.index)
+        if buf is None:
+            import torch
+            buf = _EMPTY[t.device.index] = torch.zeros(64, dtype=torch.uint8, device=t.device)
+        return C.c_void_p(buf.data_ptr())
+    return C.c_void_p(t.data_ptr())
 
 
 def stream_ptr():

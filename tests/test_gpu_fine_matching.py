@@ -241,3 +241,26 @@ def test_rgb_guided_prune_mirror():
     keep, Tb, m2 = rgb_guided.refine_local_rigid_correspondences_batched(dev(np.concatenate([corr, corr[:50]])),
                                                                           dev(np.array([0, 200, 250], dtype=np.int64)))
     assert np.array_equal(keep.cpu().numpy()[:200][~near], want[~near]) and Tb.shape == (2, 4, 4) and m2.shape == (2,)
+
+
+def test_a_tile_without_a_single_point_match():
+    """No source point of the tile has a match (`corres_3d_voxel_from_3d_idx[:, 1]` all -1): every patch match fails the
+    num_min_fine_match test (:3338, :3436) and the outputs are empty -- the empty correspondence arrays are arrays, not missing
+    arguments.  The same for the operators called on their own."""
+    from fusion4landslide_amd import engine
+    from fusion4landslide_amd.src.fine_matching import fine_matching_3d
+    src, tgt, so, soff, to, toff, corr = _scene(seed=2, n=6_000, cells=4)
+    none = np.full_like(corr, -1)
+    for check in (False, True):
+        out = fine_matching_3d(dev(src), dev(tgt), dev(so), dev(soff), dev(to), dev(toff), dev(none),
+                               remove_low_quality_patch_matches=check, output_tgt2src=True)
+        P = len(soff) - 1
+        assert out["dense"].shape == (0, 6) and out["sparse"].shape == (0, 6) and out["tgt2src"].shape == (0, 6)
+        assert not out["mask_global"].any() and (out["iters"] == -1).all() and int(out["n_pairs"].sum()) == 0
+        assert out["mask_useful"].all() and out["T"].shape == (P, 4, 4)
+    off0 = torch.zeros(4, dtype=torch.int64, device="cuda")
+    empty = torch.zeros((0, 3), dtype=torch.float32, device="cuda")
+    dm, ri = engine.rigidity_check(empty, empty, off0, 0.05)
+    assert (dm == 0).all() and (ri == 0).all()
+    R, t = engine.kabsch_batched(empty, empty, off0)
+    assert R.shape == (3, 3, 3) and torch.isfinite(R).all()
