@@ -60,6 +60,41 @@ def test_lpt_assign_balances_and_covers():
     assert sub.shape == (0, 3) and np.array_equal(so, [0, 0])
 
 
+def test_lpt_assign_and_take_patches_properties():
+    """Random patch costs (zeros, ties, one giant among dwarfs, fewer patches than ranks) and worlds 1..9: every patch goes to
+    exactly one rank, ids ascending per rank, the greedy bound max - min <= largest cost, the same answer twice; and
+    take_patches re-packs exactly the chosen patches' rows, on numpy arrays and torch tensors alike."""
+    from hypothesis import given, settings, strategies as st
+    from fusion4landslide_amd import sharding
+
+    @settings(max_examples=150, deadline=None)
+    @given(st.lists(st.integers(0, 10**6), min_size=0, max_size=120), st.integers(1, 9), st.integers(0, 2**31 - 1))
+    def prop(costs, world, seed):
+        sizes = np.asarray(costs, dtype=np.int64)
+        parts = sharding.lpt_assign(sizes, world)
+        assert len(parts) == world and all(np.all(np.diff(p) > 0) for p in parts)
+        allp = np.sort(np.concatenate(parts)) if len(sizes) else np.zeros(0, np.int64)
+        assert np.array_equal(allp, np.arange(len(sizes)))
+        loads = np.array([sizes[p].sum() for p in parts])
+        assert loads.max() - loads.min() <= (sizes.max() if len(sizes) else 0)
+        again = sharding.lpt_assign(sizes, world)
+        assert all(np.array_equal(a, b) for a, b in zip(parts, again))
+        # the rows of a rank's patches, re-packed
+        rng = np.random.default_rng(seed)
+        cnt = rng.integers(0, 5, len(sizes))
+        off = np.zeros(len(sizes) + 1, np.int64)
+        np.cumsum(cnt, out=off[1:])
+        pts = rng.normal(size=(int(off[-1]), 3))
+        for ids in parts[:2]:
+            sub, so = sharding.take_patches(pts, off, ids)
+            want = [pts[off[i]:off[i + 1]] for i in ids]
+            assert np.array_equal(np.diff(so), cnt[ids]) and np.array_equal(sub, np.concatenate(want) if want else np.zeros((0, 3)))
+            sub_t, so_t = sharding.take_patches(torch.from_numpy(pts), torch.from_numpy(off), ids)
+            assert np.array_equal(sub_t.numpy(), sub) and np.array_equal(so_t.numpy(), so)
+
+    prop()
+
+
 @pytest.mark.timeout(300)
 def test_sharded_icp_world2_matches_single_process():
     from fusion4landslide_amd import synthetic
