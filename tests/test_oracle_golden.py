@@ -20,7 +20,7 @@ def test_golden_files_present(golden_dir):
 
 
 @pytest.mark.parametrize("name", ["surf_s0_n2000_k15", "surf_s1_n2000_k30", "vol_s2_n2000_k15",
-                                  "georef_s3_n3000_k30", "lattice_m24_k9", "surf_s4_n20000_k30"])
+                                  "georef_s3_n3000_k30", "lattice_m24_k9", "surf_s4_n20000_k30", "step_s5_n4000_k12", "slab_s6_n3000_k20"])
 def test_supervoxel_oracle_vs_golden(golden_dir, name):
     g = np.load(os.path.join(golden_dir, f"supervoxel_{name}.npz"))
     xyz, k, res = g["xyz"], int(g["k"]), float(g["resolution"])

@@ -29,6 +29,18 @@ def volume_cloud(seed, n):
     return rng.uniform(-1, 1, (n, 3)).astype(np.float32)
 
 
+def step_cloud(seed, n):
+    rng = np.random.default_rng(seed)
+    xy = rng.uniform(0, 1, (n, 2))
+    z = np.where(xy[:, 0] > 0.5, 0.08, 0.0) + rng.normal(0, 0.002, n)
+    return np.c_[xy, z].astype(np.float32)
+
+
+def slab_cloud(seed, n):
+    rng = np.random.default_rng(seed)
+    return (rng.uniform(0, 1, (n, 3)) * np.array([2.0, 2.0, 0.3])).astype(np.float32)
+
+
 def lattice_cloud(m):
     g = np.arange(m, dtype=np.float32) * np.float32(0.125)  # exactly representable -> exact distance ties
     x, y = np.meshgrid(g, g, indexing="ij")
@@ -46,6 +58,9 @@ def main():
         ("georef_s3_n3000_k30", surface_cloud(3, 3000, extent=20.0, noise=0.01) + np.array([2647.0, 1177.0, 1500.0], np.float32), 30, 2.5, True),
         ("lattice_m24_k9", lattice_cloud(24), 9, 0.5, True),
         ("surf_s4_n20000_k30", surface_cloud(4, 20000), 30, 0.1, False),
+        # round 3: a step between two levels (the normal term of the metric decides along the edge) and a thin slab of volume
+        ("step_s5_n4000_k12", step_cloud(5, 4000), 12, 0.12, False),
+        ("slab_s6_n3000_k20", slab_cloud(6, 3000), 20, 0.35, False),
     ]
     for name, xyz, k, res, with_d2 in cases:
         r = O.ref_supervoxel(xyz, k, res)
