@@ -50,15 +50,17 @@ for case in range(n_cases):
     ref = O.piecewise_icp(src, soff, tgt, toff, max_corr_dist=r, max_iter=30, icp_type=icp_type, fixed_iters=fixed)
     t1 = time.perf_counter()
     dv = lambda a: torch.from_numpy(a).cuda()
+    nrm = engine.patch_normals(dv(tgt), dv(toff), 30) if icp_type == "point2plane" and len(tgt) else None  # (what the launch computes itself)
     out = engine.piecewise_icp(dv(src), dv(soff), dv(tgt), dv(toff), max_corr_dist=r, max_iter=30, icp_type=icp_type,
-                               fixed_iters=fixed, search="f64")
+                               fixed_iters=fixed, search="f64", tgt_normals=nrm)
+    nrm_h = None if nrm is None else nrm.cpu().numpy().astype(np.float64)
     T = out["T"].cpu().numpy()
     fit = ref["fitness"]
     # (point-to-plane: the normals reach the kernel as float32, the oracle keeps its own in double -- 6e-8 relative on every normal,
     #  times what the patch's conditioning makes of it: 1.6e-6 m was seen on a 47-point patch whose radius exceeds its size;
     #  the contract's tolerance is 1e-4 m)
     tol = 1e-9 if icp_type == "point2point" else 5e-6
-    worst, worst_posed, n_bad, n_bad_posed, n_unstable, detail = 0.0, 0.0, 0, 0, 0, []
+    worst, worst_posed, n_bad, n_bad_posed, n_unstable, n_order, detail = 0.0, 0.0, 0, 0, 0, 0, []
     for p in range(P):
         s = src[soff[p]:soff[p + 1]].astype(np.float64)
         if not len(s):
@@ -81,6 +83,18 @@ for case in range(n_cases):
             if e_self > tol:
                 posed = False
                 n_unstable += 1
+            else:
+                # ... or on the ORDER of the sums: the oracle on the same patch with its source points in reverse order (Open3D
+                # adds them up in whatever order its threads finish).  Point-to-plane far from the origin is the typical case:
+                # the 6 x 6 system is solved in the caller's frame, its conditioning grows with (distance to the origin / patch
+                # size)^2, the update is linearised about that origin, and the first pass differs by centimetres from the same
+                # pass in the patch's own frame; on such a plateau the early exit, or a pair at the radius, turns on the last bits.
+                sd, td = one(src, soff)[::-1].copy(), one(tgt, toff)
+                rev = O.piecewise_icp(sd, z2[0], td, z2[1], max_corr_dist=r, max_iter=30, icp_type=icp_type, fixed_iters=fixed)
+                e_rev = float(np.abs((s @ rev["T"][0, :3, :3].T + rev["T"][0, :3, 3]) - (s @ ref["T"][p, :3, :3].T + ref["T"][p, :3, 3])).max())
+                if e_rev > tol:
+                    posed = False
+                    n_order += 1
         if e > tol:
             n_bad += 1
             if posed:
@@ -92,6 +106,7 @@ for case in range(n_cases):
     bad += not ok
     print(f"case {seed0 + case:3d} P={P:4d} {kind:8s} n={len(src):6d} max_src={int(np.diff(soff).max()):5d} r={r} dens={density:6.0f} "
           f"{'geo' if origin[0] else 'loc'} {icp_type:11s} fixed={int(fixed)}  worst {worst:.1e} (well-posed patches {worst_posed:.1e}), "
-          f"{n_bad} patches differ, {n_bad_posed} of them well-posed{f' ({n_unstable} more where the oracle itself moves by more than the tolerance when started 1e-13 m off)' if n_unstable else ''}  "
+          f"{n_bad} patches differ, {n_bad_posed} of them well-posed{f' ({n_unstable} more where the oracle itself moves by more than the tolerance when started 1e-13 m off)' if n_unstable else ''}"
+          f"{f' ({n_order} more where the oracle moves by more than the tolerance when the source points come in reverse order)' if n_order else ''}  "
           f"{'ok' if ok else 'MISMATCH ' + str(detail[:4])}", flush=True)
 print("FUZZ", "CLEAN" if bad == 0 else f"{bad} MISMATCHES")
