@@ -19,6 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     ("fuzz_ops.py", 40, 14),            # nn_query, voxel filter, ragged Kabsch, CSR, median, rigidity check
     ("fuzz_fine_matching.py", 20, 15),  # the batched loop body against the patch-by-patch replay of the reference's loop
     ("fuzz_full_path.py", 30, 16),      # the whole path on small clouds of random shape and overlap
+    ("fuzz_piecewise_octree.py", 12, 17),  # the Piecewise_ICP entry (reference mode) against the pointer-octree restatement
 ])
 def test_randomised_checker_is_clean(tool, cases, seed):
     import torch
