@@ -1,7 +1,7 @@
 """Randomised check of the device segmentation (f4l_supervoxel_parallel: kNN, normals and the segmentation on the GPU) against its
 numpy restatement (oracle/sv_parallel.py) on clouds of random size, shape, density, resolution and k: identical labels,
 representatives, counts, starting lambda, rounds and sweeps; K = occupied cells; labels contiguous, non-empty; the exchange's
-fixed point.   python3 tools/gpu/fuzz_supervoxel.py [cases] [seed]"""
+fixed point.   python3 tools/gpu/fuzz_supervoxel.py [cases] [seed] [big]"""
 import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -13,7 +13,7 @@ seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 bad = 0
 for case in range(n_cases):
     rng = np.random.default_rng(seed0 + case)
-    n = int(rng.choice([400, 3000, 12_000, 40_000]))
+    n = int(rng.choice([400, 3000, 12_000, 40_000] if len(sys.argv) <= 3 else [150_000, 400_000]))  # (third argument: large clouds)
     k = int(rng.choice([8, 16, 30]))
     kind = rng.choice(["surface", "rough", "volume", "two sheets", "strip"])
     side = float(rng.choice([3.0, 10.0, 40.0]))
