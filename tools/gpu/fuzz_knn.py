@@ -1,7 +1,7 @@
 """Randomised check of the kNN lane kernel (four groups of 16 lanes with candidate blocks of their own) against the wave-per-query
 search of round 1 (F4L_KNN_WAVE_PER_QUERY: identical indices, bit-equal d2, bit-equal fused normals) and against scipy's KD-tree
 (distances), on clouds of random size and shape: surfaces, volumes, lines, lattices, clusters with duplicates, georeferenced
-offsets, k = 1 .. 36, also n barely above k.   python3 tools/gpu/fuzz_knn.py [cases] [seed]"""
+offsets, k = 1 .. 36, also n barely above k.   python3 tools/gpu/fuzz_knn.py [cases] [seed] [big]"""
 import os, sys
 import numpy as np, torch
 from scipy.spatial import cKDTree
@@ -14,7 +14,7 @@ bad = 0
 for case in range(n_cases):
     rng = np.random.default_rng(seed0 + case)
     k = int(rng.integers(1, 37))
-    n = int(rng.choice([k + 1, k + 5, 63, 64, 65, 200, 1000, 5000, 40_000, 150_000]))
+    n = int(rng.choice([k + 1, k + 5, 63, 64, 65, 200, 1000, 5000, 40_000, 150_000] if len(sys.argv) <= 3 else [600_000, 2_000_000]))  # (third argument: large clouds)
     n = max(n, k + 1)
     kind = rng.choice(["surface", "volume", "line", "lattice", "clusters", "strip"])
     if kind == "surface":
@@ -48,9 +48,10 @@ for case in range(n_cases):
         # (k coincident neighbours have no covariance: the reference's formula gives NaN there, on both paths)
         flags["normals"] = torch.equal(torch.nan_to_num(n1, nan=7.0), torch.nan_to_num(n2, nan=7.0)) and torch.equal(torch.isnan(n1), torch.isnan(n2))
     xs = x.cpu().numpy().astype(np.float64)
-    dd, _ = cKDTree(xs).query(xs, k=k)
-    dd = dd.reshape(n, k)
-    flags["kdtree"] = bool(np.allclose(np.sqrt(d1.cpu().numpy()), dd, rtol=1e-12, atol=1e-12))
+    if n <= 700_000:
+        dd, _ = cKDTree(xs).query(xs, k=k)
+        dd = dd.reshape(n, k)
+        flags["kdtree"] = bool(np.allclose(np.sqrt(d1.cpu().numpy()), dd, rtol=1e-12, atol=1e-12))
     # the row starts with the point itself, or -- coincident points -- with a lower index at distance 0
     first = i1[:, 0].cpu().numpy()
     flags["self"] = bool(((first == np.arange(n)) | ((first < np.arange(n)) & (d1[:, 0].cpu().numpy() == 0.0))).all())
