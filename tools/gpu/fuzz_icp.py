@@ -14,6 +14,9 @@ def rot(axis, ang):
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+# third argument "f32": the float32 search (fast mode) instead of the parity mode -- held to the fast mode's own bounds
+# (tests/test_gpu_parity.py): a well-posed patch within 2e-3 m of the oracle, nine in ten within 1e-4 m
+SEARCH = sys.argv[3] if len(sys.argv) > 3 else "f64"
 bad = 0
 for case in range(n_cases):
     rng = np.random.default_rng(seed0 + case)
@@ -52,7 +55,7 @@ for case in range(n_cases):
     dv = lambda a: torch.from_numpy(a).cuda()
     nrm = engine.patch_normals(dv(tgt), dv(toff), 30) if icp_type == "point2plane" and len(tgt) else None  # (what the launch computes itself)
     out = engine.piecewise_icp(dv(src), dv(soff), dv(tgt), dv(toff), max_corr_dist=r, max_iter=30, icp_type=icp_type,
-                               fixed_iters=fixed, search="f64", tgt_normals=nrm)
+                               fixed_iters=fixed, search=SEARCH, tgt_normals=nrm)
     nrm_h = None if nrm is None else nrm.cpu().numpy().astype(np.float64)
     T = out["T"].cpu().numpy()
     fit = ref["fitness"]
@@ -60,6 +63,8 @@ for case in range(n_cases):
     #  times what the patch's conditioning makes of it: 1.6e-6 m was seen on a 47-point patch whose radius exceeds its size;
     #  the contract's tolerance is 1e-4 m)
     tol = 1e-9 if icp_type == "point2point" else 5e-6
+    if SEARCH == "f32":
+        tol = 2e-3
     worst, worst_posed, n_bad, n_bad_posed, n_unstable, n_order, detail = 0.0, 0.0, 0, 0, 0, 0, []
     for p in range(P):
         s = src[soff[p]:soff[p + 1]].astype(np.float64)
