@@ -395,7 +395,7 @@ def extras(torch, engine, synthetic, prob, dev, args):
     # the other estimator of utils/o3d_tools.py:46-50: point-to-plane, with the target normals `estimate_normals()` gives every
     # patch cloud (:29-30, f4l_patch_normals) -- the same step on the same cloud
     def normals():
-        return engine.patch_normals(prob.d["tgt"], prob.d["tgt_off"], 30, max_patch=prob.d["max_tgt"])
+        return engine.patch_normals(prob.d["tgt"], prob.d["tgt_off"], 30, max_patch=prob.d["max_tgt"], f64=True)  # (doubles, like Open3D's)
     normals()
     s_n = _timed(torch, normals, 2)
     nrm = normals()

@@ -73,6 +73,7 @@ struct IcpArgs {
     int64_t min_corr;  // patch matches with fewer correspondences are skipped (:3338, `num_min_fine_match`)
     int init_round_f32;  // the Kabsch transform reaches ICP as float32 values (scripts/weighted_svd.py:148-151: a float32 4 x 4)
     const float *tgt_normals;
+    int normals_f64;  // tgt_normals points at doubles (F4L_ICP_NORMALS_F64)
     double r, r2;
     int max_iter;
     double rel_fitness, rel_rmse;
@@ -470,8 +471,14 @@ __global__ __launch_bounds__(NW * 64, WIDE ? 3 : (sizeof(F) == 8 ? ICP_WAVES_PER
                 acc[11] += dqy * dpx; acc[12] += dqy * dpy; acc[13] += dqy * dpz;
                 acc[14] += dqz * dpx; acc[15] += dqz * dpy; acc[16] += dqz * dpz;
             } else {
-                const float *nn = a.tgt_normals + 3 * (t0 + bj);
-                const A nx = nn[0], ny = nn[1], nz = nn[2];
+                A nx, ny, nz;  // (float32 normals, or the doubles Open3D keeps: F4L_ICP_NORMALS_F64)
+                if (a.normals_f64) {
+                    const double *nn = reinterpret_cast<const double *>(a.tgt_normals) + 3 * (t0 + bj);
+                    nx = (A)nn[0]; ny = (A)nn[1]; nz = (A)nn[2];
+                } else {
+                    const float *nn = a.tgt_normals + 3 * (t0 + bj);
+                    nx = nn[0]; ny = nn[1]; nz = nn[2];
+                }
                 const A r = (dpx - dqx) * nx + (dpy - dqy) * ny + (dpz - dqz) * nz;
                 A J[6];
                 J[0] = dpy * nz - dpz * ny; J[1] = dpz * nx - dpx * nz; J[2] = dpx * ny - dpy * nx;
@@ -1001,6 +1008,7 @@ struct IcpFusedExtra {
     const int64_t *rows_off = nullptr;
     int64_t min_corr = 0;
     int init_round_f32 = 0;
+    int normals_f64 = 0;
 };
 static int icp_launch_host(const float *src, const int64_t *src_off, const float *tgt, const int64_t *tgt_off,
                            int64_t P, const double *init_T, const float *tgt_normals, double max_corr_dist,
@@ -1016,9 +1024,12 @@ extern "C" int f4l_piecewise_icp(const float *src, const int64_t *src_off, const
                                  int search_precision, int64_t max_src_patch_host, int64_t max_tgt_patch_host,
                                  int64_t n_src_host, double *T_out, double *fitness_out, double *rmse_out,
                                  int32_t *iters_out, int32_t *corr_out, void *stream) {
+    f4l::IcpFusedExtra fx;
+    fx.normals_f64 = (mode & F4L_ICP_NORMALS_F64) ? 1 : 0;
+    mode &= ~F4L_ICP_NORMALS_F64;
     return f4l::icp_launch_host(src, src_off, tgt, tgt_off, P, init_T, tgt_normals, max_corr_dist, max_iter, rel_fitness,
                                 rel_rmse, mode, fixed_iters, search_precision, max_src_patch_host, max_tgt_patch_host,
-                                n_src_host, T_out, fitness_out, rmse_out, iters_out, corr_out, f4l::IcpFusedExtra(), stream);
+                                n_src_host, T_out, fitness_out, rmse_out, iters_out, corr_out, fx, stream);
 }
 
 extern "C" int f4l_patch_loop(const float *src, const int64_t *src_off, const float *tgt, const int64_t *tgt_off,
@@ -1037,7 +1048,8 @@ extern "C" int f4l_patch_loop(const float *src, const int64_t *src_off, const fl
     fx.w_thresh = kabsch_w_thresh; fx.eps = kabsch_eps; fx.rows_out = rows_out;
     fx.rows_src = rows_src; fx.rows_off = rows_off; fx.min_corr = min_corr;
     fx.init_round_f32 = (mode & F4L_ICP_INIT_ROUND_F32) ? 1 : 0;
-    mode &= ~F4L_ICP_INIT_ROUND_F32;
+    fx.normals_f64 = (mode & F4L_ICP_NORMALS_F64) ? 1 : 0;
+    mode &= ~(F4L_ICP_INIT_ROUND_F32 | F4L_ICP_NORMALS_F64);
     return f4l::icp_launch_host(src, src_off, tgt, tgt_off, P, nullptr, tgt_normals, max_corr_dist, max_iter, rel_fitness,
                                 rel_rmse, mode, fixed_iters, search_precision, max_src_patch_host, max_tgt_patch_host,
                                 n_src_host, T_out, fitness_out, rmse_out, iters_out, corr_out, fx, stream);
@@ -1068,6 +1080,7 @@ static int f4l::icp_launch_host(const float *src, const int64_t *src_off, const 
     a.corr_src = fx.corr_src; a.corr_ref = fx.corr_ref; a.corr_w = fx.corr_w; a.corr_off = fx.corr_off;
     a.kabsch_w_thresh = fx.w_thresh; a.kabsch_eps = fx.eps; a.rows_out = fx.rows_out;
     a.rows_src = fx.rows_src; a.rows_off = fx.rows_off; a.min_corr = fx.min_corr; a.init_round_f32 = fx.init_round_f32;
+    a.normals_f64 = fx.normals_f64;
     a.r = max_corr_dist > 0.0 ? max_corr_dist : 0.0;
     a.r2 = a.r * a.r;
     a.max_iter = max_iter; a.rel_fitness = rel_fitness; a.rel_rmse = rel_rmse; a.fixed_iters = fixed_iters;

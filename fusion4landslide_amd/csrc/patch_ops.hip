@@ -88,6 +88,12 @@ __device__ __forceinline__ void eigvec1(const double *A, const double *e0, doubl
 }
 
 // unit eigenvector of the smallest eigenvalue of symmetric C (c00,c01,c02,c11,c12,c22); zero vector if C == 0
+// the normal of point i: as double where the caller asked for doubles (Open3D keeps its normals in double and registration_icp
+// reads them so), else rounded to float32
+__device__ __forceinline__ void store_normal(float *__restrict__ f32, double *__restrict__ f64, int64_t i, const double *nv) {
+    if (f64) { f64[3 * i] = nv[0]; f64[3 * i + 1] = nv[1]; f64[3 * i + 2] = nv[2]; }
+    else { f32[3 * i] = (float)nv[0]; f32[3 * i + 1] = (float)nv[1]; f32[3 * i + 2] = (float)nv[2]; }
+}
 __device__ __forceinline__ void smallest_eigvec3(const double *C, double *out) {
     double mx = C[0];
 #pragma unroll
@@ -138,7 +144,8 @@ __device__ __forceinline__ void smallest_eigvec3(const double *C, double *out) {
 // One workgroup per patch, one wave per query point (queries strided over the 4 waves).
 __global__ __launch_bounds__(PN_NT) void patch_normals_kernel(const float *__restrict__ pts,
                                                                const int64_t *__restrict__ off, int64_t P, int knn,
-                                                               int lds_cap, int min_n, float *__restrict__ normals) {
+                                                               int lds_cap, int min_n, float *__restrict__ normals,
+                                                               double *__restrict__ normals64) {
     extern __shared__ __attribute__((aligned(16))) float pl[];  // packed xyz of the patch
     const int64_t p = blockIdx.x;
     if (p >= P) return;
@@ -199,8 +206,7 @@ __global__ __launch_bounds__(PN_NT) void patch_normals_kernel(const float *__res
             if (nv[0] * nv[0] + nv[1] * nv[1] + nv[2] * nv[2] == 0.0) { nv[0] = 0.0; nv[1] = 0.0; nv[2] = 1.0; }
         }
         if (lane == 0) {
-            float *out = normals + 3 * (o + q);
-            out[0] = (float)nv[0]; out[1] = (float)nv[1]; out[2] = (float)nv[2];
+            store_normal(normals, normals64, o + q, nv);
         }
     }
 }
@@ -242,7 +248,8 @@ __device__ __forceinline__ void pl_covariance_normal(const float *__restrict__ x
     if (nv[0] * nv[0] + nv[1] * nv[1] + nv[2] * nv[2] == 0.0) { nv[0] = 0.0; nv[1] = 0.0; nv[2] = 1.0; }
 }
 __global__ __launch_bounds__(PL_NT, 2) void patch_normals_lanes_kernel(const float *__restrict__ pts, const int64_t *__restrict__ off,
-                                                                       int64_t P, int knn, int cap_pad, float *__restrict__ normals) {
+                                                                       int64_t P, int knn, int cap_pad, float *__restrict__ normals,
+                                                                       double *__restrict__ normals64) {
     extern __shared__ __attribute__((aligned(16))) unsigned char pl_smem[];
     float *xs = reinterpret_cast<float *>(pl_smem), *ys = xs + cap_pad, *zs = ys + cap_pad;  // the patch, SoA (original coordinates)
     unsigned int *hist_all = reinterpret_cast<unsigned int *>(zs + cap_pad);                 // [PL_NW][PL_NB / 2][64]: two 16-bit bins per word
@@ -372,8 +379,7 @@ __global__ __launch_bounds__(PL_NT, 2) void patch_normals_lanes_kernel(const flo
         double nv[3];
         pl_covariance_normal(xs, ys, zs, pay, k, nv);
         if (valid && !fb) {
-            float *out = normals + 3 * (o + q);
-            out[0] = (float)nv[0]; out[1] = (float)nv[1]; out[2] = (float)nv[2];
+            store_normal(normals, normals64, o + q, nv);
         }
         // the rare query whose survivors overflowed the list: the wave's exact top-k (patch_normals_kernel's arithmetic)
         unsigned long long redo = __ballot(fb);
@@ -415,8 +421,7 @@ __global__ __launch_bounds__(PL_NT, 2) void patch_normals_lanes_kernel(const flo
                 if (rn[0] * rn[0] + rn[1] * rn[1] + rn[2] * rn[2] == 0.0) { rn[0] = 0.0; rn[1] = 0.0; rn[2] = 1.0; }
             }
             if (lane == 0) {
-                float *out = normals + 3 * (o + rq);
-                out[0] = (float)rn[0]; out[1] = (float)rn[1]; out[2] = (float)rn[2];
+                store_normal(normals, normals64, o + rq, rn);
             }
         }
     }
@@ -504,10 +509,10 @@ __global__ __launch_bounds__(PN_NT) void nn_refine_kernel(NnRefineArgs a) {
 
 }  // namespace f4l
 
-extern "C" int f4l_patch_normals(const float *pts, const int64_t *off, int64_t P, int knn, int64_t max_patch_host,
-                                 float *normals_out, void *stream) {
+static int patch_normals_launch(const float *pts, const int64_t *off, int64_t P, int knn, int64_t max_patch_host,
+                                float *normals_out, double *normals64_out, void *stream) {
     using namespace f4l;
-    if (P < 0 || !off || knn < 1 || max_patch_host < 0 || (max_patch_host > 0 && (!pts || !normals_out))) return F4L_EINVAL;
+    if (P < 0 || !off || knn < 1 || max_patch_host < 0 || (max_patch_host > 0 && (!pts || (!normals_out && !normals64_out)))) return F4L_EINVAL;
     if (knn > F4L_MAX_K) return F4L_EUNSUPPORTED;
     if (P == 0 || max_patch_host == 0) return F4L_OK;
     if (P > 0x7fffffffLL || max_patch_host > 0x3fffffffLL) return F4L_EUNSUPPORTED;
@@ -519,7 +524,7 @@ extern "C" int f4l_patch_normals(const float *pts, const int64_t *off, int64_t P
         const size_t lds = (size_t)cap_pad * 12 + (size_t)PL_NW * (PL_NB / 2) * 64 * 4 + (size_t)PL_NW * (PL_CAP + 1) * 64 * 2;
         if (lds > 64 * 1024)
             F4L_HIP_CHECK(hipFuncSetAttribute((const void *)patch_normals_lanes_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(patch_normals_lanes_kernel, dim3((unsigned)P), dim3(PL_NT), lds, (hipStream_t)stream, pts, off, P, knn, cap_pad, normals_out);
+        hipLaunchKernelGGL(patch_normals_lanes_kernel, dim3((unsigned)P), dim3(PL_NT), lds, (hipStream_t)stream, pts, off, P, knn, cap_pad, normals_out, normals64_out);
         F4L_LAUNCH_CHECK();
         min_n = big;
         if (max_patch_host <= big) return F4L_OK;
@@ -529,9 +534,20 @@ extern "C" int f4l_patch_normals(const float *pts, const int64_t *off, int64_t P
     if (lds > 64 * 1024)
         F4L_HIP_CHECK(hipFuncSetAttribute((const void *)patch_normals_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(patch_normals_kernel, dim3((unsigned)P), dim3(PN_NT), lds, (hipStream_t)stream, pts, off, P, knn,
-                       cap, min_n, normals_out);
+                       cap, min_n, normals_out, normals64_out);
     F4L_LAUNCH_CHECK();
     return F4L_OK;
+}
+
+extern "C" int f4l_patch_normals(const float *pts, const int64_t *off, int64_t P, int knn, int64_t max_patch_host,
+                                 float *normals_out, void *stream) {
+    return patch_normals_launch(pts, off, P, knn, max_patch_host, normals_out, nullptr, stream);
+}
+// The same normals as doubles: what Open3D's `estimate_normals()` leaves in the cloud and `registration_icp` reads
+// (utils/o3d_tools.py:29-30, 46-50); pass them to f4l_piecewise_icp / f4l_patch_loop with F4L_ICP_NORMALS_F64.
+extern "C" int f4l_patch_normals_f64(const float *pts, const int64_t *off, int64_t P, int knn, int64_t max_patch_host,
+                                     double *normals_out, void *stream) {
+    return patch_normals_launch(pts, off, P, knn, max_patch_host, nullptr, normals_out, stream);
 }
 
 extern "C" int f4l_nn_refine(const float *src, const int64_t *src_off, const float *tgt, const int64_t *tgt_off, int64_t P,

@@ -144,18 +144,29 @@ def kabsch_residuals(src, ref, off, R, t):
     return res
 
 
-def patch_normals(pts, off, knn=30, max_patch=None):
-    """Per-patch `estimate_normals()` (utils/o3d_tools.py:29-30) -> (n, 3) float32."""
+def patch_normals(pts, off, knn=30, max_patch=None, f64=False):
+    """Per-patch `estimate_normals()` (utils/o3d_tools.py:29-30) -> (n, 3) float32, or float64 with f64=True (what Open3D keeps
+    and `registration_icp` reads: the point-to-plane launches take either)."""
     torch = require_gpu()
     pts = _dev(pts, torch.float32, "pts", (3,))
     off = _dev(off, torch.int64, "off")
     P = off.shape[0] - 1
     if max_patch is None:
         max_patch = _max_patch(off)
-    out = torch.empty_like(pts)
-    check(lib().f4l_patch_normals(ptr(pts), ptr(off), P, int(knn), int(max_patch), ptr(out), stream_ptr()),
-          "f4l_patch_normals")
+    out = torch.empty(pts.shape, dtype=torch.float64 if f64 else torch.float32, device=pts.device)
+    fn = lib().f4l_patch_normals_f64 if f64 else lib().f4l_patch_normals
+    check(fn(ptr(pts), ptr(off), P, int(knn), int(max_patch), ptr(out), stream_ptr()), "f4l_patch_normals")
     return out
+
+
+def _target_normals(torch, tgt, tgt_off, max_tgt_patch, tgt_normals):
+    """The target normals of a point-to-plane launch and the mode bit that says what they are: the caller's float32 or float64
+    tensor, or -- none given -- float64 normals made here, like the doubles Open3D's `estimate_normals()` leaves in the cloud."""
+    if tgt_normals is None:
+        return patch_normals(tgt, tgt_off, 30, max_tgt_patch, f64=True), 0x200
+    if tgt_normals.dtype == torch.float64:
+        return _dev(tgt_normals, torch.float64, "tgt_normals", (3,)), 0x200
+    return _dev(tgt_normals, torch.float32, "tgt_normals", (3,)), 0
 
 
 def piecewise_icp(src, src_off, tgt, tgt_off, init_T=None, max_corr_dist=0.1, max_iter=30, rel_fitness=1e-6,
@@ -190,10 +201,9 @@ def piecewise_icp(src, src_off, tgt, tgt_off, init_T=None, max_corr_dist=0.1, ma
         T0 = _dev(init_T, torch.float64, "init_T")
         if T0.numel() != P * 16:
             raise ValueError("init_T must be (P, 4, 4)")
-    tn = None
+    tn, nbit = None, 0
     if mode == _lib.ICP_POINT2PLANE:
-        tn = patch_normals(tgt, tgt_off, 30, max_tgt_patch) if tgt_normals is None else _dev(
-            tgt_normals, torch.float32, "tgt_normals", (3,))
+        tn, nbit = _target_normals(torch, tgt, tgt_off, max_tgt_patch, tgt_normals)
     dev = src.device
     T = torch.empty((P, 4, 4), dtype=torch.float64, device=dev)
     fit = torch.empty((P,), dtype=torch.float64, device=dev)
@@ -201,7 +211,7 @@ def piecewise_icp(src, src_off, tgt, tgt_off, init_T=None, max_corr_dist=0.1, ma
     iters = torch.empty((P,), dtype=torch.int32, device=dev)
     corr = torch.empty((src.shape[0],), dtype=torch.int32, device=dev) if return_corr else None
     check(lib().f4l_piecewise_icp(ptr(src), ptr(src_off), ptr(tgt), ptr(tgt_off), P, ptr(T0), ptr(tn),
-                                  float(max_corr_dist), int(max_iter), float(rel_fitness), float(rel_rmse), mode,
+                                  float(max_corr_dist), int(max_iter), float(rel_fitness), float(rel_rmse), mode | nbit,
                                   int(bool(fixed_iters)), {"f32": _lib.SEARCH_F32, "f64": _lib.SEARCH_F64}[search],
                                   int(max_src_patch), int(max_tgt_patch), int(src.shape[0]), ptr(T), ptr(fit),
                                   ptr(rmse), ptr(iters), ptr(corr), stream_ptr()), "f4l_piecewise_icp")
@@ -248,10 +258,9 @@ def patch_loop(src, src_off, tgt, tgt_off, corr_src, corr_ref, corr_off, corr_we
         max_src_patch = _max_patch(src_off)
     if max_tgt_patch is None:
         max_tgt_patch = _max_patch(tgt_off)
-    tn = None
+    tn, nbit = None, 0
     if mode == _lib.ICP_POINT2PLANE:
-        tn = patch_normals(tgt, tgt_off, 30, max_tgt_patch) if tgt_normals is None else _dev(
-            tgt_normals, torch.float32, "tgt_normals", (3,))
+        tn, nbit = _target_normals(torch, tgt, tgt_off, max_tgt_patch, tgt_normals)
     dev = src.device
     T = torch.empty((P, 4, 4), dtype=torch.float64, device=dev)
     fit = torch.empty((P,), dtype=torch.float64, device=dev)
@@ -270,7 +279,7 @@ def patch_loop(src, src_off, tgt, tgt_off, corr_src, corr_ref, corr_off, corr_we
     rows = (torch.zeros if min_corr > 0 else torch.empty)((n_rows, 6), dtype=torch.float32, device=dev) if return_rows else None
     check(lib().f4l_patch_loop(ptr(src), ptr(src_off), ptr(tgt), ptr(tgt_off), P, ptr(corr_src), ptr(corr_ref), ptr(cw),
                                ptr(corr_off), int(min_corr), float(weight_thresh), float(eps), ptr(tn), float(max_corr_dist),
-                               int(max_iter), float(rel_fitness), float(rel_rmse), mode | (0x100 if init_round_f32 else 0),
+                               int(max_iter), float(rel_fitness), float(rel_rmse), mode | nbit | (0x100 if init_round_f32 else 0),
                                int(bool(fixed_iters)),
                                {"f32": _lib.SEARCH_F32, "f64": _lib.SEARCH_F64}[search], int(max_src_patch),
                                int(max_tgt_patch), int(src.shape[0]), ptr(T), ptr(fit), ptr(rmse), ptr(iters), ptr(corr),

@@ -44,11 +44,11 @@ def icp_registration(src_pcd, tgt_pcd, initial_transform, threshold=0.1, icp_typ
     to = torch.tensor([0, t.shape[0]], dtype=torch.int64, device=dev)
     tn = None
     if icp_type == 'point2plane' or isinstance(tgt_pcd, PointCloud):
-        tn = engine.patch_normals(t, to, 30)
+        tn = engine.patch_normals(t, to, 30, f64=True)  # (doubles, like the normals Open3D keeps)
         if isinstance(tgt_pcd, PointCloud):  # the reference mutates its inputs the same way
-            tgt_pcd.normals = tn.cpu().numpy().astype(np.float64)
+            tgt_pcd.normals = tn.cpu().numpy()
     if isinstance(src_pcd, PointCloud):
-        src_pcd.normals = engine.patch_normals(s, so, 30).cpu().numpy().astype(np.float64)
+        src_pcd.normals = engine.patch_normals(s, so, 30, f64=True).cpu().numpy()
     out = engine.piecewise_icp(s, so, t, to, init_T=torch.from_numpy(T0[None]).to(dev), max_corr_dist=threshold,
                                max_iter=30, rel_fitness=1e-6, rel_rmse=1e-6, icp_type=icp_type,
                                tgt_normals=tn if icp_type == 'point2plane' else None, return_corr=True, search=search)

@@ -47,6 +47,7 @@ extern "C" {
  * reference hands Open3D the float32 4 x 4 of refine_local_rigid_correspondences (scripts/weighted_svd.py:148-151,
  * src/coarse_to_fine_matching_base.py:3360 `initial_transform=est_transform_svd.cpu()`). */
 #define F4L_ICP_INIT_ROUND_F32 0x100
+#define F4L_ICP_NORMALS_F64 0x200 /* tgt_normals points at doubles */
 
 #define F4L_SEARCH_F32 0 /* nearest-neighbour search in float32 on patch-relative coordinates (fast path)   */
 #define F4L_SEARCH_F64 1 /* ... in float64, the arithmetic of the reference's Open3D path (parity mode)     */
@@ -108,7 +109,8 @@ int f4l_kabsch_residuals(const float *src, const float *ref, const int64_t *off,
  * (source patch, target patch) pairs in one launch, with zero host round trips.
  *   src/src_off, tgt/tgt_off : CSR patches (float32 [.][3], int64 [P+1])
  *   init_T      : double [P][16] or NULL (identity)              (o3d `init`, utils/o3d_tools.py:47)
- *   tgt_normals : float32 [n_tgt][3]; required for POINT2PLANE (see f4l_patch_normals), else NULL
+ *   tgt_normals : float32 [n_tgt][3] -- or, with F4L_ICP_NORMALS_F64 or-ed into `mode`, double [n_tgt][3] passed through the same
+ *                 pointer --; required for POINT2PLANE (see f4l_patch_normals / f4l_patch_normals_f64), else NULL
  *   max_corr_dist, max_iter, rel_fitness, rel_rmse : o3d ICPConvergenceCriteria (utils/o3d_tools.py:47-50)
  *   fixed_iters != 0 disables the early exit: exactly max_iter updates (benchmark mode)
  *   search_precision : F4L_SEARCH_F32 | F4L_SEARCH_F64.  The transform, all sums and the solves are double in
@@ -175,6 +177,11 @@ int f4l_patch_loop(const float *src, const int64_t *src_off, const float *tgt, c
  * (0,0,1) when degenerate; unoriented).  normals_out float32 [n][3]. */
 int f4l_patch_normals(const float *pts, const int64_t *off, int64_t P, int knn, int64_t max_patch_host,
                       float *normals_out, void *stream);
+/* ... as doubles, normals_out double [n][3]: Open3D keeps normals in double and `registration_icp` reads them so; hand them to
+ * f4l_piecewise_icp / f4l_patch_loop with F4L_ICP_NORMALS_F64 in `mode` (float32 normals move some point-to-plane results by
+ * millimetres: tools/gpu/fuzz_icp.py). */
+int f4l_patch_normals_f64(const float *pts, const int64_t *off, int64_t P, int knn, int64_t max_patch_host,
+                          double *normals_out, void *stream);
 
 /* a14: dense displacement rows [s, T_p s] for every point of every patch
  * (src/coarse_to_fine_matching_base.py:3371-3374,3408); out6 float32 [n][6].

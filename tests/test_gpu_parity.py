@@ -237,10 +237,17 @@ def test_icp_point2plane_vs_oracle(eng, search):
     else:
         assert np.median(disp) <= 1e-6 and (disp <= 1e-4).mean() >= 0.9 and disp.max() <= 2e-3
         assert np.abs(out["rmse"].cpu().numpy() - ref["rmse"]).max() <= 1e-4
-    # implicit normals (computed inside) give the same answer as explicit ones
+    # normals computed inside the call are the DOUBLES Open3D's estimate_normals() leaves in the cloud (f4l_patch_normals_f64):
+    # the same answer as handing those over explicitly, and -- float64 search -- closer to the oracle than with float32 normals
+    nrm64 = eng.patch_normals(dev(d["tgt"]), dev(d["tgt_off"]), 30, f64=True)
+    assert nrm64.dtype == torch.float64 and torch.equal(nrm64.to(torch.float32), nrm)
     out2 = eng.piecewise_icp(dev(d["src"]), dev(d["src_off"]), dev(d["tgt"]), dev(d["tgt_off"]), max_corr_dist=0.1,
                              max_iter=30, icp_type="point2plane", search=search)
-    assert torch.equal(out2["T"], out["T"])
+    out3 = eng.piecewise_icp(dev(d["src"]), dev(d["src_off"]), dev(d["tgt"]), dev(d["tgt_off"]), max_corr_dist=0.1,
+                             max_iter=30, icp_type="point2plane", tgt_normals=nrm64, search=search)
+    assert torch.equal(out2["T"], out3["T"])
+    if search == "f64":
+        assert _disp_per_patch(d, out2["T"].cpu().numpy(), ref["T"]).max() <= 1e-8
     with pytest.raises(ValueError):
         eng.piecewise_icp(dev(d["src"]), dev(d["src_off"]), dev(d["tgt"]), dev(d["tgt_off"]), icp_type="generalized")
 
