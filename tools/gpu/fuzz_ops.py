@@ -64,6 +64,27 @@ for case in range(n_cases):
     well = sizes >= 12  # (fewer points: rank-deficient sums, any rotation about the null space is a solution)
     dR = np.abs(R.cpu().numpy() - Rr).reshape(P, -1).max(1); dt = np.abs(t.cpu().numpy() - tr).max(1)
     flags["kabsch"] = bool((dR[well] <= 2e-5).all() and (dt[well] <= 2e-3 * max(1.0, np.abs(off).max())).all() and np.isfinite(R.cpu().numpy()).all())
+    # ---- Kabsch #2 of src/functions.py (the F2S3 path), float64 sets, set by set against the numpy restatement
+    R2, t2 = engine.kabsch2_batched(dv(ks.astype(np.float64)), dv(kr.astype(np.float64)), dv(koff), None if w is None else dv(w.astype(np.float64)),
+                                    normalize_w=bool(rng.random() < 0.5), w_threshold=thr, eps=1e-7)
+    ok2 = True
+    nrm_flag = None
+    for pset in np.nonzero(well)[0][:40]:
+        a0, a1 = koff[pset], koff[pset + 1]
+        for normalize in (True, False):
+            Rr2, tr2 = O.kabsch_transformation_estimation(ks[None, a0:a1].astype(np.float64), kr[None, a0:a1].astype(np.float64),
+                                                          None if w is None else w[None, a0:a1].astype(np.float64), normalize_w=normalize, eps=1e-7, w_threshold=thr)
+            if np.abs(R2[pset].cpu().numpy() - Rr2[0]).max() <= 1e-6 and np.abs(t2[pset].cpu().numpy() - tr2[0, :, 0]).max() <= 1e-5 * max(1.0, np.abs(off).max()):
+                break
+        else:
+            # (weights below the threshold count for nothing: a set left with a handful of effective points, or with all its weight on
+            #  one of them, has no unique rotation)
+            weff = np.ones(a1 - a0) if w is None else np.where(w[a0:a1] >= thr, w[a0:a1], 0.0)
+            if (weff > 0).sum() >= 8 and weff.max() < 0.5 * weff.sum():
+                ok2 = False
+                print("   kabsch2 set", int(pset), "n", int(a1 - a0), "effective", int((weff > 0).sum()), "dR", float(np.abs(R2[pset].cpu().numpy() - Rr2[0]).max()),
+                      "dt", float(np.abs(t2[pset].cpu().numpy() - tr2[0, :, 0]).max()))
+    flags["kabsch2"] = ok2
     # ---- labels -> CSR, gather
     K = int(rng.choice([1, 7, 500, 20_000]))
     lab = rng.integers(0, K, n).astype(np.int32)
