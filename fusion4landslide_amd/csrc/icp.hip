@@ -1072,7 +1072,10 @@ static int f4l::icp_launch_host(const float *src, const int64_t *src_off, const 
     if (P == 0) return F4L_OK;
     if (P > 0x7fffffffLL || max_src_patch_host > 0x3fffffffLL || max_tgt_patch_host > 0x3fffffffLL)
         return F4L_EUNSUPPORTED;
-    const bool f64 = search_precision == F4L_SEARCH_F64;
+    // Point-to-plane always measures in double: its 6 x 6 system is ill-conditioned on near-planar or half-matched patches, and the
+    // 1e-7 of a float32 position, harmless to the Umeyama sums, was seen to throw such a patch out of reach of every target
+    // (fitness 0 after 20 passes where the float64 search follows the oracle to 1e-8 m: tools/gpu/fuzz_icp.py 1 2002788 f32).
+    const bool f64 = search_precision == F4L_SEARCH_F64 || mode == F4L_ICP_POINT2PLANE;
     static_assert(sizeof(GridPt<double>) == sizeof(GridPt<float>), "grid records are 16 B in both modes");
     IcpArgs a;
     a.src = src; a.src_off = src_off; a.tgt = tgt; a.tgt_off = tgt_off; a.P = P;

@@ -113,7 +113,7 @@ int f4l_kabsch_residuals(const float *src, const float *ref, const int64_t *off,
  *                 pointer --; required for POINT2PLANE (see f4l_patch_normals / f4l_patch_normals_f64), else NULL
  *   max_corr_dist, max_iter, rel_fitness, rel_rmse : o3d ICPConvergenceCriteria (utils/o3d_tools.py:47-50)
  *   fixed_iters != 0 disables the early exit: exactly max_iter updates (benchmark mode)
- *   search_precision : F4L_SEARCH_F32 | F4L_SEARCH_F64.  The transform, all sums and the solves are double in
+ *   search_precision : F4L_SEARCH_F32 | F4L_SEARCH_F64 (F4L_ICP_POINT2PLANE always runs F64).  The transform, all sums and the solves are double in
  *                 both; F64 also evaluates point positions and squared distances in double, like Open3D.
  *   max_src_patch_host / max_tgt_patch_host : largest patch sizes (host-known; size LDS and pick the path)
  *   n_src_host  : src_off[P] if the host knows it, else 0.  With it the launcher sees whether patch sizes are uneven
