@@ -35,6 +35,7 @@ SIGNATURES = {
                                  _P, _P, _P, _P, _P, _P, _P, _P]),
     "f4l_mutual_correspondences": (C.c_int, [_P, _P, _P, _P, _I64, _P, _I64, _P, _P, _P]),
     "f4l_rigidity_check": (C.c_int, [_P, _P, _P, _I64, _D, _P, _P, _P]),
+    "f4l_rigidity_check_f32": (C.c_int, [_P, _P, _P, _I64, _D, _P, _P, _P]),
     "f4l_patch_normals": (C.c_int, [_P, _P, _I64, _I, _I64, _P, _P]),
     "f4l_patch_normals_f64": (C.c_int, [_P, _P, _I64, _I, _I64, _P, _P]),
     "f4l_apply_transform": (C.c_int, [_P, _P, _I64, _I64, _P, _I, _P, _P]),

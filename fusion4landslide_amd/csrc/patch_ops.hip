@@ -636,12 +636,21 @@ __device__ __forceinline__ double rg_sqrt(double x) {
     g = __builtin_fma(e, h, g);
     return x > 0.0 ? g : 0.0;
 }
+__device__ __forceinline__ float rg_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }  // (v_sqrt_f32, 1 ulp)
+// R = double: the pair arithmetic of the parity mode.  R = float (f4l_rigidity_check_f32): the differences of two float32
+// coordinates of one patch are exact in float32 (both are multiples of the larger one's ulp and the result needs no more bits
+// than the operands), so only the three products, their sum and the square root round: a distance is off by <= 3e-7 of
+// itself, where the reference's own float32 torch.cdist -- the matrix-product form from 25 points on -- is off by ulp(|x|^2).
+// Half the LDS, no double-rate arithmetic; the sums leave a unit of RG_B pairs as doubles.
+template <typename R>
 __global__ __launch_bounds__(256) void rigidity_kernel(const float *__restrict__ cs, const float *__restrict__ ct,
                                                       const int64_t *__restrict__ off, int64_t P, double thr,
                                                       double *__restrict__ dist_mean, double *__restrict__ ratio_inlier) {
-    __shared__ double pa[3][RG_CAP], pb[3][RG_CAP];
+    typedef R R2 __attribute__((ext_vector_type(2)));  // (source, target) side by side: one LDS read, packed float32 arithmetic
+    __shared__ R2 pq[3][RG_CAP];
     __shared__ double s_sum[4];
     __shared__ long long s_in[4];
+    const R thr_r = (R)thr;
     for (int64_t p = blockIdx.x; p < P; p += gridDim.x) {
         const int64_t o = off[p];
         const int n = (int)(off[p + 1] - o);
@@ -650,8 +659,10 @@ __global__ __launch_bounds__(256) void rigidity_kernel(const float *__restrict__
         int inl = 0;  // (a thread sees < 2^31 pairs)
         if (n <= RG_CAP) {
             for (int t = (int)threadIdx.x; t < 3 * n; t += 256) {
-                pa[t % 3][t / 3] = (double)a[t];
-                pb[t % 3][t / 3] = (double)b[t];
+                R2 v;
+                v.x = (R)a[t];
+                v.y = (R)b[t];
+                pq[t % 3][t / 3] = v;
             }
             __syncthreads();
             // a unit of work = one point i against RG_B consecutive shifts (its coordinates are read once per unit): units are
@@ -660,29 +671,32 @@ __global__ __launch_bounds__(256) void rigidity_kernel(const float *__restrict__
             int i = (int)threadIdx.x, blk = 0;
             while (i >= n && blk < nblk) { i -= n; ++blk; }  // (n < 256: this thread's first unit lies in a later block)
             while (blk < nblk) {
-                const double ax = pa[0][i], ay = pa[1][i], az = pa[2][i], bx = pb[0][i], by = pb[1][i], bz = pb[2][i];
+                const R2 px = pq[0][i], py = pq[1][i], pz = pq[2][i];
                 const int s0 = 1 + blk * RG_B, s1 = s0 + RG_B - 1 < h ? s0 + RG_B - 1 : h;
+                R usum = 0;
                 for (int sft = s0; sft <= s1; ++sft) {
                     const int j = i + sft < n ? i + sft : i + sft - n;
-                    const double dx = ax - pa[0][j], dy = ay - pa[1][j], dz = az - pa[2][j];
-                    const double ex = bx - pb[0][j], ey = by - pb[1][j], ez = bz - pb[2][j];
-                    const double diff = fabs(rg_sqrt(dx * dx + dy * dy + dz * dz) - rg_sqrt(ex * ex + ey * ey + ez * ez));
-                    sum += diff;
-                    inl += diff <= thr ? 1 : 0;
+                    const R2 dx = px - pq[0][j], dy = py - pq[1][j], dz = pz - pq[2][j];
+                    const R2 d2 = dx * dx + dy * dy + dz * dz;
+                    const R diff = fabs(rg_sqrt(d2.x) - rg_sqrt(d2.y));
+                    usum += diff;
+                    inl += diff <= thr_r ? 1 : 0;
                 }
+                sum += (double)usum;
                 i += 256;
                 while (i >= n) { i -= n; ++blk; }
             }
             if ((n & 1) == 0)  // the opposite points of an even ring: each pair once
                 for (int r = (int)threadIdx.x; r < n / 2; r += 256) {
                     const int j = r + n / 2;
-                    const double dx = pa[0][r] - pa[0][j], dy = pa[1][r] - pa[1][j], dz = pa[2][r] - pa[2][j];
-                    const double ex = pb[0][r] - pb[0][j], ey = pb[1][r] - pb[1][j], ez = pb[2][r] - pb[2][j];
-                    const double diff = fabs(rg_sqrt(dx * dx + dy * dy + dz * dz) - rg_sqrt(ex * ex + ey * ey + ez * ez));
-                    sum += diff;
-                    inl += diff <= thr ? 1 : 0;
+                    const R2 dx = pq[0][r] - pq[0][j], dy = pq[1][r] - pq[1][j], dz = pq[2][r] - pq[2][j];
+                    const R2 d2 = dx * dx + dy * dy + dz * dz;
+                    const R diff = fabs(rg_sqrt(d2.x) - rg_sqrt(d2.y));
+                    sum += (double)diff;
+                    inl += diff <= thr_r ? 1 : 0;
                 }
         } else {
+            // (sets beyond the LDS capacity: double in both modes)
             // pairs (i, j), i < j, dealt round-robin by row: thread t takes rows t, t + 256, ... (row i has n - 1 - i pairs)
             for (int i = (int)threadIdx.x; i < n; i += 256) {
                 const double ax = a[3 * i], ay = a[3 * i + 1], az = a[3 * i + 2], bx = b[3 * i], by = b[3 * i + 1], bz = b[3 * i + 2];
@@ -724,13 +738,26 @@ extern "C" int f4l_mutual_correspondences(const int64_t *src_ids, const int64_t 
     return F4L_OK;
 }
 
-extern "C" int f4l_rigidity_check(const float *corr_src, const float *corr_ref, const int64_t *corr_off, int64_t P,
-                                  double thres_dist_diff, double *dist_mean_out, double *ratio_inlier_out, void *stream) {
+namespace f4l {
+template <typename R>
+static int rigidity_launch(const float *corr_src, const float *corr_ref, const int64_t *corr_off, int64_t P, double thres_dist_diff,
+                           double *dist_mean_out, double *ratio_inlier_out, void *stream) {
     if (P < 0 || !corr_off || !dist_mean_out || !ratio_inlier_out || (P > 0 && (!corr_src || !corr_ref))) return F4L_EINVAL;
     if (P == 0) return F4L_OK;
     const unsigned grid = (unsigned)(P < 65535 * 8 ? P : 65535 * 8);
-    hipLaunchKernelGGL(f4l::rigidity_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, corr_src, corr_ref, corr_off, P,
+    hipLaunchKernelGGL(rigidity_kernel<R>, dim3(grid), dim3(256), 0, (hipStream_t)stream, corr_src, corr_ref, corr_off, P,
                        thres_dist_diff, dist_mean_out, ratio_inlier_out);
     F4L_LAUNCH_CHECK();
     return F4L_OK;
+}
+}  // namespace f4l
+
+extern "C" int f4l_rigidity_check(const float *corr_src, const float *corr_ref, const int64_t *corr_off, int64_t P,
+                                  double thres_dist_diff, double *dist_mean_out, double *ratio_inlier_out, void *stream) {
+    return f4l::rigidity_launch<double>(corr_src, corr_ref, corr_off, P, thres_dist_diff, dist_mean_out, ratio_inlier_out, stream);
+}
+
+extern "C" int f4l_rigidity_check_f32(const float *corr_src, const float *corr_ref, const int64_t *corr_off, int64_t P,
+                                      double thres_dist_diff, double *dist_mean_out, double *ratio_inlier_out, void *stream) {
+    return f4l::rigidity_launch<float>(corr_src, corr_ref, corr_off, P, thres_dist_diff, dist_mean_out, ratio_inlier_out, stream);
 }

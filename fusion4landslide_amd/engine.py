@@ -374,10 +374,13 @@ def mutual_correspondences(src_ids, src_off, tgt_ids, tgt_off, corr_tgt):
     return mask.to(torch.bool), count
 
 
-def rigidity_check(corr_src, corr_ref, corr_off, thres_dist_diff):
+def rigidity_check(corr_src, corr_ref, corr_off, thres_dist_diff, precision="f64"):
     """The quality test of a patch match before the rigid fit (src/coarse_to_fine_matching_base.py:3304-3320,
     f4l_rigidity_check): per match, the mean of |d(s_i, s_j) - d(t_i, t_j)| over its mutual pairs and the share of pairs
-    with that difference <= thres_dist_diff.  Returns (dist_mean (P,), ratio_inlier (P,)) float64."""
+    with that difference <= thres_dist_diff.  precision "f64" (parity mode) or "f32" (f4l_rigidity_check_f32: float32 pair
+    arithmetic, distances within 3e-7 of themselves).  Returns (dist_mean (P,), ratio_inlier (P,)) float64."""
+    if precision not in ("f64", "f32"):
+        raise ValueError("precision must be 'f64' or 'f32', not %r" % (precision,))
     torch = require_gpu()
     corr_src = _dev(corr_src, torch.float32, "corr_src", (3,))
     corr_ref = _dev(corr_ref, torch.float32, "corr_ref", (3,))
@@ -385,8 +388,8 @@ def rigidity_check(corr_src, corr_ref, corr_off, thres_dist_diff):
     P = corr_off.shape[0] - 1
     dm = torch.empty((P,), dtype=torch.float64, device=corr_src.device)
     ri = torch.empty((P,), dtype=torch.float64, device=corr_src.device)
-    check(lib().f4l_rigidity_check(ptr(corr_src), ptr(corr_ref), ptr(corr_off), P, float(thres_dist_diff), ptr(dm), ptr(ri),
-                                   stream_ptr()), "f4l_rigidity_check")
+    name = "f4l_rigidity_check" if precision == "f64" else "f4l_rigidity_check_f32"
+    check(getattr(lib(), name)(ptr(corr_src), ptr(corr_ref), ptr(corr_off), P, float(thres_dist_diff), ptr(dm), ptr(ri), stream_ptr()), name)
     return dm, ri
 
 

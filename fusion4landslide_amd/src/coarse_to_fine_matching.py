@@ -270,7 +270,8 @@ class Coarse2Fine:
             icp_threshold=float(self.para.icp_threshold), remove_low_quality_patch_matches=bool(_get(m, "remove_low_quality_patch_matches", False)),
             num_min_matches_for_quality_check=int(_get(m, "num_min_matches_for_quality_check", 10)), thres_dist_diff=float(_get(m, "thres_dist_diff", 0.1)),
             thres_inlier_ratio=float(_get(m, "thres_inlier_ratio", 0.5)), assign_type=m.assign_type, output_tgt2src=bool(_get(m, "output_tgt2src", False)),
-            median_max_resolution=float(self.para.median_max_resolution))
+            median_max_resolution=float(self.para.median_max_resolution),
+            rigidity_precision=str(_get(m, "rigidity_precision", "f64")))  # (this build's key; the reference has no such choice)
         O.fine = res
         O.corres_3d_refine_apply_icp = res["dense"]
         O.corres_3d_refine_apply_icp_discrete = res["sparse"]

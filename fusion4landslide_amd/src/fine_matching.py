@@ -25,7 +25,8 @@ from .. import engine
 def fine_matching_3d(src_pts, tgt_pts, src_ids, src_off, tgt_ids, tgt_off, corr_tgt, *, corr_tgt_2d=None, matching="only_3d",
                      weighting_svd=False, num_min_fine_match=3, icp_threshold=0.1, remove_low_quality_patch_matches=False,
                      num_min_matches_for_quality_check=10, thres_dist_diff=0.05, thres_inlier_ratio=0.5, assign_type="assign_all_src",
-                     output_tgt2src=False, median_max_resolution=0.0, icp_type="point2point", init_round_f32=True):
+                     output_tgt2src=False, median_max_resolution=0.0, icp_type="point2point", init_round_f32=True,
+                     rigidity_precision="f64"):
     """corr_tgt (n_src_points,) int64: `corres_3d_voxel_from_3d_idx[:, 1]`, the target point matched to each source point, -1 for
     none; corr_tgt_2d: `corres_3d_from_2d_idx[:, 1]` likewise (needed for matching = "only_2d" / "fusion").
     matching: "only_3d" | "only_2d" | "fusion" -- `method.fine_matching_only_3d / _only_2d / _fusion` (:3257-3276); in "fusion" a
@@ -35,6 +36,7 @@ def fine_matching_3d(src_pts, tgt_pts, src_ids, src_off, tgt_ids, tgt_off, corr_
     with n2 where n3 was meant -- 0.01 from pair n2 on, 1 in between; a match that passes the quality check is fitted without
     weights (:3329).
     init_round_f32: ICP starts from the float32 values of the Kabsch transform (the reference's float32 4 x 4, :3360).
+    rigidity_precision: "f64" | "f32", the pair arithmetic of the quality check (engine.rigidity_check).
 
     Returns a dict:
       dense        (m, 6) float32 [s, T s] for every point of every registered match's source patch, in match order (:3408)
@@ -90,7 +92,8 @@ def fine_matching_3d(src_pts, tgt_pts, src_ids, src_off, tgt_ids, tgt_off, corr_
     passed_check = torch.zeros(P, dtype=torch.bool, device=dev)
     if remove_low_quality_patch_matches:
         rows, tids, _ = pair_list(mask3, mask2)
-        dist_mean, ratio_inlier = engine.rigidity_check(src_pts[rows].contiguous(), tgt_pts[tids].contiguous(), offsets(count), thres_dist_diff)
+        dist_mean, ratio_inlier = engine.rigidity_check(src_pts[rows].contiguous(), tgt_pts[tids].contiguous(), offsets(count), thres_dist_diff,
+                                                        precision=rigidity_precision)
         checked = count >= num_min_matches_for_quality_check
         bad = checked & ((ratio_inlier <= thres_inlier_ratio) | (dist_mean >= thres_dist_diff))
         mask_useful = ~bad

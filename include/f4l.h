@@ -143,12 +143,16 @@ int f4l_piecewise_icp(const float *src, const int64_t *src_off, const float *tgt
  *   dist_mean = mean over i < j of |d(s_i, s_j) - d(t_i, t_j)|,  ratio_inlier = share of pairs with that difference <=
  *   thres_dist_diff (the reference counts both triangles and takes the diagonal off again: the same ratio); both 0 for
  *   n < 2.  The caller drops a match when ratio_inlier <= thres_inlier_ratio or dist_mean >= thres_dist_diff (:3322).
- *   Distances in double (the reference: float32 torch.cdist). */
+ *   Distances in double (the reference: float32 torch.cdist).  f4l_rigidity_check_f32: the same test with the pair
+ *   arithmetic in float32 -- coordinate differences inside a patch are exact there, a distance is within 3e-7 of itself
+ *   (closer than the reference's own float32 cdist) -- several times faster; match sets beyond 1024 pairs run in double. */
 int f4l_mutual_correspondences(const int64_t *src_ids, const int64_t *src_off, const int64_t *tgt_ids,
                                const int64_t *tgt_off, int64_t P, const int64_t *corr_tgt, int64_t n_corr,
                                uint8_t *mask_out, int64_t *count_out, void *stream);
 int f4l_rigidity_check(const float *corr_src, const float *corr_ref, const int64_t *corr_off, int64_t P,
                        double thres_dist_diff, double *dist_mean_out, double *ratio_inlier_out, void *stream);
+int f4l_rigidity_check_f32(const float *corr_src, const float *corr_ref, const int64_t *corr_off, int64_t P,
+                           double thres_dist_diff, double *dist_mean_out, double *ratio_inlier_out, void *stream);
 
 /* The rest of the loop body of src/coarse_to_fine_matching_base.py:3254-3436 for P patch matches in ONE launch:
  *   weighted Kabsch of the match's correspondences (:3341, scripts/weighted_svd.py:58-129; corr_src / corr_ref float32

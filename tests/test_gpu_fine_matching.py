@@ -220,6 +220,37 @@ def test_mutual_correspondences_and_rigidity_small_cases():
     assert ri[0].item() == 1.0 and ri[1].item() < 0.5
 
 
+@pytest.mark.parametrize("shift", [0.0, 2.6e3, -7.1e5])
+def test_rigidity_check_float32_pairs(shift):
+    """f4l_rigidity_check_f32: the pair arithmetic in float32 (coordinate differences inside a patch are exact there).  Sets of
+    2 ... 1100 pairs (the last beyond the LDS capacity: double in both modes), local and georeferenced coordinates: mean
+    difference within 3e-7 of the distances involved, the inlier ratio apart only by pairs AT the threshold, and the verdicts
+    of the caller (:3322) equal wherever the float64 metrics are not at a threshold themselves."""
+    from fusion4landslide_amd import engine
+    rng = np.random.default_rng(5)
+    sizes = [2, 3, 9, 10, 63, 64, 65, 255, 256, 257, 600, 1024, 1100, 0, 1]
+    off = np.cumsum([0] + sizes).astype(np.int64)
+    a = (rng.uniform(-2, 2, (off[-1], 3)) + shift * np.array([1.0, 0.7, 0.01])).astype(np.float32)
+    b = (a.astype(np.float64) + rng.normal(0, rng.choice([0.005, 0.03, 0.2], (len(a), 1)), a.shape)).astype(np.float32)
+    thr = 0.05
+    dm, ri = (x.cpu().numpy() for x in engine.rigidity_check(dev(a), dev(b), dev(off), thr))
+    dm32, ri32 = (x.cpu().numpy() for x in engine.rigidity_check(dev(a), dev(b), dev(off), thr, precision="f32"))
+    for p, n in enumerate(sizes):
+        if n < 2:
+            assert dm32[p] == 0.0 and ri32[p] == 0.0
+            continue
+        x, y = a[off[p]:off[p + 1]].astype(np.float64), b[off[p]:off[p + 1]].astype(np.float64)
+        iu = np.triu_indices(n, 1)
+        dd = np.abs(np.linalg.norm(x[iu[0]] - x[iu[1]], axis=1) - np.linalg.norm(y[iu[0]] - y[iu[1]], axis=1))
+        assert abs(dm[p] - dd.mean()) < 1e-12 and abs(ri[p] - (dd <= thr).mean()) < 1e-12
+        assert abs(dm32[p] - dd.mean()) <= 3e-6, (n, dm32[p], dd.mean())  # (distances <= 7 m: 3e-7 of them, twice)
+        assert abs(ri32[p] - ri[p]) <= (np.abs(dd - thr) <= 5e-6).mean() + 1e-12, (n, ri32[p], ri[p])
+    clear = (np.abs(dm - thr) > 1e-5) & (np.abs(ri - 0.5) > 1e-3)
+    assert np.array_equal(((ri32 <= 0.5) | (dm32 >= thr))[clear], ((ri <= 0.5) | (dm >= thr))[clear])
+    with pytest.raises(ValueError):
+        engine.rigidity_check(dev(a), dev(b), dev(off), thr, precision="half")
+
+
 def test_rgb_guided_prune_mirror():
     """src/rgb_guided.py:99-125: 2.5 x (lower) median prune, four return values."""
     from fusion4landslide_amd.src import rgb_guided

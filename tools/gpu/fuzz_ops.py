@@ -102,16 +102,20 @@ for case in range(n_cases):
     Pm = int(rng.choice([1, 20, 400]))
     ms = rng.integers(0, 60, Pm)
     moff = np.zeros(Pm + 1, np.int64); np.cumsum(ms, out=moff[1:])
-    a_ = rng.uniform(0, 3, (int(moff[-1]), 3)).astype(np.float32); b_ = (a_ + rng.normal(0, 0.02, a_.shape)).astype(np.float32)
+    shift = rng.choice([0.0, 0.0, 2.6e3, -7.1e5]) * rng.uniform(0.5, 1, 3)  # (local or georeferenced coordinates)
+    a_ = (rng.uniform(-1.5, 1.5, (int(moff[-1]), 3)) + shift).astype(np.float32); b_ = (a_ + rng.normal(0, 0.02, a_.shape)).astype(np.float32)
     dm, ri = engine.rigidity_check(dv(a_), dv(b_), dv(moff), 0.05)
-    dm_r, ri_r = np.zeros(Pm), np.zeros(Pm)
+    dm32, ri32 = engine.rigidity_check(dv(a_), dv(b_), dv(moff), 0.05, precision="f32")
+    dm_r, ri_r, near = np.zeros(Pm), np.zeros(Pm), np.zeros(Pm)
     for p in range(Pm):
         s_, t_ = a_[moff[p]:moff[p + 1]].astype(np.float64), b_[moff[p]:moff[p + 1]].astype(np.float64)
         if len(s_) >= 2:
             iu = np.triu_indices(len(s_), 1)
             dd = np.abs(np.linalg.norm(s_[iu[0]] - s_[iu[1]], axis=1) - np.linalg.norm(t_[iu[0]] - t_[iu[1]], axis=1))
-            dm_r[p], ri_r[p] = dd.mean(), (dd <= 0.05).mean()
+            dm_r[p], ri_r[p], near[p] = dd.mean(), (dd <= 0.05).mean(), (np.abs(dd - 0.05) <= 5e-6).mean()
     flags["rigidity"] = bool(np.abs(dm.cpu().numpy() - dm_r).max(initial=0) <= 1e-12 and np.abs(ri.cpu().numpy() - ri_r).max(initial=0) <= 1e-12)
+    # float32 pair arithmetic: every distance within 3e-7 of itself (sets span <= 5.2 m), only pairs AT the threshold may change sides
+    flags["rigidity_f32"] = bool(np.abs(dm32.cpu().numpy() - dm_r).max(initial=0) <= 3e-6 and (np.abs(ri32.cpu().numpy() - ri_r) <= near + 1e-12).all())
     ok = all(flags.values())
     bad += not ok
     print(f"case {seed0 + case:4d} n={n:6d} m={m:6d} k={k:2d} P={P:5d}  {'ok' if ok else 'MISMATCH ' + str([f for f, v_ in flags.items() if not v_])}", flush=True)

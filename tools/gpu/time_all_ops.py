@@ -36,6 +36,7 @@ T0 = timed("kabsch_transforms (4x4 out)", lambda: engine.kabsch_transforms(cs, c
 timed("kabsch_residuals", lambda: engine.kabsch_residuals(cs, ct, coff, R, t), unit_pts=m)
 timed("kabsch2_batched (src/functions.py Kabsch #2)", lambda: engine.kabsch2_batched(cs, ct, coff), unit_pts=m)
 timed("rigidity_check (all pairs of every match set)", lambda: engine.rigidity_check(cs, ct, coff, 0.03), unit_pts=m, reps=3)
+timed("rigidity_check, float32 pair arithmetic", lambda: engine.rigidity_check(cs, ct, coff, 0.03, precision="f32"), unit_pts=m, reps=3)
 timed("apply_transform (rows [s, T s])", lambda: engine.apply_transform(src, soff, T0))
 timed("nn_refine (refine_dvfs_with_threshold)", lambda: engine.nn_refine(src, soff, tgt, toff, T0, thr, max_tgt_patch=d["max_tgt"]))
 timed("patch_normals (estimate_normals per patch, k = 30)", lambda: engine.patch_normals(tgt, toff, 30, max_patch=d["max_tgt"]), reps=3)

@@ -17,7 +17,7 @@ for name in ("C2_1M_2k", "C2x16_16M_32k"):
     pid = torch.repeat_interleave(torch.arange(P, device=dev), soff[1:] - soff[:-1])
     corr = torch.where(nn >= 0, toff[pid] + nn.to(torch.int64), torch.full_like(pid, -1))
     sid, tid = torch.arange(n, device=dev), torch.arange(tgt.shape[0], device=dev)
-    for kw in (dict(remove_low_quality_patch_matches=False), dict(remove_low_quality_patch_matches=True), dict(remove_low_quality_patch_matches=True, assign_type="assign_then_nn", output_tgt2src=True, median_max_resolution=0.03)):
+    for kw in (dict(remove_low_quality_patch_matches=False), dict(remove_low_quality_patch_matches=True), dict(remove_low_quality_patch_matches=True, rigidity_precision="f32"), dict(remove_low_quality_patch_matches=True, assign_type="assign_then_nn", output_tgt2src=True, median_max_resolution=0.03)):
         f = lambda: fine_matching_3d(src, tgt, sid, soff, tid, toff, corr, thres_dist_diff=0.03, **kw)
         f(); torch.cuda.synchronize()
         ts = []
