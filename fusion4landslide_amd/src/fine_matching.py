@@ -77,6 +77,8 @@ def fine_matching_3d(src_pts, tgt_pts, src_ids, src_off, tgt_ids, tgt_off, corr_
             rows.append(src_ids[r])
             tids.append(corr[src_ids[r]])
             pids.append(pid_rows[r])
+        if len(rows) == 1:  # (one matching: the pairs already stand in match order)
+            return rows[0], tids[0], pids[0]
         rows, tids, pids = torch.cat(rows), torch.cat(tids), torch.cat(pids)
         order = torch.argsort(pids, stable=True)  # (stable: a match's 3D pairs stay ahead of its 2D pairs, each in patch order)
         return rows[order], tids[order], pids[order]
@@ -140,7 +142,13 @@ def fine_matching_3d(src_pts, tgt_pts, src_ids, src_off, tgt_ids, tgt_off, corr_
         nn, rws = engine.nn_refine(rows_src, src_off, tgt_pts[tgt_ids].contiguous(), tgt_off, out["T"], thr)
         keep = (nn >= 0) & done[pid_rows]
         rws, pid_k = rws[keep], pid_rows[keep]
-        # the reference appends every match's block twice (:3428 and :3434)
-        order = torch.argsort(torch.cat([2 * pid_k, 2 * pid_k + 1]), stable=True)
-        res["sparse"] = torch.cat([rws, rws])[order]
+        # the reference appends every match's block twice (:3428 and :3434): row l of a match with c rows, o rows before it, goes to
+        # 2 o + l and to 2 o + c + l
+        c = torch.bincount(pid_k, minlength=P)
+        o = torch.cumsum(c, 0) - c
+        pos = torch.arange(rws.shape[0], device=dev) + o[pid_k]  # (= 2 o + l, with l = index - o)
+        sparse = torch.empty((2 * rws.shape[0], rws.shape[1]), dtype=rws.dtype, device=dev)
+        sparse[pos] = rws
+        sparse[pos + c[pid_k]] = rws
+        res["sparse"] = sparse
     return res
