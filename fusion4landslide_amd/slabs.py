@@ -205,6 +205,8 @@ def slab_supervoxel(local_xyz, local_gid, k, resolution, dist, rank, world, halo
     if world > 1:
         _all_reduce(dist, counts, dist.ReduceOp.SUM)
     offset = int(counts[:rank].sum())
+    if world > 1 and bool((counts == 0).any()):  # (from the reduced counts: every rank raises, nobody is left in a later collective)
+        raise ValueError(f"slab(s) {[int(r) for r in torch.nonzero(counts == 0).flatten().tolist()]} hold no source point: use fewer ranks")
     return dict(xyz=xyz_all[:n_own], gid=gid_all[:n_own], labels=labels.to(torch.int64) + offset, knn_gid=gid_all[idx], d2=d2, normals=nrm,
                 K_local=int(K_local), K_total=int(counts.sum()), offset=offset, n_uncertified=int(bad.item()), plan=plan, n_halo=int(halo_pts.shape[0]),
                 xyz_all=xyz_all, gid_all=gid_all, n_own=n_own, cuts=cuts, labels_local=labels.to(torch.int64))
