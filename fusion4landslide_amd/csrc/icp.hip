@@ -121,9 +121,16 @@ __device__ __forceinline__ void nn_global(const float *__restrict__ tg, int nt, 
 }
 
 // Solve the 6x6 system M[:, :6] x = M[:, 6] in place by Gaussian elimination with partial pivoting.
-// All indices are compile-time after unrolling, so M lives in registers.  Returns false when singular.
+// All indices are compile-time after unrolling, so M lives in registers.  Returns false when singular -- a pivot that is
+// zero, or below 1e-13 of the largest diagonal entry: the system is built about the patch's own origin, where a patch that
+// pins its six degrees of freedom keeps its pivots above 1e-6 of that; below the bound the "solution" is rounding noise
+// times 1e13 (a patch left with four correspondences was thrown 55 m by it), and the step is not taken.
 __device__ __forceinline__ bool solve6(double (&M)[6][7], double (&x)[6]) {
     bool ok = true;
+    double dmax = 0.0;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) dmax = fmax(dmax, fabs(M[c][c]));
+    const double tiny = 1e-13 * dmax;
 #pragma unroll
     for (int c = 0; c < 6; ++c) {
 #pragma unroll
@@ -134,7 +141,7 @@ __device__ __forceinline__ bool solve6(double (&M)[6][7], double (&x)[6]) {
             }
         }
         const double piv = M[c][c];
-        if (piv == 0.0 || !isfinite(piv)) ok = false;
+        if (!(fabs(piv) > tiny) || !isfinite(piv)) ok = false;
         const double ip = 1.0 / piv;
 #pragma unroll
         for (int r = c + 1; r < 6; ++r) {
@@ -721,7 +728,9 @@ __global__ __launch_bounds__(NW * 64, WIDE ? 3 : (sizeof(F) == 8 ? ICP_WAVES_PER
                         for (int v = u; v < 6; ++v) { M[u][v] = tot[k]; M[v][u] = tot[k]; ++k; }
 #pragma unroll
                     for (int u = 0; u < 6; ++u) M[u][6] = -tot[23 + u];
-                    have = solve6(M, x);
+                    // (fewer than six correspondences cannot pin six unknowns: no step, the transform stays and the loop ends
+                    //  on its criteria -- Open3D solves the singular system and applies whatever comes out)
+                    have = m >= 6.0 && solve6(M, x);
                     if (have) {
                         // o3d TransformVector6dToMatrix4d: Rz(x2) Ry(x1) Rx(x0), translation x[3:6]
                         const double ca = cos(x[0]), sa = sin(x[0]), cb = cos(x[1]), sb = sin(x[1]), cg = cos(x[2]),

@@ -658,11 +658,13 @@ __global__ __launch_bounds__(256) void rigidity_kernel(const float *__restrict__
         double sum = 0.0;
         int inl = 0;  // (a thread sees < 2^31 pairs)
         if (n <= RG_CAP) {
+            const bool twice = 2 * n <= RG_CAP;  // the ring unrolled: point j again at j + n, no wrap of i + shift
             for (int t = (int)threadIdx.x; t < 3 * n; t += 256) {
                 R2 v;
                 v.x = (R)a[t];
                 v.y = (R)b[t];
                 pq[t % 3][t / 3] = v;
+                if (twice) pq[t % 3][t / 3 + n] = v;
             }
             __syncthreads();
             // a unit of work = one point i against RG_B consecutive shifts (its coordinates are read once per unit): units are
@@ -674,13 +676,25 @@ __global__ __launch_bounds__(256) void rigidity_kernel(const float *__restrict__
                 const R2 px = pq[0][i], py = pq[1][i], pz = pq[2][i];
                 const int s0 = 1 + blk * RG_B, s1 = s0 + RG_B - 1 < h ? s0 + RG_B - 1 : h;
                 R usum = 0;
-                for (int sft = s0; sft <= s1; ++sft) {
-                    const int j = i + sft < n ? i + sft : i + sft - n;
-                    const R2 dx = px - pq[0][j], dy = py - pq[1][j], dz = pz - pq[2][j];
-                    const R2 d2 = dx * dx + dy * dy + dz * dz;
-                    const R diff = fabs(rg_sqrt(d2.x) - rg_sqrt(d2.y));
-                    usum += diff;
-                    inl += diff <= thr_r ? 1 : 0;
+                if (twice && s1 - s0 + 1 == RG_B) {
+                    const R2 *__restrict__ qx = &pq[0][i + s0], *__restrict__ qy = &pq[1][i + s0], *__restrict__ qz = &pq[2][i + s0];
+#pragma unroll
+                    for (int u = 0; u < RG_B; ++u) {
+                        const R2 dx = px - qx[u], dy = py - qy[u], dz = pz - qz[u];
+                        const R2 d2 = dx * dx + dy * dy + dz * dz;
+                        const R diff = fabs(rg_sqrt(d2.x) - rg_sqrt(d2.y));
+                        usum += diff;
+                        inl += diff <= thr_r ? 1 : 0;
+                    }
+                } else {
+                    for (int sft = s0; sft <= s1; ++sft) {
+                        const int j = i + sft < n ? i + sft : i + sft - n;
+                        const R2 dx = px - pq[0][j], dy = py - pq[1][j], dz = pz - pq[2][j];
+                        const R2 d2 = dx * dx + dy * dy + dz * dz;
+                        const R diff = fabs(rg_sqrt(d2.x) - rg_sqrt(d2.y));
+                        usum += diff;
+                        inl += diff <= thr_r ? 1 : 0;
+                    }
                 }
                 sum += (double)usum;
                 i += 256;

@@ -43,6 +43,8 @@ extern "C" {
 
 #define F4L_ICP_POINT2POINT 0 /* o3d TransformationEstimationPointToPoint(False), utils/o3d_tools.py:34 */
 #define F4L_ICP_POINT2PLANE 1 /* o3d TransformationEstimationPointToPlane(),     utils/o3d_tools.py:39 */
+/*   (a point-to-plane step with fewer than six correspondences, or whose 6 x 6 system is singular to 1e-13, is not taken:
+ *    the transform stays and the loop ends on its criteria) */
 /* f4l_patch_loop only, OR-ed into `mode`: the Kabsch transform is rounded to float32 before ICP starts from it, as the
  * reference hands Open3D the float32 4 x 4 of refine_local_rigid_correspondences (scripts/weighted_svd.py:148-151,
  * src/coarse_to_fine_matching_base.py:3360 `initial_transform=est_transform_svd.cpu()`). */

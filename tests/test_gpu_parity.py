@@ -252,6 +252,37 @@ def test_icp_point2plane_vs_oracle(eng, search):
         eng.piecewise_icp(dev(d["src"]), dev(d["src_off"]), dev(d["tgt"]), dev(d["tgt_off"]), icp_type="generalized")
 
 
+def test_icp_point2plane_refuses_a_singular_step(eng):
+    """A point-to-plane step that cannot pin its six unknowns is not taken: fewer than six correspondences (the oracle's rule
+    too), or an exactly planar target with parallel normals (rank 3: pivots below 1e-13 of the diagonal).  The transform stays
+    where it was, fitness and rmse are those of the start, and the loop ends on its criteria -- where solving the singular
+    system threw a four-pair patch 55 m (tools/gpu/fuzz_icp.py 1 2250095 f64 n32)."""
+    rng = np.random.default_rng(12)
+    gx, gy = np.meshgrid(np.arange(8) * 0.1, np.arange(8) * 0.1)
+    tgt_a = np.c_[gx.ravel(), gy.ravel(), 0.05 * np.sin(3 * gx.ravel()) * np.cos(2 * gy.ravel())]
+    near = tgt_a[[9, 20, 35, 50]] + rng.normal(0, 0.004, (4, 3))
+    far = tgt_a[:7] + np.array([0.0, 0.0, 1.0])
+    src_a = np.r_[near, far]
+    tgt_b = np.c_[rng.uniform(0, 1, (300, 2)), np.zeros(300)]  # a plane, normals exactly (0, 0, 1)
+    src_b = np.c_[rng.uniform(0.1, 0.9, (200, 2)), np.full(200, 0.01)]
+    origin = np.array([2647.0, 1177.0, 1500.0])
+    for shift in (np.zeros(3), origin):
+        src = (np.r_[src_a, src_b] + shift).astype(np.float32)
+        tgt = (np.r_[tgt_a, tgt_b] + shift).astype(np.float32)
+        soff, toff = np.array([0, len(src_a), len(src)], np.int64), np.array([0, len(tgt_a), len(tgt)], np.int64)
+        nrm = np.r_[O.o3d_estimate_normals(tgt[:len(tgt_a)].astype(np.float64), 30), np.tile([0.0, 0.0, 1.0], (len(tgt_b), 1))]
+        out = eng.piecewise_icp(dev(src), dev(soff), dev(tgt), dev(toff), max_corr_dist=0.05, max_iter=30, icp_type="point2plane",
+                                tgt_normals=dev(nrm))
+        T = out["T"].cpu().numpy()
+        assert np.array_equal(T[0], np.eye(4)) and np.array_equal(T[1], np.eye(4)), T
+        fit = out["fitness"].cpu().numpy()
+        assert abs(fit[0] - 4 / 11) < 1e-12 and fit[1] == 1.0
+        ref = O.icp(src[:len(src_a)].astype(np.float64), tgt[:len(tgt_a)].astype(np.float64), max_corr_dist=0.05, max_iter=30,
+                    icp_type="point2plane", tgt_normals=nrm[:len(tgt_a)])
+        assert np.array_equal(ref["est_transform"], np.eye(4)) and abs(ref["fitness"] - 4 / 11) < 1e-12
+        assert abs(out["rmse"].cpu().numpy()[0] - ref["inlier_rmse"]) < 1e-9
+
+
 def test_patch_normals_lane_per_query_equals_wave_per_query(eng):
     """f4l_patch_normals: the lane-per-query kernel (patches up to 8192 points, k <= 36) against the wave-per-query kernel it
     replaces there (F4L_PATCH_NORMALS_WAVES): the same neighbour sets, hence the same normals to rounding -- patches of every

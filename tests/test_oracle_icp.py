@@ -88,6 +88,54 @@ def test_icp_oracle_walks_the_same_trajectory_as_numpy_restatement(icp_type):
         assert np.array_equal(cs[:, 0], np.nonzero(ref[4])[0]) and np.array_equal(cs[:, 1], ref[5][ref[4]])
 
 
+def test_icp_oracle_point2plane_far_from_the_origin_is_the_extended_precision_step():
+    """orc_point2plane sums and solves the 6 x 6 equations in long double: 3 km from the origin one pass of the oracle is the
+    numpy `longdouble` pass to 1e-10 m, where the same pass with double sums is 1e-8 m away (its own rounding: the entries are
+    |origin|^2 per pair, the information is in their patch-sized variation).  And a step with fewer pairs than unknowns is not
+    taken (the kernel's rule)."""
+    rng = np.random.default_rng(8)
+    origin = np.array([2647.0, 1177.0, 1500.0])
+    tgt = (_surface(rng, 6000, noise=0.002) + origin).astype(np.float32).astype(np.float64)
+    src0 = _surface(rng, 5000)
+    src0 = src0[(src0[:, 0] > 0.15) & (src0[:, 0] < 1.85) & (src0[:, 1] > 0.15) & (src0[:, 1] < 1.85)]
+    src = ((src0 @ rot_from_axis_angle(rng.normal(size=3), 0.006).T + rng.uniform(-0.02, 0.02, 3)) + origin).astype(np.float32).astype(np.float64)
+    normals = O.o3d_estimate_normals(tgt, 30)
+    got = O.icp(src, tgt, np.eye(4), max_corr_dist=0.1, max_iter=1, icp_type="point2plane", tgt_normals=normals, fixed_iters=True)
+    d, j = cKDTree(tgt).query(src)
+    ok = d < 0.1
+
+    def one_pass(dtype):
+        a, b, n = src[ok].astype(dtype), tgt[j[ok]].astype(dtype), normals[j[ok]].astype(dtype)
+        J = np.concatenate([np.cross(a, n), n], axis=1)
+        res = ((a - b) * n).sum(1)
+        A, rhs = np.zeros((6, 6), dtype), np.zeros(6, dtype)
+        for i in range(len(a)):  # (one pair after the other, like the oracle)
+            A += np.outer(J[i], J[i])
+            rhs -= J[i] * res[i]
+        M = np.concatenate([A.astype(np.longdouble), rhs.astype(np.longdouble)[:, None]], axis=1)
+        for c in range(6):
+            pv = c + int(np.argmax(np.abs(M[c:, c])))
+            M[[c, pv]] = M[[pv, c]]
+            for r_ in range(c + 1, 6):
+                M[r_] -= M[r_, c] / M[c, c] * M[c]
+        x = np.zeros(6, np.longdouble)
+        for r_ in range(5, -1, -1):
+            x[r_] = (M[r_, 6] - M[r_, r_ + 1:6] @ x[r_ + 1:]) / M[r_, r_]
+        x = x.astype(np.float64)
+        al, be, ga = x[:3]
+        Rz = np.array([[np.cos(ga), -np.sin(ga), 0], [np.sin(ga), np.cos(ga), 0], [0, 0, 1]])
+        Ry = np.array([[np.cos(be), 0, np.sin(be)], [0, 1, 0], [-np.sin(be), 0, np.cos(be)]])
+        Rx = np.array([[1, 0, 0], [0, np.cos(al), -np.sin(al)], [0, np.sin(al), np.cos(al)]])
+        return src @ (Rz @ Ry @ Rx).T + x[3:]
+
+    T = got["est_transform"]
+    moved = src @ T[:3, :3].T + T[:3, 3]
+    e_ld, e_d = np.abs(moved - one_pass(np.longdouble)).max(), np.abs(moved - one_pass(np.float64)).max()
+    assert e_ld <= 1e-10 and e_d >= 5 * e_ld, (e_ld, e_d)
+    few = O.icp(src[:5], tgt, np.eye(4), max_corr_dist=0.1, max_iter=30, icp_type="point2plane", tgt_normals=normals)
+    assert np.array_equal(few["est_transform"], np.eye(4)) and few["fitness"] == 1.0 and few["iters"] == 1
+
+
 def test_icp_oracle_recovers_planted_motion_and_reports_definitional_scores():
     rng = np.random.default_rng(11)
     tgt = _surface(rng, 4000)

@@ -19,6 +19,7 @@ seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 SEARCH = sys.argv[3] if len(sys.argv) > 3 and sys.argv[3] in ("f32", "f64") else "f64"
 # "n32": float32 target normals for point-to-plane (f4l_patch_normals) instead of the doubles Open3D keeps (f4l_patch_normals_f64)
 NORMALS_F64 = "n32" not in sys.argv[3:]
+TRACE = "trace" in sys.argv[3:]  # (every mismatching patch again, pass by pass)
 bad = 0
 for case in range(n_cases):
     rng = np.random.default_rng(seed0 + case)
@@ -67,7 +68,8 @@ for case in range(n_cases):
     tol = 1e-9 if icp_type == "point2point" else (5e-7 if NORMALS_F64 else 5e-6)
     if SEARCH == "f32":
         tol = 2e-3
-    worst, worst_posed, n_bad, n_bad_posed, n_unstable, n_order, n_normals, n_posed, detail = 0.0, 0.0, 0, 0, 0, 0, 0, 0, []
+    worst, worst_posed, n_bad, n_bad_posed, n_unstable, n_order, n_normals, n_exit, n_posed, detail = 0.0, 0.0, 0, 0, 0, 0, 0, 0, 0, []
+    it_k = out["iters"].cpu().numpy()
     for p in range(P):
         s = src[soff[p]:soff[p + 1]].astype(np.float64)
         if not len(s):
@@ -129,15 +131,47 @@ for case in range(n_cases):
                     if e_same <= tol:
                         posed = False
                         n_normals += 1
+                if posed and not fixed and int(it_k[p]) != int(ref["iters"][p]):
+                    # ... or on the EXIT decision: both sides walk the same trajectory and leave it at different passes (the
+                    # criteria compare a change of the rmse with 1e-6; on a plateau -- point-to-plane far from the origin -- the
+                    # change crosses that value within rounding while a pass still moves the patch by more than the tolerance).
+                    # The oracle made to run exactly the kernel's number of passes must land where the kernel landed.
+                    forced = O.icp(one(src, soff).astype(np.float64), one(tgt, toff).astype(np.float64), max_corr_dist=r, max_iter=int(it_k[p]),
+                                   icp_type=icp_type, fixed_iters=True,
+                                   tgt_normals=None if nrm_h is None else np.ascontiguousarray(nrm_h[toff[p]:toff[p + 1]]))
+                    Tf = forced["est_transform"]
+                    e_forced = float(np.abs((s @ Tf[:3, :3].T + Tf[:3, 3]) - (s @ T[p, :3, :3].T + T[p, :3, 3])).max())
+                    if e_forced <= tol:
+                        posed = False
+                        n_exit += 1
+                        detail.append(("exit", p, int(it_k[p]), int(ref["iters"][p]), e, e_forced))
+        if e > tol and posed and TRACE:
+            # pass by pass: the kernel and the oracle on this patch alone, both made to run exactly k passes -- in the caller's frame
+            # and with both clouds moved to the patch (exact in float32: the coordinates share the origin's exponent)
+            one = lambda a, off: np.ascontiguousarray(a[off[p]:off[p + 1]])
+            for frame, sh in (("caller's frame", np.zeros(3, np.float32)), ("patch frame", one(tgt, toff)[0])):
+                s1, t1_ = one(src, soff) - sh, one(tgt, toff) - sh
+                z = np.array([0, len(s1)], np.int64), np.array([0, len(t1_)], np.int64)
+                n1 = None if nrm_h is None else np.ascontiguousarray(nrm_h[toff[p]:toff[p + 1]])
+                line = []
+                for kk in range(1, int(max(it_k[p], ref["iters"][p])) + 3):
+                    o_ = O.icp(s1.astype(np.float64), t1_.astype(np.float64), max_corr_dist=r, max_iter=kk, icp_type=icp_type, fixed_iters=True, tgt_normals=n1)
+                    k_ = engine.piecewise_icp(dv(s1), dv(z[0]), dv(t1_), dv(z[1]), max_corr_dist=r, max_iter=kk, icp_type=icp_type, fixed_iters=True,
+                                              search=SEARCH, tgt_normals=None if n1 is None else dv(n1))
+                    Tk, To = k_["T"].cpu().numpy()[0], o_["est_transform"]
+                    s64 = s1.astype(np.float64)
+                    line.append("%.1e (rmse %.9f)" % (float(np.abs((s64 @ Tk[:3, :3].T + Tk[:3, 3]) - (s64 @ To[:3, :3].T + To[:3, 3])).max()), o_["inlier_rmse"]))
+                print(f"    patch {p}, {frame}: kernel against oracle after 1, 2, ... passes: " + ", ".join(line), flush=True)
         if e > tol:
             n_bad += 1
             if posed:
                 n_bad_posed += 1
-                detail.append((p, len(s), int(toff[p + 1] - toff[p]), round(float(fit[p]), 2), e))
+                detail.append((p, len(s), int(toff[p + 1] - toff[p]), round(float(fit[p]), 2), e, int(it_k[p]), int(ref["iters"][p])))
         if posed:
             worst_posed = max(worst_posed, e)
             n_posed += 1
     ok = n_bad_posed == 0
+    exits = [d[1:] for d in detail if d[0] == "exit"]  # (patch, kernel passes, oracle passes, difference, difference at equal passes)
     if SEARCH == "f32":
         # the fast mode adds a float32 rounding to every pass: on a patch whose iteration does not settle (point-to-plane, a radius
         # beyond the patch, half the points matched: the oracle's rmse wanders for all 30 passes) that grows to centimetres where
@@ -149,6 +183,7 @@ for case in range(n_cases):
           f"{'geo' if origin[0] else 'loc'} {icp_type:11s} fixed={int(fixed)}  worst {worst:.1e} (well-posed patches {worst_posed:.1e}), "
           f"{n_bad} patches differ, {n_bad_posed} of them well-posed{f' ({n_unstable} more where the oracle itself moves by more than the tolerance when started 1e-13 m off)' if n_unstable else ''}"
           f"{f' ({n_order} more where the oracle moves by more than the tolerance when the source points come in reverse order)' if n_order else ''}"
-          f"{f' ({n_normals} more where the oracle, given the float32 normals the kernel had, lands where the kernel landed)' if n_normals else ''}  "
-          f"{'ok' if ok else 'MISMATCH ' + str(detail[:4])}", flush=True)
+          f"{f' ({n_normals} more where the oracle, given the float32 normals the kernel had, lands where the kernel landed)' if n_normals else ''}"
+          f"{f' ({n_exit} more that left the same trajectory at another pass: the oracle run for exactly the passes of the kernel lands where the kernel landed {exits[:2]})' if n_exit else ''}  "
+          f"{'ok' if ok else 'MISMATCH ' + str([d for d in detail if d[0] != 'exit'][:4])}", flush=True)
 print("FUZZ", "CLEAN" if bad == 0 else f"{bad} MISMATCHES")
