@@ -8,6 +8,7 @@ and never returns -- hence few counters per pass and a time limit on each).  Thi
 program rocprofv3 starts is the one after `--`.  Output: {kernel substring: {counter: mean per launch, "launches": n,
 "ns": mean duration, "per_call": {...}}}, counters in their own units (FETCH_SIZE / WRITE_SIZE: KB).
 
+`--counters "A B;C D"`: passes of one's own instead of the built-in list (an unknown counter name fails that pass only).
 `--group N`: the command issues the kernel N times per logical call (e.g. two icp_kernel launches per f4l_patch_loop step, or the
 ~270 launches of one segmentation); "per_call" sums N consecutive launches.  `--sum-all`: per_call = the sum over ALL kernels
 whose name contains the substring, divided by --calls (for a family like `svg::`)."""
@@ -40,6 +41,8 @@ def main():
             sum_all = True; argv = argv[1:]
         elif argv[0] == "--passes":
             passes = [PASSES[int(i)] for i in argv[1].split(",")]; argv = argv[2:]
+        elif argv[0] == "--counters":  # passes of one's own: "A B;C D" = two passes
+            passes = [c.strip() for c in argv[1].split(";") if c.strip()]; argv = argv[2:]
         else:
             raise SystemExit("unknown option " + argv[0])
     out_path, names = argv[0], argv[1].split(",")

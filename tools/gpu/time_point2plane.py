@@ -1,5 +1,5 @@
 """The point-to-plane estimator on the headline cloud (C4), with double and with float32 target normals, beside point-to-point:
-the program the A/B builds of DESIGN.md section 7 (next step (g)) were timed with (F4L_LIB_PATH selects the build)."""
+the program the counter passes of DESIGN.md section 7 (g) were pointed at (F4L_LIB_PATH selects another build)."""
 import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from fusion4landslide_amd import engine, synthetic
