@@ -162,6 +162,70 @@ __device__ __forceinline__ bool solve6(double (&M)[6][7], double (&x)[6]) {
     return ok;
 }
 
+// The point-to-plane system is symmetric positive definite (J^T J): L D L^T without pivoting -- what Open3D's own solve does
+// (Eigen ldlt) -- a quarter of the instructions of the pivoted elimination above, which the solving wave issues once per patch and
+// pass while the rest of the workgroup waits.  M[:, :6] is read in its lower triangle, M[:, 6] is the right-hand side.  Returns
+// false when a pivot is not above 1e-13 of the largest diagonal entry (see solve6) or anything is not finite.
+__device__ __forceinline__ bool solve6_spd(const double (&M)[6][7], double (&x)[6]) {
+    double dmax = 0.0;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) dmax = fmax(dmax, fabs(M[c][c]));
+    const double tiny = 1e-13 * dmax;
+    bool ok = true;
+    double L[6][6], W[6][6], D[6];  // W[i][k] = L[i][k] D[k]
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        double dj = M[j][j];
+#pragma unroll
+        for (int k = 0; k < j; ++k) dj -= L[j][k] * W[j][k];
+        D[j] = dj;
+        if (!(dj > tiny) || !isfinite(dj)) ok = false;
+        const double inv = 1.0 / dj;
+#pragma unroll
+        for (int i = j + 1; i < 6; ++i) {
+            double v = M[i][j];
+#pragma unroll
+            for (int k = 0; k < j; ++k) v -= L[i][k] * W[j][k];
+            W[i][j] = v;
+            L[i][j] = v * inv;
+        }
+    }
+    double y[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        double v = M[i][6];
+#pragma unroll
+        for (int k = 0; k < i; ++k) v -= L[i][k] * y[k];
+        y[i] = v;
+    }
+#pragma unroll
+    for (int i = 5; i >= 0; --i) {
+        double v = y[i] / D[i];
+#pragma unroll
+        for (int k = i + 1; k < 6; ++k) v -= L[k][i] * x[k];
+        x[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) if (!isfinite(x[i])) ok = false;
+    return ok;
+}
+
+// sin and cos of a step's Euler angle: below half a radian (every step but a wild one) the Taylor series to x^15 / x^16, whose
+// next terms are below 1e-19; the library pair, with its range reduction, costs five times the instructions.
+__device__ __forceinline__ void sincos_step(double x, double &sn, double &cs) {
+    if (fabs(x) < 0.5) {
+        const double x2 = x * x;
+        double p = -1.0 / 1307674368000.0;
+        p = p * x2 + 1.0 / 6227020800.0; p = p * x2 - 1.0 / 39916800.0; p = p * x2 + 1.0 / 362880.0;
+        p = p * x2 - 1.0 / 5040.0; p = p * x2 + 1.0 / 120.0; p = p * x2 - 1.0 / 6.0;
+        sn = x + x * (x2 * p);
+        double q = 1.0 / 20922789888000.0;
+        q = q * x2 - 1.0 / 87178291200.0; q = q * x2 + 1.0 / 479001600.0; q = q * x2 - 1.0 / 3628800.0;
+        q = q * x2 + 1.0 / 40320.0; q = q * x2 - 1.0 / 720.0; q = q * x2 + 1.0 / 24.0;
+        cs = 1.0 - x2 * (0.5 - x2 * q);
+    } else { sn = sin(x); cs = cos(x); }
+}
+
 // uniform double held in LDS -> scalar registers
 __device__ __forceinline__ double uniform_f64(double v) {
     const long long b = __double_as_longlong(v);
@@ -730,11 +794,13 @@ __global__ __launch_bounds__(NW * 64, WIDE ? 3 : (sizeof(F) == 8 ? ICP_WAVES_PER
                     for (int u = 0; u < 6; ++u) M[u][6] = -tot[23 + u];
                     // (fewer than six correspondences cannot pin six unknowns: no step, the transform stays and the loop ends
                     //  on its criteria -- Open3D solves the singular system and applies whatever comes out)
-                    have = m >= 6.0 && solve6(M, x);
+                    have = m >= 6.0 && ((a.debug & 256) ? solve6(M, x) : solve6_spd(M, x));
                     if (have) {
                         // o3d TransformVector6dToMatrix4d: Rz(x2) Ry(x1) Rx(x0), translation x[3:6]
-                        const double ca = cos(x[0]), sa = sin(x[0]), cb = cos(x[1]), sb = sin(x[1]), cg = cos(x[2]),
-                                     sgm = sin(x[2]);
+                        double ca, sa, cb, sb, cg, sgm;
+                        sincos_step(x[0], sa, ca);
+                        sincos_step(x[1], sb, cb);
+                        sincos_step(x[2], sgm, cg);
                         Ru[0] = cg * cb; Ru[1] = cg * sb * sa - sgm * ca; Ru[2] = cg * sb * ca + sgm * sa;
                         Ru[3] = sgm * cb; Ru[4] = sgm * sb * sa + cg * ca; Ru[5] = sgm * sb * ca - cg * sa;
                         Ru[6] = -sb; Ru[7] = cb * sa; Ru[8] = cb * ca;

@@ -248,6 +248,15 @@ def test_icp_point2plane_vs_oracle(eng, search):
     assert torch.equal(out2["T"], out3["T"])
     if search == "f64":
         assert _disp_per_patch(d, out2["T"].cpu().numpy(), ref["T"]).max() <= 1e-8
+        # the L D L^T solve (Open3D's own kind) against the pivoted elimination it replaced (F4L_ICP_DEBUG bit 256)
+        os.environ["F4L_ICP_DEBUG"] = "256"
+        try:
+            out4 = eng.piecewise_icp(dev(d["src"]), dev(d["src_off"]), dev(d["tgt"]), dev(d["tgt_off"]), max_corr_dist=0.1,
+                                     max_iter=30, icp_type="point2plane", tgt_normals=nrm64, search=search)
+        finally:
+            del os.environ["F4L_ICP_DEBUG"]
+        assert torch.equal(out4["iters"], out3["iters"])
+        assert _disp_per_patch(d, out4["T"].cpu().numpy(), out3["T"].cpu().numpy()).max() <= 1e-11
     with pytest.raises(ValueError):
         eng.piecewise_icp(dev(d["src"]), dev(d["src_off"]), dev(d["tgt"]), dev(d["tgt_off"]), icp_type="generalized")
 
