@@ -12,6 +12,7 @@ LIB_PATH = os.environ.get("F4L_LIB_PATH") or os.path.join(_HERE, "lib", "libf4l_
 F4L_OK = 0
 ICP_POINT2POINT = 0
 ICP_POINT2PLANE = 1
+ICP_P2PL_OPEN3D = 0x400  # point-to-plane steps with Open3D's own semantics (include/f4l.h)
 SEARCH_F32 = 0
 SEARCH_F64 = 1
 MAX_K = 64

@@ -39,6 +39,7 @@
 #include <mutex>
 
 #include "f4l_device.h"
+#include "ldlt6.h"
 #include "patch_grid.h"
 
 namespace f4l {
@@ -74,6 +75,7 @@ struct IcpArgs {
     int init_round_f32;  // the Kabsch transform reaches ICP as float32 values (scripts/weighted_svd.py:148-151: a float32 4 x 4)
     const float *tgt_normals;
     int normals_f64;  // tgt_normals points at doubles (F4L_ICP_NORMALS_F64)
+    int p2pl_open3d;  // point-to-plane steps with Open3D's own semantics (F4L_ICP_P2PL_OPEN3D), see p2plane_step_open3d
     double r, r2;
     int max_iter;
     double rel_fitness, rel_rmse;
@@ -86,12 +88,14 @@ struct IcpArgs {
     double *T_out, *fitness_out, *rmse_out;
     int32_t *iters_out, *corr_out;
     int subdiv;     // cells per radius the grid may use (patch_grid.h: grid_build)
+    int xsub;       // x-cells per cell edge at most (1, 2, 4, 8: patch_grid.h "Cell shape")
     float dens;     // points per bounding-box cell a subdivided grid keeps on average
     double mu_frac; // certificate margin as a fraction of the correspondence radius ...
     double mu_cell; // ... and of the cell edge (the smaller of the two counts: fine grids, i.e. dense patches, get less)
     int debug;  // F4L_ICP_DEBUG env, bit switches for A/B measurements and tests: 4 = no certificates, 8 = no bound from
                 // the previous correspondence, 16 = no narrow look-up before pass 0 on fine grids, 128 = always the Jacobi
-                // SVD (no Newton), 64 = search counters (profiling build)
+                // SVD (no Newton), 64 = search counters (profiling build), 512 = no column grids (layers of cells in z for
+                // flat patches too), 1024 = no finer cells along x (512 + 1024: the cubic cells of rounds 1-3)
     unsigned long long *prof;  // F4L_ICP_PROF builds only: per-phase shader-clock totals (see f4l_piecewise_icp)
     // size-class launches (icp_launch_host): workgroup b handles patch list[b] if b < *list_cnt, else nothing
     const int *list, *list_cnt;
@@ -162,9 +166,10 @@ __device__ __forceinline__ bool solve6(double (&M)[6][7], double (&x)[6]) {
     return ok;
 }
 
-// The point-to-plane system is symmetric positive definite (J^T J): L D L^T without pivoting -- what Open3D's own solve does
-// (Eigen ldlt) -- a quarter of the instructions of the pivoted elimination above, which the solving wave issues once per patch and
-// pass while the rest of the workgroup waits.  M[:, :6] is read in its lower triangle, M[:, 6] is the right-hand side.  Returns
+// The point-to-plane system is symmetric positive definite (J^T J): L D L^T WITHOUT pivoting (Open3D's own solve is Eigen's
+// ldlt, which pivots on the diagonal: ldlt6.h, the F4L_ICP_P2PL_OPEN3D step; on the well-conditioned systems this one accepts
+// the pivot order does not show) -- a quarter of the instructions of the pivoted elimination above, which the solving wave
+// issues once per patch and pass while the rest of the workgroup waits.  M[:, :6] is read in its lower triangle, M[:, 6] is the right-hand side.  Returns
 // false when a pivot is not above 1e-13 of the largest diagonal entry (see solve6) or anything is not finite.
 __device__ __forceinline__ bool solve6_spd(const double (&M)[6][7], double (&x)[6]) {
     double dmax = 0.0;
@@ -224,6 +229,37 @@ __device__ __forceinline__ void sincos_step(double x, double &sn, double &cs) {
         q = q * x2 + 1.0 / 40320.0; q = q * x2 - 1.0 / 720.0; q = q * x2 + 1.0 / 24.0;
         cs = 1.0 - x2 * (0.5 - x2 * q);
     } else { sn = sin(x); cs = cos(x); }
+}
+
+// The point-to-plane step with Open3D's own semantics (F4L_ICP_P2PL_OPEN3D; utils/o3d_tools.py:38-39,46-50 ->
+// TransformationEstimationPointToPlane::ComputeTransformation -> SolveLinearSystemPSD, checks off): the system, summed about
+// the patch origin for accuracy, is moved to the CALLER's origin -- the frame Open3D builds it in, which decides what the
+// pseudo-inverse does to a singular system -- and solved by Eigen's diagonal-pivoted L D L^T (ldlt6.h), whatever its rank.
+// Reads the row partials of the pass from LDS (rows x 29 doubles at byte offset scratch_off, added in the order the kernel adds
+// them) and leaves x[0..6) at state[40..46).  Not inlined: the default path's register allocation must not see it.
+__device__ __noinline__ void p2plane_step_open3d(int scratch_off, int rows, int state_off, float ox, float oy, float oz) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const double *scratch = reinterpret_cast<const double *>(smem_raw + scratch_off);
+    double *state = reinterpret_cast<double *>(smem_raw + state_off);
+    double M[6][6], b[6], x[6];
+    auto total = [&](int v) {
+        double t = scratch[v];
+        for (int w = 1; w < rows; ++w) t += scratch[w * 29 + v];
+        return t;
+    };
+    int k = 2;
+#pragma unroll
+    for (int u = 0; u < 6; ++u)
+#pragma unroll
+        for (int v = u; v < 6; ++v) { const double t = total(k++); M[u][v] = t; M[v][u] = t; }
+#pragma unroll
+    for (int u = 0; u < 6; ++u) b[u] = -total(23 + u);
+    p2plane_system_to_caller_frame(M, b, (double)ox, (double)oy, (double)oz);
+    ldlt6_solve_eigen(M, b, x);
+    if (lane_id() == 0) {
+#pragma unroll
+        for (int u = 0; u < 6; ++u) state[40 + u] = x[u];
+    }
 }
 
 // uniform double held in LDS -> scalar registers
@@ -374,10 +410,11 @@ __global__ __launch_bounds__(NW * 64, WIDE ? 3 : (sizeof(F) == 8 ? ICP_WAVES_PER
     const F rF = (F)a.r, r2 = (F)a.r2;
     const F rs = rF * (F)1.0625, rs2 = rs * rs;
     PatchGrid<F> g;
-    g.minx = g.miny = g.minz = (F)0; g.h = (F)1; g.inv_h = (F)1; g.nx = g.ny = g.nz = 1;
+    g.minx = g.miny = g.minz = (F)0; g.h = (F)1; g.inv_h = (F)1; g.inv_hx = (F)1; g.inv_hz = (F)1; g.nx = g.ny = g.nz = 1; g.xs = 1; g.wmax = 1;
     double cs[3] = {0.0, 0.0, 0.0}, srad = 0.0;
     if (active) {  // uniform across the workgroup
-        if (tgt_in_lds) grid_build<F, NT>(tg, nt, ox, oy, oz, rs, a.cell_cap, tl, E, reinterpret_cast<F *>(scratch), g, a.subdiv, (F)a.dens);
+        if (tgt_in_lds) grid_build<F, NT>(tg, nt, ox, oy, oz, rs, a.cell_cap, tl, E, reinterpret_cast<F *>(scratch), g, a.subdiv, (F)a.dens,
+                                            (a.debug & 1024) ? 1 : a.xsub, !(a.debug & 512));
         {
             // centroid and radius of the source patch (origin-relative): the lever arm of the motion bound
             double sum[3] = {0.0, 0.0, 0.0};
@@ -784,17 +821,29 @@ __global__ __launch_bounds__(NW * 64, WIDE ? 3 : (sizeof(F) == 8 ? ICP_WAVES_PER
                     tu[1] = mq1 - (Ru[3] * mp0 + Ru[4] * mp1 + Ru[5] * mp2);
                     tu[2] = mq2 - (Ru[6] * mp0 + Ru[7] * mp1 + Ru[8] * mp2);
                 } else {
-                    double M[6][7], x[6];
-                    int k = 2;
+                    double x[6];
+                    bool caller_frame = false;  // x is the solution about the caller's origin (else about the patch's)
+                    if (a.p2pl_open3d) {
+                        // Open3D's own step: solved whatever the rank of the system, applied whenever there is a correspondence
+                        p2plane_step_open3d((int)((const unsigned char *)scratch - smem_raw), SUM_ROWS,
+                                            (int)((const unsigned char *)state - smem_raw), ox, oy, oz);
+                        have = true;
+                        caller_frame = true;
 #pragma unroll
-                    for (int u = 0; u < 6; ++u)
+                        for (int u = 0; u < 6; ++u) { x[u] = state[40 + u]; have = have && isfinite(x[u]); }
+                    } else {
+                        double M[6][7];
+                        int k = 2;
 #pragma unroll
-                        for (int v = u; v < 6; ++v) { M[u][v] = tot[k]; M[v][u] = tot[k]; ++k; }
+                        for (int u = 0; u < 6; ++u)
 #pragma unroll
-                    for (int u = 0; u < 6; ++u) M[u][6] = -tot[23 + u];
-                    // (fewer than six correspondences cannot pin six unknowns: no step, the transform stays and the loop ends
-                    //  on its criteria -- Open3D solves the singular system and applies whatever comes out)
-                    have = m >= 6.0 && ((a.debug & 256) ? solve6(M, x) : solve6_spd(M, x));
+                            for (int v = u; v < 6; ++v) { M[u][v] = tot[k]; M[v][u] = tot[k]; ++k; }
+#pragma unroll
+                        for (int u = 0; u < 6; ++u) M[u][6] = -tot[23 + u];
+                        // (fewer than six correspondences cannot pin six unknowns: no step, the transform stays and the loop
+                        //  ends on its criteria -- the ROBUST rule of include/f4l.h; Open3D's own is the branch above)
+                        have = m >= 6.0 && ((a.debug & 256) ? solve6(M, x) : solve6_spd(M, x));
+                    }
                     if (have) {
                         // o3d TransformVector6dToMatrix4d: Rz(x2) Ry(x1) Rx(x0), translation x[3:6]
                         double ca, sa, cb, sb, cg, sgm;
@@ -808,9 +857,9 @@ __global__ __launch_bounds__(NW * 64, WIDE ? 3 : (sizeof(F) == 8 ? ICP_WAVES_PER
                         // the reference's update [Rot(x) | t] (a rotation about the GLOBAL origin) in origin-relative
                         // coordinates: tu = Rot(x) o + t - o.
                         const double o0 = ox, o1 = oy, o2 = oz;
-                        const double tg0 = x[3] - (x[1] * o2 - x[2] * o1);
-                        const double tg1 = x[4] - (x[2] * o0 - x[0] * o2);
-                        const double tg2 = x[5] - (x[0] * o1 - x[1] * o0);
+                        const double tg0 = caller_frame ? x[3] : x[3] - (x[1] * o2 - x[2] * o1);
+                        const double tg1 = caller_frame ? x[4] : x[4] - (x[2] * o0 - x[0] * o2);
+                        const double tg2 = caller_frame ? x[5] : x[5] - (x[0] * o1 - x[1] * o0);
                         tu[0] = Ru[0] * o0 + Ru[1] * o1 + Ru[2] * o2 + tg0 - o0;
                         tu[1] = Ru[3] * o0 + Ru[4] * o1 + Ru[5] * o2 + tg1 - o1;
                         tu[2] = Ru[6] * o0 + Ru[7] * o1 + Ru[8] * o2 + tg2 - o2;
@@ -1084,6 +1133,7 @@ struct IcpFusedExtra {
     int64_t min_corr = 0;
     int init_round_f32 = 0;
     int normals_f64 = 0;
+    int p2pl_open3d = 0;
 };
 static int icp_launch_host(const float *src, const int64_t *src_off, const float *tgt, const int64_t *tgt_off,
                            int64_t P, const double *init_T, const float *tgt_normals, double max_corr_dist,
@@ -1101,7 +1151,8 @@ extern "C" int f4l_piecewise_icp(const float *src, const int64_t *src_off, const
                                  int32_t *iters_out, int32_t *corr_out, void *stream) {
     f4l::IcpFusedExtra fx;
     fx.normals_f64 = (mode & F4L_ICP_NORMALS_F64) ? 1 : 0;
-    mode &= ~F4L_ICP_NORMALS_F64;
+    fx.p2pl_open3d = (mode & F4L_ICP_P2PL_OPEN3D) ? 1 : 0;
+    mode &= ~(F4L_ICP_NORMALS_F64 | F4L_ICP_P2PL_OPEN3D);
     return f4l::icp_launch_host(src, src_off, tgt, tgt_off, P, init_T, tgt_normals, max_corr_dist, max_iter, rel_fitness,
                                 rel_rmse, mode, fixed_iters, search_precision, max_src_patch_host, max_tgt_patch_host,
                                 n_src_host, T_out, fitness_out, rmse_out, iters_out, corr_out, fx, stream);
@@ -1124,7 +1175,8 @@ extern "C" int f4l_patch_loop(const float *src, const int64_t *src_off, const fl
     fx.rows_src = rows_src; fx.rows_off = rows_off; fx.min_corr = min_corr;
     fx.init_round_f32 = (mode & F4L_ICP_INIT_ROUND_F32) ? 1 : 0;
     fx.normals_f64 = (mode & F4L_ICP_NORMALS_F64) ? 1 : 0;
-    mode &= ~(F4L_ICP_INIT_ROUND_F32 | F4L_ICP_NORMALS_F64);
+    fx.p2pl_open3d = (mode & F4L_ICP_P2PL_OPEN3D) ? 1 : 0;
+    mode &= ~(F4L_ICP_INIT_ROUND_F32 | F4L_ICP_NORMALS_F64 | F4L_ICP_P2PL_OPEN3D);
     return f4l::icp_launch_host(src, src_off, tgt, tgt_off, P, nullptr, tgt_normals, max_corr_dist, max_iter, rel_fitness,
                                 rel_rmse, mode, fixed_iters, search_precision, max_src_patch_host, max_tgt_patch_host,
                                 n_src_host, T_out, fitness_out, rmse_out, iters_out, corr_out, fx, stream);
@@ -1159,11 +1211,14 @@ static int f4l::icp_launch_host(const float *src, const int64_t *src_off, const 
     a.kabsch_w_thresh = fx.w_thresh; a.kabsch_eps = fx.eps; a.rows_out = fx.rows_out;
     a.rows_src = fx.rows_src; a.rows_off = fx.rows_off; a.min_corr = fx.min_corr; a.init_round_f32 = fx.init_round_f32;
     a.normals_f64 = fx.normals_f64;
+    a.p2pl_open3d = fx.p2pl_open3d;
     a.r = max_corr_dist > 0.0 ? max_corr_dist : 0.0;
     a.r2 = a.r * a.r;
     a.max_iter = max_iter; a.rel_fitness = rel_fitness; a.rel_rmse = rel_rmse; a.fixed_iters = fixed_iters;
     { const char *dbg = getenv("F4L_ICP_DEBUG"); a.debug = dbg ? atoi(dbg) : 0; }
     a.subdiv = 8; a.mu_frac = 0.125; a.dens = 2.f;
+    a.xsub = 8;  // (C3 15.4 ms with 8, 15.7 with 4, 16.8 with 2, 20.1 with cubic cells; C4 18.3 / 18.3 / 19.0 / 19.3)
+    { const char *e = getenv("F4L_ICP_XSUB"); if (e && (atoi(e) == 1 || atoi(e) == 2 || atoi(e) == 4 || atoi(e) == 8)) a.xsub = atoi(e); }
     { const char *e = getenv("F4L_ICP_DENS"); if (e && atof(e) > 0.0) a.dens = (float)atof(e); }
     { const char *e = getenv("F4L_ICP_SUBDIV"); if (e && atoi(e) >= 1) a.subdiv = atoi(e); }
     { const char *e = getenv("F4L_ICP_MU"); if (e && atof(e) > 0.0) a.mu_frac = atof(e); }

@@ -1008,7 +1008,18 @@ __global__ void normals_listed_kernel(const float *__restrict__ xyz, const float
 __global__ void iota_kernel(int32_t *v, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) v[i] = (int32_t)i;
 }
-// CSR offsets straight from the SORTED labels: off[l] = first position whose label is >= l.  Position i (0 .. n) writes the
+// Sort keys of f4l_labels_to_csr: the label itself, or K for a label outside [0, K) (an "unlabelled" -1, a label beyond the
+// caller's count): those points sort behind every patch -- order[off[K] ..) -- and belong to none, as the histogram this path
+// replaced skipped them.  (Sorting the raw labels over the low bits of K only would place them by their low bits.)
+__global__ void label_keys_kernel(const int32_t *__restrict__ labels, int64_t n, int64_t K, int32_t *__restrict__ keys,
+                                  int32_t *__restrict__ iota) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t l = labels[i];
+        keys[i] = (l >= 0 && (int64_t)l < K) ? l : (int32_t)K;
+        iota[i] = (int32_t)i;
+    }
+}
+// CSR offsets straight from the SORTED keys (labels 0 .. K - 1, then K = "no patch"): off[l] = first position whose key is >= l.  Position i (0 .. n) writes the
 // offsets of the labels that begin there: those above its left neighbour's label up to its own (one, unless labels are
 // skipped); position n those above the last label up to K.  No histogram, no atomics, no scan.
 __global__ void label_bounds_kernel(const int32_t *__restrict__ sorted, int64_t n, int64_t K, int64_t *__restrict__ off) {
@@ -1653,8 +1664,7 @@ extern "C" int f4l_normals(const float *xyz, int64_t n, const int32_t *knn_idx, 
 // ---- labels -> CSR ---------------------------------------------------------------------------------
 namespace f4l {
 struct CsrWs {
-    int32_t *keys_out, *iota;
-    unsigned long long *hist;
+    int32_t *keys_out, *iota, *keys_in;
     void *prim_temp;
     size_t prim_bytes, total;
 };
@@ -1670,7 +1680,7 @@ static int csr_ws_layout(int64_t n, int64_t K, CsrWs &w, unsigned char *base) {
     auto carve = [&](size_t bytes) { size_t at = o; o += align_up(bytes); return base ? base + at : (unsigned char *)nullptr; };
     w.keys_out = (int32_t *)carve((size_t)n * 4);
     w.iota = (int32_t *)carve((size_t)n * 4);
-    w.hist = (unsigned long long *)carve(((size_t)K + 1) * 8);
+    w.keys_in = (int32_t *)carve((size_t)n * 4);
     w.prim_temp = carve(prim);
     w.prim_bytes = prim;
     w.total = o;
@@ -1717,7 +1727,7 @@ extern "C" int f4l_labels_to_csr(const int32_t *labels, int64_t n, int64_t K, in
                                  void *workspace, size_t workspace_bytes, void *stream) {
     using namespace f4l;
     if (n < 0 || K <= 0 || !off_out || (n > 0 && (!labels || !order_out || !workspace))) return F4L_EINVAL;
-    if (n > 0x7fffffffLL) return F4L_EUNSUPPORTED;
+    if (n > 0x7fffffffLL || K >= 0x7fffffffLL) return F4L_EUNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     if (n == 0) {
         F4L_HIP_CHECK(hipMemsetAsync(off_out, 0, ((size_t)K + 1) * 8, st));
@@ -1727,12 +1737,12 @@ extern "C" int f4l_labels_to_csr(const int32_t *labels, int64_t n, int64_t K, in
     int rc = csr_ws_layout(n, K, w, (unsigned char *)workspace);
     if (rc != F4L_OK) return rc;
     if (workspace_bytes < w.total) return F4L_EWORKSPACE;
-    hipLaunchKernelGGL(iota_kernel, dim3(grid_for(n)), dim3(256), 0, st, w.iota, n);
+    hipLaunchKernelGGL(label_keys_kernel, dim3(grid_for(n)), dim3(256), 0, st, labels, n, K, w.keys_in, w.iota);
     F4L_LAUNCH_CHECK();
     int end_bit = 1;
-    while (end_bit < 31 && (1LL << end_bit) < K) ++end_bit;
+    while (end_bit < 31 && (1LL << end_bit) <= K) ++end_bit;  // the keys run 0 .. K inclusive
     size_t tb = w.prim_bytes;
-    F4L_HIP_CHECK(rocprim::radix_sort_pairs<KeySortConfig>(w.prim_temp, tb, labels, w.keys_out, w.iota, order_out, (size_t)n, 0,
+    F4L_HIP_CHECK(rocprim::radix_sort_pairs<KeySortConfig>(w.prim_temp, tb, w.keys_in, w.keys_out, w.iota, order_out, (size_t)n, 0,
                                             (unsigned)end_bit, st, false));  // LSD radix sort is stable
     hipLaunchKernelGGL(label_bounds_kernel, dim3(grid_for(n + 1)), dim3(256), 0, st, (const int32_t *)w.keys_out, n, K, off_out);
     F4L_LAUNCH_CHECK();

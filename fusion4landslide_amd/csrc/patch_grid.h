@@ -24,6 +24,14 @@
 // wider stencil (grid_nn_wide).  Callers usually know a bound well below the radius (the previous correspondence,
 // re-measured), which narrows every run to the cells the bound reaches and drops runs beyond it.
 //
+// Cell shape (round 4).  A cell is h x h in (y, z) -- the stencil of rows is decided there -- but only hx = h / XS along x,
+// XS = 1, 2, 4 or 8 (the finest the cell table holds): finer cells along the run do not change which rows a query walks, only how tightly the run's x-range
+// [px - bound, px + bound] is cut (whole cells): at C4 (2.6 points per h-cell, bounds of ~4 cm against h = 10 cm) a query
+// measures 6-7 candidates instead of 11.  And a patch that is FLAT (terrain: z-extent below 3/4 of the larger of its x- and
+// y-extents) gets ONE layer of cells, columns unbounded in z: with cubic cells most of the bounding box's z layers are empty
+// and still count against the cell table, which kept the table from being spent on x.  Both are exact for any cloud (z simply
+// stops pruning in a column grid); F4L_ICP_DEBUG bits 512 / 1024 switch them off (cubic cells, the round-3 grid).
+//
 // Exactness of the stencil (3x3x3 cells when h >= r, (2 w + 1)^3 with w = ceil(bound / h) otherwise): cell
 // coordinates are floor((x - min) / h) evaluated in floating point for
 // targets and queries alike (a monotone function of x); h = r * (1 + 2^-7) leaves 7e-3 cells of slack for its
@@ -42,8 +50,11 @@ template <> struct __attribute__((aligned(16))) GridPt<double> { float x, y, z; 
 
 template <typename F> struct PatchGrid {
     F minx, miny, minz, h, inv_h;
+    F inv_hx;        // cells along x (the direction of a run) are h / XS wide: inv_hx = XS * inv_h
+    F inv_hz;        // inv_h, or 0 for a column grid (nz == 1: every z lands in layer 0)
     int nx, ny, nz;  // nx * ny * nz <= cell capacity
-    int wmax;        // cells per side of the stencil that covers the radius the grid was built for (>= 1)
+    int wmax;        // cells per side of the stencil that covers the radius the grid was built for (>= 1), in units of h
+    int xs;          // XS: x-cells per h
     F ox, oy, oz;    // patch origin (only the float64 records need it: they hold absolute coordinates)
 };
 
@@ -80,9 +91,9 @@ __device__ __forceinline__ int floor_to_int(double v) { return __double2int_rd(v
 
 template <typename F>
 __device__ __forceinline__ void grid_cell(const PatchGrid<F> &g, F x, F y, F z, int &cx, int &cy, int &cz) {
-    cx = floor_to_int((x - g.minx) * g.inv_h);
+    cx = floor_to_int((x - g.minx) * g.inv_hx);
     cy = floor_to_int((y - g.miny) * g.inv_h);
-    cz = floor_to_int((z - g.minz) * g.inv_h);
+    cz = floor_to_int((z - g.minz) * g.inv_hz);
 }
 
 // Squared distance: float32 with the fused chain fma(dz,dz, fma(dy,dy, dx*dx)); float64 with separately rounded
@@ -159,7 +170,8 @@ template <> struct Best<double> {
 template <typename F, int NT>
 __device__ __forceinline__ void grid_build(const float *__restrict__ tg, int nt, float ox, float oy, float oz, F r,
                                            int cell_cap, GridPt<F> *__restrict__ tl, unsigned short *__restrict__ E,
-                                           F *__restrict__ red, PatchGrid<F> &g, int subdiv = 4, F dens = (F)4) {
+                                           F *__restrict__ red, PatchGrid<F> &g, int subdiv = 4, F dens = (F)4,
+                                           int xsub = 4, bool allow_columns = true) {
     constexpr int NW = NT / 64;
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
@@ -202,16 +214,19 @@ __device__ __forceinline__ void grid_build(const float *__restrict__ tg, int nt,
     //    query then scans the whole patch).
     const F ex = mx[0] - mn[0], ey = mx[1] - mn[1], ez = mx[2] - mn[2];
     const F rpad = r * (F)1.0078125;
+    // a flat patch (terrain) gets one layer of cells: columns, unbounded in z
+    const bool columns = allow_columns && ez <= (F)0.75 * (ex > ey ? ex : ey);
+    auto cell_count = [&](F ih) {
+        return (floor(ex * ih) + (F)1) * (floor(ey * ih) + (F)1) * (columns ? (F)1 : floor(ez * ih) + (F)1);
+    };
     F h = rpad;
     if (subdiv > 1) {
         // subdivide only patches that are dense relative to the radius: the finest of r/1 .. r/subdiv that still leaves
-        // `dens` points per cell of the bounding box on average (surfaces leave most of the box empty, so occupied
-        // cells hold several times that)
+        // `dens` points per cell of the bounding box on average (layered grids: surfaces leave most of the box empty, so
+        // occupied cells hold several times that)
         int sd = 1;
         for (int c = 2; c <= subdiv; ++c) {
-            const F ih = (F)c / rpad;
-            const F cells = (floor(ex * ih) + (F)1) * (floor(ey * ih) + (F)1) * (floor(ez * ih) + (F)1);
-            if (cells * dens <= (F)nt) sd = c;
+            if (cell_count((F)c / rpad) * dens <= (F)nt) sd = c;
         }
         h = rpad / (F)sd;
     }
@@ -220,18 +235,29 @@ __device__ __forceinline__ void grid_build(const float *__restrict__ tg, int nt,
     if (finite) {
         for (int it = 0; it < 64; ++it) {
             const F ih = (F)1 / h;
-            const F fx = ex * ih, fy = ey * ih, fz = ez * ih;
-            const F cells = (floor(fx) + (F)1) * (floor(fy) + (F)1) * (floor(fz) + (F)1);
-            if (cells <= (F)cell_cap) { nx = (int)fx + 1; ny = (int)fy + 1; nz = (int)fz + 1; break; }
+            const F cells = cell_count(ih);
+            if (cells <= (F)cell_cap) { nx = (int)(ex * ih) + 1; ny = (int)(ey * ih) + 1; nz = columns ? 1 : (int)(ez * ih) + 1; break; }
             if (it == 63) { h = (ex + ey + ez) * (F)2 + r; break; }  // gives a single cell
-            F f = cbrt(cells / (F)cell_cap);  // exact for a volume; a surface needs a few rounds
+            F f = columns ? sqrt(cells / (F)cell_cap) : cbrt(cells / (F)cell_cap);  // exact for a volume; a surface needs a few rounds
             h *= f < (F)1.05 ? (F)1.05 : f;
+        }
+    }
+    // cells along x: the finest of h / xsub, h / (xsub / 2) .. h that the table still holds
+    int xs = 1;
+    if (finite && nx * ny * nz > 0) {
+        for (int c = xsub; c > 1; c >>= 1) {
+            const F nxs = floor(ex * ((F)c / h)) + (F)1;
+            if (nxs * (F)(ny * nz) <= (F)cell_cap) { xs = c; break; }
         }
     }
     g.minx = finite ? mn[0] : (F)0; g.miny = finite ? mn[1] : (F)0; g.minz = finite ? mn[2] : (F)0;
     g.ox = (F)ox; g.oy = (F)oy; g.oz = (F)oz;
     g.h = h; g.inv_h = (F)1 / h;
+    g.inv_hx = (F)xs / h;
+    g.inv_hz = (finite && nz > 1) ? g.inv_h : (F)0;
+    if (finite && xs > 1) nx = (int)(ex * g.inv_hx) + 1;
     g.nx = nx; g.ny = ny; g.nz = nz;
+    g.xs = xs;
     {
         const F wf = ceil(rpad / h - (F)1e-4);
         g.wmax = wf < (F)1 ? 1 : (wf > (F)4096 ? 4096 : (int)wf);
@@ -239,8 +265,10 @@ __device__ __forceinline__ void grid_build(const float *__restrict__ tg, int nt,
     // every thread computed the same grid: tell the compiler, so that it lives in scalar registers
     g.minx = grid_uniform(g.minx); g.miny = grid_uniform(g.miny); g.minz = grid_uniform(g.minz);
     g.h = grid_uniform(g.h); g.inv_h = grid_uniform(g.inv_h);
+    g.inv_hx = grid_uniform(g.inv_hx); g.inv_hz = grid_uniform(g.inv_hz);
     g.nx = __builtin_amdgcn_readfirstlane(g.nx); g.ny = __builtin_amdgcn_readfirstlane(g.ny);
     g.nz = __builtin_amdgcn_readfirstlane(g.nz); g.wmax = __builtin_amdgcn_readfirstlane(g.wmax);
+    g.xs = __builtin_amdgcn_readfirstlane(g.xs);
     const int ncell = nx * ny * nz;
 
     // 3. histogram: E[c + 1] += 1 through 32-bit LDS atomics on the packed uint16 pairs
@@ -455,9 +483,10 @@ __device__ __forceinline__ void grid_nn(const PatchGrid<F> &g, const GridPt<F> *
     const F slack = (F)1e-5 * g.h + (F)1e-6 * (fabs(px) + fabs(py) + fabs(pz) + fabs(g.minx) + fabs(g.miny) + fabs(g.minz));
     const F b2 = best.d2();
     const F bnd = grid_sqrt<F>(b2) * (F)1.00001 + slack;
-    int x0 = floor_to_int((px - bnd - g.minx) * g.inv_h), x1 = floor_to_int((px + bnd - g.minx) * g.inv_h);
-    x0 = x0 < cx - g.wmax ? cx - g.wmax : x0;  // never wider than the stencil the grid was built for
-    x1 = x1 > cx + g.wmax ? cx + g.wmax : x1;
+    int x0 = floor_to_int((px - bnd - g.minx) * g.inv_hx), x1 = floor_to_int((px + bnd - g.minx) * g.inv_hx);
+    const int wx = __mul24(g.wmax, g.xs);  // (x-cells are h / XS wide)
+    x0 = x0 < cx - wx ? cx - wx : x0;  // never wider than the stencil the grid was built for
+    x1 = x1 > cx + wx ? cx + wx : x1;
     x0 = x0 < 0 ? 0 : x0;
     x1 = x1 >= g.nx ? g.nx - 1 : x1;
     const bool xok = valid && x0 <= x1;

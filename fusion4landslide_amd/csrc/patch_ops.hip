@@ -464,7 +464,7 @@ __global__ __launch_bounds__(PN_NT) void nn_refine_kernel(NnRefineArgs a) {
     float ox = 0.f, oy = 0.f, oz = 0.f;
     if (nt > 0) { ox = tg[0]; oy = tg[1]; oz = tg[2]; }
     PatchGrid<float> g;
-    g.minx = g.miny = g.minz = 0.f; g.h = 1.f; g.inv_h = 1.f; g.nx = g.ny = g.nz = 1;
+    g.minx = g.miny = g.minz = 0.f; g.h = 1.f; g.inv_h = 1.f; g.inv_hx = 1.f; g.inv_hz = 1.f; g.nx = g.ny = g.nz = 1; g.xs = 1; g.wmax = 1;
     if (in_lds) grid_build<float, PN_NT>(tg, nt, ox, oy, oz, (float)th * 1.000001f, a.cell_cap, tl, E, red, g);
     const double *Tp = a.T + 16 * p;
     // p' = R (s' + o) + t - o with s' = s - o

@@ -1112,11 +1112,23 @@ __device__ __forceinline__ void wg_sync() {
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 }
+// fusing(st) as ONE value for the whole workgroup: thread 0 reads the state (written before the last wg_sync) and hands its
+// verdict round through LDS.  Every wave reading the state for itself is not enough: the bodies that follow a check write the
+// very words it reads (cand_body: `stalled`, `live_snap`), so a wave that arrives late could see another verdict than the waves
+// already inside the body and leave the loop while they wait at the next barrier.
+__device__ __forceinline__ bool wg_fusing(const State *st) {
+    __shared__ int verdict;
+    if (threadIdx.x == 0) verdict = fusing(st) ? 1 : 0;
+    __syncthreads();
+    const bool f = verdict != 0;
+    __syncthreads();  // (the next call rewrites the word)
+    return f;
+}
 __global__ __launch_bounds__(1024) void segment_rest_kernel(SegArgs a, int first_round, int first_sweep) {
     State *st = a.st;
     if (first_round >= 0) {
         for (int r = first_round; r < LAMBDA_ROUNDS; ++r) {
-            if (!fusing(st)) break;  // (state written before the last barrier: the whole workgroup takes the same branch)
+            if (!wg_fusing(st)) break;
             node_body(a, r);
             if (r >= 1) table_clear_body(a, r);
             wg_sync();
@@ -1124,10 +1136,10 @@ __global__ __launch_bounds__(1024) void segment_rest_kernel(SegArgs a, int first
             else build_body(a, r);
             wg_sync();
             for (int s = 0; s < SUBROUNDS; ++s) {
-                if (!fusing(st)) break;
+                if (!wg_fusing(st)) break;
                 cand_body(a, r, s);
                 wg_sync();
-                if (!fusing(st)) break;  // (cand may have found the list empty)
+                if (!wg_fusing(st)) break;  // (cand may have found the list empty)
                 cand2_body(a, r, s);
                 wg_sync();
                 apply_body(a, r, s);

@@ -15,6 +15,12 @@ from ._lib import check, lib, ptr, require_gpu, stream_ptr
 _ICP_MODES = {"point2point": _lib.ICP_POINT2POINT, "point2plane": _lib.ICP_POINT2PLANE}
 
 
+def _p2plane_bit(p2plane):
+    if p2plane not in ("robust", "open3d"):
+        raise ValueError("p2plane must be 'robust' or 'open3d'")
+    return _lib.ICP_P2PL_OPEN3D if p2plane == "open3d" else 0
+
+
 def _dev(t, dtype, name, shape_tail=None):
     torch = require_gpu()
     if not isinstance(t, torch.Tensor):
@@ -171,7 +177,7 @@ def _target_normals(torch, tgt, tgt_off, max_tgt_patch, tgt_normals):
 
 def piecewise_icp(src, src_off, tgt, tgt_off, init_T=None, max_corr_dist=0.1, max_iter=30, rel_fitness=1e-6,
                   rel_rmse=1e-6, icp_type="point2point", fixed_iters=False, tgt_normals=None, return_corr=False,
-                  max_src_patch=None, max_tgt_patch=None, search="f64"):
+                  max_src_patch=None, max_tgt_patch=None, search="f64", p2plane="robust"):
     """Batched per-patch ICP (utils/o3d_tools.py:12-71 for P patch pairs in one launch).
 
     Returns dict(T (P,4,4) f64, fitness (P,) f64, rmse (P,) f64, iters (P,) i32[, corr (n_src,) i32]).
@@ -180,11 +186,15 @@ def piecewise_icp(src, src_off, tgt, tgt_off, init_T=None, max_corr_dist=0.1, ma
     and reproduces the CPU oracle to 1e-9 m; ``"f32"`` is the fast mode (float32 search on patch-relative coordinates,
     ~1.5x faster): same answer to ~1e-8 m on well-posed patches, but an ill-posed patch (displaced beyond the radius,
     low fitness) can end in a different local solution.
+    ``p2plane`` (point-to-plane only): ``"robust"`` (default of the batched calls) leaves out a step whose 6 x 6 system does not
+    pin its six unknowns (fewer than six pairs, singular to 1e-13); ``"open3d"`` is Open3D's own semantics -- Eigen's pivoted
+    L D L^T in the caller's frame, applied whenever there is one correspondence (F4L_ICP_P2PL_OPEN3D, include/f4l.h) -- what
+    the mirror of ``icp_registration`` asks for.  The same minimiser wherever the system is well posed.
     """
     torch = require_gpu()
     if icp_type not in _ICP_MODES:
         raise ValueError("ICP type not supported")  # utils/o3d_tools.py:43
-    mode = _ICP_MODES[icp_type]
+    mode = _ICP_MODES[icp_type] | _p2plane_bit(p2plane)
     src = _dev(src, torch.float32, "src", (3,))
     tgt = _dev(tgt, torch.float32, "tgt", (3,))
     src_off = _dev(src_off, torch.int64, "src_off")
@@ -202,7 +212,7 @@ def piecewise_icp(src, src_off, tgt, tgt_off, init_T=None, max_corr_dist=0.1, ma
         if T0.numel() != P * 16:
             raise ValueError("init_T must be (P, 4, 4)")
     tn, nbit = None, 0
-    if mode == _lib.ICP_POINT2PLANE:
+    if icp_type == "point2plane":
         tn, nbit = _target_normals(torch, tgt, tgt_off, max_tgt_patch, tgt_normals)
     dev = src.device
     T = torch.empty((P, 4, 4), dtype=torch.float64, device=dev)
@@ -224,7 +234,7 @@ def piecewise_icp(src, src_off, tgt, tgt_off, init_T=None, max_corr_dist=0.1, ma
 def patch_loop(src, src_off, tgt, tgt_off, corr_src, corr_ref, corr_off, corr_weights=None, weight_thresh=0.0, eps=1e-6,
                max_corr_dist=0.1, max_iter=30, rel_fitness=1e-6, rel_rmse=1e-6, icp_type="point2point", fixed_iters=False,
                tgt_normals=None, return_corr=False, return_rows=True, max_src_patch=None, max_tgt_patch=None, search="f64",
-               rows_src=None, rows_off=None, min_corr=0, init_round_f32=False):
+               rows_src=None, rows_off=None, min_corr=0, init_round_f32=False, p2plane="robust"):
     """The per-patch loop body of src/coarse_to_fine_matching_base.py:3338-3408 in one launch (f4l_patch_loop):
     weighted Kabsch of each patch match's correspondences -> ICP from that on (src, tgt) -> displacement rows [s, T s].
 
@@ -240,7 +250,7 @@ def patch_loop(src, src_off, tgt, tgt_off, corr_src, corr_ref, corr_off, corr_we
     torch = require_gpu()
     if icp_type not in _ICP_MODES:
         raise ValueError("ICP type not supported")  # utils/o3d_tools.py:43
-    mode = _ICP_MODES[icp_type]
+    mode = _ICP_MODES[icp_type] | _p2plane_bit(p2plane)
     src = _dev(src, torch.float32, "src", (3,))
     tgt = _dev(tgt, torch.float32, "tgt", (3,))
     src_off = _dev(src_off, torch.int64, "src_off")
@@ -259,7 +269,7 @@ def patch_loop(src, src_off, tgt, tgt_off, corr_src, corr_ref, corr_off, corr_we
     if max_tgt_patch is None:
         max_tgt_patch = _max_patch(tgt_off)
     tn, nbit = None, 0
-    if mode == _lib.ICP_POINT2PLANE:
+    if icp_type == "point2plane":
         tn, nbit = _target_normals(torch, tgt, tgt_off, max_tgt_patch, tgt_normals)
     dev = src.device
     T = torch.empty((P, 4, 4), dtype=torch.float64, device=dev)

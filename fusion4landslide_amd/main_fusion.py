@@ -7,6 +7,11 @@ The config keys are the reference's (path_name / data / method / parameter_setti
 its learned models -- point matches, patch matches, the 2D matches lifted to 3D -- enters through hooks on the cfg
 (src/coarse_to_fine_matching.py of this package); without them the 3D stand-ins run (nearest neighbours), and
 `fine_matching_fusion` / `_only_2d` need `cfg.point_matches_from_2d`.  `method.partition_type` must be `supervoxel`.
+
+Steps of the reference's main() that are NOT done here, on purpose: loading the DIP weights (main_fusion.py:35-45: the learned
+descriptor is out of scope), the `project_dir` setting and the dump of the whole config into the log (:66-104), and the
+end-of-run clean-up that deletes the `processed` / `raw` folders of the data directory (:150-153) -- this entry never deletes
+anything it did not write.
 """
 import argparse
 import copy
@@ -53,7 +58,11 @@ def run(cfg, first_tile=0):
 
 def main(argv=None):
     parser = argparse.ArgumentParser()
-    parser.add_argument('--config', type=str, default='./configs/landslide/fusion_3d_brienz.yaml', help='Path to config file.')
+    # (the reference defaults to ./configs/landslide/fusion_3d_brienz.yaml of ITS tree; this package ships no data sets and no
+    #  configs, so the path is asked for -- any of the reference's fusion configs with `partition_type: supervoxel` works)
+    parser.add_argument('--config', type=str, required=True,
+                        help="Path to a fusion config of the reference's layout (e.g. its configs/landslide/fusion_3d_brienz.yaml); "
+                             "`method.partition_type` must be `supervoxel`.")
     parser.add_argument('--partition', type=str, default=None, choices=['identical', 'parallel'],
                         help="supervoxel segmentation: the reference's labels (host replay) or the device segmentation")
     parser.add_argument('--first-tile', type=int, default=0)

@@ -45,6 +45,10 @@ def _staged(dist, t):
 
 
 def _all_reduce(dist, t, op):
+    # the NCCL (= RCCL) process group has no bitwise reductions ("Cannot use ReduceOp.BOR with NCCL"): refuse them wherever the
+    # backend is not gloo, so that a path that only ever ran over gloo cannot carry one onto the GPUs
+    if op in (dist.ReduceOp.BOR, dist.ReduceOp.BAND, dist.ReduceOp.BXOR) and dist.get_backend() != "gloo":
+        raise ValueError(f"{op} is not available on the {dist.get_backend()} backend: reduce bits with MAX / SUM instead")
     if _staged(dist, t):
         h = t.cpu()
         dist.all_reduce(h, op=op)
@@ -78,13 +82,21 @@ def _a2a_v(dist, torch, payload, dest, world):
     return recv
 
 
+_FLAG_BITS = 16
+
+
 def _raise_together(dist, torch, dev, world, flag, what):
-    """Every rank raises when ANY rank reports `flag` != 0 (bitwise OR over the ranks, one small all_reduce)."""
-    f = torch.tensor([int(flag)], dtype=torch.int64, device=dev)
+    """Every rank raises when ANY rank reports `flag` != 0: the OR of the ranks' flags (small non-negative bit masks) as ONE
+    all_reduce(MAX) over their bits -- RCCL has no bitwise reduction (ReduceOp.BOR is gloo only)."""
+    flag = int(flag)
+    if flag < 0 or flag >= 1 << _FLAG_BITS:
+        raise ValueError("flag must be a bit mask below 2^%d" % _FLAG_BITS)
+    f = torch.tensor([(flag >> b) & 1 for b in range(_FLAG_BITS)], dtype=torch.int64, device=dev)
     if world > 1:
-        _all_reduce(dist, f, dist.ReduceOp.BOR)
-    if int(f.item()):
-        raise RuntimeError(f"{what} [flags over all ranks: {int(f.item())}]")
+        _all_reduce(dist, f, dist.ReduceOp.MAX)
+    allf = sum(int(v) << b for b, v in enumerate(f.tolist()))
+    if allf:
+        raise RuntimeError(f"{what} [flags over all ranks: {allf}]")
 
 
 def plan_slabs(local_xyz, resolution, dist, world):

@@ -13,14 +13,18 @@ from .. import engine
 from .pointcloud import PointCloud, as_points
 
 
-def icp_registration(src_pcd, tgt_pcd, initial_transform, threshold=0.1, icp_type='point2point', search='f64'):
+def icp_registration(src_pcd, tgt_pcd, initial_transform, threshold=0.1, icp_type='point2point', search='f64',
+                     p2plane='open3d'):
     """Point-to-point / point-to-plane ICP with Open3D's ICPConvergenceCriteria(1e-6, 1e-6, 30)
     (utils/o3d_tools.py:46-50).  Accepts Open3D clouds, `PointCloud`, numpy arrays or torch tensors.
 
     Returns the reference's dict: fitness, inlier_rmse, correspondence_set (m,2) int, est_transform (4,4) float64,
     src_corr_pts, tgt_corr_pts.  Like the reference it estimates normals on both clouds first
     (utils/o3d_tools.py:29-30); they only influence the result for 'point2plane'.
-    `search` selects the nearest-neighbour arithmetic ('f64' = the reference's double precision)."""
+    `search` selects the nearest-neighbour arithmetic ('f64' = the reference's double precision).
+    'point2plane' steps follow Open3D's own semantics (F4L_ICP_P2PL_OPEN3D: Eigen's pivoted L D L^T, applied whenever there is a
+    correspondence), not the batched calls' robust default; `p2plane='robust'` asks for that one.  (The solve's frame is the
+    shifted one below: for a SINGULAR system -- whose "solution" depends on the frame -- that is not Open3D's number either.)"""
     import torch
     if icp_type == 'generalized_icp':
         raise NotImplementedError("generalized ICP has no caller on the hot path and is not implemented")
@@ -51,7 +55,8 @@ def icp_registration(src_pcd, tgt_pcd, initial_transform, threshold=0.1, icp_typ
         src_pcd.normals = engine.patch_normals(s, so, 30, f64=True).cpu().numpy()
     out = engine.piecewise_icp(s, so, t, to, init_T=torch.from_numpy(T0[None]).to(dev), max_corr_dist=threshold,
                                max_iter=30, rel_fitness=1e-6, rel_rmse=1e-6, icp_type=icp_type,
-                               tgt_normals=tn if icp_type == 'point2plane' else None, return_corr=True, search=search)
+                               tgt_normals=tn if icp_type == 'point2plane' else None, return_corr=True, search=search,
+                               p2plane=p2plane)
     T = out["T"][0].cpu().numpy()
     T[:3, 3] = T[:3, 3] + o - T[:3, :3] @ o
     corr = out["corr"].cpu().numpy()

@@ -43,8 +43,19 @@ extern "C" {
 
 #define F4L_ICP_POINT2POINT 0 /* o3d TransformationEstimationPointToPoint(False), utils/o3d_tools.py:34 */
 #define F4L_ICP_POINT2PLANE 1 /* o3d TransformationEstimationPointToPlane(),     utils/o3d_tools.py:39 */
-/*   (a point-to-plane step with fewer than six correspondences, or whose 6 x 6 system is singular to 1e-13, is not taken:
- *    the transform stays and the loop ends on its criteria) */
+/* Two semantics of the point-to-plane STEP, which differ only where the 6 x 6 system does not pin its six unknowns:
+ *   default (ROBUST, this library's own rule): a step with fewer than six correspondences, or whose system is singular to
+ *     1e-13 of its largest diagonal entry, is not taken -- the transform stays and the loop ends on its criteria.  The default
+ *     of the batched entry points because ONE rank-deficient patch of a 100 k-patch launch otherwise leaves with a transform
+ *     made of rounding noise (a four-pair patch was thrown 55 m, tools/gpu/fuzz_icp.py 1 2250095 f64 n32).
+ *   F4L_ICP_P2PL_OPEN3D, OR-ed into `mode`: Open3D's own semantics, what the reference's call
+ *     utils/o3d_tools.py:38-39,46-50 does -- TransformationEstimationPointToPlane::ComputeTransformation ->
+ *     SolveJacobianSystemAndObtainExtrinsicMatrix -> SolveLinearSystemPSD with its checks off: x = JTJ.ldlt().solve(-JTr) in
+ *     the CALLER's frame (Eigen's diagonal-pivoted L D L^T, pseudo-inverse of D), applied whenever there is at least ONE
+ *     correspondence.  What the host-side mirror of `icp_registration` passes (a drop-in does what the reference does).
+ *     Only a step whose solution is not finite is left out (Open3D would carry the NaNs on).
+ *   On patches that pin their six unknowns the two are the same minimiser (tested to 1e-7 m). */
+#define F4L_ICP_P2PL_OPEN3D 0x400
 /* f4l_patch_loop only, OR-ed into `mode`: the Kabsch transform is rounded to float32 before ICP starts from it, as the
  * reference hands Open3D the float32 4 x 4 of refine_local_rigid_correspondences (scripts/weighted_svd.py:148-151,
  * src/coarse_to_fine_matching_base.py:3360 `initial_transform=est_transform_svd.cpu()`). */
@@ -306,8 +317,9 @@ int f4l_write_partition_txt(const char *path, const float *xyz_host, const int32
                             int32_t n_supervoxels);
 
 /* Sort-by-label -> CSR (replaces the O(K*N) mask loop of prepare_pts2spt_dict,
- * src/coarse_to_fine_matching_base.py:1327-1332).  labels int32 [n] in [0,K); order_out int32 [n] = point ids
- * grouped by label (stable); off_out int64 [K+1]. */
+ * src/coarse_to_fine_matching_base.py:1327-1332).  labels int32 [n]; order_out int32 [n] = point ids grouped by label
+ * (stable); off_out int64 [K+1].  A label outside [0, K) (an "unlabelled" -1, a label beyond the caller's count) belongs to no
+ * patch: those point ids follow the last patch, order_out[off_out[K] ..), in ascending order. */
 size_t f4l_labels_to_csr_workspace_bytes(int64_t n, int64_t K);
 int f4l_labels_to_csr(const int32_t *labels, int64_t n, int64_t K, int32_t *order_out, int64_t *off_out,
                       void *workspace, size_t workspace_bytes, void *stream);

@@ -86,3 +86,24 @@ def piecewise_motion_scene(xyz, block=0.25, seed=11, tmax=0.004, noise=0.0005, e
     p = xyz.astype(np.float64)
     moved = np.einsum("nij,nj->ni", R[bid], p - c) + c + t[bid]
     return (moved + rng.normal(0, noise, p.shape)).astype(np.float32), moved - p
+
+
+# ---- the LARGE reference-pinned partition fixture (tests/golden/sv_large_ref.npz, tools/make_golden_supervoxel.py --large) -------
+LARGE_CASE = dict(seed=17, n=300_000, extent=5.0, k=30, resolution=0.12)
+
+
+def large_surface_cloud(seed, n, extent):
+    """The fixture's cloud, regenerated from its seed (the fixture stores no coordinates and no neighbour lists: only what the
+    reference computed).  numpy's PCG64 streams of `uniform` / `normal` are stable across the versions in use; the fixture also
+    keeps a checksum of the float32 bits, checked before anything else is."""
+    rng = np.random.default_rng(seed)
+    xy = rng.uniform(0, extent, (n, 2))
+    z = 0.4 * np.sin(2.1 * xy[:, 0]) * np.cos(1.7 * xy[:, 1]) + 0.05 * np.sin(9.0 * xy[:, 0] + 1.0) * np.sin(7.0 * xy[:, 1])
+    z = z + np.where((xy[:, 0] > 0.6 * extent) & (xy[:, 1] > 0.5 * extent), 0.15, 0.0)  # a step: the normal term decides along it
+    return np.c_[xy, z + rng.normal(0, 0.003, n)].astype(np.float32)
+
+
+def bits_checksum(a):
+    """Order-dependent 64-bit checksum of an array's bytes (sum of the 32-bit words times their 1-based position, mod 2^64)."""
+    w = np.frombuffer(np.ascontiguousarray(a).tobytes(), dtype=np.uint32).astype(np.uint64)
+    return int((w * (np.arange(1, len(w) + 1, dtype=np.uint64) | np.uint64(1))).sum(dtype=np.uint64))

@@ -214,11 +214,17 @@ def test_icp_known_answer_planted_motion(eng):
         assert _max_disp(d, T, ref["T"]) <= 1e-7
 
 
+@pytest.mark.parametrize("semantics", ["open3d", "robust"])
 @pytest.mark.parametrize("search", ["f64", "f32"])
-def test_icp_point2plane_vs_oracle(eng, search):
+def test_icp_point2plane_vs_oracle(eng, search, semantics):
+    """Both semantics of the point-to-plane step against their own oracle: `open3d` = F4L_ICP_P2PL_OPEN3D against the STRICT
+    restatement of Open3D's step (oracle mode 1: double sums in the caller's frame, Eigen's pivoted L D L^T, applied whenever
+    there is a correspondence; utils/o3d_tools.py:38-39,46-50), `robust` = the kernel's default against the oracle's robust
+    variant (mode 2).  Well-posed patches: 1e-7 m (float32 normals 1e-6), and the two semantics agree with each other."""
     # metre-scale relief: a patch of a near-planar surface leaves the in-plane motion undetermined, and any two
     # solvers then differ by what they do to the null space (not a parity question)
     d = synthetic_patches(n=24_000, cells=5, seed=4, roughness=0.15)
+    oracle_type = "point2plane" if semantics == "open3d" else "point2plane_robust"
     nrm = eng.patch_normals(dev(d["tgt"]), dev(d["tgt_off"]), 30)
     nrm_h = nrm.cpu().numpy().astype(np.float64)
     for p in range(d["P"]):
@@ -227,9 +233,9 @@ def test_icp_point2plane_vs_oracle(eng, search):
         dots = np.abs(np.sum(nrm_h[t0:t1] * ref_n, axis=1))
         assert dots.min() >= 1 - 1e-6, p
     out = eng.piecewise_icp(dev(d["src"]), dev(d["src_off"]), dev(d["tgt"]), dev(d["tgt_off"]), max_corr_dist=0.1,
-                            max_iter=30, icp_type="point2plane", tgt_normals=nrm, search=search)
+                            max_iter=30, icp_type="point2plane", tgt_normals=nrm, search=search, p2plane=semantics)
     ref = O.piecewise_icp(d["src"], d["src_off"], d["tgt"], d["tgt_off"], max_corr_dist=0.1, max_iter=30,
-                          icp_type="point2plane")
+                          icp_type=oracle_type)
     disp = _disp_per_patch(d, out["T"].cpu().numpy(), ref["T"])
     if search == "f64":
         assert disp.max() <= 1e-6  # normals are handed over as float32 here, double in the oracle
@@ -242,13 +248,20 @@ def test_icp_point2plane_vs_oracle(eng, search):
     nrm64 = eng.patch_normals(dev(d["tgt"]), dev(d["tgt_off"]), 30, f64=True)
     assert nrm64.dtype == torch.float64 and torch.equal(nrm64.to(torch.float32), nrm)
     out2 = eng.piecewise_icp(dev(d["src"]), dev(d["src_off"]), dev(d["tgt"]), dev(d["tgt_off"]), max_corr_dist=0.1,
-                             max_iter=30, icp_type="point2plane", search=search)
+                             max_iter=30, icp_type="point2plane", search=search, p2plane=semantics)
     out3 = eng.piecewise_icp(dev(d["src"]), dev(d["src_off"]), dev(d["tgt"]), dev(d["tgt_off"]), max_corr_dist=0.1,
-                             max_iter=30, icp_type="point2plane", tgt_normals=nrm64, search=search)
+                             max_iter=30, icp_type="point2plane", tgt_normals=nrm64, search=search, p2plane=semantics)
     assert torch.equal(out2["T"], out3["T"])
     if search == "f64":
-        assert _disp_per_patch(d, out2["T"].cpu().numpy(), ref["T"]).max() <= 1e-8
-        # the L D L^T solve (Open3D's own kind) against the pivoted elimination it replaced (F4L_ICP_DEBUG bit 256)
+        assert _disp_per_patch(d, out2["T"].cpu().numpy(), ref["T"]).max() <= 1e-7
+        assert np.array_equal(out2["iters"].cpu().numpy(), ref["iters"])
+        # the other semantics on the same patches: the same minimiser where the six unknowns are pinned
+        other = eng.piecewise_icp(dev(d["src"]), dev(d["src_off"]), dev(d["tgt"]), dev(d["tgt_off"]), max_corr_dist=0.1,
+                                  max_iter=30, icp_type="point2plane", tgt_normals=nrm64, search=search,
+                                  p2plane="robust" if semantics == "open3d" else "open3d")
+        assert _disp_per_patch(d, other["T"].cpu().numpy(), out3["T"].cpu().numpy()).max() <= 1e-7
+    if search == "f64" and semantics == "robust":
+        # the L D L^T solve against the pivoted elimination it replaced (F4L_ICP_DEBUG bit 256)
         os.environ["F4L_ICP_DEBUG"] = "256"
         try:
             out4 = eng.piecewise_icp(dev(d["src"]), dev(d["src_off"]), dev(d["tgt"]), dev(d["tgt_off"]), max_corr_dist=0.1,
@@ -259,11 +272,52 @@ def test_icp_point2plane_vs_oracle(eng, search):
         assert _disp_per_patch(d, out4["T"].cpu().numpy(), out3["T"].cpu().numpy()).max() <= 1e-11
     with pytest.raises(ValueError):
         eng.piecewise_icp(dev(d["src"]), dev(d["src_off"]), dev(d["tgt"]), dev(d["tgt_off"]), icp_type="generalized")
+    with pytest.raises(ValueError):
+        eng.piecewise_icp(dev(d["src"]), dev(d["src_off"]), dev(d["tgt"]), dev(d["tgt_off"]), icp_type="point2plane", p2plane="eigen")
+
+
+def test_icp_point2plane_where_the_two_semantics_part(eng):
+    """Where Open3D's step and the robust one differ (include/f4l.h, F4L_ICP_P2PL_OPEN3D): (a) a patch left with four
+    correspondences -- robust: no step; Open3D (kernel and strict oracle alike): the singular system's "solution" is applied,
+    the patch moves, and since that solution is rounding noise the two sides need not agree on where to; (b) an exactly planar
+    target with normals (0, 0, 1) near the origin -- robust: no step (rank 3); Open3D: Eigen's pseudo-inverse of D moves the
+    sheet along what the data sees (tilt, lift) and not at all along what it does not: kernel = strict oracle to 1e-9 m."""
+    rng = np.random.default_rng(12)
+    gx, gy = np.meshgrid(np.arange(8) * 0.1, np.arange(8) * 0.1)
+    tgt_a = np.c_[gx.ravel(), gy.ravel(), 0.05 * np.sin(3 * gx.ravel()) * np.cos(2 * gy.ravel())]
+    near = tgt_a[[9, 20, 35, 50]] + rng.normal(0, 0.004, (4, 3))
+    far = tgt_a[:7] + np.array([0.0, 0.0, 1.0])
+    src_a = np.r_[near, far]
+    tgt_b = np.c_[rng.uniform(0, 1, (300, 2)), np.zeros(300)]
+    src_b = np.c_[rng.uniform(0.1, 0.9, (200, 2)), np.zeros(200)]
+    src_b[:, 2] = 0.01 + 0.02 * (src_b[:, 0] - 0.5)
+    src = np.r_[src_a, src_b].astype(np.float32)
+    tgt = np.r_[tgt_a, tgt_b].astype(np.float32)
+    soff, toff = np.array([0, len(src_a), len(src)], np.int64), np.array([0, len(tgt_a), len(tgt)], np.int64)
+    nrm = np.r_[O.o3d_estimate_normals(tgt[:len(tgt_a)].astype(np.float64), 30), np.tile([0.0, 0.0, 1.0], (len(tgt_b), 1))]
+    res = {}
+    for sem in ("robust", "open3d"):
+        out = eng.piecewise_icp(dev(src), dev(soff), dev(tgt), dev(toff), max_corr_dist=0.05, max_iter=1, fixed_iters=True,
+                                icp_type="point2plane", tgt_normals=dev(nrm), p2plane=sem)
+        res[sem] = out["T"].cpu().numpy()
+    assert np.array_equal(res["robust"][0], np.eye(4)) and np.array_equal(res["robust"][1], np.eye(4))
+    assert not np.array_equal(res["open3d"][0], np.eye(4)) and np.isfinite(res["open3d"]).all()
+    ref_a = O.icp(src[:len(src_a)].astype(np.float64), tgt[:len(tgt_a)].astype(np.float64), max_corr_dist=0.05, max_iter=1,
+                  fixed_iters=True, icp_type="point2plane", tgt_normals=nrm[:len(tgt_a)])
+    assert not np.array_equal(ref_a["est_transform"], np.eye(4))
+    ref_b = O.icp(src[len(src_a):].astype(np.float64), tgt[len(tgt_a):].astype(np.float64), max_corr_dist=0.05, max_iter=1,
+                  fixed_iters=True, icp_type="point2plane", tgt_normals=nrm[len(tgt_a):])
+    Tb, Rb = res["open3d"][1], ref_b["est_transform"]
+    sb = src[len(src_a):].astype(np.float64)
+    assert np.abs((sb @ Tb[:3, :3].T + Tb[:3, 3]) - (sb @ Rb[:3, :3].T + Rb[:3, 3])).max() <= 1e-9
+    assert Tb[0, 3] == 0.0 and Tb[1, 3] == 0.0 and Tb[1, 0] == 0.0   # nothing along what the data does not see
+    assert np.abs((sb @ Tb[:3, :3].T + Tb[:3, 3])[:, 2]).max() <= 1e-5
 
 
 def test_icp_point2plane_refuses_a_singular_step(eng):
-    """A point-to-plane step that cannot pin its six unknowns is not taken: fewer than six correspondences (the oracle's rule
-    too), or an exactly planar target with parallel normals (rank 3: pivots below 1e-13 of the diagonal).  The transform stays
+    """The ROBUST semantics (the batched calls' default; Open3D's own are F4L_ICP_P2PL_OPEN3D, tested above): a point-to-plane
+    step that cannot pin its six unknowns is not taken: fewer than six correspondences (the robust oracle's rule too), or an
+    exactly planar target with parallel normals (rank 3: pivots below 1e-13 of the diagonal).  The transform stays
     where it was, fitness and rmse are those of the start, and the loop ends on its criteria -- where solving the singular
     system threw a four-pair patch 55 m (tools/gpu/fuzz_icp.py 1 2250095 f64 n32)."""
     rng = np.random.default_rng(12)
@@ -287,7 +341,7 @@ def test_icp_point2plane_refuses_a_singular_step(eng):
         fit = out["fitness"].cpu().numpy()
         assert abs(fit[0] - 4 / 11) < 1e-12 and fit[1] > 0.8  # (the plane: nearly every point matched, and still rank 3)
         ref = O.icp(src[:len(src_a)].astype(np.float64), tgt[:len(tgt_a)].astype(np.float64), max_corr_dist=0.05, max_iter=30,
-                    icp_type="point2plane", tgt_normals=nrm[:len(tgt_a)])
+                    icp_type="point2plane_robust", tgt_normals=nrm[:len(tgt_a)])
         assert np.array_equal(ref["est_transform"], np.eye(4)) and abs(ref["fitness"] - 4 / 11) < 1e-12
         assert abs(out["rmse"].cpu().numpy()[0] - ref["inlier_rmse"]) < 1e-9
 
@@ -610,7 +664,7 @@ def test_icp_vs_open3d_goldens_when_present(eng, golden_dir):
     T0 = np.stack([g[f"init_{c}"] for c in range(C)])
     for icp_type in ("point2point", "point2plane"):
         out = eng.piecewise_icp(dev(np.concatenate(src)), dev(soff), dev(np.concatenate(tgt)), dev(toff), init_T=dev(T0),
-                                max_corr_dist=float(g["threshold"]), max_iter=30, icp_type=icp_type, search="f64")
+                                max_corr_dist=float(g["threshold"]), max_iter=30, icp_type=icp_type, search="f64", p2plane="open3d")
         T = out["T"].cpu().numpy()
         for c in range(C):
             Tr = g[f"T_{icp_type}_{c}"]
@@ -796,6 +850,18 @@ def test_labels_to_csr_and_gather(eng):
         o, f = eng.labels_to_csr(dev(lab.astype(np.int32)), k)
         assert np.array_equal(np.diff(f.cpu().numpy()), np.bincount(lab, minlength=k)) and int(f[0]) == 0
         assert np.array_equal(o.cpu().numpy(), np.argsort(lab, kind="stable"))
+    # labels outside [0, K) -- an "unlabelled" -1, labels beyond the caller's count -- belong to no patch: their points follow the
+    # last patch in `order`, the offsets are those of the labelled points alone (they used to land by their low bits)
+    bad = labels.copy()
+    bad[rng.choice(n, 300, replace=False)] = -1
+    bad[rng.choice(n, 200, replace=False)] = K + rng.integers(0, 1000, 200).astype(np.int32)
+    bad[-1] = -7
+    o, f = eng.labels_to_csr(dev(bad), K)
+    o, f = o.cpu().numpy(), f.cpu().numpy()
+    ok = (bad >= 0) & (bad < K)
+    assert f[0] == 0 and f[-1] == ok.sum() and np.array_equal(np.diff(f), np.bincount(bad[ok], minlength=K))
+    key = np.where(ok, bad, K)
+    assert np.array_equal(o, np.argsort(key, kind="stable"))
 
 
 # --------------------------------------------------------------- size-independent properties, full size
@@ -907,3 +973,50 @@ def test_patch_loop_over_several_tiles_in_one_launch(eng):
         assert m["T"].shape == one["T"].shape and m["rows"].shape == one["rows"].shape == (t["src"].shape[0], 6)
         assert torch.equal(m["iters"], one["iters"]) and torch.equal(m["rows"][:, :3], t["src"])
         assert float((m["T"] - one["T"]).abs().max()) < 1e-9 and float((m["rows"] - one["rows"]).abs().max()) < 1e-5
+
+
+@pytest.mark.parametrize("search", ["f64", "f32"])
+def test_icp_cell_shape_changes_no_answer(eng, search, monkeypatch):
+    """The grid of a target patch is a search structure only: the answer of every search is the minimiser of (d2, original
+    index) whatever the cells look like.  So the column grids of flat patches and the finer cells along x (patch_grid.h "Cell
+    shape", round 4) must give what the cubic cells of rounds 1-3 give (F4L_ICP_DEBUG bits 512 + 1024) -- on terrain patches
+    (columns), on a volume (layers), on a dense patch (cells finer than the radius: the wide stencils):
+      * with every point searched in every pass (bit 4: no certificates) BIT FOR BIT: the sums then run in point order;
+      * with certificates the scanned candidates, hence the runner-up distances, hence WHICH points are searched and in which
+        lane their pair is summed, depend on the cells: the same trajectories to rounding (float64: 1e-9 m, equal iteration
+        counts, fitness and final correspondences).
+    (f4l_nn_refine shares the grid; its tests hold it to the oracle's KD-tree.)"""
+    from fusion4landslide_amd import synthetic
+    d = synthetic.make_patches(40_000, 6, 1.386, seed=5, roughness=0.1)
+    rng = np.random.default_rng(9)
+    vol_t = rng.uniform(0, 0.6, (900, 3)).astype(np.float32)            # a volume: layered cells
+    vol_s = (vol_t[:700] + rng.normal(0, 0.004, (700, 3))).astype(np.float32)
+    xy = rng.uniform(0, 0.25, (2500, 2))                                  # dense against the radius: a subdivided grid
+    den_t = np.c_[xy, 0.02 * np.sin(20 * xy[:, 0])].astype(np.float32)
+    den_s = (den_t[:2000] + rng.normal(0, 0.002, (2000, 3))).astype(np.float32)
+    src = np.concatenate([d["src"], vol_s, den_s])
+    tgt = np.concatenate([d["tgt"], vol_t, den_t])
+    soff = np.r_[d["src_off"], d["src_off"][-1] + len(vol_s), d["src_off"][-1] + len(vol_s) + len(den_s)].astype(np.int64)
+    toff = np.r_[d["tgt_off"], d["tgt_off"][-1] + len(vol_t), d["tgt_off"][-1] + len(vol_t) + len(den_t)].astype(np.int64)
+    args = (dev(src), dev(soff), dev(tgt), dev(toff))
+    kw = dict(max_corr_dist=0.1, max_iter=20, fixed_iters=True, search=search, return_corr=True)
+    out = eng.piecewise_icp(*args, **kw)
+    assert float(out["fitness"].min()) > 0.3
+    monkeypatch.setenv("F4L_ICP_DEBUG", "4")
+    plain = eng.piecewise_icp(*args, **kw)
+    dd = dict(src=src, src_off=soff, P=len(soff) - 1)
+    for bits in (512, 1024, 1536):
+        monkeypatch.setenv("F4L_ICP_DEBUG", str(4 + bits))
+        ref = eng.piecewise_icp(*args, **kw)
+        for key in ("T", "fitness", "rmse", "iters", "corr"):
+            assert torch.equal(plain[key], ref[key]), (bits, key)
+        monkeypatch.setenv("F4L_ICP_DEBUG", str(bits))
+        ref = eng.piecewise_icp(*args, **kw)
+        if search == "f64":
+            assert _disp_per_patch(dd, out["T"].cpu().numpy(), ref["T"].cpu().numpy()).max() <= 1e-9, bits
+            for key in ("fitness", "iters", "corr"):
+                assert torch.equal(out[key], ref[key]), (bits, key)
+        else:
+            per = _disp_per_patch(dd, out["T"].cpu().numpy(), ref["T"].cpu().numpy())
+            assert np.median(per) <= 1e-5 and (per <= 1e-4).mean() >= 0.85, (bits, per)
+    monkeypatch.delenv("F4L_ICP_DEBUG")

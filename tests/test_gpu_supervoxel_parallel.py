@@ -6,6 +6,7 @@ the device's partition against its labels; the invariants (labels 0..K-1 non-emp
 the per-patch displacements a piecewise motion yields on its partition and on the device's."""
 import glob
 import os
+import time
 
 import numpy as np
 import pytest
@@ -66,6 +67,46 @@ def test_device_segmentation_equals_its_numpy_model(eng, path):
         finally:
             del os.environ[name]
         assert torch.equal(other, labels) and np.array_equal(info2.cpu().numpy(), info), (name, value)
+
+
+def test_partition_against_the_large_reference_fixture(eng, golden_dir):
+    """tests/golden/sv_large_ref.npz: what the REFERENCE's own templates compute on a 300 k-point cloud (15 x the largest small
+    fixture; labels, K, grid cells, lambda0, checksums of its neighbour lists -- tools/make_golden_supervoxel.py --large; the
+    cloud comes back from its seed).  f4l_supervoxel (kNN + normals on the device, the reference's visiting order replayed)
+    reproduces EVERY label; f4l_supervoxel_parallel has K and lambda0 bit-exact and its partition's quality within the bounds
+    of the small fixtures.  Where the reference-compiled checker travelled with the snapshot (oracle/_ref/libf4l_ref.so, built
+    in the build container by oracle/Makefile), a FRESH cloud of the same size is also put through the live reference here."""
+    from tests._util import LARGE_CASE, bits_checksum, large_surface_cloud
+    g = np.load(os.path.join(golden_dir, "sv_large_ref.npz"))
+    c = LARGE_CASE
+    xyz = large_surface_cloud(c["seed"], c["n"], c["extent"])
+    assert bits_checksum(xyz) == int(g["xyz_checksum"]), "the generator no longer reproduces the fixture's cloud"
+    idx, d2 = eng.knn(dev(xyz), c["k"], return_d2=True)
+    assert bits_checksum(d2.cpu().numpy()) == int(g["knn_d2_checksum"])      # every squared distance, bit for bit
+    assert bits_checksum(idx.cpu().numpy()) == int(g["knn_idx_checksum"])    # (random floats: no exact ties to reorder)
+    labels, K = eng.supervoxel(dev(xyz), c["k"], c["resolution"])
+    assert K == int(g["n_supervoxels"]) == int(g["n_grid_cells"])
+    assert np.array_equal(labels.cpu().numpy(), g["labels"]), "labels differ from the reference's"
+    par, Kp, knn, nrm, reps, info = eng.supervoxel_parallel(dev(xyz), c["k"], c["resolution"], return_intermediates=True)
+    info = info.cpu().numpy() if hasattr(info, "cpu") else np.asarray(info)
+    assert Kp == int(g["n_grid_cells"]) and int(info[1]) == int(g["n_grid_cells"]) and int(info[2]) == 0
+    assert eng.supervoxel_lambda0(info) == float(g["lambda0"])
+    nrm_h = nrm.cpu().numpy()
+    assert np.allclose(np.abs(nrm_h).sum(axis=0), g["normals_abs_sum"], rtol=1e-9)
+    rms_ref, dev_ref, cv_ref = partition_quality(xyz, nrm_h, g["labels"])
+    rms, dvn, cv = partition_quality(xyz, nrm_h, par.cpu().numpy())
+    assert rms <= 1.10 * rms_ref and dvn <= 1.15 * dev_ref + 1e-4 and cv <= 1.3 * cv_ref, ((rms, dvn, cv), (rms_ref, dev_ref, cv_ref))
+    if O.have_ref():  # the live reference, on a cloud no fixture has seen
+        fresh = large_surface_cloud(c["seed"] + int(time.time()) % 1000 + 1, 200_000, 4.0)
+        r = O.ref_supervoxel(fresh, c["k"], c["resolution"])
+        lab2, K2 = eng.supervoxel(dev(fresh), c["k"], c["resolution"])
+        assert K2 == r["n_supervoxels"] and np.array_equal(lab2.cpu().numpy(), r["labels"])
+        par2, Kp2, _, nrm2, _, info2 = eng.supervoxel_parallel(dev(fresh), c["k"], c["resolution"], return_intermediates=True)
+        info2 = info2.cpu().numpy() if hasattr(info2, "cpu") else np.asarray(info2)
+        assert Kp2 == r["n_grid_cells"]
+        assert eng.supervoxel_lambda0(info2) == O.ref_lambda0(fresh, r["normals"], r["knn_idx"], c["resolution"])
+        q_ref, q_par = partition_quality(fresh, r["normals"], r["labels"]), partition_quality(fresh, r["normals"], par2.cpu().numpy())
+        assert q_par[0] <= 1.10 * q_ref[0] and q_par[1] <= 1.15 * q_ref[1] + 1e-4 and q_par[2] <= 1.3 * q_ref[2], (q_par, q_ref)
 
 
 def test_whole_partition_on_the_device_and_edge_cases(eng):

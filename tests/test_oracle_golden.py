@@ -50,6 +50,28 @@ def test_supervoxel_oracle_vs_golden(golden_dir, name):
     assert np.array_equal(out["labels"], g["labels"]), "labels differ from the reference's"
 
 
+def test_supervoxel_oracle_vs_large_reference_fixture(golden_dir):
+    """The reference-held partition of a 300 k-point cloud (tests/golden/sv_large_ref.npz: labels, K, grid cells, lambda0 and
+    checksums produced by the reference's own templates, tools/make_golden_supervoxel.py --large; the cloud comes back from its
+    seed): 15 x the largest small fixture.  The C oracle reproduces every label, and its neighbour lists and squared distances
+    checksum to the reference's bits."""
+    from _util import LARGE_CASE, bits_checksum, large_surface_cloud
+    g = np.load(os.path.join(golden_dir, "sv_large_ref.npz"))
+    c = LARGE_CASE
+    xyz = large_surface_cloud(c["seed"], c["n"], c["extent"])
+    assert bits_checksum(xyz) == int(g["xyz_checksum"]), "the generator no longer reproduces the fixture's cloud"
+    O.set_threads(0)  # (kNN and normals of 300 k points: all cores; the segmentation itself is sequential)
+    try:
+        out = O.supervoxel(xyz, c["k"], c["resolution"])
+    finally:
+        O.set_threads(1)
+    assert bits_checksum(out["knn_idx"]) == int(g["knn_idx_checksum"])
+    assert bits_checksum(out["knn_d2"]) == int(g["knn_d2_checksum"])
+    assert np.allclose(np.abs(out["normals"]).sum(axis=0), g["normals_abs_sum"], rtol=1e-12)
+    assert O.grid_cell_count(xyz, c["resolution"]) == int(g["n_grid_cells"]) == int(g["n_supervoxels"]) == out["n_supervoxels"]
+    assert np.array_equal(out["labels"], g["labels"])
+
+
 def test_supervoxel_oracle_vs_live_reference():
     if not O.have_ref():
         pytest.skip("oracle/_ref not built (no /root/reference at build time)")

@@ -88,11 +88,12 @@ def test_icp_oracle_walks_the_same_trajectory_as_numpy_restatement(icp_type):
         assert np.array_equal(cs[:, 0], np.nonzero(ref[4])[0]) and np.array_equal(cs[:, 1], ref[5][ref[4]])
 
 
-def test_icp_oracle_point2plane_far_from_the_origin_is_the_extended_precision_step():
-    """orc_point2plane sums and solves the 6 x 6 equations in long double: 3 km from the origin one pass of the oracle is the
-    numpy `longdouble` pass to 1e-10 m, where the same pass with double sums is 1e-8 m away (its own rounding: the entries are
-    |origin|^2 per pair, the information is in their patch-sized variation).  And a step with fewer pairs than unknowns is not
-    taken (the kernel's rule)."""
+def test_icp_oracle_robust_point2plane_far_from_the_origin_is_the_extended_precision_step():
+    """The ROBUST variant (`point2plane_robust`, orc_point2plane_robust: this repository's rule, the kernel's default -- not
+    Open3D's semantics, which are `point2plane`) sums and solves the 6 x 6 equations in long double: 3 km from the origin one
+    pass of it is the numpy `longdouble` pass to 1e-10 m, where the same pass with double sums is 1e-8 m away (its own
+    rounding: the entries are |origin|^2 per pair, the information is in their patch-sized variation).  And a step with fewer
+    pairs than unknowns is not taken."""
     rng = np.random.default_rng(8)
     origin = np.array([2647.0, 1177.0, 1500.0])
     tgt = (_surface(rng, 6000, noise=0.002) + origin).astype(np.float32).astype(np.float64)
@@ -100,7 +101,7 @@ def test_icp_oracle_point2plane_far_from_the_origin_is_the_extended_precision_st
     src0 = src0[(src0[:, 0] > 0.15) & (src0[:, 0] < 1.85) & (src0[:, 1] > 0.15) & (src0[:, 1] < 1.85)]
     src = ((src0 @ rot_from_axis_angle(rng.normal(size=3), 0.006).T + rng.uniform(-0.02, 0.02, 3)) + origin).astype(np.float32).astype(np.float64)
     normals = O.o3d_estimate_normals(tgt, 30)
-    got = O.icp(src, tgt, np.eye(4), max_corr_dist=0.1, max_iter=1, icp_type="point2plane", tgt_normals=normals, fixed_iters=True)
+    got = O.icp(src, tgt, np.eye(4), max_corr_dist=0.1, max_iter=1, icp_type="point2plane_robust", tgt_normals=normals, fixed_iters=True)
     d, j = cKDTree(tgt).query(src)
     ok = d < 0.1
 
@@ -132,8 +133,147 @@ def test_icp_oracle_point2plane_far_from_the_origin_is_the_extended_precision_st
     moved = src @ T[:3, :3].T + T[:3, 3]
     e_ld, e_d = np.abs(moved - one_pass(np.longdouble)).max(), np.abs(moved - one_pass(np.float64)).max()
     assert e_ld <= 1e-10 and e_d >= 5 * e_ld, (e_ld, e_d)
-    few = O.icp(src[:5], tgt, np.eye(4), max_corr_dist=0.1, max_iter=30, icp_type="point2plane", tgt_normals=normals)
+    few = O.icp(src[:5], tgt, np.eye(4), max_corr_dist=0.1, max_iter=30, icp_type="point2plane_robust", tgt_normals=normals)
     assert np.array_equal(few["est_transform"], np.eye(4)) and few["fitness"] == 1.0 and few["iters"] == 1
+    # Open3D's own semantics take that step all the same (one correspondence is enough for it)
+    few = O.icp(src[:5], tgt, np.eye(4), max_corr_dist=0.1, max_iter=1, icp_type="point2plane", tgt_normals=normals, fixed_iters=True)
+    assert not np.array_equal(few["est_transform"], np.eye(4))
+    # ... and in double: the strict restatement's single pass sits with the numpy float64 pass, not with the extended one
+    strict = O.icp(src, tgt, np.eye(4), max_corr_dist=0.1, max_iter=1, icp_type="point2plane", tgt_normals=normals, fixed_iters=True)
+    Ts = strict["est_transform"]
+    moved_s = src @ Ts[:3, :3].T + Ts[:3, 3]
+    assert np.abs(moved_s - one_pass(np.float64)).max() <= np.abs(moved_s - one_pass(np.longdouble)).max() + 1e-9
+
+
+def _numpy_eigen_ldlt_solve(A, b):
+    """Eigen::LDLT::compute + solve, statement by statement in numpy (independent of the C restatement): bordered
+    factorisation, pivot = largest |stored diagonal| of the rows left (first on ties), pseudo-inverse of D."""
+    A = np.array(A, dtype=np.float64)
+    n = 6
+    tr = np.arange(n)
+    for k in range(n):
+        big = k + int(np.argmax(np.abs(np.diag(A)[k:])))
+        tr[k] = big
+        if big != k:
+            A[[k, big], :k] = A[[big, k], :k]
+            A[big + 1:, [k, big]] = A[big + 1:, [big, k]]
+            A[k, k], A[big, big] = A[big, big], A[k, k]
+            for i in range(k + 1, big):
+                A[i, k], A[big, i] = A[big, i], A[i, k]
+        if k > 0:
+            temp = np.diag(A)[:k] * A[k, :k]
+            A[k, k] -= sum(A[k, j] * temp[j] for j in range(k))
+            for i in range(k + 1, n):
+                A[i, k] -= sum(A[i, j] * temp[j] for j in range(k))
+        if abs(A[k, k]) > 0:
+            A[k + 1:, k] /= A[k, k]
+        elif k == 0:
+            tr = np.arange(n)
+            break
+    y = np.array(b, dtype=np.float64)
+    for k in range(n):
+        y[[k, tr[k]]] = y[[tr[k], k]]
+    for i in range(n):
+        for j in range(i):
+            y[i] -= A[i, j] * y[j]
+    d = np.diag(A)
+    y = np.where(np.abs(d) > np.finfo(np.float64).tiny, y / np.where(d == 0, 1, d), 0.0)
+    for i in range(n - 1, -1, -1):
+        for j in range(i + 1, n):
+            y[i] -= A[j, i] * y[j]
+    for k in range(n - 1, -1, -1):
+        y[[k, tr[k]]] = y[[tr[k], k]]
+    return y
+
+
+def test_eigen_ldlt_restatement_three_ways(tmp_path):
+    """x = A.ldlt().solve(b), the solve inside Open3D's SolveLinearSystemPSD: the oracle's C restatement, an independent numpy
+    one, and the PRODUCT's register version (fusion4landslide_amd/csrc/ldlt6.h, compiled here as host code) give the same bits
+    on full-rank, rank-deficient and exactly-zero-structured systems; on full-rank ones it is the solution."""
+    import ctypes
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "ldlt6_host.cpp"
+    src.write_text('#include "ldlt6.h"\n'
+                   'extern "C" void prod_ldlt6_solve(const double *A36, const double *b6, double *x6) {\n'
+                   '    double A[6][6], b[6], x[6];\n'
+                   '    for (int i = 0; i < 6; ++i) { b[i] = b6[i]; for (int j = 0; j < 6; ++j) A[i][j] = A36[6 * i + j]; }\n'
+                   '    f4l::ldlt6_solve_eigen(A, b, x);\n'
+                   '    for (int i = 0; i < 6; ++i) x6[i] = x[i];\n}\n'
+                   'extern "C" void prod_to_caller(double *M36, double *b6, double o0, double o1, double o2) {\n'
+                   '    double M[6][6], b[6];\n'
+                   '    for (int i = 0; i < 6; ++i) { b[i] = b6[i]; for (int j = 0; j < 6; ++j) M[i][j] = M36[6 * i + j]; }\n'
+                   '    f4l::p2plane_system_to_caller_frame(M, b, o0, o1, o2);\n'
+                   '    for (int i = 0; i < 6; ++i) { b6[i] = b[i]; for (int j = 0; j < 6; ++j) M36[6 * i + j] = M[i][j]; }\n}\n')
+    so = tmp_path / "ldlt6_host.so"
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-I",
+                           os.path.join(root, "fusion4landslide_amd", "csrc"), str(src), "-o", str(so)])
+    L = ctypes.CDLL(str(so))
+    f = np.ctypeslib.ndpointer(np.float64, flags="C")
+    L.prod_ldlt6_solve.argtypes = [f, f, f]
+    L.prod_to_caller.argtypes = [f, f, ctypes.c_double, ctypes.c_double, ctypes.c_double]
+    rng = np.random.default_rng(5)
+    for it in range(400):
+        J = rng.normal(size=(rng.integers(1, 12), 6)) * rng.uniform(0.1, 10, size=6)
+        if it % 5 == 0:
+            J[:, rng.integers(0, 6)] = 0.0   # an exactly zero row and column
+        if it % 7 == 0:
+            J[:, 2:5] = 0.0                  # the plane with normals (0, 0, 1): rank 3 with exact zeros
+        A, b = J.T @ J, rng.normal(size=6)
+        x_c = O.ldlt6_solve(A, b)
+        x_p = np.empty(6)
+        L.prod_ldlt6_solve(np.ascontiguousarray(A.reshape(36)), b, x_p)
+        assert np.array_equal(x_c, x_p), it
+        if it < 120:
+            assert np.array_equal(x_c, _numpy_eigen_ldlt_solve(A, b)), it
+        if J.shape[0] >= 6 and it % 5 and it % 7:
+            assert np.allclose(A @ x_c, b, rtol=1e-8, atol=1e-8)
+        if it % 7 == 0:
+            assert (x_c[2:5] == 0.0).all()   # the pseudo-inverse of D: no motion along what the data does not see
+    # the system summed about a patch origin, moved to the caller's origin, is the system summed there
+    for it in range(50):
+        m = 20
+        s, n, r = rng.normal(size=(m, 3)), rng.normal(size=(m, 3)), rng.normal(size=m)
+        n /= np.linalg.norm(n, axis=1)[:, None]
+        o = rng.normal(size=3) * 100
+        Jp, Jc = np.c_[np.cross(s, n), n], np.c_[np.cross(s + o, n), n]
+        M, b = np.ascontiguousarray((Jp.T @ Jp).reshape(36)), -(Jp.T @ r)
+        L.prod_to_caller(M, b, *o)
+        assert np.allclose(M.reshape(6, 6), Jc.T @ Jc, rtol=1e-9, atol=1e-6) and np.allclose(b, -(Jc.T @ r), rtol=1e-9, atol=1e-6)
+
+
+def test_icp_oracle_point2plane_semantics_part_only_where_the_system_is_singular():
+    """`point2plane` (Open3D's step, strict) and `point2plane_robust` walk the same trajectory on patches that pin their six
+    unknowns (1e-9 m, same iteration count near the origin); they part on a four-pair patch (robust: no step; Open3D: whatever
+    the singular system gives) and on an exactly planar target with normals (0, 0, 1) (robust: no step; Open3D: the tilt and the
+    lift the data does see, nothing along the three directions it does not -- Eigen's pseudo-inverse of D)."""
+    rng = np.random.default_rng(21)
+    tgt = _surface(rng, 1200, noise=0.002)
+    src0 = _surface(rng, 700)
+    src0 = src0[(src0[:, 0] > 0.15) & (src0[:, 0] < 1.85) & (src0[:, 1] > 0.15) & (src0[:, 1] < 1.85)]
+    src = src0 @ rot_from_axis_angle(rng.normal(size=3), 0.005).T + rng.uniform(-0.02, 0.02, 3)
+    normals = O.o3d_estimate_normals(tgt, 30)
+    a = O.icp(src, tgt, np.eye(4), max_corr_dist=0.1, max_iter=30, icp_type="point2plane", tgt_normals=normals)
+    b = O.icp(src, tgt, np.eye(4), max_corr_dist=0.1, max_iter=30, icp_type="point2plane_robust", tgt_normals=normals)
+    ma = src @ a["est_transform"][:3, :3].T + a["est_transform"][:3, 3]
+    mb = src @ b["est_transform"][:3, :3].T + b["est_transform"][:3, 3]
+    assert a["iters"] == b["iters"] and np.abs(ma - mb).max() <= 1e-9
+    # four pairs
+    few_a = O.icp(src[:4], tgt, np.eye(4), max_corr_dist=0.1, max_iter=1, icp_type="point2plane", tgt_normals=normals, fixed_iters=True)
+    few_b = O.icp(src[:4], tgt, np.eye(4), max_corr_dist=0.1, max_iter=1, icp_type="point2plane_robust", tgt_normals=normals, fixed_iters=True)
+    assert np.array_equal(few_b["est_transform"], np.eye(4)) and not np.array_equal(few_a["est_transform"], np.eye(4))
+    # the plane z = 0 with exact normals, sources 1 cm above it and tilted
+    tp = np.c_[rng.uniform(0, 1, (300, 2)), np.zeros(300)]
+    sp = np.c_[rng.uniform(0.1, 0.9, (200, 2)), np.zeros(200)]
+    sp[:, 2] = 0.01 + 0.02 * (sp[:, 0] - 0.5)
+    npl = np.tile([0.0, 0.0, 1.0], (300, 1))
+    pa = O.icp(sp, tp, np.eye(4), max_corr_dist=0.05, max_iter=1, icp_type="point2plane", tgt_normals=npl, fixed_iters=True)
+    pb = O.icp(sp, tp, np.eye(4), max_corr_dist=0.05, max_iter=1, icp_type="point2plane_robust", tgt_normals=npl, fixed_iters=True)
+    assert np.array_equal(pb["est_transform"], np.eye(4))
+    Ta = pa["est_transform"]
+    assert Ta[0, 3] == 0.0 and Ta[1, 3] == 0.0 and Ta[1, 0] == 0.0  # no shift in the plane, no spin about z (sin(gamma) cos(beta))
+    lifted = sp @ Ta[:3, :3].T + Ta[:3, 3]
+    assert np.abs(lifted[:, 2]).max() <= 1e-5   # one step puts the tilted sheet into the plane (small-angle residue)
 
 
 def test_icp_oracle_recovers_planted_motion_and_reports_definitional_scores():

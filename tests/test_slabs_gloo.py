@@ -176,3 +176,36 @@ def test_a_slab_without_columns_is_refused_on_every_rank():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert len(res) == world and all("own no grid column" in msg for msg in res.values()), res
+
+
+def test_no_bitwise_reduction_reaches_a_backend_that_lacks_it():
+    """RCCL has no ReduceOp.BOR / BAND / BXOR (torch: "Cannot use ReduceOp.BOR with NCCL"); the slab path ran only over gloo
+    until round 4 and carried one.  `_all_reduce` refuses them wherever the backend is not gloo, and the flag
+    exchange of `_raise_together` is a MAX over the flags' bits: the OR, on any backend."""
+    from fusion4landslide_amd import slabs
+
+    class FakeDist:
+        ReduceOp = dist.ReduceOp
+
+        def __init__(self, backend, others):
+            self.backend, self.others, self.ops = backend, others, []
+
+        def get_backend(self):
+            return self.backend
+
+        def all_reduce(self, t, op=None):
+            self.ops.append(op)
+            assert op == dist.ReduceOp.MAX
+            for o in self.others:  # what the other ranks contribute
+                t.copy_(torch.maximum(t, o))
+
+    for op in (dist.ReduceOp.BOR, dist.ReduceOp.BAND, dist.ReduceOp.BXOR):
+        with pytest.raises(ValueError):
+            slabs._all_reduce(FakeDist("nccl", []), torch.zeros(1, dtype=torch.int64), op)
+    bits = lambda v: torch.tensor([(v >> b) & 1 for b in range(slabs._FLAG_BITS)], dtype=torch.int64)  # noqa: E731
+    quiet = FakeDist("nccl", [bits(0), bits(0)])
+    slabs._raise_together(quiet, torch, torch.device("cpu"), 3, 0, "nothing")
+    assert quiet.ops == [dist.ReduceOp.MAX]
+    loud = FakeDist("nccl", [bits(4), bits(2)])
+    with pytest.raises(RuntimeError, match=r"flags over all ranks: 7\]"):
+        slabs._raise_together(loud, torch, torch.device("cpu"), 3, 1, "three ranks, three different bits")

@@ -52,12 +52,16 @@ for case in range(n_cases):
     toff = np.zeros(P + 1, np.int64); np.cumsum([len(a) for a in tgt_l], out=toff[1:])
     if icp_type == "point2plane" and any(0 < len(a) < 3 for a in tgt_l):
         icp_type = "point2point"
+    # which semantics of the point-to-plane step (include/f4l.h): Open3D's own against the strict restatement, or the robust default
+    # against the oracle's robust variant (drawn from a generator of its own: the cases keep their seeds)
+    sem = "open3d" if np.random.default_rng(seed0 + case + 7919).random() < 0.5 else "robust"
+    otype = icp_type if icp_type != "point2plane" else ("point2plane" if sem == "open3d" else "point2plane_robust")
     t0 = time.perf_counter()
-    ref = O.piecewise_icp(src, soff, tgt, toff, max_corr_dist=r, max_iter=30, icp_type=icp_type, fixed_iters=fixed)
+    ref = O.piecewise_icp(src, soff, tgt, toff, max_corr_dist=r, max_iter=30, icp_type=otype, fixed_iters=fixed)
     t1 = time.perf_counter()
     dv = lambda a: torch.from_numpy(a).cuda()
     nrm = engine.patch_normals(dv(tgt), dv(toff), 30, f64=NORMALS_F64) if icp_type == "point2plane" and len(tgt) else None  # (what the launch computes itself)
-    out = engine.piecewise_icp(dv(src), dv(soff), dv(tgt), dv(toff), max_corr_dist=r, max_iter=30, icp_type=icp_type,
+    out = engine.piecewise_icp(dv(src), dv(soff), dv(tgt), dv(toff), max_corr_dist=r, max_iter=30, icp_type=icp_type, p2plane=sem,
                                fixed_iters=fixed, search=SEARCH, tgt_normals=nrm)
     nrm_h = None if nrm is None else nrm.cpu().numpy().astype(np.float64)
     T = out["T"].cpu().numpy()
@@ -93,7 +97,7 @@ for case in range(n_cases):
             if SEARCH == "f32":
                 nudge = 1e-6  # (the fast mode measures in float32 on patch-relative coordinates: a few of ITS ulps over a metre)
             Tp[0, :3, 3] = (nudge, -nudge, nudge)
-            again = O.piecewise_icp(one(src, soff), z2[0], one(tgt, toff), z2[1], init_T=Tp, max_corr_dist=r, max_iter=30, icp_type=icp_type,
+            again = O.piecewise_icp(one(src, soff), z2[0], one(tgt, toff), z2[1], init_T=Tp, max_corr_dist=r, max_iter=30, icp_type=otype,
                                     fixed_iters=fixed)
             e_self = float(np.abs((s @ again["T"][0, :3, :3].T + again["T"][0, :3, 3]) - (s @ ref["T"][p, :3, :3].T + ref["T"][p, :3, 3])).max())
             if e_self > tol:
@@ -106,7 +110,7 @@ for case in range(n_cases):
                 # size)^2, the update is linearised about that origin, and the first pass differs by centimetres from the same
                 # pass in the patch's own frame; on such a plateau the early exit, or a pair at the radius, turns on the last bits.
                 sd, td = one(src, soff)[::-1].copy(), one(tgt, toff)
-                rev = O.piecewise_icp(sd, z2[0], td, z2[1], max_corr_dist=r, max_iter=30, icp_type=icp_type, fixed_iters=fixed)
+                rev = O.piecewise_icp(sd, z2[0], td, z2[1], max_corr_dist=r, max_iter=30, icp_type=otype, fixed_iters=fixed)
                 e_rev = float(np.abs((s @ rev["T"][0, :3, :3].T + rev["T"][0, :3, 3]) - (s @ ref["T"][p, :3, :3].T + ref["T"][p, :3, 3])).max())
                 if e_rev > tol:
                     posed = False
@@ -117,8 +121,8 @@ for case in range(n_cases):
                     s64, t64 = one(src, soff).astype(np.float64), one(tgt, toff).astype(np.float64)
                     o = t64[0] if len(t64) else np.zeros(3)
                     s_r = (s64 - o).astype(np.float32).astype(np.float64) * (1.0 + 2.0 ** -23) + o  # (one float32 step outward)
-                    base = O.icp(s64, t64, max_corr_dist=r, max_iter=30, icp_type=icp_type, fixed_iters=fixed)
-                    pert = O.icp(s_r, t64, max_corr_dist=r, max_iter=30, icp_type=icp_type, fixed_iters=fixed)
+                    base = O.icp(s64, t64, max_corr_dist=r, max_iter=30, icp_type=otype, fixed_iters=fixed)
+                    pert = O.icp(s_r, t64, max_corr_dist=r, max_iter=30, icp_type=otype, fixed_iters=fixed)
                     Tb, Tq = base["est_transform"], pert["est_transform"]
                     e_f32 = float(np.abs((s @ Tb[:3, :3].T + Tb[:3, 3]) - (s @ Tq[:3, :3].T + Tq[:3, 3])).max())
                     if e_f32 > tol:
@@ -128,7 +132,7 @@ for case in range(n_cases):
                     # ... or, point-to-plane, on the last bits of the NORMALS: the kernel is handed float32 normals, the oracle made
                     # its own in double.  The oracle run on the very normals the kernel had must land where the kernel landed.
                     same = O.icp(one(src, soff).astype(np.float64), one(tgt, toff).astype(np.float64), max_corr_dist=r, max_iter=30,
-                                 icp_type=icp_type, fixed_iters=fixed, tgt_normals=np.ascontiguousarray(nrm_h[toff[p]:toff[p + 1]]))
+                                 icp_type=otype, fixed_iters=fixed, tgt_normals=np.ascontiguousarray(nrm_h[toff[p]:toff[p + 1]]))
                     Ts = same["est_transform"]
                     e_same = float(np.abs((s @ Ts[:3, :3].T + Ts[:3, 3]) - (s @ T[p, :3, :3].T + T[p, :3, 3])).max())
                     if e_same <= tol:
@@ -140,7 +144,7 @@ for case in range(n_cases):
                     # change crosses that value within rounding while a pass still moves the patch by more than the tolerance).
                     # The oracle made to run exactly the kernel's number of passes must land where the kernel landed.
                     forced = O.icp(one(src, soff).astype(np.float64), one(tgt, toff).astype(np.float64), max_corr_dist=r, max_iter=int(it_k[p]),
-                                   icp_type=icp_type, fixed_iters=True,
+                                   icp_type=otype, fixed_iters=True,
                                    tgt_normals=None if nrm_h is None else np.ascontiguousarray(nrm_h[toff[p]:toff[p + 1]]))
                     Tf = forced["est_transform"]
                     e_forced = float(np.abs((s @ Tf[:3, :3].T + Tf[:3, 3]) - (s @ T[p, :3, :3].T + T[p, :3, 3])).max())
@@ -158,8 +162,8 @@ for case in range(n_cases):
                 n1 = None if nrm_h is None else np.ascontiguousarray(nrm_h[toff[p]:toff[p + 1]])
                 line = []
                 for kk in range(1, int(max(it_k[p], ref["iters"][p])) + 3):
-                    o_ = O.icp(s1.astype(np.float64), t1_.astype(np.float64), max_corr_dist=r, max_iter=kk, icp_type=icp_type, fixed_iters=True, tgt_normals=n1)
-                    k_ = engine.piecewise_icp(dv(s1), dv(z[0]), dv(t1_), dv(z[1]), max_corr_dist=r, max_iter=kk, icp_type=icp_type, fixed_iters=True,
+                    o_ = O.icp(s1.astype(np.float64), t1_.astype(np.float64), max_corr_dist=r, max_iter=kk, icp_type=otype, fixed_iters=True, tgt_normals=n1)
+                    k_ = engine.piecewise_icp(dv(s1), dv(z[0]), dv(t1_), dv(z[1]), max_corr_dist=r, max_iter=kk, icp_type=icp_type, p2plane=sem, fixed_iters=True,
                                               search=SEARCH, tgt_normals=None if n1 is None else dv(n1))
                     Tk, To = k_["T"].cpu().numpy()[0], o_["est_transform"]
                     s64 = s1.astype(np.float64)

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Usage (GPU box, repo root): bash tools/gpu/profile_r3.sh <outdir> -- the rocprofv3 --kernel-trace --stats summaries committed under profiles/r3_*
-OUT=$1; mkdir -p $OUT
-cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+OUT="${1:?usage: $0 <outdir>}"; mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp; cd "${GRAFT_REPO_ROOT:?set GRAFT_REPO_ROOT (gpurun exports it: the root of the snapshot)}"
 run() {  # name, command...
   local name=$1; shift
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$name -- "$@" > $OUT/$name.log 2>&1

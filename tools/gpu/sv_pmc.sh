@@ -1,7 +1,7 @@
 #!/bin/bash
 # Usage (GPU box, repo root): bash tools/gpu/sv_pmc.sh <outdir>  -- counter passes of tools/gpu/sv_only.py, per-kernel means of the svg:: kernels
-OUT=$1; mkdir -p $OUT
-cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+OUT="${1:?usage: $0 <outdir>}"; mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp; cd "${GRAFT_REPO_ROOT:?set GRAFT_REPO_ROOT (gpurun exports it: the root of the snapshot)}"
 i=0
 # (a pass that asks for more counters of one block than the hardware has aborts inside rocprofv3 and never returns: two per pass, and a time limit)
 SETS=${SV_PMC_SETS:-"SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_ANY|SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_INSTS_LDS SQ_INSTS_BRANCH SQ_INST_CYCLES_SALU SQ_THREAD_CYCLES_VALU|TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum|TCC_HIT_sum TCC_MISS_sum|TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum|TA_BUSY_avr TCP_PENDING_STALL_CYCLES_sum|FETCH_SIZE|WRITE_SIZE"}

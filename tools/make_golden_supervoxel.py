@@ -76,6 +76,27 @@ def main():
               f"-> {os.path.getsize(path)} bytes")
 
 
+def large_fixture():
+    """tests/golden/sv_large_ref.npz: what the reference's own templates compute on a 300 k-point cloud -- 15 x the largest
+    of the small fixtures -- WITHOUT the cloud and its neighbour lists (regenerated from the seed at test time,
+    tests/_util.py::large_surface_cloud): labels, K, the grid-cell count, lambda0, and checksums of the cloud's bits, of the
+    neighbour indices and of the squared distances' bits."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from _util import LARGE_CASE, bits_checksum, large_surface_cloud
+    c = LARGE_CASE
+    xyz = large_surface_cloud(c["seed"], c["n"], c["extent"])
+    r = O.ref_supervoxel(xyz, c["k"], c["resolution"])
+    lam = O.ref_lambda0(xyz, r["normals"], r["knn_idx"], c["resolution"])
+    out = os.path.join(ROOT, "tests", "golden", "sv_large_ref.npz")
+    np.savez_compressed(out, labels=r["labels"].astype(np.int32), n_supervoxels=np.int32(r["n_supervoxels"]),
+                        n_grid_cells=np.int32(r["n_grid_cells"]), lambda0=np.float64(lam),
+                        xyz_checksum=np.uint64(bits_checksum(xyz)), knn_idx_checksum=np.uint64(bits_checksum(r["knn_idx"])),
+                        knn_d2_checksum=np.uint64(bits_checksum(r["knn_d2"])),
+                        normals_abs_sum=np.abs(r["normals"]).sum(axis=0))
+    print(f"large: n={c['n']} k={c['k']} res={c['resolution']} K={r['n_supervoxels']} cells={r['n_grid_cells']} lambda0={lam!r} "
+          f"-> {os.path.getsize(out)} bytes")
+
+
 def partition_text_fixture():
     """tests/golden/partition_txt_ref.npz: a small labelled cloud and the bytes the reference's own writer
     (codelibrary/geometry/io/xyz_io.h:192-221, driven like supervoxel.cpp:45-64) puts into the partition text file for it:
@@ -99,6 +120,9 @@ def partition_text_fixture():
 
 
 if __name__ == "__main__":
-    if "--text-only" not in sys.argv:
-        main()
-    partition_text_fixture()
+    if "--large" in sys.argv:
+        large_fixture()
+    else:
+        if "--text-only" not in sys.argv:
+            main()
+        partition_text_fixture()
