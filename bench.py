@@ -146,7 +146,8 @@ def run_rank(args, world):
     else:
         # every rank produces ITS share of the one cloud straight from the counter-based generator (a counting pass for the LPT
         # assignment, a keeping pass): no rank ever holds the whole 50 M-point cloud, and nothing is scattered between ranks
-        d, ids_per_rank = synthetic.make_rank_share_device(n, cells, res, dev, rank, world, seed=0)
+        # (the counting pass is shared between the ranks: every world-th chunk each, one all_reduce of the counts)
+        d, ids_per_rank = synthetic.make_rank_share_device(n, cells, res, dev, rank, world, seed=0, dist=dist)
         P_total = cells * cells
     if not dry:
         torch.cuda.empty_cache()
@@ -204,6 +205,9 @@ def run_rank(args, world):
                        "points_on_rank0": n_mine, "patches_on_rank0": P,
                        "icp": "point2point, 20 fixed iters, max_corr_dist 0.1 m, float64 search (parity mode)",
                        "parallelism": f"one cloud, patches LPT-sharded x{world}, all-gather of per-patch results",
+                       # what the process group really is (the first multi-GPU run proves "RCCL saw N ranks" from this line alone)
+                       "dist_backend": dist.get_backend() if world > 1 else None,
+                       "dist_world_size": dist.get_world_size() if world > 1 else 1,
                        "setup_seconds": round(t_setup, 2),
                        # (on a fresh box most of it is the first device call -- context, code objects paged in from a cold image --
                        #  and the allocator's first gigabytes; untimed, outside the metric)

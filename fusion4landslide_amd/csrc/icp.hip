@@ -92,6 +92,7 @@ struct IcpArgs {
     float dens;     // points per bounding-box cell a subdivided grid keeps on average
     double mu_frac; // certificate margin as a fraction of the correspondence radius ...
     double mu_cell; // ... and of the cell edge (the smaller of the two counts: fine grids, i.e. dense patches, get less)
+    double mu_cell_fine;  // ... of the cell edge on grids finer than the radius (wmax > 1)
     int debug;  // F4L_ICP_DEBUG env, bit switches for A/B measurements and tests: 4 = no certificates, 8 = no bound from
                 // the previous correspondence, 16 = no narrow look-up before pass 0 on fine grids, 128 = always the Jacobi
                 // SVD (no Newton), 64 = search counters (profiling build), 512 = no column grids (layers of cells in z for
@@ -448,7 +449,8 @@ __global__ __launch_bounds__(NW * 64, WIDE ? 3 : (sizeof(F) == 8 ? ICP_WAVES_PER
     __syncthreads();  // scratch is free again
     // margin of the certificates beyond the re-measured correspondence: a fraction of the radius, less on grids
     // finer than the radius (dense patches), where a wide margin would pull many points into every search
-    const F mu = rF * (F)a.mu_frac < g.h * (F)a.mu_cell ? rF * (F)a.mu_frac : g.h * (F)a.mu_cell;
+    const F mcell = g.h * (F)(g.wmax > 1 ? a.mu_cell_fine : a.mu_cell);
+    const F mu = rF * (F)a.mu_frac < mcell ? rF * (F)a.mu_frac : mcell;
 
     // Fused initialisation: weighted Kabsch of this patch's correspondences (scripts/weighted_svd.py:58-129, the same
     // arithmetic as kabsch_kernel<float, NW, false>): two streaming passes, block reductions, SVD on one thread.
@@ -978,6 +980,8 @@ __global__ __launch_bounds__(NW * 64, WIDE ? 3 : (sizeof(F) == 8 ? ICP_WAVES_PER
 
 }  // namespace f4l
 
+#include "icp_rows.h"
+
 namespace f4l {
 
 // Size classes: patch p goes to the first class whose bound holds max(sources, targets) of the patch.  The order inside
@@ -1028,6 +1032,16 @@ static int launch_icp(const IcpArgs &a, int mode, int nw, size_t lds, hipStream_
     return launch_icp_one<1, 4, F>(a, lds, st);
 }
 
+template <typename F>
+static int launch_rows(const IcpArgs &a, int lp, hipStream_t st) {
+    const int per_block = ROWS_WAVES * (64 / lp);
+    const unsigned blocks = (unsigned)((a.P + per_block - 1) / per_block);
+    if (lp == 16) hipLaunchKernelGGL((icp_rows_kernel<F, 16>), dim3(blocks), dim3(ROWS_WAVES * 64), 0, st, a);
+    else hipLaunchKernelGGL((icp_rows_kernel<F, 32>), dim3(blocks), dim3(ROWS_WAVES * 64), 0, st, a);
+    F4L_LAUNCH_CHECK();
+    return F4L_OK;
+}
+
 static inline int pow2_ceil(int64_t v) {
     int r = 1;
     while (r < v) r <<= 1;
@@ -1051,10 +1065,11 @@ static hipStream_t class_stream(int which) {
 }
 
 // Workgroup shape and LDS layout for patches of at most max_src sources and max_tgt targets.
-struct IcpPlan { int nw, tgt_cap, cell_cap, cert_cap, src_cap, pp_cap; size_t lds; bool wide; };
+struct IcpPlan { int nw, tgt_cap, cell_cap, cert_cap, src_cap, pp_cap; size_t lds; bool wide; int rows_lp; };
 // `throughput`: the launch holds many rounds of workgroups (see icp_launch_host): the shape that moves the most patches per
 // second wins, not the one that finishes a single patch soonest.
-static IcpPlan icp_plan(int64_t max_src_patch_host, int64_t max_tgt_patch_host, bool f64, int mode, bool throughput = false) {
+static IcpPlan icp_plan(int64_t max_src_patch_host, int64_t max_tgt_patch_host, bool f64, int mode, bool throughput = false,
+                        bool rows_ok = false) {
     const size_t pt = sizeof(GridPt<float>);  // 16 B in both modes
     // Waves per patch.  A patch's pass is a chain (certify, search, reduce, solve, three barriers): four waves finish it
     // soonest, which is what counts while a launch is only a few rounds of workgroups (C2: 0.72 ms against 0.80 ms with two
@@ -1118,6 +1133,15 @@ static IcpPlan icp_plan(int64_t max_src_patch_host, int64_t max_tgt_patch_host, 
     pl.nw = nw; pl.tgt_cap = tgt_cap; pl.cell_cap = cell_cap; pl.cert_cap = cert_cap; pl.src_cap = src_cap; pl.pp_cap = pp_cap;
     pl.lds = lds;
     pl.wide = wide;
+    // small patches, point-to-point: several patches per wave (icp_rows.h) -- 16 lanes per patch up to 64 points, 32 up to 128;
+    // where the caller allows it (icp_launch_host: `rows_ok`)
+    pl.rows_lp = 0;
+#ifndef F4L_ICP_PROF
+    if (rows_ok && mode == F4L_ICP_POINT2POINT && !getenv("F4L_ICP_WAVES")) {
+        const int64_t m = max_src_patch_host > max_tgt_patch_host ? max_src_patch_host : max_tgt_patch_host;
+        pl.rows_lp = m <= 64 ? 16 : (m <= 128 ? 32 : 0);
+    }
+#endif
     return pl;
 }
 }  // namespace f4l
@@ -1225,7 +1249,9 @@ static int f4l::icp_launch_host(const float *src, const int64_t *src_off, const 
     // (an eighth of a cell: C3 20.3 ms against 22.3 with a quarter -- a search scans everything within the previous
     //  correspondence's distance plus this margin, and on a fine grid the runner-up limits the certificate long before it)
     a.mu_cell = 0.125;
-    { const char *e = getenv("F4L_ICP_MU_CELL"); if (e && atof(e) > 0.0) a.mu_cell = atof(e); }
+    // (grids finer than the radius: a sixteenth -- C3 14.8 ms against 15.3 with an eighth and 17.1 with a quarter, round 4)
+    a.mu_cell_fine = 0.0625;
+    { const char *e = getenv("F4L_ICP_MU_CELL"); if (e && atof(e) > 0.0) a.mu_cell = a.mu_cell_fine = atof(e); }
     a.T_out = T_out; a.fitness_out = fitness_out; a.rmse_out = rmse_out; a.iters_out = iters_out; a.corr_out = corr_out;
 
     // throughput regime: six and more rounds of workgroups (1024 slots of four waves on the chip), where patches per second
@@ -1235,7 +1261,13 @@ static int f4l::icp_launch_host(const float *src, const int64_t *src_off, const 
     // 27.1 against 30.0 ms there.
     bool throughput = P >= 6144 && icp_plan(max_src_patch_host, max_tgt_patch_host, f64, mode, false).lds <= 48 * 1024;
     if (const char *e = getenv("F4L_ICP_THROUGHPUT")) throughput = atoi(e) != 0;
-    const IcpPlan pl = icp_plan(max_src_patch_host, max_tgt_patch_host, f64, mode, throughput);
+    // Several small patches per wave (icp_rows.h) pay where the launch is bound by issue slots, not by one wave's latency, and
+    // where the kernel does not spill: the float32 search from ~64 k patches on (10 M-point tile cut into 167 k supervoxel
+    // patches: 6.05 ms against 7.7 ms; float64: 9.0 against 8.8 ms -- 432 B of scratch per lane; the 1 M-point tile, 16.7 k
+    // patches, is slower with it in both modes: 1.57 against 1.22 ms).  F4L_ICP_ROWS = 1 / 0 forces it on / off.
+    bool rows_ok = !f64 && P >= 65536;
+    if (const char *e = getenv("F4L_ICP_ROWS")) rows_ok = atoi(e) != 0;
+    const IcpPlan pl = icp_plan(max_src_patch_host, max_tgt_patch_host, f64, mode, throughput, rows_ok);
     const int nw = pl.nw, tgt_cap = pl.tgt_cap, cell_cap = pl.cell_cap, cert_cap = pl.cert_cap, src_cap = pl.src_cap;
     const size_t lds = pl.lds;
     a.tgt_cap = tgt_cap; a.cert_cap = cert_cap; a.cell_cap = cell_cap; a.src_cap = src_cap; a.pp_cap = pl.pp_cap;
@@ -1333,9 +1365,11 @@ static int f4l::icp_launch_host(const float *src, const int64_t *src_off, const 
             }
         }
     }
-    if (cb.n == 0)
+    if (cb.n == 0) {
+        if (pl.rows_lp) return f64 ? launch_rows<double>(a, pl.rows_lp, (hipStream_t)stream) : launch_rows<float>(a, pl.rows_lp, (hipStream_t)stream);
         return f64 ? launch_icp<double>(a, mode, nw, lds, (hipStream_t)stream, pl.wide)
                    : launch_icp<float>(a, mode, nw, lds, (hipStream_t)stream, pl.wide);
+    }
     cb.bound[cb.n++] = (int)(big > 0x7fffffff ? 0x7fffffff : big);
     hipStream_t st = (hipStream_t)stream;
     int *buf = nullptr;
@@ -1369,7 +1403,7 @@ static int f4l::icp_launch_host(const float *src, const int64_t *src_off, const 
         for (int k = cb.n - 1; k >= 0 && rc == F4L_OK; --k) {
             const int64_t ms = max_src_patch_host < cb.bound[k] ? max_src_patch_host : cb.bound[k];
             const int64_t mt = max_tgt_patch_host < cb.bound[k] ? max_tgt_patch_host : cb.bound[k];
-            const IcpPlan pk = icp_plan(ms, mt, f64, mode, throughput);
+            const IcpPlan pk = icp_plan(ms, mt, f64, mode, throughput, rows_ok);
             IcpArgs ak = a;
             ak.tgt_cap = pk.tgt_cap; ak.cert_cap = pk.cert_cap; ak.cell_cap = pk.cell_cap; ak.src_cap = pk.src_cap; ak.pp_cap = pk.pp_cap;
             ak.list = buf + (size_t)k * (size_t)P; ak.list_cnt = cnt + k;
@@ -1380,7 +1414,8 @@ static int f4l::icp_launch_host(const float *src, const int64_t *src_off, const 
                 if (fail(hipStreamWaitEvent(sk, forked, 0))) break;
                 used[k] = sk;  // from here on the helper stream may hold work that reads the caller's buffers
             }
-            rc = f64 ? launch_icp<double>(ak, mode, pk.nw, pk.lds, sk, pk.wide) : launch_icp<float>(ak, mode, pk.nw, pk.lds, sk, pk.wide);
+            if (pk.rows_lp) rc = f64 ? launch_rows<double>(ak, pk.rows_lp, sk) : launch_rows<float>(ak, pk.rows_lp, sk);
+            else rc = f64 ? launch_icp<double>(ak, mode, pk.nw, pk.lds, sk, pk.wide) : launch_icp<float>(ak, mode, pk.nw, pk.lds, sk, pk.wide);
         }
     } while (false);
     // join every helper stream that was handed work (also after an error), then release

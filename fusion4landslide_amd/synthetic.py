@@ -254,22 +254,30 @@ def make_patches_device(n, cells, resolution, device, seed=0, noise=0.005, chunk
                 max_src=int((soff[1:] - soff[:-1]).max().item()), max_tgt=int((toff[1:] - toff[:-1]).max().item()))
 
 
-def make_rank_share_device(n, cells, resolution, device, rank, world, seed=0, noise=0.005, chunk=8_000_000):
+def make_rank_share_device(n, cells, resolution, device, rank, world, seed=0, noise=0.005, chunk=8_000_000, dist=None):
     """The share of `make_patches_device`'s cloud that rank `rank` of `world` owns under the LPT assignment of
     sharding.shard_cloud -- the same dict, bit for bit, as `shard_cloud(make_patches_device(...), rank, world)` -- WITHOUT any rank
     ever holding the whole cloud: a first pass over the generator counts the points per patch (both epochs; the assignment needs
-    nothing else), a second pass keeps the rank's own points.  Returns (share dict, ids_per_rank)."""
+    nothing else), a second pass keeps the rank's own points.  With `dist` (an initialised torch.distributed of `world` ranks)
+    the counting pass is SHARED: rank r counts every world-th chunk and one all_reduce(SUM) of the 2 P counts gives every rank
+    the whole cloud's -- one pass over the cloud per node instead of one per rank (integer sums: the same counts in any order).
+    Returns (share dict, ids_per_rank)."""
     import torch
 
     from .sharding import lpt_assign
     gen = _DeviceCloud(cells, resolution, device, seed, noise)
     P = cells * cells
-    cnt_s = torch.zeros(P, dtype=torch.int64, device=device)
-    cnt_t = torch.zeros(P, dtype=torch.int64, device=device)
-    for lo in range(0, n, chunk):
+    cnt = torch.zeros(2 * P, dtype=torch.int64, device=device)
+    shared = dist is not None and world > 1
+    for ci, lo in enumerate(range(0, n, chunk)):
+        if shared and ci % world != rank:
+            continue
         s, t = gen.chunk(lo, min(n, lo + chunk))
-        cnt_s += torch.bincount(gen.cell_of(s), minlength=P)
-        cnt_t += torch.bincount(gen.cell_of(t), minlength=P)
+        cnt[:P] += torch.bincount(gen.cell_of(s), minlength=P)
+        cnt[P:] += torch.bincount(gen.cell_of(t), minlength=P)
+    if shared:
+        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+    cnt_s, cnt_t = cnt[:P], cnt[P:]
     cs, ct = cnt_s.cpu().numpy(), cnt_t.cpu().numpy()
     ids_per_rank = lpt_assign(cs.astype(np.float64) * np.maximum(ct, 1), world)  # (sharding.patch_costs on the counts)
     mine = ids_per_rank[rank]

@@ -295,3 +295,115 @@ def test_a_tile_without_a_single_point_match():
     assert (dm == 0).all() and (ri == 0).all()
     R, t = engine.kabsch_batched(empty, empty, off0)
     assert R.shape == (3, 3, 3) and torch.isfinite(R).all()
+
+
+def test_rgb_guided_local_rigid_refinement_replay():
+    """`local_rigid_refinement_batched` + `segment_patches_from_labels` against a patch-by-patch replay of the reference's loop
+    (src/rgb_guided.py:935-979 and :981-1062) written with the oracle's per-patch functions in the reference's own order:
+
+        labels of the valid points -> segments with more than 10 of them, ascending id (:938-956) -> per patch: the rows whose
+        source id is in the patch, in the patch's order (:990-992) -> Kabsch of all rows, residuals, 2.5 x lower-median prune,
+        the 70 % flag (:994, 99-125) -> mask_valid_local (:1007) -> ICP of ALL rows (sources against targets) from the float32
+        Kabsch transform (:1009-1020) -> rows [src, float32(T_icp) src] (:1022-1047) -> filtered arrays, stacked rows (:1050-1061).
+
+    The scene holds a segment below the size bound, points labelled -1, a patch whose ids have no correspondence row at all
+    (contributes nothing), and a patch where fewer than 70 % of the rows survive the prune."""
+    from fusion4landslide_amd.src import rgb_guided
+    from tests._util import rot_from_axis_angle
+    rng = np.random.default_rng(31)
+    N = 6000
+    xy = rng.uniform(0, 4, (N, 2))
+    pts = np.c_[xy, 0.3 * np.sin(1.3 * xy[:, 0]) * np.cos(1.1 * xy[:, 1])].astype(np.float32)
+    labels = (np.floor(xy[:, 0]) * 4 + np.floor(xy[:, 1])).astype(np.int64)          # 16 square segments
+    labels[rng.choice(N, 150, replace=False)] = -1                                    # unlabelled points
+    labels[(xy[:, 0] < 0.12) & (xy[:, 1] < 0.12)] = 99                                # a tiny segment (a handful of valid points)
+    # 3D correspondences for 70 % of the points: per segment its own small rigid motion, plus noise and some outliers
+    valid = np.nonzero(rng.uniform(size=N) < 0.7)[0]
+    rng.shuffle(valid)                                                                # rows are NOT in id order
+    valid = valid[labels[valid] != 7]                                                 # segment 7: no valid point at all
+    tgt_pts = np.zeros((len(valid), 3))
+    for s in np.unique(labels):
+        m = labels[valid] == s
+        if not m.any():
+            continue
+        R = rot_from_axis_angle(rng.normal(size=3), rng.uniform(0, 0.006))
+        c = pts[valid[m]].mean(0).astype(np.float64)
+        tgt_pts[m] = (pts[valid[m]].astype(np.float64) - c) @ R.T + c + rng.uniform(-0.02, 0.02, 3) + rng.normal(0, 0.002, (m.sum(), 3))
+    out_rows = np.nonzero(labels[valid] == 5)[0]
+    tgt_pts[out_rows[: int(0.45 * len(out_rows))]] += rng.normal(0, 0.08, (int(0.45 * len(out_rows)), 3))  # segment 5: < 70 % survive
+    corres = np.c_[pts[valid], tgt_pts].astype(np.float32)
+    idx_src = valid.astype(np.int64)
+    idx_tgt = rng.permutation(len(valid)).astype(np.int64)
+    mag = np.linalg.norm(corres[:, 3:] - corres[:, :3], axis=1)[:, None].astype(np.float32)
+
+    seg = rgb_guided.segment_patches_from_labels(dev(labels), dev(idx_src), dev(idx_tgt), dev(corres), dev(mag))
+    # ---- replay of :938-979
+    lab_v = labels[idx_src]
+    uniq, cnt = np.unique(lab_v, return_counts=True)
+    keep_seg = [int(u) for u, c in zip(uniq, cnt) if c > 10 and u != -1]
+    assert 99 not in keep_seg and 7 not in keep_seg and len(keep_seg) == 15
+    ref_patches = [idx_src[np.where(lab_v == u)[0]] for u in keep_seg]
+    mask_pts = np.isin(lab_v, keep_seg)
+    assert len(seg["segment_patches"]) == len(ref_patches)
+    for a, b in zip(seg["segment_patches"], ref_patches):
+        assert np.array_equal(a.cpu().numpy(), b)
+    assert np.array_equal(seg["idx_valid_src_refine"].cpu().numpy(), idx_src[mask_pts])
+    assert np.array_equal(seg["idx_valid_tgt_refine"].cpu().numpy(), idx_tgt[mask_pts])
+    assert np.array_equal(seg["corres_3d_refine"].cpu().numpy(), corres[mask_pts])
+    assert seg["corres_3d_magnitude_refine"].shape[0] == len(mag)   # (the reference's mask never applies, :976-977)
+
+    # a patch whose ids have no row (ids of points without a correspondence) goes in front, like any other list entry
+    no_row = torch.from_numpy(np.setdiff1d(np.arange(N), idx_src)[:25]).cuda()
+    patches = [no_row] + seg["segment_patches"]
+    icp_thres = 0.05
+    got = rgb_guided.local_rigid_refinement_batched(seg["corres_3d_refine"], seg["idx_valid_src_refine"], patches, icp_thres,
+                                                    icp_refine=True, idx_valid_tgt_refine=seg["idx_valid_tgt_refine"],
+                                                    corres_3d_magnitude_refine=dev(mag[mask_pts]))
+    # ---- replay of :987-1061
+    ivs, c3 = idx_src[mask_pts], corres[mask_pts]
+    mask_valid_local, rows_ref, robust_ref, n_amb = [], [], [], 0
+    for patch_i in [no_row.cpu().numpy()] + ref_patches:
+        idx = np.concatenate([np.where(ivs == v)[0] for v in patch_i]) if len(patch_i) else np.zeros(0, np.int64)
+        if len(idx) == 0:
+            robust_ref.append(None)
+            continue
+        tc = c3[idx].astype(np.float64)
+        R, t, res = O.refine_local_rigid_correspondences_rgb(tc)
+        res32 = res.astype(np.float32)
+        med = np.sort(res32)[(len(res32) - 1) // 2]
+        m = res32 < np.float32(2.5) * med
+        n_amb += int((np.abs(res - 2.5 * float(med)) < 1e-5).sum())
+        mask_valid_local.append(idx[m])
+        robust_ref.append(m.sum() / len(m) >= 0.70)
+        T0 = np.eye(4)
+        T0[:3, :3], T0[:3, 3] = R, t
+        T0 = T0.astype(np.float32).astype(np.float64)                              # a float32 4 x 4 (:120-124)
+        icp = O.icp(tc[:, :3], tc[:, 3:], init_T=T0, max_corr_dist=icp_thres, max_iter=30)
+        T32 = icp["est_transform"].astype(np.float32)
+        s32 = c3[idx][:, :3]
+        rows_ref.append(np.c_[s32, (T32[:3, :3] @ s32.T).T + T32[:3, 3]])
+    mask_valid_local = np.concatenate(mask_valid_local)
+    rows_ref = np.concatenate(rows_ref)
+    assert robust_ref[0] is None and not robust_ref[1 + keep_seg.index(5)] and sum(bool(r) for r in robust_ref[1:]) >= 12
+    got_mask = got["mask_valid_local"].cpu().numpy()
+    if n_amb == 0:
+        assert np.array_equal(got_mask, mask_valid_local)
+    else:  # float32 residuals at the threshold may fall either side
+        assert len(np.setxor1d(got_mask, mask_valid_local)) <= 2 * n_amb
+    rb = got["mask_robust"].cpu().numpy()
+    assert [bool(x) for x in rb[1:]] == [bool(x) for x in robust_ref[1:]]
+    assert np.array_equal(got["idx_valid_src_refine"].cpu().numpy(), ivs[got_mask])
+    assert np.array_equal(got["idx_valid_tgt_refine"].cpu().numpy(), idx_tgt[mask_pts][got_mask])
+    assert np.array_equal(got["corres_3d_refine"].cpu().numpy(), c3[got_mask])
+    assert np.array_equal(got["corres_3d_magnitude_refine"].cpu().numpy(), mag[mask_pts][got_mask])
+    rows = got["corres_3d_refine_apply_icp"].cpu().numpy()
+    assert rows.shape == rows_ref.shape and np.array_equal(rows[:, :3], rows_ref[:, :3])
+    assert np.abs(rows[:, 3:] - rows_ref[:, 3:]).max() <= 2e-6 * np.abs(rows_ref).max() + 1e-6
+    assert np.allclose(got["corres_3d_magnitude_refine_apply_icp"].cpu().numpy()[:, 0],
+                       np.linalg.norm(rows[:, 3:] - rows[:, :3], axis=1), atol=1e-6)
+    assert int(got["iters"][0]) == -1 and int(got["patch_off"][1]) == 0               # the patch without rows: skipped
+    assert (got["iters"][1:] >= 1).all() and float(got["fitness"][1:].min()) > 0.3
+    # without ICP: the prune alone
+    lite = rgb_guided.local_rigid_refinement_batched(seg["corres_3d_refine"], seg["idx_valid_src_refine"], patches, icp_thres,
+                                                     icp_refine=False)
+    assert torch.equal(lite["mask_valid_local"], got["mask_valid_local"]) and "corres_3d_refine_apply_icp" not in lite

@@ -446,6 +446,82 @@ def test_icp_every_workgroup_shape_matches_oracle(eng, waves, monkeypatch):
     assert np.median(disp) <= 1e-5 and (disp <= 1e-4).mean() >= 0.85 and disp.max() <= 2e-3
 
 
+@pytest.mark.parametrize("fused", [False, True])
+def test_icp_several_small_patches_per_wave_match_oracle(eng, fused, monkeypatch):
+    """icp_rows.h (F4L_ICP_ROWS=1; by itself it runs for the float32 search from 64 k patches on): patches of up to 64 points on
+    16 lanes, up to 128 on 32, four / two per wave, no workgroup barrier.  Supervoxel-sized patches of every size from empty to
+    128 points (uneven: both lane widths and the ordinary kernel for the larger ones run side by side), float64 search against
+    the oracle's trajectories (1e-9 m on well-posed patches, equal iteration counts, fitness, final correspondences), the float32
+    search against its own bounds, and the fused launch (Kabsch start from correspondences, rows) against the three calls."""
+    rng = np.random.default_rng(41)
+    sizes = np.r_[rng.integers(20, 64, 150), rng.integers(64, 128, 100), rng.integers(128, 300, 12), [0, 1, 2, 3, 5, 64, 128, 63, 65]]
+    src_l, tgt_l = [], []
+    for m in sizes:
+        m = int(m)
+        side = max(0.15, np.sqrt(max(m, 1) / 120.0))
+        mt = max(0, m + int(rng.integers(-4, 5))) if m > 3 else m
+        mt = min(mt, 64) if m <= 64 else (min(mt, 128) if m <= 128 else mt)
+        xy = rng.uniform(0, side, (mt, 2))
+        t = np.c_[xy, 0.2 * np.sin(2.3 * xy[:, 0] / side) * np.cos(1.9 * xy[:, 1] / side) + rng.normal(0, 0.002, mt)]
+        xy2 = rng.uniform(0.05 * side, 0.95 * side, (m, 2))
+        s = np.c_[xy2, 0.2 * np.sin(2.3 * xy2[:, 0] / side) * np.cos(1.9 * xy2[:, 1] / side)]
+        s = s @ rot_from_axis_angle(rng.normal(size=3), rng.uniform(0, 0.008)).T + rng.uniform(-0.02, 0.02, 3)
+        o = rng.uniform(0, 40, 3)
+        src_l.append(s + o); tgt_l.append(t + o)
+    src, tgt = np.concatenate(src_l).astype(np.float32), np.concatenate(tgt_l).astype(np.float32)
+    soff, toff = ragged(None, [len(a) for a in src_l]), ragged(None, [len(a) for a in tgt_l])
+    d = dict(src=src, src_off=soff, P=len(sizes))
+
+    def _disp_per_patch(dd, Ta, Tb):  # (like the module's, with a 0 for an empty patch: indexable by patch masks)
+        out = np.zeros(dd["P"])
+        for p in range(dd["P"]):
+            s = dd["src"][dd["src_off"][p]:dd["src_off"][p + 1]].astype(np.float64)
+            if len(s):
+                out[p] = np.abs((s @ Ta[p, :3, :3].T + Ta[p, :3, 3]) - (s @ Tb[p, :3, :3].T + Tb[p, :3, 3])).max()
+        return out
+    args = (dev(src), dev(soff), dev(tgt), dev(toff))
+    monkeypatch.setenv("F4L_ICP_ROWS", "1")
+    monkeypatch.setenv("F4L_ICP_SMALLCLASSES", "1")
+    if not fused:
+        ref = O.piecewise_icp(src, soff, tgt, toff, max_corr_dist=0.1, max_iter=30)
+        out = eng.piecewise_icp(*args, max_corr_dist=0.1, max_iter=30, search="f64", return_corr=True)
+        well = (ref["fitness"] > 0.8) & (np.diff(soff) >= 12)
+        assert well.sum() > 200
+        assert _disp_per_patch(d, out["T"].cpu().numpy(), ref["T"])[well].max() <= 1e-9
+        assert np.array_equal(out["iters"].cpu().numpy()[well], ref["iters"][well])
+        assert np.array_equal(out["fitness"].cpu().numpy()[well], ref["fitness"][well])
+        assert np.abs(out["rmse"].cpu().numpy() - ref["rmse"])[well].max() <= 1e-10
+        monkeypatch.setenv("F4L_ICP_ROWS", "0")
+        plain = eng.piecewise_icp(*args, max_corr_dist=0.1, max_iter=30, search="f64", return_corr=True)
+        monkeypatch.setenv("F4L_ICP_ROWS", "1")
+        wt = torch.from_numpy(well).cuda()
+        pt_well = torch.repeat_interleave(wt, torch.from_numpy(np.diff(soff)).cuda())
+        assert torch.equal(out["corr"][pt_well], plain["corr"][pt_well])
+        assert (out["iters"][np.diff(soff) == 0] == 0).all()  # an empty source patch: nothing to iterate on
+        out32 = eng.piecewise_icp(*args, max_corr_dist=0.1, max_iter=30, search="f32")
+        disp = _disp_per_patch(d, out32["T"].cpu().numpy(), ref["T"])[well]
+        assert np.median(disp) <= 1e-5 and (disp <= 1e-4).mean() >= 0.85 and disp.max() <= 2e-3
+        again = eng.piecewise_icp(*args, max_corr_dist=0.1, max_iter=30, search="f64", return_corr=True)
+        for key in ("T", "fitness", "rmse", "iters", "corr"):
+            assert torch.equal(out[key], again[key]), key   # run-to-run bit identical
+    else:
+        cs, ct = dev(src), dev(src.astype(np.float64) + 0.003)  # Kabsch input: every source point and a shifted copy
+        ct = ct.to(torch.float32)
+        loop = eng.patch_loop(*args, cs, ct, dev(soff), None, 0.0, 1e-6, max_corr_dist=0.1, max_iter=20, fixed_iters=True,
+                              search="f64", min_corr=3)
+        T0 = eng.kabsch_transforms(cs, ct, dev(soff), None, 0.0, 1e-6)
+        monkeypatch.setenv("F4L_ICP_ROWS", "0")
+        sep = eng.piecewise_icp(*args, init_T=T0, max_corr_dist=0.1, max_iter=20, fixed_iters=True, search="f64")
+        n_corr = np.diff(soff)
+        run = torch.from_numpy(n_corr >= 3).cuda()
+        well = ((sep["fitness"] > 0.8) & run).cpu().numpy()
+        assert _disp_per_patch(d, loop["T"].cpu().numpy(), sep["T"].cpu().numpy())[well].max() <= 1e-9
+        assert torch.equal(loop["iters"][~run], torch.full_like(loop["iters"][~run], -1))   # fewer than min_corr pairs: skipped
+        rows = eng.apply_transform(dev(src), dev(soff), loop["T"])
+        pt_run = torch.repeat_interleave(run, torch.from_numpy(n_corr).cuda())
+        assert torch.equal(loop["rows"][pt_run], rows[pt_run]) and bool((loop["rows"][~pt_run] == 0).all())
+
+
 @pytest.mark.parametrize("switch,what", [("4", "no certificates: every point searched in every pass"),
                                          ("8", "no bound from the previous correspondence"),
                                          ("128", "Jacobi SVD instead of Newton on SO(3)")])
@@ -1001,7 +1077,7 @@ def test_icp_cell_shape_changes_no_answer(eng, search, monkeypatch):
     args = (dev(src), dev(soff), dev(tgt), dev(toff))
     kw = dict(max_corr_dist=0.1, max_iter=20, fixed_iters=True, search=search, return_corr=True)
     out = eng.piecewise_icp(*args, **kw)
-    assert float(out["fitness"].min()) > 0.3
+    assert float((out["fitness"] > 0.3).double().mean()) > 0.4 and float(out["fitness"][-2:].min()) > 0.9  # (blocks moved out of reach: 0)
     monkeypatch.setenv("F4L_ICP_DEBUG", "4")
     plain = eng.piecewise_icp(*args, **kw)
     dd = dict(src=src, src_off=soff, P=len(soff) - 1)

@@ -196,6 +196,7 @@ def test_bench_gpus2_dry_run_starts_two_ranks():
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["dry_run"] and line["dry_run_gather_ok"] and line["value"] is None
     assert line["scaling"] == "strong" and line["config"]["patches"] == 64 and line["config"]["patches_on_rank0"] == 32
+    assert line["config"]["dist_backend"] == "gloo" and line["config"]["dist_world_size"] == 2  # (nccl = RCCL on the GPUs)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], capture_output=True, text=True,
                        env=dict(env, WORLD_SIZE="4"), timeout=60)
     assert r.returncode == 2 and "WORLD_SIZE=4" in r.stderr
@@ -222,6 +223,42 @@ def test_rank_share_generated_alone_equals_the_share_of_the_whole_cloud():
         assert (seen == 1).all()
 
 
+def _share_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from fusion4landslide_amd import synthetic
+    b, ids = synthetic.make_rank_share_device(120_000, 11, 1.386, torch.device("cpu"), rank, world, seed=3, chunk=17_000, dist=dist)
+    q.put((rank, {k: (v.numpy() if hasattr(v, "numpy") else v) for k, v in b.items()}, [i.tolist() for i in ids]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rank_share_with_the_counting_pass_shared_between_the_ranks():
+    """make_rank_share_device(dist=...): every rank counts every world-th chunk of the generator and ONE all_reduce(SUM) of the
+    per-patch counts gives all of them the whole cloud's (one counting pass per node instead of one per
+    rank).  Three gloo ranks, eight chunks: every rank's share is still bit for bit the share of the whole cloud."""
+    from fusion4landslide_amd import sharding, synthetic
+    world = 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_share_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    whole = synthetic.make_patches_device(120_000, 11, 1.386, torch.device("cpu"), seed=3, chunk=50_000)
+    for rank, b, ids in got:
+        a, ids_a = sharding.shard_cloud(whole, rank, world)
+        assert all(np.array_equal(x, np.asarray(y)) for x, y in zip(ids_a, ids))
+        for k in ("src", "src_off", "tgt", "tgt_off"):
+            assert np.array_equal(a[k].numpy(), b[k]), (rank, k)
+
+
 @pytest.mark.timeout(600)
 def test_bench_gpus8_dry_run_is_one_line_of_eight_ranks():
     """The orchestration of an 8-GPU node (`--gpus 8 --dry-run`: eight gloo ranks on CPU tensors, every rank generating only its own
@@ -238,3 +275,4 @@ def test_bench_gpus8_dry_run_is_one_line_of_eight_ranks():
     line = json.loads(lines[0])
     assert line["n_gpus"] == 8 and line["dry_run"] and line["dry_run_gather_ok"] and line["value"] is None
     assert line["config"]["patches"] == 64 and line["config"]["patches_on_rank0"] == 8
+    assert line["config"]["dist_backend"] == "gloo" and line["config"]["dist_world_size"] == 8

@@ -21,10 +21,10 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _cloud():
+def _cloud(n=N, lx=6.0):
     rng = np.random.default_rng(11)
-    xy = rng.uniform(0, 1, (N, 2)) * [6.0, 3.0]
-    z = 0.2 * np.sin(2 * xy[:, 0]) * np.cos(3 * xy[:, 1]) + rng.normal(0, 0.003, N)
+    xy = rng.uniform(0, 1, (n, 2)) * [lx, 3.0]
+    z = 0.2 * np.sin(2 * xy[:, 0]) * np.cos(3 * xy[:, 1]) + rng.normal(0, 0.003, n)
     return np.c_[xy, z].astype(np.float32)
 
 
@@ -41,11 +41,11 @@ def _segment(p, normals, knn, res, grid_bbox):
     return torch.from_numpy(r["labels"]), r["n_supervoxels"]
 
 
-def _target_cloud():
+def _target_cloud(n=N, lx=6.0):
     """The second epoch: the same surface sampled elsewhere and displaced by a few centimetres (more than the point spacing)."""
     rng = np.random.default_rng(12)
-    xy = rng.uniform(0, 1, (N + 500, 2)) * [6.0, 3.0]
-    z = 0.2 * np.sin(2 * xy[:, 0]) * np.cos(3 * xy[:, 1]) + rng.normal(0, 0.003, N + 500)
+    xy = rng.uniform(0, 1, (n + 500, 2)) * [lx, 3.0]
+    z = 0.2 * np.sin(2 * xy[:, 0]) * np.cos(3 * xy[:, 1]) + rng.normal(0, 0.003, n + 500)
     return (np.c_[xy, z] + [0.07, -0.05, 0.02]).astype(np.float32)
 
 
@@ -55,17 +55,18 @@ def _nn(cloud, queries):
     return torch.from_numpy(i.astype(np.int64)), torch.from_numpy(d * d)
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, n=N, lx=6.0):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("OMP_NUM_THREADS", "1")
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from fusion4landslide_amd import slabs
-    xyz = _cloud()
-    mine = np.arange(rank, N, world)  # an arbitrary chunk per rank: every world-th point
+    xyz = _cloud(n, lx)
+    mine = np.arange(rank, n, world)  # an arbitrary chunk per rank: every world-th point
     out = slabs.slab_supervoxel(torch.from_numpy(xyz[mine]), torch.from_numpy(mine.astype(np.int64)), K_NN, RES, dist, rank, world, HALO,
                                 knn_normals_fn=_knn_normals, segment_fn=_segment)
-    tgt = _target_cloud()
+    tgt = _target_cloud(n, lx)
     tmine = np.arange(world - 1 - rank, len(tgt), world)
     tg = slabs.slab_targets(torch.from_numpy(tgt[tmine]), out, dist, rank, world, HALO, nn_fn=_nn)
     out["tgt_xyz"], out["tgt_src_gid"], out["tgt_d2"] = tg["xyz"], out["gid"][tg["nn"]], tg["d2"]
@@ -75,22 +76,24 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.timeout(600)
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_slab_split_matches_the_whole_cloud(world):
+    """(world 8: the split of a whole node, on a cloud long enough along x for eight slabs wider than the halo.)"""
     from oracle import oracle as O
     from oracle import sv_parallel as M
+    N, lx = (9000, 6.0) if world < 8 else (24000, 16.0)  # noqa: N806 (shadows the module's default on purpose)
     port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, N, lx)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=500) for _ in range(world)], key=lambda r: r[0])
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    xyz = _cloud()
+    xyz = _cloud(N, lx)
     gidx, gd2 = O.knn(xyz, K_NN)
     bounds = res[0][2]
     assert all(r[2] == bounds for r in res) and bounds[0] == 0 and sorted(bounds) == bounds
@@ -123,7 +126,7 @@ def test_slab_split_matches_the_whole_cloud(world):
     # the second epoch: every target point ends on exactly one rank, the one that owns its nearest source point of the WHOLE
     # first epoch (so that it joins a patch that lives there); points near a cut were forwarded
     from scipy.spatial import cKDTree
-    tgt = _target_cloud()
+    tgt = _target_cloud(N, lx)
     d_ref, i_ref = cKDTree(xyz.astype(np.float64)).query(tgt.astype(np.float64), k=1)
     got_xyz = np.concatenate([r[1]["tgt_xyz"] for r in res])
     got_gid = np.concatenate([r[1]["tgt_src_gid"] for r in res])
