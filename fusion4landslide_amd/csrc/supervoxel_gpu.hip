@@ -653,11 +653,22 @@ __device__ __forceinline__ void block_reserve2(unsigned long long *counter0, int
     at1 = s.base[1] + (unsigned long long)(s.c1[wave] + x1 - n1);
     __syncthreads();  // (the scratch is reused by the next call)
 }
-__device__ __forceinline__ unsigned int edge_slot(int32_t u, int32_t v, unsigned int ts32) {
+__device__ __forceinline__ unsigned int edge_hash(int32_t u, int32_t v) {
     unsigned int h = (unsigned int)u * 0x9E3779B1u ^ ((unsigned int)v * 0x85EBCA6Bu + 0x7F4A7C15u);
     h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12; h *= 0x297A2D39u; h ^= h >> 15;
-    return __umulhi(h * 0x9E3779B1u, ts32);
+    return h;
 }
+__device__ __forceinline__ unsigned int edge_slot(int32_t u, int32_t v, unsigned int ts32) {
+    return __umulhi(edge_hash(u, v) * 0x9E3779B1u, ts32);
+}
+// The workgroup's own filter of the round that writes the first list (r = KNN_ROUNDS), in LDS, in front of the device-wide one:
+// by then a supervoxel holds a dozen points, so the 256 consecutive points (Z-curve order) a workgroup takes at a time belong to a
+// few dozen supervoxels, and nine of ten of their rows' edges repeat an edge the workgroup has just passed on.  Every one of those
+// used to be an exchange with a random word of a table of n k / 4 words (600 MB at 10 M points): a 64-byte read-modify-write at
+// the memory side each -- that round alone took 4.7 of the 9.4 ms of the four neighbour-list rounds (profiles/r4_e_sv_trace_10M.log).
+// Direct mapped like the others: an edge that finds itself in its slot is parallel to one already listed in this launch and is
+// dropped; what another edge displaced is forgotten (it then meets the device-wide filter: nothing is lost but a slot).
+constexpr int ROW_FILTER = 2048;  // slots (16 KB of LDS)
 constexpr int ROW_SEEN = 8;
 constexpr int ROW_CHUNK = 10;
 constexpr int SWEEP_CHUNK = 10;  // representatives a lane remembers having met in its row (most of a row's edges lead to a few supervoxels)
@@ -676,6 +687,11 @@ __device__ __forceinline__ void rows_body(const SegArgs &a, int r) {
     const float *__restrict__ xyz = a.xyz;
     const int32_t *__restrict__ knnT = a.knnT;
     __shared__ CountScratch scratch;
+    __shared__ unsigned long long row_filter[ROW_FILTER];
+    if (emit) {
+        for (int t = (int)threadIdx.x; t < ROW_FILTER; t += (int)blockDim.x) row_filter[t] = DEAD;
+        __syncthreads();
+    }
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x; i0 < n; i0 += stride) {  // whole workgroups iterate together
         const int64_t i = i0 + threadIdx.x;
@@ -724,6 +740,14 @@ __device__ __forceinline__ void rows_body(const SegArgs &a, int r) {
                     // a list: an edge between two representatives without members cannot be any other edge of the list too; the
                     // others pass the device-wide filter (see build_body) -- the chunk's exchanges are issued together
                     asked[c] = fresh[c] && emit && !(nu.size == 1 && nq[c].size == 1);
+                    if (asked[c]) {  // the workgroup's own filter first (see ROW_FILTER)
+                        const unsigned long long key = ((unsigned long long)(unsigned int)u << 32) | (unsigned int)v;
+                        if (__hip_atomic_exchange(&row_filter[edge_hash(u, v) & (ROW_FILTER - 1)], key, __ATOMIC_RELAXED,
+                                                  __HIP_MEMORY_SCOPE_WORKGROUP) == key) {
+                            asked[c] = false;
+                            fresh[c] = false;
+                        }
+                    }
                 }
                 unsigned long long found[ROW_CHUNK];
 #pragma unroll
