@@ -42,7 +42,6 @@ template <typename F> __device__ __forceinline__ Nn3<F> nn3_merge(const Nn3<F> &
     r.second = loser < s ? loser : s;
     return r;
 }
-template <int CTRL, typename F> __device__ __forceinline__ Nn3<F> nn3_dpp(const Nn3<F> &v);
 template <int CTRL> __device__ __forceinline__ Nn3<double> nn3_dpp_d(const Nn3<double> &v) {
     Nn3<double> o; o.d = dpp_f64<CTRL>(v.d); o.t = dpp_u32<CTRL>(v.t); o.second = dpp_f64<CTRL>(v.second); return o;
 }
