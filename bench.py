@@ -57,7 +57,7 @@ MAX_CORR = 0.1
 SV_BYTES_PER_PT = 160        # kNN 132 B + normals 24 B + labels 4 B per point
 VALU_PEAK_GCYC = 256 * 4 * 2.4  # G SIMD-cycles of vector issue per second: 256 CUs x 4 SIMD-32 x 2.4 GHz (MI355X_MICROARCH.md); a wave64
                                 # float32 / integer instruction takes 2 of them, a float64 one 4
-KERNEL_SOURCES = {"icp": ("icp.hip", "patch_grid.h", "f4l_device.h"), "knn": ("knn.hip", "lane_topk.h", "topk.h", "f4l_device.h"),
+KERNEL_SOURCES = {"icp": ("icp.hip", "icp_rows.h", "ldlt6.h", "patch_grid.h", "f4l_device.h"), "knn": ("knn.hip", "lane_topk.h", "topk.h", "f4l_device.h"),
                   "supervoxel": ("supervoxel_gpu.hip", "sv_metric.h", "select.hip", "knn.hip", "lane_topk.h", "topk.h", "f4l_device.h")}
 
 
