@@ -32,6 +32,8 @@ SIGNATURES = {
     "f4l_kabsch_residuals": (C.c_int, [_P, _P, _P, _I64, _I64, _P, _P, _P, _P]),
     "f4l_piecewise_icp": (C.c_int, [_P, _P, _P, _P, _I64, _P, _P, _D, _I, _D, _D, _I, _I, _I, _I64, _I64, _I64, _P, _P,
                                     _P, _P, _P, _P]),
+    "f4l_piecewise_gicp": (C.c_int, [_P, _P, _P, _P, _I64, _P, _P, _P, _D, _D, _I, _D, _D, _I, _I64, _I64, _I64, _P, _P, _P, _P, _P,
+                                     _P]),
     "f4l_patch_loop": (C.c_int, [_P, _P, _P, _P, _I64, _P, _P, _P, _P, _I64, _D, _D, _P, _D, _I, _D, _D, _I, _I, _I, _I64, _I64, _I64, _P,
                                  _P, _P, _P, _P, _P, _P, _P, _P]),
     "f4l_mutual_correspondences": (C.c_int, [_P, _P, _P, _P, _I64, _P, _I64, _P, _P, _P]),

@@ -76,6 +76,10 @@ struct IcpArgs {
     const float *tgt_normals;
     int normals_f64;  // tgt_normals points at doubles (F4L_ICP_NORMALS_F64)
     int p2pl_open3d;  // point-to-plane steps with Open3D's own semantics (F4L_ICP_P2PL_OPEN3D), see p2plane_step_open3d
+    // generalized ICP (F4L_ICP_GENERALIZED, f4l_piecewise_gicp): the source's normals (double [n_src][3]; the target's through
+    // tgt_normals, double) and the estimator's epsilon
+    const double *src_normals;
+    double gicp_eps;
     double r, r2;
     int max_iter;
     double rel_fitness, rel_rmse;
@@ -569,7 +573,9 @@ __global__ __launch_bounds__(NW * 64, WIDE ? 3 : (sizeof(F) == 8 ? ICP_WAVES_PER
         PROF_T(pt_p0);
 
         // one accepted correspondence (p: moved source point, q: target, d: squared distance, bj: target index)
-        auto accumulate = [&](F px, F py, F pz, F qx, F qy, F qz, F d, int bj) {
+        // (si: the source point's index inside its patch -- generalized ICP reads its normal)
+        auto accumulate = [&](F px, F py, F pz, F qx, F qy, F qz, F d, int bj, int si) {
+            (void)si;
             const A dpx = (A)(px - cpx), dpy = (A)(py - cpy), dpz = (A)(pz - cpz);
             const A dqx = (A)(qx - cpx), dqy = (A)(qy - cpy), dqz = (A)(qz - cpz);
             acc[0] += (A)1;
@@ -580,6 +586,52 @@ __global__ __launch_bounds__(NW * 64, WIDE ? 3 : (sizeof(F) == 8 ? ICP_WAVES_PER
                 acc[8] += dqx * dpx; acc[9] += dqx * dpy; acc[10] += dqx * dpz;
                 acc[11] += dqy * dpx; acc[12] += dqy * dpy; acc[13] += dqy * dpz;
                 acc[14] += dqz * dpx; acc[15] += dqz * dpy; acc[16] += dqz * dpz;
+            } else if (MODE == F4L_ICP_GENERALIZED) {
+                // Open3D's TransformationEstimationForGeneralizedICP (GeneralizedICP.cpp): per pair M = C_q + C_s, three residual
+                // rows W (p - q) with W = M^-1/2 and Jacobian rows W [-[p]x | I].  Only W^T W = M^-1 enters the normal
+                // equations: J^T J = A^T M^-1 A, J^T r = A^T M^-1 d with A = [-[p]x | I] -- no matrix square root here (the
+                // oracle takes it, as Open3D does).  The covariances come from the normals (InitializePointCloudFor
+                // GeneralizedICP: Rx diag(eps, 1, 1) Rx^T = I - (1 - eps) n n^T for a unit normal; GetRotationFromE1ToX
+                // returns the identity for n.x < -0.99, i.e. such a point gets e1's covariance), and the source's turns with
+                // the cloud (PointCloud::Transform): R C_s R^T = I - (1 - eps) (R n)(R n)^T with the accumulated rotation.
+                // Rows p x w and w, like point-to-plane's: the system moves to the caller's origin the same way.
+                const double *nq = reinterpret_cast<const double *>(a.tgt_normals) + 3 * (t0 + bj);
+                const double *np_ = a.src_normals + 3 * (s0 + si);
+                double tx = nq[0], ty = nq[1], tz = nq[2];
+                if (tx < -0.99) { tx = 1.0; ty = 0.0; tz = 0.0; }
+                double sx = np_[0], sy = np_[1], sz = np_[2];
+                if (sx < -0.99) { sx = 1.0; sy = 0.0; sz = 0.0; }
+                const double ux = (double)R0 * sx + (double)R1 * sy + (double)R2 * sz;
+                const double uy = (double)R3 * sx + (double)R4 * sy + (double)R5 * sz;
+                const double uz = (double)R6 * sx + (double)R7 * sy + (double)R8 * sz;
+                const double k = 1.0 - a.gicp_eps;
+                const double m00 = 2.0 - k * (tx * tx + ux * ux), m01 = -k * (tx * ty + ux * uy), m02 = -k * (tx * tz + ux * uz);
+                const double m11 = 2.0 - k * (ty * ty + uy * uy), m12 = -k * (ty * tz + uy * uz), m22 = 2.0 - k * (tz * tz + uz * uz);
+                // inverse by cofactors over the determinant (what Eigen's 3 x 3 inverse does; no singularity check there either)
+                const double c00 = m11 * m22 - m12 * m12, c01 = m02 * m12 - m01 * m22, c02 = m01 * m12 - m02 * m11;
+                const double idet = 1.0 / (m00 * c00 + m01 * c01 + m02 * c02);
+                double I[3][3];
+                I[0][0] = c00 * idet; I[0][1] = c01 * idet; I[0][2] = c02 * idet;
+                I[1][1] = (m00 * m22 - m02 * m02) * idet; I[1][2] = (m01 * m02 - m00 * m12) * idet;
+                I[2][2] = (m00 * m11 - m01 * m01) * idet;
+                I[1][0] = I[0][1]; I[2][0] = I[0][2]; I[2][1] = I[1][2];
+                const double p3[3] = {(double)dpx, (double)dpy, (double)dpz};
+                const double dd[3] = {(double)(dpx - dqx), (double)(dpy - dqy), (double)(dpz - dqz)};
+                // columns of A: a0 = (0, -pz, py), a1 = (pz, 0, -px), a2 = (-py, px, 0), a3..5 = e0..2;  h_v = M^-1 a_v
+                double Acol[6][3] = {{0.0, -p3[2], p3[1]}, {p3[2], 0.0, -p3[0]}, {-p3[1], p3[0], 0.0}, {1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+                double H[6][3];
+#pragma unroll
+                for (int v = 0; v < 6; ++v)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) H[v][c] = I[c][0] * Acol[v][0] + I[c][1] * Acol[v][1] + I[c][2] * Acol[v][2];
+                int kk = 2;
+#pragma unroll
+                for (int u = 0; u < 6; ++u)
+#pragma unroll
+                    for (int v = u; v < 6; ++v)
+                        acc[kk++] += (A)(Acol[u][0] * H[v][0] + Acol[u][1] * H[v][1] + Acol[u][2] * H[v][2]);
+#pragma unroll
+                for (int u = 0; u < 6; ++u) acc[23 + u] += (A)(H[u][0] * dd[0] + H[u][1] * dd[1] + H[u][2] * dd[2]);
             } else {
                 A nx, ny, nz;  // (float32 normals, or the doubles Open3D keeps: F4L_ICP_NORMALS_F64)
                 if (a.normals_f64) {
@@ -646,7 +698,7 @@ __global__ __launch_bounds__(NW * 64, WIDE ? 3 : (sizeof(F) == 8 ? ICP_WAVES_PER
                 cert = cert && valid;
                 const bool hit = cert && pv < 0xfffe && d < r2;
                 const int qid = (int)(q.tag >> 16);
-                if (hit) accumulate(px, py, pz, qx, qy, qz, d, qid);
+                if (hit) accumulate(px, py, pz, qx, qy, qz, d, qid, ii);
                 if (a.corr_out && cert) a.corr_out[s0 + i] = hit ? qid : -1;
                 const bool need = valid && !cert;
                 const unsigned long long m = __ballot(need);
@@ -725,7 +777,7 @@ __global__ __launch_bounds__(NW * 64, WIDE ? 3 : (sizeof(F) == 8 ? ICP_WAVES_PER
                 F qx, qy, qz;
                 if (tgt_in_lds) { const GridPt<F> q = tl[best.slot()]; grid_rel(g, q, qx, qy, qz); }
                 else { qx = (F)tg[3 * bj] - (F)ox; qy = (F)tg[3 * bj + 1] - (F)oy; qz = (F)tg[3 * bj + 2] - (F)oz; }
-                accumulate(px, py, pz, qx, qy, qz, best.d2(), bj);
+                accumulate(px, py, pz, qx, qy, qz, best.d2(), bj, i);
             }
         }
 
@@ -825,8 +877,8 @@ __global__ __launch_bounds__(NW * 64, WIDE ? 3 : (sizeof(F) == 8 ? ICP_WAVES_PER
                 } else {
                     double x[6];
                     bool caller_frame = false;  // x is the solution about the caller's origin (else about the patch's)
-                    if (a.p2pl_open3d) {
-                        // Open3D's own step: solved whatever the rank of the system, applied whenever there is a correspondence
+                    if (MODE == F4L_ICP_GENERALIZED || a.p2pl_open3d) {
+                        // Open3D's own step (SolveJacobianSystemAndObtainExtrinsicMatrix; the only one generalized ICP has): solved whatever the rank of the system, applied whenever there is a correspondence
                         p2plane_step_open3d((int)((const unsigned char *)scratch - smem_raw), SUM_ROWS,
                                             (int)((const unsigned char *)state - smem_raw), ox, oy, oz);
                         have = true;
@@ -1027,6 +1079,13 @@ static int launch_icp(const IcpArgs &a, int mode, int nw, size_t lds, hipStream_
         if (nw == 2) return wide ? launch_icp_one<0, 2, F, true>(a, lds, st) : launch_icp_one<0, 2, F>(a, lds, st);
         return launch_icp_one<0, 4, F>(a, lds, st);
     }
+    if (mode == F4L_ICP_GENERALIZED) {  // double only, no wide shape (icp_plan)
+        if constexpr (sizeof(F) == 8) {
+            if (nw == 1) return launch_icp_one<2, 1, F>(a, lds, st);
+            if (nw == 2) return launch_icp_one<2, 2, F>(a, lds, st);
+            return launch_icp_one<2, 4, F>(a, lds, st);
+        } else return F4L_EUNSUPPORTED;
+    }
     if (nw == 1) return launch_icp_one<1, 1, F>(a, lds, st);
     if (nw == 2) return wide ? launch_icp_one<1, 2, F, true>(a, lds, st) : launch_icp_one<1, 2, F>(a, lds, st);
     return launch_icp_one<1, 4, F>(a, lds, st);
@@ -1080,10 +1139,11 @@ static IcpPlan icp_plan(int64_t max_src_patch_host, int64_t max_tgt_patch_host, 
     bool wide = false;
     if (max_src_patch_host <= 64) nw = 1;
     else if (max_src_patch_host <= 128) nw = 2;
-    else if (throughput && !getenv("F4L_ICP_NOWIDE")) { nw = 2; wide = f64; }  // (the float32 build fits 128 VGPRs without scratch)
+    else if (throughput && mode != F4L_ICP_GENERALIZED && !getenv("F4L_ICP_NOWIDE")) { nw = 2; wide = f64; }  // (the float32 build fits 128 VGPRs without scratch)
     const bool tiers = throughput && nw == 2;
     { const char *e = getenv("F4L_ICP_WAVES"); if (e) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) { nw = v; wide = wide && v == 2; } } }
     if (getenv("F4L_ICP_WIDE")) wide = nw == 2;
+    if (mode == F4L_ICP_GENERALIZED) wide = false;
 
     // LDS plan: targets first (they make the grid possible), then the prefix table, then the certificate arrays
     // (partial-sum region: as SCRATCH in icp_kernel)
@@ -1158,6 +1218,8 @@ struct IcpFusedExtra {
     int init_round_f32 = 0;
     int normals_f64 = 0;
     int p2pl_open3d = 0;
+    const double *src_normals = nullptr;
+    double gicp_eps = 0.0;
 };
 static int icp_launch_host(const float *src, const int64_t *src_off, const float *tgt, const int64_t *tgt_off,
                            int64_t P, const double *init_T, const float *tgt_normals, double max_corr_dist,
@@ -1180,6 +1242,22 @@ extern "C" int f4l_piecewise_icp(const float *src, const int64_t *src_off, const
     return f4l::icp_launch_host(src, src_off, tgt, tgt_off, P, init_T, tgt_normals, max_corr_dist, max_iter, rel_fitness,
                                 rel_rmse, mode, fixed_iters, search_precision, max_src_patch_host, max_tgt_patch_host,
                                 n_src_host, T_out, fitness_out, rmse_out, iters_out, corr_out, fx, stream);
+}
+
+extern "C" int f4l_piecewise_gicp(const float *src, const int64_t *src_off, const float *tgt, const int64_t *tgt_off, int64_t P,
+                                  const double *init_T, const double *src_normals, const double *tgt_normals, double epsilon,
+                                  double max_corr_dist, int max_iter, double rel_fitness, double rel_rmse, int fixed_iters,
+                                  int64_t max_src_patch_host, int64_t max_tgt_patch_host, int64_t n_src_host, double *T_out,
+                                  double *fitness_out, double *rmse_out, int32_t *iters_out, int32_t *corr_out, void *stream) {
+    f4l::IcpFusedExtra fx;
+    fx.normals_f64 = 1;
+    fx.p2pl_open3d = 1;
+    fx.src_normals = src_normals;
+    fx.gicp_eps = epsilon;
+    return f4l::icp_launch_host(src, src_off, tgt, tgt_off, P, init_T, reinterpret_cast<const float *>(tgt_normals), max_corr_dist,
+                                max_iter, rel_fitness, rel_rmse, F4L_ICP_GENERALIZED, fixed_iters, F4L_SEARCH_F64,
+                                max_src_patch_host, max_tgt_patch_host, n_src_host, T_out, fitness_out, rmse_out, iters_out,
+                                corr_out, fx, stream);
 }
 
 extern "C" int f4l_patch_loop(const float *src, const int64_t *src_off, const float *tgt, const int64_t *tgt_off,
@@ -1216,9 +1294,11 @@ static int f4l::icp_launch_host(const float *src, const int64_t *src_off, const 
     if (P < 0 || !src_off || !tgt_off || !T_out || max_iter < 0 || max_src_patch_host < 0 || max_tgt_patch_host < 0 ||
         n_src_host < 0)
         return F4L_EINVAL;
-    if (mode != F4L_ICP_POINT2POINT && mode != F4L_ICP_POINT2PLANE) return F4L_EINVAL;
+    if (mode != F4L_ICP_POINT2POINT && mode != F4L_ICP_POINT2PLANE && mode != F4L_ICP_GENERALIZED) return F4L_EINVAL;
     if (search_precision != F4L_SEARCH_F32 && search_precision != F4L_SEARCH_F64) return F4L_EINVAL;
-    if (mode == F4L_ICP_POINT2PLANE && max_tgt_patch_host > 0 && !tgt_normals) return F4L_EINVAL;
+    if (mode != F4L_ICP_POINT2POINT && max_tgt_patch_host > 0 && !tgt_normals) return F4L_EINVAL;
+    if (mode == F4L_ICP_GENERALIZED && ((max_src_patch_host > 0 && !fx.src_normals) || !fx.normals_f64 || !(fx.gicp_eps >= 0.0)))
+        return F4L_EINVAL;
     if ((max_src_patch_host > 0 && !src) || (max_tgt_patch_host > 0 && !tgt)) return F4L_EINVAL;
     if (P == 0) return F4L_OK;
     if (P > 0x7fffffffLL || max_src_patch_host > 0x3fffffffLL || max_tgt_patch_host > 0x3fffffffLL)
@@ -1226,7 +1306,7 @@ static int f4l::icp_launch_host(const float *src, const int64_t *src_off, const 
     // Point-to-plane always measures in double: its 6 x 6 system is ill-conditioned on near-planar or half-matched patches, and the
     // 1e-7 of a float32 position, harmless to the Umeyama sums, was seen to throw such a patch out of reach of every target
     // (fitness 0 after 20 passes where the float64 search follows the oracle to 1e-8 m: tools/gpu/fuzz_icp.py 1 2002788 f32).
-    const bool f64 = search_precision == F4L_SEARCH_F64 || mode == F4L_ICP_POINT2PLANE;
+    const bool f64 = search_precision == F4L_SEARCH_F64 || mode != F4L_ICP_POINT2POINT;
     static_assert(sizeof(GridPt<double>) == sizeof(GridPt<float>), "grid records are 16 B in both modes");
     IcpArgs a;
     a.src = src; a.src_off = src_off; a.tgt = tgt; a.tgt_off = tgt_off; a.P = P;
@@ -1236,6 +1316,7 @@ static int f4l::icp_launch_host(const float *src, const int64_t *src_off, const 
     a.rows_src = fx.rows_src; a.rows_off = fx.rows_off; a.min_corr = fx.min_corr; a.init_round_f32 = fx.init_round_f32;
     a.normals_f64 = fx.normals_f64;
     a.p2pl_open3d = fx.p2pl_open3d;
+    a.src_normals = fx.src_normals; a.gicp_eps = fx.gicp_eps;
     a.r = max_corr_dist > 0.0 ? max_corr_dist : 0.0;
     a.r2 = a.r * a.r;
     a.max_iter = max_iter; a.rel_fitness = rel_fitness; a.rel_rmse = rel_rmse; a.fixed_iters = fixed_iters;

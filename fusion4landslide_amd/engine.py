@@ -177,7 +177,7 @@ def _target_normals(torch, tgt, tgt_off, max_tgt_patch, tgt_normals):
 
 def piecewise_icp(src, src_off, tgt, tgt_off, init_T=None, max_corr_dist=0.1, max_iter=30, rel_fitness=1e-6,
                   rel_rmse=1e-6, icp_type="point2point", fixed_iters=False, tgt_normals=None, return_corr=False,
-                  max_src_patch=None, max_tgt_patch=None, search="f64", p2plane="robust"):
+                  max_src_patch=None, max_tgt_patch=None, search="f64", p2plane="robust", src_normals=None, gicp_epsilon=0.0):
     """Batched per-patch ICP (utils/o3d_tools.py:12-71 for P patch pairs in one launch).
 
     Returns dict(T (P,4,4) f64, fitness (P,) f64, rmse (P,) f64, iters (P,) i32[, corr (n_src,) i32]).
@@ -190,11 +190,15 @@ def piecewise_icp(src, src_off, tgt, tgt_off, init_T=None, max_corr_dist=0.1, ma
     pin its six unknowns (fewer than six pairs, singular to 1e-13); ``"open3d"`` is Open3D's own semantics -- Eigen's pivoted
     L D L^T in the caller's frame, applied whenever there is one correspondence (F4L_ICP_P2PL_OPEN3D, include/f4l.h) -- what
     the mirror of ``icp_registration`` asks for.  The same minimiser wherever the system is well posed.
+    ``icp_type="generalized_icp"`` (utils/o3d_tools.py:40-41,51-56; f4l_piecewise_gicp): both patches' normals (float64, made here
+    like `estimate_normals()` unless given) become Open3D's covariances; ``gicp_epsilon`` is the estimator's first parameter --
+    the reference passes ``False`` = 0.0, Open3D's default is 1e-3.  Always the float64 search and Open3D's step semantics.
     """
     torch = require_gpu()
-    if icp_type not in _ICP_MODES:
+    generalized = icp_type == "generalized_icp"
+    if icp_type not in _ICP_MODES and not generalized:
         raise ValueError("ICP type not supported")  # utils/o3d_tools.py:43
-    mode = _ICP_MODES[icp_type] | _p2plane_bit(p2plane)
+    mode = 0 if generalized else _ICP_MODES[icp_type] | _p2plane_bit(p2plane)
     src = _dev(src, torch.float32, "src", (3,))
     tgt = _dev(tgt, torch.float32, "tgt", (3,))
     src_off = _dev(src_off, torch.int64, "src_off")
@@ -220,6 +224,22 @@ def piecewise_icp(src, src_off, tgt, tgt_off, init_T=None, max_corr_dist=0.1, ma
     rmse = torch.empty((P,), dtype=torch.float64, device=dev)
     iters = torch.empty((P,), dtype=torch.int32, device=dev)
     corr = torch.empty((src.shape[0],), dtype=torch.int32, device=dev) if return_corr else None
+    if generalized:
+        sn = (patch_normals(src, src_off, 30, max_src_patch, f64=True) if src_normals is None
+              else _dev(src_normals, torch.float64, "src_normals", (3,)))
+        tn = (patch_normals(tgt, tgt_off, 30, max_tgt_patch, f64=True) if tgt_normals is None
+              else _dev(tgt_normals, torch.float64, "tgt_normals", (3,)))
+        if sn.shape[0] != src.shape[0] or tn.shape[0] != tgt.shape[0]:
+            raise ValueError("one normal per point")
+        check(lib().f4l_piecewise_gicp(ptr(src), ptr(src_off), ptr(tgt), ptr(tgt_off), P, ptr(T0), ptr(sn), ptr(tn),
+                                       float(gicp_epsilon), float(max_corr_dist), int(max_iter), float(rel_fitness),
+                                       float(rel_rmse), int(bool(fixed_iters)), int(max_src_patch), int(max_tgt_patch),
+                                       int(src.shape[0]), ptr(T), ptr(fit), ptr(rmse), ptr(iters), ptr(corr), stream_ptr()),
+              "f4l_piecewise_gicp")
+        out = dict(T=T, fitness=fit, rmse=rmse, iters=iters)
+        if return_corr:
+            out["corr"] = corr
+        return out
     check(lib().f4l_piecewise_icp(ptr(src), ptr(src_off), ptr(tgt), ptr(tgt_off), P, ptr(T0), ptr(tn),
                                   float(max_corr_dist), int(max_iter), float(rel_fitness), float(rel_rmse), mode | nbit,
                                   int(bool(fixed_iters)), {"f32": _lib.SEARCH_F32, "f64": _lib.SEARCH_F64}[search],

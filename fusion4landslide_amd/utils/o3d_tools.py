@@ -14,8 +14,8 @@ from .pointcloud import PointCloud, as_points
 
 
 def icp_registration(src_pcd, tgt_pcd, initial_transform, threshold=0.1, icp_type='point2point', search='f64',
-                     p2plane='open3d'):
-    """Point-to-point / point-to-plane ICP with Open3D's ICPConvergenceCriteria(1e-6, 1e-6, 30)
+                     p2plane='open3d', gicp_epsilon=float(False)):
+    """Point-to-point / point-to-plane / generalized ICP with Open3D's ICPConvergenceCriteria(1e-6, 1e-6, 30)
     (utils/o3d_tools.py:46-50).  Accepts Open3D clouds, `PointCloud`, numpy arrays or torch tensors.
 
     Returns the reference's dict: fitness, inlier_rmse, correspondence_set (m,2) int, est_transform (4,4) float64,
@@ -24,11 +24,13 @@ def icp_registration(src_pcd, tgt_pcd, initial_transform, threshold=0.1, icp_typ
     `search` selects the nearest-neighbour arithmetic ('f64' = the reference's double precision).
     'point2plane' steps follow Open3D's own semantics (F4L_ICP_P2PL_OPEN3D: Eigen's pivoted L D L^T, applied whenever there is a
     correspondence), not the batched calls' robust default; `p2plane='robust'` asks for that one.  (The solve's frame is the
-    shifted one below: for a SINGULAR system -- whose "solution" depends on the frame -- that is not Open3D's number either.)"""
+    shifted one below: for a SINGULAR system -- whose "solution" depends on the frame -- that is not Open3D's number either.)
+    'generalized_icp' (:40-41, 51-56) is `registration_generalized_icp` with the covariances Open3D derives from the normals of
+    :29-30.  The reference builds its estimator as `TransformationEstimationForGeneralizedICP(False)`: the first parameter is
+    `epsilon`, so it runs with epsilon = float(False) = 0.0 (plane-to-plane with nothing along the normals; Open3D's default is
+    1e-3) -- the default here too; `gicp_epsilon` sets another."""
     import torch
-    if icp_type == 'generalized_icp':
-        raise NotImplementedError("generalized ICP has no caller on the hot path and is not implemented")
-    if icp_type not in ('point2point', 'point2plane'):
+    if icp_type not in ('point2point', 'point2plane', 'generalized_icp'):
         raise ValueError('ICP type not supported')  # utils/o3d_tools.py:43,58
     src = as_points(src_pcd)
     tgt = as_points(tgt_pcd)
@@ -46,17 +48,20 @@ def icp_registration(src_pcd, tgt_pcd, initial_transform, threshold=0.1, icp_typ
     t = torch.from_numpy((np.asarray(tgt, dtype=np.float64) - o).astype(np.float32)).to(dev)
     so = torch.tensor([0, s.shape[0]], dtype=torch.int64, device=dev)
     to = torch.tensor([0, t.shape[0]], dtype=torch.int64, device=dev)
-    tn = None
-    if icp_type == 'point2plane' or isinstance(tgt_pcd, PointCloud):
+    tn = sn = None
+    if icp_type != 'point2point' or isinstance(tgt_pcd, PointCloud):
         tn = engine.patch_normals(t, to, 30, f64=True)  # (doubles, like the normals Open3D keeps)
         if isinstance(tgt_pcd, PointCloud):  # the reference mutates its inputs the same way
             tgt_pcd.normals = tn.cpu().numpy()
-    if isinstance(src_pcd, PointCloud):
-        src_pcd.normals = engine.patch_normals(s, so, 30, f64=True).cpu().numpy()
+    if icp_type == 'generalized_icp' or isinstance(src_pcd, PointCloud):
+        sn = engine.patch_normals(s, so, 30, f64=True)
+        if isinstance(src_pcd, PointCloud):
+            src_pcd.normals = sn.cpu().numpy()
     out = engine.piecewise_icp(s, so, t, to, init_T=torch.from_numpy(T0[None]).to(dev), max_corr_dist=threshold,
                                max_iter=30, rel_fitness=1e-6, rel_rmse=1e-6, icp_type=icp_type,
-                               tgt_normals=tn if icp_type == 'point2plane' else None, return_corr=True, search=search,
-                               p2plane=p2plane)
+                               tgt_normals=tn if icp_type != 'point2point' else None, return_corr=True, search=search,
+                               p2plane=p2plane, src_normals=sn if icp_type == 'generalized_icp' else None,
+                               gicp_epsilon=gicp_epsilon)
     T = out["T"][0].cpu().numpy()
     T[:3, 3] = T[:3, 3] + o - T[:3, :3] @ o
     corr = out["corr"].cpu().numpy()

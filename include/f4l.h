@@ -43,6 +43,7 @@ extern "C" {
 
 #define F4L_ICP_POINT2POINT 0 /* o3d TransformationEstimationPointToPoint(False), utils/o3d_tools.py:34 */
 #define F4L_ICP_POINT2PLANE 1 /* o3d TransformationEstimationPointToPlane(),     utils/o3d_tools.py:39 */
+#define F4L_ICP_GENERALIZED 2 /* o3d TransformationEstimationForGeneralizedICP,    utils/o3d_tools.py:41 (f4l_piecewise_gicp only) */
 /* Two semantics of the point-to-plane STEP, which differ only where the 6 x 6 system does not pin its six unknowns:
  *   default (ROBUST, this library's own rule): a step with fewer than six correspondences, or whose system is singular to
  *     1e-13 of its largest diagonal entry, is not taken -- the transform stays and the loop ends on its criteria.  The default
@@ -143,6 +144,23 @@ int f4l_piecewise_icp(const float *src, const int64_t *src_off, const float *tgt
                       int search_precision, int64_t max_src_patch_host, int64_t max_tgt_patch_host,
                       int64_t n_src_host, double *T_out, double *fitness_out, double *rmse_out, int32_t *iters_out,
                       int32_t *corr_out, void *stream);
+
+/* ... with icp_type 'generalized_icp' (utils/o3d_tools.py:40-41,51-56: TransformationEstimationForGeneralizedICP through
+ * registration_generalized_icp), for P patch pairs in one launch.  The reference has no caller for this type; it is here so
+ * that `icp_registration` is whole.  Both clouds carry normals when Open3D reaches the call (:29-30), so their covariances are
+ *   C_i = Rx diag(epsilon, 1, 1) Rx^T,  Rx = GetRotationFromE1ToX(n_i)  (= I - (1 - epsilon) n_i n_i^T; e1's for n_i.x < -0.99),
+ * the source's turning with the cloud; per correspondence M = C_q + R C_s R^T, and the step minimises sum d^T M^-1 d through
+ * the 6 x 6 normal equations, solved and applied with Open3D's semantics (as F4L_ICP_P2PL_OPEN3D).
+ *   src_normals / tgt_normals : double [n_src][3] / [n_tgt][3], unit length (f4l_patch_normals_f64 with knn = 30)
+ *   epsilon     : the estimator's first parameter.  The reference passes `False` there, i.e. 0.0 (Open3D's default: 1e-3);
+ *                 with 0 a pair of exactly parallel normals makes M singular -- Open3D divides by zero there; this kernel
+ *                 leaves out a step that is not finite
+ *   everything else as f4l_piecewise_icp (the search runs in float64). */
+int f4l_piecewise_gicp(const float *src, const int64_t *src_off, const float *tgt, const int64_t *tgt_off, int64_t P,
+                       const double *init_T, const double *src_normals, const double *tgt_normals, double epsilon,
+                       double max_corr_dist, int max_iter, double rel_fitness, double rel_rmse, int fixed_iters,
+                       int64_t max_src_patch_host, int64_t max_tgt_patch_host, int64_t n_src_host, double *T_out,
+                       double *fitness_out, double *rmse_out, int32_t *iters_out, int32_t *corr_out, void *stream);
 
 /* The loop body's steps before the rigid fit, batched over P patch matches.
  *

@@ -69,6 +69,16 @@ def test_icp_registration_mirror():
         assert np.array_equal(res["correspondence_set"], ref["correspondence_set"])
         assert res["src_corr_pts"].shape == res["tgt_corr_pts"].shape == (len(ref["correspondence_set"]), 3)
     assert tgt_pcd.has_normals() and src_pcd.has_normals()  # the reference mutates its inputs too
+    # icp_type 'generalized_icp' (:40-41, 51-56): the reference's estimator is built with `False` where Open3D expects epsilon
+    res = icp_registration(tensor2pcd(torch.from_numpy(s)), tensor2pcd(torch.from_numpy(t)), np.eye(4), threshold=0.1,
+                           icp_type="generalized_icp")
+    ref = O.gicp(s, t, np.eye(4), 0.1, 30, epsilon=0.0)
+    assert np.abs(res["est_transform"] - ref["est_transform"]).max() < 1e-6 and res["fitness"] == ref["fitness"]
+    assert np.array_equal(res["correspondence_set"], ref["correspondence_set"])
+    res = icp_registration(tensor2pcd(torch.from_numpy(s)), tensor2pcd(torch.from_numpy(t)), np.eye(4), threshold=0.1,
+                           icp_type="generalized_icp", gicp_epsilon=1e-3)
+    ref = O.gicp(s, t, np.eye(4), 0.1, 30, epsilon=1e-3)
+    assert np.abs(res["est_transform"] - ref["est_transform"]).max() < 1e-7 and res["fitness"] == ref["fitness"]
     with pytest.raises(ValueError):
         icp_registration(src_pcd, tgt_pcd, np.eye(4), icp_type="point2line")
     # float64 clouds at georeferenced magnitudes (Open3D's clouds are double): float32 spacing there is 0.25 m, above the

@@ -214,6 +214,62 @@ def test_icp_known_answer_planted_motion(eng):
         assert _max_disp(d, T, ref["T"]) <= 1e-7
 
 
+@pytest.mark.parametrize("eps", [1e-3, 0.0])
+def test_generalized_icp_vs_oracle(eng, eps):
+    """icp_type 'generalized_icp' (utils/o3d_tools.py:40-41,51-56; f4l_piecewise_gicp) against the oracle's restatement of
+    Open3D's estimator, with Open3D's default epsilon and with the 0.0 the reference's `...ForGeneralizedICP(False)` asks for:
+    the kernel forms M^-1 in closed form from the normals and never takes the matrix square root Open3D (and the oracle) take,
+    so this is two routes to the same normal equations.  Patches of 40 to 3 000 points: every workgroup shape."""
+    d = synthetic_patches(n=24_000, cells=5, seed=4, roughness=0.15)
+    args = (dev(d["src"]), dev(d["src_off"]), dev(d["tgt"]), dev(d["tgt_off"]))
+    ref = O.piecewise_gicp(d["src"], d["src_off"], d["tgt"], d["tgt_off"], max_corr_dist=0.1, max_iter=30, epsilon=eps)
+    out = eng.piecewise_icp(*args, max_corr_dist=0.1, max_iter=30, icp_type="generalized_icp", gicp_epsilon=eps, return_corr=True)
+    tol = 1e-7 if eps else 1e-6  # (epsilon 0: weights up to 2 / angle^2 between the two normals)
+    assert _disp_per_patch(d, out["T"].cpu().numpy(), ref["T"]).max() <= tol
+    assert np.array_equal(out["iters"].cpu().numpy(), ref["iters"])
+    assert np.array_equal(out["fitness"].cpu().numpy(), ref["fitness"])
+    assert np.abs(out["rmse"].cpu().numpy() - ref["rmse"]).max() <= 1e-8
+    assert np.median(ref["fitness"]) > 0.9  # (the set carries a few displaced and half-matched patches)
+    # normals handed over = normals made inside the call; a fixed number of passes; a start that turns the covariances
+    sn = eng.patch_normals(args[0], args[1], 30, f64=True)
+    tn = eng.patch_normals(args[2], args[3], 30, f64=True)
+    out2 = eng.piecewise_icp(*args, max_corr_dist=0.1, max_iter=30, icp_type="generalized_icp", gicp_epsilon=eps,
+                             src_normals=sn, tgt_normals=tn)
+    assert torch.equal(out2["T"], out["T"])
+    T0 = np.tile(np.eye(4), (d["P"], 1, 1))
+    T0[:, :3, :3] = rot_from_axis_angle([0.3, -1.0, 0.5], 0.003)
+    ref3 = O.piecewise_gicp(d["src"], d["src_off"], d["tgt"], d["tgt_off"], init_T=T0, max_corr_dist=0.1, max_iter=4, epsilon=eps,
+                            fixed_iters=True)
+    out3 = eng.piecewise_icp(*args, init_T=dev(T0), max_corr_dist=0.1, max_iter=4, icp_type="generalized_icp", gicp_epsilon=eps,
+                             fixed_iters=True)
+    assert _disp_per_patch(d, out3["T"].cpu().numpy(), ref3["T"]).max() <= tol
+    assert (out3["iters"].cpu().numpy() == 4).all()
+    # small and ragged patches (one and two wavefronts, an empty source, an empty target)
+    rng = np.random.default_rng(3)
+    sizes = [0, 17, 64, 65, 128, 129, 300, 40]
+    src_l, tgt_l = [], []
+    for i, n in enumerate(sizes):
+        xy = rng.uniform(0, 1.0, (max(2 * n, 60), 2))
+        z = 0.2 * np.sin(3 * xy[:, 0]) * np.cos(2 * xy[:, 1]) + 0.04 * np.sin(11 * xy[:, 0]) * np.sin(9 * xy[:, 1])
+        t = np.c_[xy, z]
+        tgt_l.append(t if i != 7 else t[:0])
+        sxy = rng.uniform(0.1, 0.9, (n, 2))
+        sz = 0.2 * np.sin(3 * sxy[:, 0]) * np.cos(2 * sxy[:, 1]) + 0.04 * np.sin(11 * sxy[:, 0]) * np.sin(9 * sxy[:, 1])
+        src_l.append(np.c_[sxy, sz] @ rot_from_axis_angle(rng.normal(size=3), 0.004).T + rng.uniform(-0.01, 0.01, 3))
+    src = np.concatenate(src_l).astype(np.float32)
+    tgt = np.concatenate(tgt_l).astype(np.float32)
+    soff = np.r_[0, np.cumsum([len(x) for x in src_l])].astype(np.int64)
+    toff = np.r_[0, np.cumsum([len(x) for x in tgt_l])].astype(np.int64)
+    ref4 = O.piecewise_gicp(src, soff, tgt, toff, max_corr_dist=0.1, max_iter=30, epsilon=eps)
+    out4 = eng.piecewise_icp(dev(src), dev(soff), dev(tgt), dev(toff), max_corr_dist=0.1, max_iter=30, icp_type="generalized_icp",
+                             gicp_epsilon=eps)
+    dd = dict(P=len(sizes), src=src, src_off=soff)
+    assert np.array_equal(out4["iters"].cpu().numpy(), ref4["iters"])
+    assert _disp_per_patch(dd, out4["T"].cpu().numpy(), ref4["T"]).max() <= 10 * tol
+    assert np.array_equal(out4["fitness"].cpu().numpy(), ref4["fitness"])
+    assert np.array_equal(out4["T"][0].cpu().numpy(), np.eye(4)) and np.array_equal(out4["T"][7].cpu().numpy(), np.eye(4))
+
+
 @pytest.mark.parametrize("semantics", ["open3d", "robust"])
 @pytest.mark.parametrize("search", ["f64", "f32"])
 def test_icp_point2plane_vs_oracle(eng, search, semantics):

@@ -17,10 +17,13 @@ from oracle import oracle as O
 from _util import rot_from_axis_angle
 
 
+def _relief(xy):
+    return 0.25 * np.sin(2.1 * xy[:, 0]) * np.cos(1.7 * xy[:, 1]) + 0.05 * np.sin(9 * xy[:, 0] + 1) * np.sin(7 * xy[:, 1])
+
+
 def _surface(rng, n, side=2.0, noise=0.0):
     xy = rng.uniform(0, side, (n, 2))
-    z = 0.25 * np.sin(2.1 * xy[:, 0]) * np.cos(1.7 * xy[:, 1]) + 0.05 * np.sin(9 * xy[:, 0] + 1) * np.sin(7 * xy[:, 1])
-    return np.c_[xy, z + rng.normal(0, noise, n)]
+    return np.c_[xy, _relief(xy) + rng.normal(0, noise, n)]
 
 
 def _np_icp(src, tgt, T0, r, max_iter, icp_type="point2point", tgt_normals=None, rel=1e-6):
@@ -274,6 +277,116 @@ def test_icp_oracle_point2plane_semantics_part_only_where_the_system_is_singular
     assert Ta[0, 3] == 0.0 and Ta[1, 3] == 0.0 and Ta[1, 0] == 0.0  # no shift in the plane, no spin about z (sin(gamma) cos(beta))
     lifted = sp @ Ta[:3, :3].T + Ta[:3, 3]
     assert np.abs(lifted[:, 2]).max() <= 1e-5   # one step puts the tilted sheet into the plane (small-angle residue)
+
+
+def _np_gicp_covariance(n, eps):
+    """InitializePointCloudForGeneralizedICP's covariance from one normal, as Open3D 0.19 writes it [3P-knowledge]."""
+    c = n[0]
+    if c < -0.99:
+        R = np.eye(3)
+    else:
+        v = np.cross([1.0, 0.0, 0.0], n)
+        sv = np.array([[0, -v[2], v[1]], [v[2], 0, -v[0]], [-v[1], v[0], 0]])
+        R = np.eye(3) + sv + sv @ sv / (1 + c)
+    return R @ np.diag([eps, 1.0, 1.0]) @ R.T
+
+
+def _np_gicp(src, tgt, sn, tn, eps, r, max_iter, T0=None, rel=1e-6, fixed=False):
+    """registration_generalized_icp [3P-knowledge] in numpy / scipy: covariances from the normals, the source's turned with
+    the cloud, W = sqrtm(inv(C_q + C_s)), three rows per pair, numpy's solve of the normal equations, KD-tree search."""
+    from scipy.linalg import sqrtm
+    T = np.eye(4) if T0 is None else T0.copy()
+    Cs = np.array([_np_gicp_covariance(n, eps) for n in sn])
+    Ct = np.array([_np_gicp_covariance(n, eps) for n in tn])
+    p = src @ T[:3, :3].T + T[:3, 3]
+    Cs = np.einsum("ij,njk,lk->nil", T[:3, :3], Cs, T[:3, :3])
+    tree = cKDTree(tgt)
+
+    def evaluate(q):
+        d, j = tree.query(q, k=1)
+        ok = d * d < r * r
+        return ok, j, ok.mean(), (np.sqrt((d[ok] ** 2).sum() / ok.sum()) if ok.any() else 0.0)
+
+    ok, j, fit, rmse = evaluate(p)
+    iters = 0
+    for _ in range(max_iter):
+        JTJ, JTr = np.zeros((6, 6)), np.zeros(6)
+        for i in np.nonzero(ok)[0]:
+            vs, d = p[i], p[i] - tgt[j[i]]
+            W = np.real(sqrtm(np.linalg.inv(Ct[j[i]] + Cs[i])))
+            A = np.c_[-np.array([[0, -vs[2], vs[1]], [vs[2], 0, -vs[0]], [-vs[1], vs[0], 0]]), np.eye(3)]
+            J = W @ A
+            JTJ += J.T @ J
+            JTr += J.T @ (W @ d)
+        U4 = np.eye(4)
+        if ok.any():
+            x = np.linalg.solve(JTJ, -JTr)
+            al, be, ga = x[:3]
+            Rz = np.array([[np.cos(ga), -np.sin(ga), 0], [np.sin(ga), np.cos(ga), 0], [0, 0, 1]])
+            Ry = np.array([[np.cos(be), 0, np.sin(be)], [0, 1, 0], [-np.sin(be), 0, np.cos(be)]])
+            Rx = np.array([[1, 0, 0], [0, np.cos(al), -np.sin(al)], [0, np.sin(al), np.cos(al)]])
+            U4[:3, :3], U4[:3, 3] = Rz @ Ry @ Rx, x[3:]
+        T = U4 @ T
+        p = p @ U4[:3, :3].T + U4[:3, 3]
+        Cs = np.einsum("ij,njk,lk->nil", U4[:3, :3], Cs, U4[:3, :3])
+        pf, pr = fit, rmse
+        ok, j, fit, rmse = evaluate(p)
+        iters += 1
+        if not fixed and abs(pf - fit) < rel and abs(pr - rmse) < rel:
+            break
+    return T, fit, rmse, iters
+
+
+def test_gicp_covariances_are_open3d_s():
+    """C = Rx diag(eps, 1, 1) Rx^T with Rx turning e1 onto the normal: I - (1 - eps) n n^T for a unit normal -- except for
+    normals within 8 degrees of -e1 (c < -0.99), where GetRotationFromE1ToX returns the identity and the point gets e1's
+    covariance whatever its normal is."""
+    rng = np.random.default_rng(0)
+    for eps in (1e-3, 0.0, 0.25):
+        for _ in range(50):
+            n = rng.normal(size=3)
+            n /= np.linalg.norm(n)
+            C = O.gicp_covariance(n, eps)
+            assert np.abs(C - _np_gicp_covariance(n, eps)).max() < 1e-15
+            if n[0] >= -0.99:
+                assert np.abs(C - (np.eye(3) - (1 - eps) * np.outer(n, n))).max() < 1e-13
+        n = np.array([-0.995, np.sqrt(1 - 0.995 ** 2), 0.0])
+        assert np.array_equal(O.gicp_covariance(n, eps), np.diag([eps, 1.0, 1.0]))
+
+
+@pytest.mark.parametrize("eps", [1e-3, 0.0])
+def test_gicp_oracle_walks_the_same_trajectory_as_numpy_restatement(eps):
+    """utils/o3d_tools.py:40-41,51-56 (icp_type 'generalized_icp'; the reference's own epsilon is float(False) = 0): the C
+    oracle against an independent numpy / scipy restatement (scipy's sqrtm and inverse, numpy's solve), from the identity
+    and from a rotated start (which turns the source's covariances before the first pass)."""
+    rng = np.random.default_rng(5)
+    tgt = _surface(rng, 1500, noise=0.002)
+    xy = rng.uniform(0.15, 1.85, (900, 2))
+    src = np.c_[xy, _relief(xy)]
+    src = src @ rot_from_axis_angle(rng.normal(size=3), 0.006).T + rng.uniform(-0.02, 0.02, 3)
+    src, tgt = src.astype(np.float32).astype(np.float64), tgt.astype(np.float32).astype(np.float64)
+    sn, tn = O.o3d_estimate_normals(src, 30), O.o3d_estimate_normals(tgt, 30)
+    T0 = np.eye(4)
+    T0[:3, :3] = rot_from_axis_angle([0.3, -1.0, 0.5], 0.004)
+    T0[:3, 3] = [0.004, -0.003, 0.002]
+    for init in (None, T0):
+        for fixed, iters in ((True, 5), (False, 30)):
+            ref = O.gicp(src, tgt, init, 0.1, iters, epsilon=eps, fixed_iters=fixed, src_normals=sn, tgt_normals=tn)
+            T, fit, rmse, n_it = _np_gicp(src, tgt, sn, tn, eps, 0.1, iters, T0=init, fixed=fixed)
+            assert ref["iters"] == n_it and ref["fitness"] == fit
+            assert np.abs(ref["est_transform"] - T).max() < (1e-12 if eps else 1e-10)
+            assert abs(ref["inlier_rmse"] - rmse) < 1e-12
+            assert ref["fitness"] > 0.95
+    # normals made inside the call are the ones estimate_normals() leaves (:29-30); one patch of a batch = one call
+    a = O.gicp(src, tgt, None, 0.1, 30, epsilon=eps)
+    b = O.gicp(src, tgt, None, 0.1, 30, epsilon=eps, src_normals=sn, tgt_normals=tn)
+    assert np.array_equal(a["est_transform"], b["est_transform"])
+    batch = O.piecewise_gicp(np.r_[src, src].astype(np.float32), [0, len(src), 2 * len(src)], np.r_[tgt, tgt].astype(np.float32),
+                             [0, len(tgt), 2 * len(tgt)], max_corr_dist=0.1, max_iter=30, epsilon=eps)
+    assert np.array_equal(batch["T"][0], a["est_transform"]) and np.array_equal(batch["T"][1], a["est_transform"])
+    assert batch["iters"][0] == a["iters"]
+    with pytest.raises(Exception):
+        O.icp(src, tgt, None, 0.1, 30, icp_type="generalized_icp")
 
 
 def test_icp_oracle_recovers_planted_motion_and_reports_definitional_scores():
