@@ -804,6 +804,18 @@ def test_icp_vs_open3d_goldens_when_present(eng, golden_dir):
             assert np.abs((s @ T[c, :3, :3].T + T[c, :3, 3]) - (s @ Tr[:3, :3].T + Tr[:3, 3])).max() <= 1e-6, (icp_type, c)
             assert abs(out["fitness"][c].item() - float(g[f"fitness_{icp_type}_{c}"])) <= 1e-3
             assert abs(out["rmse"][c].item() - float(g[f"rmse_{icp_type}_{c}"])) <= 1e-5
+    for tag in ("generalized_icp", "generalized_icp_default"):
+        if f"T_{tag}_0" not in g:
+            continue
+        out = eng.piecewise_icp(dev(np.concatenate(src)), dev(soff), dev(np.concatenate(tgt)), dev(toff), init_T=dev(T0),
+                                max_corr_dist=float(g["threshold"]), max_iter=30, icp_type="generalized_icp",
+                                gicp_epsilon=float(g[f"epsilon_{tag}"]))
+        T = out["T"].cpu().numpy()
+        for c in range(C):
+            Tr = g[f"T_{tag}_{c}"]
+            s = src[c].astype(np.float64)
+            assert np.abs((s @ T[c, :3, :3].T + T[c, :3, 3]) - (s @ Tr[:3, :3].T + Tr[:3, 3])).max() <= 1e-6, (tag, c)
+            assert abs(out["fitness"][c].item() - float(g[f"fitness_{tag}_{c}"])) <= 1e-3
 
 
 def test_patch_loop_equals_the_three_launches(eng):

@@ -454,3 +454,14 @@ def test_icp_oracle_vs_open3d_goldens_when_present(golden_dir):
             assert np.abs(moved_a - moved_b).max() <= 1e-6, (c, icp_type)  # reference prints %.6f
             assert abs(out["fitness"] - float(g[f"fitness_{icp_type}_{c}"])) <= 1e-3
             assert abs(out["inlier_rmse"] - float(g[f"rmse_{icp_type}_{c}"])) <= 1e-5
+        for tag in ("generalized_icp", "generalized_icp_default"):
+            if f"T_{tag}_{c}" not in g:  # (files written before the generalized estimator was dumped)
+                continue
+            if tag == "generalized_icp":
+                assert float(g[f"epsilon_{tag}"]) == 0.0  # what utils/o3d_tools.py:41's `(False)` is read as here
+            out = O.gicp(src, tgt, g[f"init_{c}"], max_corr_dist=float(g["threshold"]), max_iter=30, epsilon=float(g[f"epsilon_{tag}"]))
+            T = g[f"T_{tag}_{c}"]
+            moved_a = src @ out["est_transform"][:3, :3].T + out["est_transform"][:3, 3]
+            assert np.abs(moved_a - (src @ T[:3, :3].T + T[:3, 3])).max() <= 1e-6, (c, tag)
+            assert abs(out["fitness"] - float(g[f"fitness_{tag}_{c}"])) <= 1e-3
+            assert abs(out["inlier_rmse"] - float(g[f"rmse_{tag}_{c}"])) <= 1e-5

@@ -10,7 +10,9 @@ from the repository root; tests/test_oracle_icp.py::test_icp_oracle_vs_open3d_go
 tests then compare against Open3D's own numbers.  The calls are the ones utils/o3d_tools.py:12-71 makes:
 estimate_normals() with default parameters on both clouds, registration_icp(source, target, threshold, init,
 estimator, ICPConvergenceCriteria(1e-6, 1e-6, 30)) with TransformationEstimationPointToPoint(False) or
-TransformationEstimationPointToPlane().  Inputs are seeded numpy data (no files needed).
+TransformationEstimationPointToPlane(), and registration_generalized_icp with TransformationEstimationForGeneralizedICP(False)
+-- the reference's own spelling, :41; `epsilon_` of that estimator is stored too, so that the file says what `False` meant --
+and with Open3D's default epsilon.  Inputs are seeded numpy data (no files needed).
 """
 import os
 import sys
@@ -59,6 +61,20 @@ def main():
             out[f"corr_{icp_type}_{c}"] = np.asarray(reg.correspondence_set, dtype=np.int32)
             if icp_type == "point2plane":
                 out[f"tgt_normals_{c}"] = np.asarray(t.normals, dtype=np.float64)
+                out[f"src_normals_{c}"] = np.asarray(s.normals, dtype=np.float64)
+        for tag, est in (("generalized_icp", o3d.pipelines.registration.TransformationEstimationForGeneralizedICP(False)),
+                         ("generalized_icp_default", o3d.pipelines.registration.TransformationEstimationForGeneralizedICP())):
+            s, t = o3d.geometry.PointCloud(), o3d.geometry.PointCloud()
+            s.points, t.points = o3d.utility.Vector3dVector(src), o3d.utility.Vector3dVector(tgt)
+            s.estimate_normals()
+            t.estimate_normals()
+            reg = o3d.pipelines.registration.registration_generalized_icp(
+                s, t, threshold, init, est,
+                o3d.pipelines.registration.ICPConvergenceCriteria(relative_fitness=1e-6, relative_rmse=1e-6, max_iteration=30))
+            out[f"epsilon_{tag}"] = np.float64(est.epsilon)
+            out[f"T_{tag}_{c}"] = np.asarray(reg.transformation, dtype=np.float64)
+            out[f"fitness_{tag}_{c}"] = np.float64(reg.fitness)
+            out[f"rmse_{tag}_{c}"] = np.float64(reg.inlier_rmse)
     out["n_cases"] = np.int64(len(cases))
     path = os.path.join(ROOT, "tests", "golden", "o3d_icp_golden.npz")
     np.savez_compressed(path, **out)

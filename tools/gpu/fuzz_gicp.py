@@ -1,0 +1,101 @@
+"""Randomised parity check of generalized ICP (f4l_piecewise_gicp, icp_type 'generalized_icp' of utils/o3d_tools.py:40-41,51-56)
+against the oracle's restatement of Open3D's estimator (oracle/f4l_oracle.c: orc_gicp): patch sets drawn like tools/gpu/fuzz_icp.py's
+(empty, tiny, uneven, beyond the LDS limits; three radii and densities; local or kilometre-reduced coordinates), epsilon = 0 (what
+the reference's call means), 1e-3 (Open3D's default) or 0.05.  A well-posed patch must end within the tolerance of the oracle;
+one on which the ORACLE itself lands elsewhere when started a few ulps away from the identity is reported as unstable, not as a
+mismatch (as fuzz_icp.py does).
+
+    python3 tools/gpu/fuzz_gicp.py [cases] [first seed]
+"""
+import os, sys, time
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from fusion4landslide_amd import engine
+from oracle import oracle as O
+
+
+def rot(axis, ang):
+    axis = np.asarray(axis, float); axis /= np.linalg.norm(axis)
+    K = np.array([[0, -axis[2], axis[1]], [axis[2], 0, -axis[0]], [-axis[1], axis[0], 0]])
+    return np.eye(3) + np.sin(ang) * K + (1 - np.cos(ang)) * K @ K
+
+
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 24
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+bad = 0
+for case in range(n_cases):
+    rng = np.random.default_rng(seed0 + case)
+    P = int(rng.choice([1, 3, 40, 70, 300]))
+    kind = rng.choice(["even", "uneven", "tiny", "one big"])
+    if kind == "even": sizes = rng.integers(150, 400, P)
+    elif kind == "uneven": sizes = rng.integers(0, 900, P)
+    elif kind == "tiny": sizes = rng.integers(0, 12, P)
+    else: sizes = np.r_[rng.integers(3000, 9500, 1), rng.integers(20, 200, max(P - 1, 0))]
+    if sizes.sum() > 30000: sizes = (sizes * (30000 / sizes.sum())).astype(int)
+    density = float(rng.choice([100.0, 400.0, 3000.0]))
+    r = float(rng.choice([0.05, 0.1, 0.3]))
+    origin = np.array([2647.0, 1177.0, 1500.0]) if rng.random() < 0.4 else np.zeros(3)
+    eps = float(rng.choice([0.0, 1e-3, 0.05]))
+    fixed = bool(rng.random() < 0.3)
+    src_l, tgt_l = [], []
+    for m in sizes:
+        m = int(m)
+        side = max(0.1, np.sqrt(max(m, 1) / density))
+        mt = max(0, m + int(rng.integers(-5, 30))) if rng.random() < 0.9 else 0
+        xy = rng.uniform(0, side, (mt, 2))
+        t = np.c_[xy, 0.3 * np.sin(1.7 * xy[:, 0] / side) * np.cos(2.3 * xy[:, 1] / side) + rng.normal(0, 0.002, mt)]
+        xy2 = rng.uniform(0.05 * side, 0.95 * side, (m, 2))
+        s = np.c_[xy2, 0.3 * np.sin(1.7 * xy2[:, 0] / side) * np.cos(2.3 * xy2[:, 1] / side)]
+        s = s @ rot(rng.normal(size=3), rng.uniform(0, 0.01)).T + rng.uniform(-0.4 * r, 0.4 * r, 3)
+        src_l.append(s + origin); tgt_l.append(t + origin)
+    src = np.concatenate(src_l).astype(np.float32) if len(src_l) else np.zeros((0, 3), np.float32)
+    tgt = np.concatenate(tgt_l).astype(np.float32) if len(tgt_l) else np.zeros((0, 3), np.float32)
+    soff = np.zeros(P + 1, np.int64); np.cumsum([len(a) for a in src_l], out=soff[1:])
+    toff = np.zeros(P + 1, np.int64); np.cumsum([len(a) for a in tgt_l], out=toff[1:])
+    t0 = time.perf_counter()
+    ref = O.piecewise_gicp(src, soff, tgt, toff, max_corr_dist=r, max_iter=30, epsilon=eps, fixed_iters=fixed)
+    t1 = time.perf_counter()
+    dv = lambda a: torch.from_numpy(a).cuda()
+    out = engine.piecewise_icp(dv(src), dv(soff), dv(tgt), dv(toff), max_corr_dist=r, max_iter=30, icp_type="generalized_icp",
+                               gicp_epsilon=eps, fixed_iters=fixed)
+    T = out["T"].cpu().numpy()
+    fit = ref["fitness"]
+    # (the kernel inverts M in closed form from the normals, the oracle goes through Rx, the inverse and its square root: they
+    #  differ by the conditioning of M times 1e-16 per pair -- unbounded for epsilon = 0, where M is singular for parallel normals)
+    tol = 5e-7 if eps > 0 else 2e-5
+    worst, worst_posed, n_bad, n_unstable, n_posed, detail = 0.0, 0.0, 0, 0, 0, []
+    finite = np.isfinite(ref["T"]).all(axis=(1, 2))
+    for p in range(P):
+        s = src[soff[p]:soff[p + 1]].astype(np.float64)
+        if not len(s):
+            continue
+        if not finite[p]:  # (epsilon = 0 and a pair of exactly parallel normals: Open3D divides by zero; the kernel leaves that step out)
+            assert eps == 0.0
+            continue
+        e = float(np.abs((s @ T[p, :3, :3].T + T[p, :3, 3]) - (s @ ref["T"][p, :3, :3].T + ref["T"][p, :3, 3])).max())
+        posed = len(s) >= 40 and fit[p] >= 0.5 and (toff[p + 1] - toff[p]) >= 40
+        worst = max(worst, e)
+        n_posed += posed
+        if posed:
+            worst_posed = max(worst_posed, e)
+        if e > tol and posed:
+            one = lambda a, off: np.ascontiguousarray(a[off[p]:off[p + 1]])
+            z2 = np.array([0, len(s)], np.int64), np.array([0, int(toff[p + 1] - toff[p])], np.int64)
+            Tp = np.eye(4)[None].copy()
+            nudge = max(1e-13, 8 * 2.2e-16 * float(np.abs(s).max()))
+            Tp[0, :3, 3] = (nudge, -nudge, nudge)
+            again = O.piecewise_gicp(one(src, soff), z2[0], one(tgt, toff), z2[1], init_T=Tp, max_corr_dist=r, max_iter=30,
+                                     epsilon=eps, fixed_iters=fixed)
+            e2 = float(np.abs((s @ again["T"][0, :3, :3].T + again["T"][0, :3, 3]) - (s @ ref["T"][p, :3, :3].T + ref["T"][p, :3, 3])).max())
+            if e2 > 0.1 * e:
+                n_unstable += 1
+                continue
+            n_bad += 1
+            detail.append((p, len(s), float(fit[p]), e, e2, int(ref["iters"][p]), int(out["iters"][p].item())))
+    ok = n_bad == 0
+    bad += not ok
+    print(f"case {seed0 + case} P={P:4d} {kind:8s} n={len(src):6d} r={r} dens={density:6.0f} eps={eps:<6g} {'loc' if origin[0] == 0 else 'geo'} "
+          f"fixed={int(fixed)}  worst {worst:.1e} (well-posed {worst_posed:.1e} of {n_posed}), unstable in the oracle {n_unstable}, "
+          f"oracle {t1 - t0:.1f} s  {'ok' if ok else 'MISMATCH ' + str(detail[:4])}", flush=True)
+print("FUZZ CLEAN" if bad == 0 else f"FUZZ: {bad} sets with mismatches")
+sys.exit(1 if bad else 0)
