@@ -1,7 +1,13 @@
 """Counterpart of the reference's main_fusion.py for the 3D hot path: `--config` (nested yaml, main_fusion.py:63) -> cfg -> tiling
 once -> per tile `Coarse2Fine(cfg).implement_c2f_matching()` (:134-148) -> `results/c2f_*_tile_<id>.txt`.
 
-    python -m fusion4landslide_amd.main_fusion --config configs/landslide/fusion_3d_brienz.yaml [--partition parallel]
+    python -m fusion4landslide_amd.main_fusion --config configs/landslide/fusion_3d_brienz.yaml [--partition identical]
+
+The supervoxel partition of this ENTRY is the device segmentation (f4l_supervoxel_parallel: the whole stage in HIP kernels, 5 ms per
+million points; the reference's K, criteria and partition quality) unless `--partition identical` -- or F4L_SV_MODE=identical --
+asks for the reference's own labels (f4l_supervoxel: its sequential fusion replayed on one host core, 1.1 s per million points);
+the displacement field needs a partition of that quality, not those labels.  The SWIG-module mirror `computeSupervoxel`, whose
+result IS the label vector, keeps `identical` as its own default.
 
 The config keys are the reference's (path_name / data / method / parameter_setting / misc).  What the reference computes with
 its learned models -- point matches, patch matches, the 2D matches lifted to 3D -- enters through hooks on the cfg
@@ -64,16 +70,19 @@ def main(argv=None):
                         help="Path to a fusion config of the reference's layout (e.g. its configs/landslide/fusion_3d_brienz.yaml); "
                              "`method.partition_type` must be `supervoxel`.")
     parser.add_argument('--partition', type=str, default=None, choices=['identical', 'parallel'],
-                        help="supervoxel segmentation: the reference's labels (host replay) or the device segmentation")
+                        help="supervoxel segmentation: the device segmentation (default) or the reference's labels (host replay)")
     parser.add_argument('--first-tile', type=int, default=0)
     args = parser.parse_args(argv)
     setup_seed(0)
     cfg, log_path = build_config(args.config)
-    if args.partition:
-        from .cpp_core.supervoxel_segmentation.build import supervoxel
-        supervoxel.SEGMENTATION = args.partition
+    from .cpp_core.supervoxel_segmentation.build import supervoxel
+    mode_before = supervoxel.SEGMENTATION
+    supervoxel.SEGMENTATION = args.partition or os.environ.get("F4L_SV_MODE", "parallel")
     start = time.time()
-    run(cfg, args.first_tile)
+    try:
+        run(cfg, args.first_tile)
+    finally:
+        supervoxel.SEGMENTATION = mode_before  # (the module's own default is its callers' business, not this entry's)
     if cfg.verbose:
         cfg.logging.info(f"Displacement estimation is done! Save log information to: '{log_path}'.")
         cfg.logging.info(f"Save results to: '{cfg.path_name.output_root}'. Total time taken: {time.time() - start:.1f} seconds.")

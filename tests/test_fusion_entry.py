@@ -69,7 +69,15 @@ def test_main_fusion_entry_runs_the_tiles_and_writes_the_dvf_files(tmp_path):
         parameter_setting=dict(n_normals=30, icp_threshold=0.1, max_magnitude=5))
     path = tmp_path / "fusion_3d.yaml"
     yaml.safe_dump(cfg, open(path, "w"))
-    main_fusion.main(["--config", str(path), "--partition", "parallel"])
+    from fusion4landslide_amd.cpp_core.supervoxel_segmentation.build import supervoxel
+    seen = []
+    run_before = main_fusion.run
+    main_fusion.run = lambda *a, **k: (seen.append(supervoxel.SEGMENTATION), run_before(*a, **k))[1]
+    try:
+        main_fusion.main(["--config", str(path)])  # (no --partition: the entry's default is the device segmentation)
+    finally:
+        main_fusion.run = run_before
+    assert seen == ["parallel"] and supervoxel.SEGMENTATION == "identical"
     res = out_root / "results"
     for t in (0, 1):
         dvfs = np.loadtxt(res / f"c2f_dense_dvfs_src2tgt_tile_{t}.txt")
@@ -95,7 +103,6 @@ def test_main_fusion_entry_runs_the_tiles_and_writes_the_dvf_files(tmp_path):
     c = clouds[0]
     d, j = cKDTree(c["tgt"].astype(np.float64)).query(c["src"].astype(np.float64), k=2, distance_upper_bound=0.3)
     cfg2.point_matches_from_2d = np.where(np.isfinite(d[:, 1]) & (np.arange(len(d)) % 3 == 0), j[:, 1], -1)
-    from fusion4landslide_amd.cpp_core.supervoxel_segmentation.build import supervoxel
     supervoxel.SEGMENTATION = "parallel"
     try:
         main_fusion.run(cfg2)

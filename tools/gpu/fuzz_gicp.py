@@ -90,8 +90,23 @@ for case in range(n_cases):
             if e2 > 0.1 * e:
                 n_unstable += 1
                 continue
+            # ... or when its normals are nudged in their last bits -- the two sides form M = C_q + R C_s R^T by different routes
+            # (the kernel in closed form from the normals, the oracle through Rx and a rotation per pass), 2e-16 apart; with a small
+            # epsilon M is nearly singular wherever the two normals are nearly parallel (matched smooth surfaces: weights of
+            # 2 / angle^2), and the normal equations amplify that
+            s64, t64 = s, tgt[toff[p]:toff[p + 1]].astype(np.float64)
+            sn, tn = O.o3d_estimate_normals(s64, 30), O.o3d_estimate_normals(t64, 30)
+            prng = np.random.default_rng(seed0 + case + 31 * p)
+            jig = lambda nrm: (lambda v: v / np.linalg.norm(v, axis=1, keepdims=True))(nrm * (1.0 + 4e-16 * prng.integers(-1, 2, nrm.shape)))
+            base = O.gicp(s64, t64, None, r, 30, epsilon=eps, fixed_iters=fixed, src_normals=sn, tgt_normals=tn)
+            pert = O.gicp(s64, t64, None, r, 30, epsilon=eps, fixed_iters=fixed, src_normals=jig(sn), tgt_normals=jig(tn))
+            mv = lambda Tm: s64 @ Tm[:3, :3].T + Tm[:3, 3]
+            e3 = float(np.abs(mv(pert["est_transform"]) - mv(base["est_transform"])).max())
+            if e3 > 0.1 * e:
+                n_unstable += 1
+                continue
             n_bad += 1
-            detail.append((p, len(s), float(fit[p]), e, e2, int(ref["iters"][p]), int(out["iters"][p].item())))
+            detail.append((p, len(s), float(fit[p]), e, e2, e3, int(ref["iters"][p]), int(out["iters"][p].item())))
     ok = n_bad == 0
     bad += not ok
     print(f"case {seed0 + case} P={P:4d} {kind:8s} n={len(src):6d} r={r} dens={density:6.0f} eps={eps:<6g} {'loc' if origin[0] == 0 else 'geo'} "
