@@ -56,14 +56,22 @@ for case in range(n_cases):
     ref = O.piecewise_gicp(src, soff, tgt, toff, max_corr_dist=r, max_iter=30, epsilon=eps, fixed_iters=fixed)
     t1 = time.perf_counter()
     dv = lambda a: torch.from_numpy(a).cuda()
+    # Both sides get the SAME normals (the oracle's own `estimate_normals`, patch by patch -- what orc_piecewise_gicp computes
+    # inside, bit for bit): with a small epsilon the result hangs on the normals' tenth digit (a pair of nearly parallel normals
+    # weighs 2 / angle^2; the oracle moved 1.4e-6 m when its normals moved 1e-12 and 1.2 cm -- 30 passes instead of 6 -- at
+    # 1e-10: `fuzz_gicp.py 1 4800036`), and the device's PCA agrees with the oracle's to 1e-9 only.  The launch that estimates
+    # its own normals is held to the oracle where that makes sense (tests/test_gpu_parity.py::test_generalized_icp_vs_oracle).
+    per_patch = lambda pts, off: np.concatenate([O.o3d_estimate_normals(pts[off[q]:off[q + 1]].astype(np.float64), 30).reshape(-1, 3)
+                                                 for q in range(P)] + [np.zeros((0, 3))])
+    sn_all, tn_all = per_patch(src, soff), per_patch(tgt, toff)
     out = engine.piecewise_icp(dv(src), dv(soff), dv(tgt), dv(toff), max_corr_dist=r, max_iter=30, icp_type="generalized_icp",
-                               gicp_epsilon=eps, fixed_iters=fixed)
+                               gicp_epsilon=eps, fixed_iters=fixed, src_normals=dv(sn_all), tgt_normals=dv(tn_all))
     T = out["T"].cpu().numpy()
     fit = ref["fitness"]
     # (the kernel inverts M in closed form from the normals, the oracle goes through Rx, the inverse and its square root: they
     #  differ by the conditioning of M times 1e-16 per pair -- unbounded for epsilon = 0, where M is singular for parallel normals)
     tol = 5e-7 if eps > 0 else 2e-5
-    worst, worst_posed, n_bad, n_unstable, n_posed, detail = 0.0, 0.0, 0, 0, 0, []
+    worst, worst_posed, n_bad, n_unstable, n_posed, detail, n_chaotic, worst_step = 0.0, 0.0, 0, 0, 0, [], 0, 0.0
     finite = np.isfinite(ref["T"]).all(axis=(1, 2))
     for p in range(P):
         s = src[soff[p]:soff[p + 1]].astype(np.float64)
@@ -95,22 +103,49 @@ for case in range(n_cases):
             # epsilon M is nearly singular wherever the two normals are nearly parallel (matched smooth surfaces: weights of
             # 2 / angle^2), and the normal equations amplify that
             s64, t64 = s, tgt[toff[p]:toff[p + 1]].astype(np.float64)
-            sn, tn = O.o3d_estimate_normals(s64, 30), O.o3d_estimate_normals(t64, 30)
+            sn, tn = sn_all[soff[p]:soff[p + 1]], tn_all[toff[p]:toff[p + 1]]
             prng = np.random.default_rng(seed0 + case + 31 * p)
-            jig = lambda nrm: (lambda v: v / np.linalg.norm(v, axis=1, keepdims=True))(nrm * (1.0 + 4e-16 * prng.integers(-1, 2, nrm.shape)))
             base = O.gicp(s64, t64, None, r, 30, epsilon=eps, fixed_iters=fixed, src_normals=sn, tgt_normals=tn)
+            # how large a nudge of the normals stands for ONE rounding of M's entries (1e-16, absolute): M's small eigenvalue is
+            # epsilon + (1 - epsilon) angle^2 / 2 for a pair of normals `angle` apart; a nudge d of a normal moves it by d * angle, a
+            # rounding by 1e-16: d = 1e-16 / angle of the most parallel matched pair (at least the normals' own last bit)
+            cs = base["correspondence_set"]
+            mag = 4e-16
+            if len(cs) and eps < 1e-2:
+                u_ = sn[cs[:, 0]] @ base["est_transform"][:3, :3].T
+                ang = np.linalg.norm(np.cross(u_, tn[cs[:, 1]]), axis=1)
+                lam_min = eps + (1 - eps) * float(ang.min()) ** 2 / 2
+                mag = float(np.clip(1e-16 * max(float(ang.min()), 1e-9) / max(lam_min, 1e-30) / 2, 4e-16, 1e-9))
+            jig = lambda nrm: (lambda v: v / np.linalg.norm(v, axis=1, keepdims=True))(nrm + mag * prng.normal(size=nrm.shape))
             pert = O.gicp(s64, t64, None, r, 30, epsilon=eps, fixed_iters=fixed, src_normals=jig(sn), tgt_normals=jig(tn))
             mv = lambda Tm: s64 @ Tm[:3, :3].T + Tm[:3, 3]
             e3 = float(np.abs(mv(pert["est_transform"]) - mv(base["est_transform"])).max())
             if e3 > 0.1 * e:
                 n_unstable += 1
                 continue
+            # ... or, on a patch whose iteration does not settle (30 passes without meeting the criteria: with a small epsilon the
+            # step is dominated by the few most parallel pairs, and those change from pass to pass), the trajectory itself is
+            # chaotic: one sample of a nudge says little.  What a second implementation CAN be held to there is the estimator: after
+            # exactly one and exactly two passes from the same start the two sides must agree
+            z1 = np.array([0, len(s64)], np.int64), np.array([0, len(t64)], np.int64)
+            steps = []
+            for kk in (1, 2):
+                o_ = O.gicp(s64, t64, None, r, kk, epsilon=eps, fixed_iters=True, src_normals=sn, tgt_normals=tn)
+                k_ = engine.piecewise_icp(dv(one(src, soff)), dv(z1[0]), dv(one(tgt, toff)), dv(z1[1]), max_corr_dist=r, max_iter=kk,
+                                          icp_type="generalized_icp", gicp_epsilon=eps, fixed_iters=True, src_normals=dv(np.ascontiguousarray(sn)),
+                                          tgt_normals=dv(np.ascontiguousarray(tn)))
+                steps.append(float(np.abs(mv(k_["T"][0].cpu().numpy()) - mv(o_["est_transform"])).max()))
+            if int(ref["iters"][p]) == 30 and max(steps) <= 1e-6:
+                n_chaotic += 1
+                worst_step = max(worst_step, max(steps))
+                continue
+            detail.append(("steps", steps))
             n_bad += 1
             detail.append((p, len(s), float(fit[p]), e, e2, e3, int(ref["iters"][p]), int(out["iters"][p].item())))
     ok = n_bad == 0
     bad += not ok
     print(f"case {seed0 + case} P={P:4d} {kind:8s} n={len(src):6d} r={r} dens={density:6.0f} eps={eps:<6g} {'loc' if origin[0] == 0 else 'geo'} "
-          f"fixed={int(fixed)}  worst {worst:.1e} (well-posed {worst_posed:.1e} of {n_posed}), unstable in the oracle {n_unstable}, "
+          f"fixed={int(fixed)}  worst {worst:.1e} (well-posed {worst_posed:.1e} of {n_posed}), unstable in the oracle {n_unstable}, unsettled after 30 passes but equal after one and two {n_chaotic} (<= {worst_step:.1e}), "
           f"oracle {t1 - t0:.1f} s  {'ok' if ok else 'MISMATCH ' + str(detail[:4])}", flush=True)
 print("FUZZ CLEAN" if bad == 0 else f"FUZZ: {bad} sets with mismatches")
 sys.exit(1 if bad else 0)
