@@ -44,6 +44,10 @@ import subprocess
 import sys
 import time
 
+# (RCCL / tensor sharing between the ranks' processes needs dmabuf IPC on this pool: the box exports it already; a rank started
+#  from a shell that lost it must not fail with `hipIpcGetMemHandle: invalid argument` -- set before any HIP call)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
