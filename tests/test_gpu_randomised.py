@@ -14,6 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.mark.parametrize("tool,cases,seed", [
     ("fuzz_icp.py", 30, 11),            # f4l_piecewise_icp against the C oracle: random patch sets, both estimators
+    ("fuzz_gicp.py", 20, 4800000),     # f4l_piecewise_gicp against the oracle's restatement of Open3D's generalized estimator
     ("fuzz_knn.py", 30, 12),            # the kNN lane kernel against the wave-per-query search and a KD-tree
     ("fuzz_supervoxel.py", 20, 13),     # the device segmentation against its numpy model, label for label
     ("fuzz_ops.py", 40, 14),            # nn_query, voxel filter, ragged Kabsch, CSR, median, rigidity check
