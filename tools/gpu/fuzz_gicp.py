@@ -135,7 +135,9 @@ for case in range(n_cases):
                                           icp_type="generalized_icp", gicp_epsilon=eps, fixed_iters=True, src_normals=dv(np.ascontiguousarray(sn)),
                                           tgt_normals=dv(np.ascontiguousarray(tn)))
                 steps.append(float(np.abs(mv(k_["T"][0].cpu().numpy()) - mv(o_["est_transform"])).max()))
-            if int(ref["iters"][p]) == 30 and max(steps) <= 1e-6:
+            # (either side unsettled: `fuzz_gicp.py 1 5100032` has a patch the oracle settles in 16 passes and leaves 3.9 cm away, after
+            #  30, when its normals move by 1e-10; the kernel, 2e-12 from it after two passes, wanders the same way)
+            if (int(ref["iters"][p]) == 30 or int(out["iters"][p].item()) == 30) and max(steps) <= 1e-6:
                 n_chaotic += 1
                 worst_step = max(worst_step, max(steps))
                 continue
