@@ -1,8 +1,9 @@
-// icp.hip -- batched per-patch ICP (point-to-point and point-to-plane) for gfx950.
+// icp.hip -- batched per-patch ICP (point-to-point, point-to-plane, generalized) for gfx950.
 //
 // Replaces, for P patch pairs in ONE launch and with zero host round trips, the loop body
 //   src/coarse_to_fine_matching_base.py:3353-3367  ->  utils/o3d_tools.py:12-71 `icp_registration`
 //   ->  Open3D 0.19 registration_icp(point2point | point2plane, criteria(1e-6, 1e-6, 30))
+//       (and registration_generalized_icp, the third icp_type of that function: MODE 2, f4l_piecewise_gicp)
 // which in the reference copies every patch GPU->CPU, builds a KD-tree, iterates on the CPU and copies
 // the 4x4 back (two device crossings per patch).
 //
