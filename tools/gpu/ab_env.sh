@@ -1,6 +1,6 @@
 #!/bin/bash
 # Usage (GPU box, repo root): bash tools/gpu/ab_env.sh "<configs>" "<env settings ...>"  -- the bench step under environment switches, e.g.
-#   bash tools/gpu/ab_env.sh "C4_50M_100k C2_1M_2k" "F4L_ICP_DEBUG=0" "F4L_ICP_DEBUG=1536" "F4L_LIB_PATH=$PWD/tools/gpu/ab/lib_x.so"
+#   bash tools/gpu/ab_env.sh "C4_50M_100k C2_1M_2k" "F4L_ICP_DEBUG=0" "F4L_ICP_DEBUG=1536" "F4L_LIB_PATH=$PWD/fusion4landslide_amd/lib/variants/lib_x.so"
 # One line per (config, setting): ms per step and M points/s of `bench.py --cpu-seconds 0 --extras 0`; two rounds, so that drift shows.
 CFGS="$1"; shift
 for rep in 1 2; do

@@ -1,7 +1,7 @@
 """Per-phase shader-clock shares of icp_kernel (profiling build: tools/build_variant.sh icp_prof PROF=1, F4L_LIB_PATH pointing
 at it), size class by size class, every class gathered into a cloud of its own so that its launch gets the class's own LDS plan.
 
-    F4L_LIB_PATH=$PWD/tools/gpu/ab/lib_icp_prof.so python3 tools/gpu/icp_phases.py C4_50M_100k     # bulk / border classes of a config
+    F4L_LIB_PATH=$PWD/fusion4landslide_amd/lib/variants/lib_icp_prof.so python3 tools/gpu/icp_phases.py C4_50M_100k     # bulk / border classes of a config
     F4L_LIB_PATH=...                               python3 tools/gpu/icp_phases.py tile [n]        # the supervoxel patches of a tile
 The library prints one `[icp prof]` line per launch on stderr (mean cycles per workgroup: build, phase1 = certify sweep, search,
 reduce = row sums + barrier, solve, barrier = wait for the solve)."""

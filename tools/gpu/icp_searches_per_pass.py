@@ -1,6 +1,6 @@
 """How many source points are SEARCHED in each pass of icp_kernel (profiling build with the search counters: F4L_LIB_PATH at a
 `make PROF=1` library): the launch is repeated with 0, 1, 2, ... iterations and the totals are differenced.
-    F4L_LIB_PATH=$PWD/tools/gpu/ab/lib_icp_prof.so python3 tools/gpu/icp_searches_per_pass.py [config] [n_patches]"""
+    F4L_LIB_PATH=$PWD/fusion4landslide_amd/lib/variants/lib_icp_prof.so python3 tools/gpu/icp_searches_per_pass.py [config] [n_patches]"""
 import os, re, subprocess, sys
 cfg = sys.argv[1] if len(sys.argv) > 1 else "C4_50M_100k"
 if len(sys.argv) > 2 and sys.argv[2] == "child":
