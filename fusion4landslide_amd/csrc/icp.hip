@@ -837,7 +837,7 @@ __global__ __launch_bounds__(NW * 64, WIDE ? 3 : (sizeof(F) == 8 ? ICP_WAVES_PER
             if (pass == a.max_iter) done = true;
             // update [Ru | tu] of this iteration (origin-relative): p_new = Ru p_old + tu
             double Ru[9], tu[3];
-            bool have = false;
+            bool have = false, bad_step = false;
             if (!done && m > 0.0) {
                 have = true;
                 if (MODE == F4L_ICP_POINT2POINT) {
@@ -886,6 +886,17 @@ __global__ __launch_bounds__(NW * 64, WIDE ? 3 : (sizeof(F) == 8 ? ICP_WAVES_PER
                         caller_frame = true;
 #pragma unroll
                         for (int u = 0; u < 6; ++u) { x[u] = state[40 + u]; have = have && isfinite(x[u]); }
+                        if (MODE == F4L_ICP_GENERALIZED) {  // (a NaN diagonal reads as "all zero" to the ldlt restatement: x = 0, finite)
+                            double chk = 0.0;
+#pragma unroll
+                            for (int u = 2; u < NV; ++u) chk += tot[u];
+                            have = have && isfinite(chk);
+                        }
+                        // A step that is not finite (generalized ICP with epsilon = 0 -- the reference's call -- on a pair of exactly
+                        // parallel normals: M is singular, 1 / det = inf, and the NaN is in every sum of the pass) would be Open3D's
+                        // NaN transform, a visible failure.  Here the patch keeps its last finite transform, stops, and says so:
+                        // iters = -2 (include/f4l.h).
+                        bad_step = !have;
                     } else {
                         double M[6][7];
                         int k = 2;
@@ -922,8 +933,8 @@ __global__ __launch_bounds__(NW * 64, WIDE ? 3 : (sizeof(F) == 8 ? ICP_WAVES_PER
                 }
             }
             if (lane == 0) {
-                state[12] = done ? 1.0 : 0.0;
-                state[13] = fit_new; state[14] = rmse_new; state[15] = (double)iters;
+                state[12] = (done || bad_step) ? 1.0 : 0.0;
+                state[13] = fit_new; state[14] = rmse_new; state[15] = bad_step ? -2.0 : (double)iters;
             }
             if (have) {  // T <- update * T; the running transform is only now fetched from LDS
                 const double cp0 = state[30], cp1 = state[31], cp2 = state[32];  // centroid image under the old T
@@ -1432,11 +1443,11 @@ static int f4l::icp_launch_host(const float *src, const int64_t *src_off, const 
         if (const char *e = getenv("F4L_ICP_CLASS_STEP")) step = atoi(e);
         if (wave_classes)  // patches that fit one or two wavefronts get workgroups of just those
             for (int64_t b = 64; b <= 128 && 3 * b <= 2 * big; b *= 2) cb.bound[cb.n++] = (int)b;
-        for (int64_t b = 256; lds_classes && b <= 4096 && 3 * b <= 2 * big && cb.n < ICP_MAX_CLASSES - 1;) {
+        for (int64_t b = 256; lds_classes && b <= 4096 && 3 * b <= 2 * big && cb.n < ICP_MAX_CLASSES - 2;) {
             cb.bound[cb.n++] = (int)b;
             b = step == 4 ? b * 4 : (step == 2 ? b * 2 : ((cb.n & 1) ? (b * 3) / 2 : (b * 4) / 3));
         }
-        if (bulk && cb.n < ICP_MAX_CLASSES - 1) {  // insert in ascending order, unless a bound that close exists already
+        if (bulk && cb.n < ICP_MAX_CLASSES - 2) {  // insert in ascending order, unless a bound that close exists already
             int at = 0;
             while (at < cb.n && cb.bound[at] < bulk) ++at;
             const bool near = (at < cb.n && cb.bound[at] <= bulk + bulk / 4) || (at > 0 && cb.bound[at - 1] >= bulk - bulk / 4);
@@ -1447,12 +1458,21 @@ static int f4l::icp_launch_host(const float *src, const int64_t *src_off, const 
             }
         }
     }
-    if (cb.n == 0) {
-        if (pl.rows_lp) return f64 ? launch_rows<double>(a, pl.rows_lp, (hipStream_t)stream) : launch_rows<float>(a, pl.rows_lp, (hipStream_t)stream);
+    if (cb.n == 0 && !pl.rows_lp)
         return f64 ? launch_icp<double>(a, mode, nw, lds, (hipStream_t)stream, pl.wide)
                    : launch_icp<float>(a, mode, nw, lds, (hipStream_t)stream, pl.wide);
-    }
     cb.bound[cb.n++] = (int)(big > 0x7fffffff ? 0x7fffffff : big);
+    // icp_rows_kernel holds at most ROWS_PPL * LP sources and targets per patch and, unlike icp_kernel, has no path for a patch
+    // beyond that: it must only ever see patches icp_bin_patches has MEASURED (the caller's max_*_patch may be understated --
+    // ADVICE r4).  So a launch that would give the last class to the rows kernel bounds that class by the kernel's capacity and
+    // adds one class behind it, planned for icp_kernel, which takes whatever is larger than the caller said (normally nothing:
+    // its workgroups return at once).
+    int overflow_class = -1;
+    if (icp_plan(big, big, f64, mode, throughput, rows_ok).rows_lp) {
+        cb.bound[cb.n - 1] = ROWS_PPL * icp_plan(big, big, f64, mode, throughput, rows_ok).rows_lp;
+        overflow_class = cb.n;
+        cb.bound[cb.n++] = 0x7fffffff;
+    }
     hipStream_t st = (hipStream_t)stream;
     int *buf = nullptr;
     const size_t buf_bytes = ((size_t)cb.n * (size_t)P + (size_t)cb.n) * sizeof(int);
@@ -1485,7 +1505,7 @@ static int f4l::icp_launch_host(const float *src, const int64_t *src_off, const 
         for (int k = cb.n - 1; k >= 0 && rc == F4L_OK; --k) {
             const int64_t ms = max_src_patch_host < cb.bound[k] ? max_src_patch_host : cb.bound[k];
             const int64_t mt = max_tgt_patch_host < cb.bound[k] ? max_tgt_patch_host : cb.bound[k];
-            const IcpPlan pk = icp_plan(ms, mt, f64, mode, throughput, rows_ok);
+            const IcpPlan pk = icp_plan(ms, mt, f64, mode, throughput, rows_ok && k != overflow_class);
             IcpArgs ak = a;
             ak.tgt_cap = pk.tgt_cap; ak.cert_cap = pk.cert_cap; ak.cell_cap = pk.cell_cap; ak.src_cap = pk.src_cap; ak.pp_cap = pk.pp_cap;
             ak.list = buf + (size_t)k * (size_t)P; ak.list_cnt = cnt + k;

@@ -169,6 +169,16 @@ __global__ __launch_bounds__(ROWS_WAVES * 64, ROWS_WPE) void icp_rows_kernel(Icp
     int64_t p = -1;
     if (a.list) { if (slot < (int64_t)*a.list_cnt) p = a.list[slot]; }
     else if (slot < a.P) p = slot;
+    // A patch beyond the kernel's capacity is never loaded (its targets would overwrite the next patch's LDS) and is flagged
+    // iters = -3; icp_launch_host only sends patches icp_bin_patches measured against ROWS_PPL * LP, so this guards other callers.
+    bool oversize = false;
+    if (p >= 0) {
+        oversize = a.src_off[p + 1] - a.src_off[p] > (int64_t)TCAP || a.tgt_off[p + 1] - a.tgt_off[p] > (int64_t)TCAP;
+        if (oversize) {
+            if (lr == 0 && a.iters_out) a.iters_out[p] = -3;
+            p = -1;
+        }
+    }
     const bool have_patch = p >= 0;
     const int64_t pp = have_patch ? p : 0;
     const int64_t s0 = a.src_off[pp], t0 = a.tgt_off[pp];

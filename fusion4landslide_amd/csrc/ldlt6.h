@@ -13,6 +13,15 @@
 // swaps of fixed register pairs), so nothing goes to scratch memory.
 #pragma once
 
+// Eigen's result depends on the last bits of these products and sums (which diagonal entry is the pivot, whether a pivot
+// passes the DBL_MIN test of the pseudo-inverse): no fused multiply-adds in this header on the device either (ADVICE r4;
+// hipcc contracts by default, the host build of the tests uses -ffp-contract=off).
+#ifdef __clang__
+#define F4L_NO_CONTRACT _Pragma("clang fp contract(off)")
+#else
+#define F4L_NO_CONTRACT
+#endif
+
 #ifndef F4L_HD
 #ifdef __HIPCC__
 #define F4L_HD __host__ __device__ __forceinline__
@@ -38,6 +47,7 @@ template <int K, int C> F4L_HD void ldlt6_transpose(double (&A)[6][6]) {
 }
 
 template <int K> F4L_HD void ldlt6_step(double (&A)[6][6], int (&tr)[6], bool &whole_diagonal_zero) {
+    F4L_NO_CONTRACT
     if (whole_diagonal_zero) return;
     int big = K;
     double best = ldlt6_abs(A[K][K]);
@@ -90,6 +100,7 @@ template <int K> F4L_HD void ldlt6_permute(double (&y)[6], const int (&tr)[6]) {
 
 // A: symmetric, read in its lower triangle and destroyed; x = A.ldlt().solve(b).
 F4L_HD void ldlt6_solve_eigen(double (&A)[6][6], const double (&b)[6], double (&x)[6]) {
+    F4L_NO_CONTRACT
     int tr[6] = {0, 1, 2, 3, 4, 5};
     bool zero_diag = false;
     ldlt6_step<0>(A, tr, zero_diag);
@@ -127,6 +138,7 @@ F4L_HD void ldlt6_solve_eigen(double (&A)[6][6], const double (&b)[6], double (&
 // CALLER's origin, the frame Open3D builds it in: J = [s x n, n] = C J' with C = [[I, [o]x], [0, I]], hence
 // M = C M' C^T, b = C b'.  M' symmetric (full storage), in place.
 F4L_HD void p2plane_system_to_caller_frame(double (&M)[6][6], double (&b)[6], double o0, double o1, double o2) {
+    F4L_NO_CONTRACT
     const double K[3][3] = {{0.0, -o2, o1}, {o2, 0.0, -o0}, {-o1, o0, 0.0}};
     double KBt[3][3], KD[3][3];
 #pragma unroll

@@ -3,11 +3,11 @@ once -> per tile `Coarse2Fine(cfg).implement_c2f_matching()` (:134-148) -> `resu
 
     python -m fusion4landslide_amd.main_fusion --config configs/landslide/fusion_3d_brienz.yaml [--partition identical]
 
-The supervoxel partition of this ENTRY is the device segmentation (f4l_supervoxel_parallel: the whole stage in HIP kernels, 5 ms per
-million points; the reference's K, criteria and partition quality) unless `--partition identical` -- or F4L_SV_MODE=identical --
-asks for the reference's own labels (f4l_supervoxel: its sequential fusion replayed on one host core, 1.1 s per million points);
-the displacement field needs a partition of that quality, not those labels.  The SWIG-module mirror `computeSupervoxel`, whose
-result IS the label vector, keeps `identical` as its own default.
+The supervoxel partition of this entry is the REFERENCE's own (`identical`: f4l_supervoxel -- kNN and normals on the device, the
+sequential fusion of supervoxel_segmentation.h:117-176 replayed label for label), so a drop-in run writes the partition and
+`c2f_*_tile` files the reference writes.  `--partition parallel` -- or F4L_SV_MODE=parallel -- opts into the all-device
+segmentation (f4l_supervoxel_parallel: the reference's K, criteria and partition quality at 200x the speed, not its labels).
+The mode is validated before anything runs and logged at start-up.
 
 The config keys are the reference's (path_name / data / method / parameter_setting / misc).  What the reference computes with
 its learned models -- point matches, patch matches, the 2D matches lifted to 3D -- enters through hooks on the cfg
@@ -64,20 +64,22 @@ def run(cfg, first_tile=0):
 
 def main(argv=None):
     parser = argparse.ArgumentParser()
-    # (the reference defaults to ./configs/landslide/fusion_3d_brienz.yaml of ITS tree; this package ships no data sets and no
-    #  configs, so the path is asked for -- any of the reference's fusion configs with `partition_type: supervoxel` works)
-    parser.add_argument('--config', type=str, required=True,
-                        help="Path to a fusion config of the reference's layout (e.g. its configs/landslide/fusion_3d_brienz.yaml); "
-                             "`method.partition_type` must be `supervoxel`.")
+    parser.add_argument('--config', type=str, default='./configs/landslide/fusion_brienz.yaml',  # main_fusion.py:57-63
+                        help="Path to a fusion config of the reference's layout; `method.partition_type` must be `supervoxel`.")
     parser.add_argument('--partition', type=str, default=None, choices=['identical', 'parallel'],
-                        help="supervoxel segmentation: the device segmentation (default) or the reference's labels (host replay)")
+                        help="supervoxel segmentation: the reference's labels (default) or the all-device segmentation")
     parser.add_argument('--first-tile', type=int, default=0)
     args = parser.parse_args(argv)
+    mode = args.partition or os.environ.get("F4L_SV_MODE", "identical")
+    if mode not in ("identical", "parallel"):  # (before tiling starts, not inside the first computeSupervoxel)
+        parser.error(f"F4L_SV_MODE must be 'identical' or 'parallel', not {mode!r}")
     setup_seed(0)
     cfg, log_path = build_config(args.config)
     from .cpp_core.supervoxel_segmentation.build import supervoxel
     mode_before = supervoxel.SEGMENTATION
-    supervoxel.SEGMENTATION = args.partition or os.environ.get("F4L_SV_MODE", "parallel")
+    supervoxel.SEGMENTATION = mode
+    cfg.logging.info(f"supervoxel partition mode: {mode!r} " + ("(the reference's labels)" if mode == "identical" else
+                     "(device segmentation: the reference's K and criteria, NOT its labels; partition files differ from the reference's)"))
     start = time.time()
     try:
         run(cfg, args.first_tile)

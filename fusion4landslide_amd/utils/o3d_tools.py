@@ -64,6 +64,12 @@ def icp_registration(src_pcd, tgt_pcd, initial_transform, threshold=0.1, icp_typ
                                gicp_epsilon=gicp_epsilon)
     T = out["T"][0].cpu().numpy()
     T[:3, 3] = T[:3, 3] + o - T[:3, :3] @ o
+    if int(out["iters"][0].item()) == -2:
+        # a step of Open3D's own semantics was not finite (generalized ICP at the reference's epsilon = 0 on a pair of exactly
+        # parallel normals): Open3D returns a NaN transform there; the kernel stopped at its last finite one (include/f4l.h)
+        import warnings
+        warnings.warn(f"icp_registration({icp_type!r}): a step was not finite (singular pair covariance?); Open3D would return "
+                      "NaN -- the transform returned is the last finite one", RuntimeWarning, stacklevel=2)
     corr = out["corr"].cpu().numpy()
     sel = np.nonzero(corr >= 0)[0]
     corr_set = np.stack([sel, corr[sel]], axis=1).astype(np.int32) if len(sel) else np.zeros((0, 2), np.int32)

@@ -135,6 +135,10 @@ int f4l_kabsch_residuals(const float *src, const float *ref, const int64_t *off,
  *                 of one or two wavefronts get workgroups of just those; results do not depend on it.
  * Outputs (any may be NULL except T_out):
  *   T_out double [P][16]; fitness_out, rmse_out double [P]; iters_out int32 [P];
+ *     iters_out[p] < 0 flags a patch that did not iterate normally: -1 skipped (f4l_patch_loop: fewer than min_corr pairs),
+ *     -2 a step with Open3D's semantics (F4L_ICP_P2PL_OPEN3D, generalized ICP) was not finite -- Open3D would return a NaN
+ *     transform there (generalized ICP with epsilon = 0 on a pair of exactly parallel normals); the patch keeps its last
+ *     finite transform and stops.  max_*_patch_host may be understated: larger patches only take a slower path.
  *   corr_out int32 [n_src]: index INSIDE the target patch of each source point's final correspondence,
  *   or -1 (utils/o3d_tools.py:64 `correspondence_set`).
  * ---------------------------------------------------------------------------------------------- */

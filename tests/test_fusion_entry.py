@@ -39,7 +39,7 @@ def test_save_process_dvf_writes_the_reference_files(tmp_path):
 
 
 @pytest.mark.gpu
-def test_main_fusion_entry_runs_the_tiles_and_writes_the_dvf_files(tmp_path):
+def test_main_fusion_entry_runs_the_tiles_and_writes_the_dvf_files(tmp_path, monkeypatch):
     """`python -m fusion4landslide_amd.main_fusion --config <yaml>` on a synthetic two-tile data set already tiled (the tiler
     is skipped like in the reference when tiled_data/ is not empty): the reference's nested yaml keys, both tiles visited in
     numeric order, the c2f_* files of save_process_dvf per tile; the dense rows are [s, T s] of the registered patches and
@@ -74,10 +74,16 @@ def test_main_fusion_entry_runs_the_tiles_and_writes_the_dvf_files(tmp_path):
     run_before = main_fusion.run
     main_fusion.run = lambda *a, **k: (seen.append(supervoxel.SEGMENTATION), run_before(*a, **k))[1]
     try:
-        main_fusion.main(["--config", str(path)])  # (no --partition: the entry's default is the device segmentation)
+        main_fusion.main(["--config", str(path), "--partition", "parallel"])  # (opt-in: the all-device segmentation)
+        main_fusion.run = lambda *a, **k: seen.append(supervoxel.SEGMENTATION)
+        main_fusion.main(["--config", str(path)])  # (no --partition: the entry's default is the reference's labels)
+        monkeypatch.setenv("F4L_SV_MODE", "fast")
+        with pytest.raises(SystemExit):            # an invalid mode is refused before anything runs
+            main_fusion.main(["--config", str(path)])
+        monkeypatch.delenv("F4L_SV_MODE")
     finally:
         main_fusion.run = run_before
-    assert seen == ["parallel"] and supervoxel.SEGMENTATION == "identical"
+    assert seen == ["parallel", "identical"] and supervoxel.SEGMENTATION == "identical"
     res = out_root / "results"
     for t in (0, 1):
         dvfs = np.loadtxt(res / f"c2f_dense_dvfs_src2tgt_tile_{t}.txt")

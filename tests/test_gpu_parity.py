@@ -332,6 +332,34 @@ def test_icp_point2plane_vs_oracle(eng, search, semantics):
         eng.piecewise_icp(dev(d["src"]), dev(d["src_off"]), dev(d["tgt"]), dev(d["tgt_off"]), icp_type="point2plane", p2plane="eigen")
 
 
+def test_generalized_icp_with_a_singular_pair_says_so(eng):
+    """generalized ICP at the reference's epsilon = 0 on an exactly planar patch (both normals (0, 0, 1): the pair
+    covariance M is singular, 1 / det = inf).  Open3D returns a NaN transform; the kernel keeps its last finite transform,
+    stops and flags the patch iters = -2 (include/f4l.h) -- and a well-posed patch of the same launch is untouched.  With
+    epsilon > 0 the same planar patch iterates normally."""
+    rng = np.random.default_rng(5)
+    tgt_a = np.c_[rng.uniform(0, 1, (300, 2)), np.zeros(300)]
+    src_a = np.c_[rng.uniform(0.1, 0.9, (200, 2)), np.full(200, 0.01)]
+    d = synthetic_patches(n=3_000, cells=1, seed=4, roughness=0.15)
+    src = np.r_[src_a, d["src"]].astype(np.float32)
+    tgt = np.r_[tgt_a, d["tgt"]].astype(np.float32)
+    soff = np.array([0, len(src_a), len(src)], np.int64)
+    toff = np.array([0, len(tgt_a), len(tgt)], np.int64)
+    nt = np.r_[np.tile([0.0, 0.0, 1.0], (len(tgt_a), 1)), O.o3d_estimate_normals(d["tgt"].astype(np.float64), 30)]
+    ns = np.r_[np.tile([0.0, 0.0, 1.0], (len(src_a), 1)), O.o3d_estimate_normals(d["src"].astype(np.float64), 30)]
+    args = (dev(src), dev(soff), dev(tgt), dev(toff))
+    out = eng.piecewise_icp(*args, max_corr_dist=0.1, max_iter=30, icp_type="generalized_icp", gicp_epsilon=0.0,
+                            tgt_normals=dev(nt), src_normals=dev(ns))
+    it = out["iters"].cpu().numpy()
+    T = out["T"].cpu().numpy()
+    assert it[0] == -2 and np.array_equal(T[0], np.eye(4))       # the first step already is not finite: the start stays
+    assert it[1] > 0 and np.isfinite(T).all()
+    ok = eng.piecewise_icp(*args, max_corr_dist=0.1, max_iter=30, icp_type="generalized_icp", gicp_epsilon=1e-3,
+                           tgt_normals=dev(nt), src_normals=dev(ns))
+    assert (ok["iters"] > 0).all()
+    assert abs(ok["T"][0, 2, 3].item() + 0.01) < 1e-5            # the sheet is lifted onto the plane
+
+
 def test_icp_point2plane_where_the_two_semantics_part(eng):
     """Where Open3D's step and the robust one differ (include/f4l.h, F4L_ICP_P2PL_OPEN3D): (a) a patch left with four
     correspondences -- robust: no step; Open3D (kernel and strict oracle alike): the singular system's "solution" is applied,
@@ -500,6 +528,50 @@ def test_icp_every_workgroup_shape_matches_oracle(eng, waves, monkeypatch):
                               max_iter=30, search="f32")
     disp = _disp_per_patch(d, out32["T"].cpu().numpy(), ref["T"])
     assert np.median(disp) <= 1e-5 and (disp <= 1e-4).mean() >= 0.85 and disp.max() <= 2e-3
+
+
+def test_icp_lane_group_kernel_never_sees_a_patch_beyond_its_capacity(eng, monkeypatch):
+    """icp_rows.h holds at most 4 * LP points per patch.  A caller that UNDERSTATES max_src_patch / max_tgt_patch
+    (the launch is planned from those two numbers) must get the same transforms as one that states them exactly: patches
+    larger than stated go to icp_kernel through a class of their own (icp_launch_host), never into the lane-group kernel,
+    whose LDS they would overrun."""
+    rng = np.random.default_rng(77)
+    sizes = np.r_[rng.integers(20, 60, 120), [300, 200, 129, 65, 90, 500]]
+    rng.shuffle(sizes)
+    src_l, tgt_l = [], []
+    for m in sizes:
+        m = int(m)
+        side = max(0.15, np.sqrt(m / 120.0))
+        xy = rng.uniform(0, side, (m + 3, 2))
+        t = np.c_[xy, 0.2 * np.sin(2.3 * xy[:, 0] / side) * np.cos(1.9 * xy[:, 1] / side)]
+        xy2 = rng.uniform(0.05 * side, 0.95 * side, (m, 2))
+        s = np.c_[xy2, 0.2 * np.sin(2.3 * xy2[:, 0] / side) * np.cos(1.9 * xy2[:, 1] / side)]
+        s = s @ rot_from_axis_angle(rng.normal(size=3), rng.uniform(0, 0.008)).T + rng.uniform(-0.02, 0.02, 3)
+        o = rng.uniform(0, 40, 3)
+        src_l.append(s + o); tgt_l.append(t + o)
+    src, tgt = np.concatenate(src_l).astype(np.float32), np.concatenate(tgt_l).astype(np.float32)
+    soff, toff = ragged(None, [len(a) for a in src_l]), ragged(None, [len(a) for a in tgt_l])
+    args = (dev(src), dev(soff), dev(tgt), dev(toff))
+    monkeypatch.setenv("F4L_ICP_ROWS", "0")
+    exact = eng.piecewise_icp(*args, max_corr_dist=0.1, max_iter=30, search="f64", return_corr=True)
+    monkeypatch.setenv("F4L_ICP_ROWS", "1")
+    for stated in (60, 64, 100, 128):   # one lane width, the other, and both class layouts (with / without the small classes)
+        for small in ("0", "1"):
+            monkeypatch.setenv("F4L_ICP_SMALLCLASSES", small) if small == "1" else monkeypatch.delenv("F4L_ICP_SMALLCLASSES", raising=False)
+            out = eng.piecewise_icp(*args, max_corr_dist=0.1, max_iter=30, search="f64", return_corr=True,
+                                    max_src_patch=stated, max_tgt_patch=stated)
+            assert (out["iters"] >= 0).all()
+            # (the two kernels sum in different orders: the oracle's trajectory to 1e-9 m either way, not the same bits)
+            well = (exact["fitness"] > 0.8).cpu().numpy()
+            assert well.sum() > 100
+            Ta, Tb = out["T"].cpu().numpy(), exact["T"].cpu().numpy()
+            for p in np.flatnonzero(well):
+                sp = src[soff[p]:soff[p + 1]].astype(np.float64)
+                assert np.abs((sp @ Ta[p, :3, :3].T + Ta[p, :3, 3]) - (sp @ Tb[p, :3, :3].T + Tb[p, :3, 3])).max() <= 1e-9, (p, stated, small)
+            wt = torch.from_numpy(well).cuda()
+            assert torch.equal(out["iters"][wt], exact["iters"][wt]) and torch.equal(out["fitness"][wt], exact["fitness"][wt])
+            pt_well = torch.repeat_interleave(wt, torch.from_numpy(np.diff(soff)).cuda())
+            assert torch.equal(out["corr"][pt_well], exact["corr"][pt_well]), (stated, small)
 
 
 @pytest.mark.parametrize("fused", [False, True])
