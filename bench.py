@@ -191,12 +191,36 @@ def run_rank(args, world):
     if world > 1:
         dist.barrier()
     sync()
-    elapsed = time.perf_counter() - t0
+    t_local = time.perf_counter() - t0   # (every rank's own clock over the same barrier-to-barrier region)
+    elapsed = t_local
+    per_rank = None
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     full = gather.latest() if args.steps + args.warmup > 0 else None
+    if world > 1:
+        # what the one number above hides: every rank's own compute time per step (events on its launch stream around
+        # its f4l_patch_loop: the LPT balance), its points and patches, and the all-gather by itself -- timed AFTER the metric's
+        # region, un-overlapped: submit + drain between two synchronisations, mean of a few
+        own_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if (ev and args.steps > 0) else 0.0
+        ag = []
+        for _ in range(5 if (args.steps + args.warmup > 0) else 0):
+            sync(); dist.barrier(); sync()
+            ta = time.perf_counter()
+            gather.submit(out); gather.drain(); sync()
+            ag.append(1e3 * (time.perf_counter() - ta))
+        mine_stats = torch.tensor([own_ms, float(n_mine), float(P), float(np.mean(ag)) if ag else 0.0, 1e3 * t_local / max(args.steps, 1)],
+                                  dtype=torch.float64, device=dev)
+        allr = torch.zeros((world, 5), dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(allr, mine_stats.view(1, 5))
+        allr = allr.cpu().numpy()
+        mm = lambda c: {"min": round(float(allr[:, c].min()), 4), "max": round(float(allr[:, c].max()), 4),  # noqa: E731
+                        "mean": round(float(allr[:, c].mean()), 4)}
+        per_rank = {"step_ms": mm(0), "points": mm(1), "patches": mm(2), "allgather_ms": mm(3), "wall_ms_per_step": mm(4),
+                    "allgather_bytes_per_rank": int(gather.pmax * 19 * 8),
+                    "note": "step_ms = a rank's own f4l_patch_loop per step (events; 0 in a dry run); allgather_ms = one all-gather of the "
+                            "per-patch results alone, after the timed region"}
 
     if rank == 0:
         ms_per_step = 1e3 * elapsed / max(args.steps, 1)
@@ -217,6 +241,8 @@ def run_rank(args, world):
                        #  and the allocator's first gigabytes; untimed, outside the metric)
                        "setup_breakdown_s": {k: round(v, 2) for k, v in setup_parts.items()}},
         }
+        if per_rank is not None:
+            line["per_rank"] = per_rank
         if dry:
             line["dry_run"] = True
             line["dry_run_gather_ok"] = bool(full is not None and torch.equal(

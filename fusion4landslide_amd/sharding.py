@@ -160,8 +160,9 @@ class PatchResultGather:
             pk[:p, :16] = out["T"].reshape(p, 16)
             pk[:p, 16], pk[:p, 17], pk[:p, 18] = out["fitness"], out["rmse"], out["iters"].to(torch.float64)
         if self.world > 1:
-            views = list(self.bufs[slot].view(self.world, self.pmax, 19).unbind(0))
-            self.inflight[slot] = self.dist.all_gather(views, pk, async_op=True)
+            # ONE flat receive buffer (rank r's rows at r * pmax): all_gather_into_tensor writes it in place -- an all_gather into a
+            # LIST of views makes c10d gather into a staging buffer of its own and copy every view back
+            self.inflight[slot] = self.dist.all_gather_into_tensor(self.bufs[slot], pk, async_op=True)
         else:
             self.bufs[slot][:self.pmax].copy_(pk)
         return slot

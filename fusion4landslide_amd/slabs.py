@@ -74,11 +74,21 @@ def _a2a_v(dist, torch, payload, dest, world):
     counts = torch.bincount(dest, minlength=world).to(torch.int64)
     if world == 1:
         return send
-    got = torch.zeros(world, dtype=torch.int64, device=payload.device)
-    _all_to_all(dist, got, counts)
-    recv = torch.empty((int(got.sum()), payload.shape[1]), dtype=payload.dtype, device=payload.device)
+    both = torch.zeros(2 * world, dtype=torch.int64, device=payload.device)  # [what I send to r | what r sends to me]
+    both[:world] = counts
+    _all_to_all(dist, both[world:], both[:world])
+    # the split sizes of the payload exchange are host integers: ONE read-back of both halves (through a pinned buffer when the
+    # tensors live on a GPU), not one `.tolist()` per half
+    if both.is_cuda:
+        host = torch.empty(2 * world, dtype=torch.int64, pin_memory=True)
+        host.copy_(both, non_blocking=True)
+        torch.cuda.current_stream(both.device).synchronize()
+    else:
+        host = both
     c = payload.shape[1]
-    _all_to_all(dist, recv.view(-1), send.view(-1), (got * c).tolist(), (counts * c).tolist())
+    sizes = (host * c).tolist()
+    recv = torch.empty((sum(sizes[world:]) // c, c), dtype=payload.dtype, device=payload.device)
+    _all_to_all(dist, recv.view(-1), send.view(-1), sizes[world:], sizes[:world])
     return recv
 
 

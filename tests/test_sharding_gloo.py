@@ -197,6 +197,13 @@ def test_bench_gpus2_dry_run_starts_two_ranks():
     assert line["n_gpus"] == 2 and line["dry_run"] and line["dry_run_gather_ok"] and line["value"] is None
     assert line["scaling"] == "strong" and line["config"]["patches"] == 64 and line["config"]["patches_on_rank0"] == 32
     assert line["config"]["dist_backend"] == "gloo" and line["config"]["dist_world_size"] == 2  # (nccl = RCCL on the GPUs)
+    # every rank's own numbers, not only the slowest rank's clock: LPT balance and the all-gather by itself
+    pr = line["per_rank"]
+    assert pr["patches"] == {"min": 32.0, "max": 32.0, "mean": 32.0} and pr["points"]["min"] > 0
+    assert abs(pr["points"]["mean"] * 2 - line["config"]["points_per_epoch"]) < 1
+    assert pr["points"]["max"] <= 1.1 * pr["points"]["mean"]                      # LPT: no rank far above its share
+    assert pr["allgather_ms"]["min"] > 0 and pr["allgather_bytes_per_rank"] == 32 * 19 * 8
+    assert pr["wall_ms_per_step"]["max"] <= line["ms_per_step"] * 1.0001 + 1e-3   # the line's time is the slowest rank's
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], capture_output=True, text=True,
                        env=dict(env, WORLD_SIZE="4"), timeout=60)
     assert r.returncode == 2 and "WORLD_SIZE=4" in r.stderr
