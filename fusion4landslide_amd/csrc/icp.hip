@@ -886,7 +886,7 @@ __global__ __launch_bounds__(NW * 64, WIDE ? 3 : (sizeof(F) == 8 ? ICP_WAVES_PER
                         caller_frame = true;
 #pragma unroll
                         for (int u = 0; u < 6; ++u) { x[u] = state[40 + u]; have = have && isfinite(x[u]); }
-                        if (MODE == F4L_ICP_GENERALIZED) {  // (a NaN diagonal reads as "all zero" to the ldlt restatement: x = 0, finite)
+                        if constexpr (MODE == F4L_ICP_GENERALIZED) {  // (a NaN diagonal reads as "all zero" to the ldlt restatement: x = 0, finite)
                             double chk = 0.0;
 #pragma unroll
                             for (int u = 2; u < NV; ++u) chk += tot[u];

@@ -90,6 +90,7 @@ struct State {
     int32_t stalled;                             // the graph of representatives has no edges left but live > K
     int32_t rounds;                              // lambda rounds entered
     int32_t sweeps_done;
+    int32_t unsorted;                            // some neighbour list is not in ascending order of distance (round 0 then reads every list to its end)
     int32_t n_prop[LAMBDA_ROUNDS * SUBROUNDS];   // proposals of sub-round rho
     int32_t sw_on[SWEEPS + 1], sw_full[SWEEPS + 1], sw_changed[SWEEPS + 1];  // per sweep: ran / looked at every point / changed a label
 };
@@ -112,6 +113,21 @@ __device__ __forceinline__ bool heads(int32_t v, int32_t round) {
     unsigned int h = (unsigned int)v * 0x9E3779B1u ^ ((unsigned int)round + 1u) * 0x85EBCA6Bu;
     h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12; h *= 0x297A2D39u; h ^= h >> 15;
     return (h & 1u) != 0u;
+}
+// An edge key is (u << 32) | v with u, v PLACES below 2^28 (f4l_supervoxel_segment_device refuses more points; its workspace for 2^28
+// points is beyond one MI355X anyway).  The eight spare bits -- 60..63 and 28..31 -- carry
+//   in the filter table: the number of the lambda round that wrote the entry: entries of earlier rounds never compare equal, and
+//     the table is cleared ONCE per segmentation instead of once per round (round 4: 2 GB of zero fill per 10 M points);
+//   in the list of active edges: bits 60..62 = the sub-rounds in which the edge can make an offer (u heads and v tails), known
+//     when the edge is picked (the coins of a round's representatives travel in their records): a sub-round tests its bit before
+//     it touches anything else, and an edge with no bit set is never listed.
+constexpr unsigned long long PLACE_MASK = 0x0fffffffULL;
+constexpr int64_t MAX_PLACES = 1LL << 28;
+__device__ __forceinline__ int32_t key_u(unsigned long long key) { return (int32_t)((key >> 32) & PLACE_MASK); }
+__device__ __forceinline__ int32_t key_v(unsigned long long key) { return (int32_t)(key & PLACE_MASK); }
+__device__ __forceinline__ unsigned long long round_stamp(int r) {
+    const unsigned long long e = (unsigned long long)(r + 1);  // 1 .. LAMBDA_ROUNDS: never the 0 of a cleared or plain key
+    return ((e & 15ULL) << 60) | (((e >> 4) & 15ULL) << 28);
 }
 __device__ __forceinline__ unsigned int lanes_below(unsigned long long m) {
     return __builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u));
@@ -218,9 +234,16 @@ __global__ void bbox_kernel(const float *__restrict__ xyz, int64_t n, State *st,
         else { atomicMax(&st->pb[d], v); if (!grid_box_given) atomicMax(&st->bb[d], v); }
     }
 }
-// grid_sample.h:48-68: size = int(len / res + 1), cell = clamp(int((p - min) / res)), all in double
-__global__ void grid_key_kernel(const float *__restrict__ xyz, int64_t n, double resolution, const State *st,
-                                unsigned long long *__restrict__ keys) {
+// grid_sample.h:48-68: size = int(len / res + 1), cell = clamp(int((p - min) / res)), all in double.  K is the number of DISTINCT
+// cell keys: counted by inserting the keys into an open-addressing hash set (linear probing, compare-and-swap; at least two
+// slots per point, so a probe always ends) -- rounds 2-4 sorted the 64-bit keys for it, eight radix passes over the cloud.  The
+// points arrive in the segmentation's spatial order, so most lanes hold the key of the lane before them and insert nothing.
+__device__ __forceinline__ unsigned long long mix64(unsigned long long x) {
+    x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
+    return x;
+}
+__global__ void grid_count_kernel(const float *__restrict__ xyz, int64_t n, double resolution, State *st,
+                                  unsigned long long *__restrict__ set, unsigned long long slots) {
 #pragma clang fp contract(off)
     double mn[3];
     int size[3];
@@ -229,6 +252,7 @@ __global__ void grid_key_kernel(const float *__restrict__ xyz, int64_t n, double
         mn[d] = (double)ord2f(st->bb[d]);
         size[d] = (int)(((double)ord2f(st->bb[3 + d]) - mn[d]) / resolution + 1);
     }
+    int cnt = 0;
     SV_FOR(i, n) {
         int c[3];
 #pragma unroll
@@ -236,13 +260,19 @@ __global__ void grid_key_kernel(const float *__restrict__ xyz, int64_t n, double
             c[d] = (int)(((double)xyz[3 * i + d] - mn[d]) / resolution);
             c[d] = c[d] < 0 ? 0 : (c[d] > size[d] - 1 ? size[d] - 1 : c[d]);
         }
-        keys[i] = ((unsigned long long)c[0] * (unsigned long long)size[1] + (unsigned long long)c[1]) * (unsigned long long)size[2] +
-                  (unsigned long long)c[2];
+        const unsigned long long key = ((unsigned long long)c[0] * (unsigned long long)size[1] + (unsigned long long)c[1]) * (unsigned long long)size[2] +
+                                       (unsigned long long)c[2];
+        const unsigned long long before = ((unsigned long long)(unsigned int)__shfl_up((int)(key >> 32), 1, 64) << 32) |
+                                          (unsigned int)__shfl_up((int)(key & 0xffffffffULL), 1, 64);
+        if (lane_id() > 0 && before == key) continue;  // (the lane before inserts it)
+        unsigned long long slot = __umul64hi(mix64(key), slots);
+        for (;;) {
+            const unsigned long long old = atomicCAS(&set[slot], DEAD, key);  // (keys are below 2^63: never DEAD)
+            if (old == DEAD) { ++cnt; break; }
+            if (old == key) break;
+            slot = slot + 1ULL == slots ? 0ULL : slot + 1ULL;
+        }
     }
-}
-__global__ void count_distinct_kernel(const unsigned long long *__restrict__ sorted, int64_t n, State *st) {  // (256 workgroups)
-    int cnt = 0;
-    SV_FOR(i, n) cnt += (i == 0 || sorted[i] != sorted[i - 1]) ? 1 : 0;
     cnt = wave_sum(cnt);
     __shared__ int part[16];
     if (lane_id() == 0) part[threadIdx.x >> 6] = cnt;
@@ -341,10 +371,11 @@ __device__ __forceinline__ bool sv_distance_at_least(const float (&pa)[3], const
 // ---- lambda0 -----------------------------------------------------------------------------------------------------
 #pragma clang fp contract(off)
 __global__ void min_metric_kernel(const float *__restrict__ xyz, const double *__restrict__ nrm, const int32_t *__restrict__ knnT,
-                                  int64_t n, int k, double resolution, double *__restrict__ dis0) {
+                                  int64_t n, int k, double resolution, double *__restrict__ dis0, State *st) {
     constexpr int CH = 6;  // neighbours whose indices and coordinates are loaded together (see rows_body)
+    bool unsorted = false;  // (a list that is NOT in ascending order of distance: round 0 may then not stop at the first far neighbour)
     SV_FOR(i, n) {
-        double best = DBL_MAX;
+        double best = DBL_MAX, d2_before = 0.0;
         const double xi = xyz[3 * i], yi = xyz[3 * i + 1], zi = xyz[3 * i + 2];
         const double c = 0.4 / resolution;
         for (int j0 = 0; j0 < k; j0 += CH) {
@@ -362,13 +393,17 @@ __global__ void min_metric_kernel(const float *__restrict__ xyz, const double *_
                 if (q[t] == i) continue;
                 // sv_metric_at_least(xyz, i, q, resolution, best) on the coordinates already here
                 const double t1 = xi - p[t][0], t2 = yi - p[t][1], t3 = zi - p[t][2], bound = best * 1.000001 + 1e-15;
-                if (c * c * (t1 * t1 + t2 * t2 + t3 * t3) > bound * bound) continue;
+                const double d2 = t1 * t1 + t2 * t2 + t3 * t3;
+                unsorted = unsorted || d2 < d2_before * 0.999999;
+                d2_before = d2;
+                if (c * c * d2 > bound * bound) continue;
                 const double m = sv_metric(xyz, nrm, i, q[t], resolution);
                 best = m < best ? m : best;
             }
         }
         dis0[i] = best;
     }
+    if (__ballot(unsorted) != 0ULL && lane_id() == 0) atomicOr(&st->unsorted, 1);
 }
 __global__ void start_kernel(State *st, const double *__restrict__ median) {
     const double med = median[0];  // median.h:27-30: nth_element at size / 2 (the element of that rank: select.hip)
@@ -382,33 +417,38 @@ __global__ void init_points_kernel(int64_t n, int32_t *__restrict__ parent, int3
 // What a pass over an edge list needs to know about an end point, in ONE 16-byte record (one load instruction): the pass is bound
 // by the scattered lanes it addresses and the cache lines they touch, not by bytes -- representative, the representative's size
 // and position through parent[], size[] and xyz[] would be five loads of which three depend on the first.  The position is
-// quantised (21 bits per axis of the cloud's bounding cube: a third of a millimetre on a 600 m tile): it only serves the test
+// quantised (20 bits per axis of the cloud's bounding cube: 0.6 mm on a 600 m tile): it only serves the test
 // "the distance term alone rules the edge out", taken with three steps of slack per axis, i.e. on a LOWER bound of the distance; the
-// edges it cannot rule out (a tenth) take the exact test on the float coordinates.
+// edges it cannot rule out (a tenth) take the exact test on the float coordinates.  Bits 60..62 of the position word: the coins
+// the representative draws in the three sub-rounds of the round the record was made for (heads(), on the caller's index).
 struct __attribute__((aligned(16))) Node { int32_t root, size; unsigned int qlo, qhi; };
 struct Quant { float mn[3]; float inv_step, step; };
+constexpr float QUANT_MAX = 1048575.f;  // 2^20 - 1
 __device__ __forceinline__ Quant quant_of(const State *st);
-__device__ __forceinline__ void node_pack(Node &nd, const Quant &q, float x, float y, float z) {
+__device__ __forceinline__ void node_pack(Node &nd, const Quant &q, float x, float y, float z, unsigned int coins) {
     const float f[3] = {x, y, z};
-    unsigned long long w = 0ULL;
+    unsigned long long w = (unsigned long long)(coins & 7u) << 60;
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
         float t = (f[d] - q.mn[d]) * q.inv_step;
-        t = t < 0.f ? 0.f : (t > 2097151.f ? 2097151.f : t);
-        w |= (unsigned long long)(unsigned int)t << (21 * d);
+        t = t < 0.f ? 0.f : (t > QUANT_MAX ? QUANT_MAX : t);
+        w |= (unsigned long long)(unsigned int)t << (20 * d);
     }
     nd.qlo = (unsigned int)w;
     nd.qhi = (unsigned int)(w >> 32);
 }
+__device__ __forceinline__ unsigned int node_coins(const Node &a) { return (a.qhi >> 28) & 7u; }
+// the sub-rounds in which an edge u -> v can make an offer: u heads and v tails (bit s: sub-round s)
+__device__ __forceinline__ unsigned int edge_eligible(const Node &u, const Node &v) { return node_coins(u) & ~node_coins(v) & 7u; }
 // a lower bound of the squared distance between two records' positions, in units of the quantisation step squared
 __device__ __forceinline__ float node_dist2_low(const Node &a, const Node &b) {
     const unsigned long long wa = ((unsigned long long)a.qhi << 32) | a.qlo, wb = ((unsigned long long)b.qhi << 32) | b.qlo;
     float s = 0.f;
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
-        const int da = (int)((wa >> (21 * d)) & 0x1fffffULL), db = (int)((wb >> (21 * d)) & 0x1fffffULL);
+        const int da = (int)((wa >> (20 * d)) & 0xfffffULL), db = (int)((wb >> (20 * d)) & 0xfffffULL);
         int g = da > db ? da - db : db - da;
-        g = g > 3 ? g - 3 : 0;  // (a quantised coordinate lies within a step and a half of the true one, float rounding at 2^21 included: three steps of slack per axis)
+        g = g > 3 ? g - 3 : 0;  // (a quantised coordinate lies within a step and a half of the true one, float rounding at 2^20 included: three steps of slack per axis)
         s += (float)g * (float)g;
     }
     return s;
@@ -423,7 +463,7 @@ __device__ __forceinline__ Quant quant_of(const State *st) {
         const float e = ord2f(st->pb[3 + d]) - q.mn[d];
         ext = e > ext ? e : ext;
     }
-    q.step = ext > 0.f ? ext / 2097150.f : 1.f;
+    q.step = ext > 0.f ? ext / (QUANT_MAX - 1.f) : 1.f;
     q.inv_step = 1.f / q.step;
     return q;
 }
@@ -452,7 +492,7 @@ __device__ __forceinline__ unsigned long long list_in_count(const SegArgs &a, in
     return r <= KNN_ROUNDS ? (unsigned long long)a.n * (unsigned long long)a.k : a.st->ne[r - 1];
 }
 // slots of the filter that merges the parallel edges of a list of n_edges
-__device__ __forceinline__ unsigned long long table_size(unsigned long long n_edges) {
+__host__ __device__ __forceinline__ unsigned long long table_size(unsigned long long n_edges) {
     return n_edges < 4096 ? 1024 : (n_edges / 4 < 0xffffffffULL ? n_edges / 4 : 0xffffffffULL);  // (indexed by the high word of a 32-bit product)
 }
 
@@ -472,21 +512,15 @@ __device__ __forceinline__ void node_body(const SegArgs &a, int r) {
         Node nd;
         nd.root = q;
         nd.size = a.size[q];
-        node_pack(nd, qt, a.xyz[3 * (int64_t)q], a.xyz[3 * (int64_t)q + 1], a.xyz[3 * (int64_t)q + 2]);
+        const int32_t oq = a.orig[q];  // (the coins are drawn on the CALLER's indices)
+        const unsigned int coins = (heads(oq, SUBROUNDS * r) ? 1u : 0u) | (heads(oq, SUBROUNDS * r + 1) ? 2u : 0u) | (heads(oq, SUBROUNDS * r + 2) ? 4u : 0u);
+        node_pack(nd, qt, a.xyz[3 * (int64_t)q], a.xyz[3 * (int64_t)q + 1], a.xyz[3 * (int64_t)q + 2], coins);
         a.node[i] = nd;
     }
 }
 __global__ void node_kernel(SegArgs a, int r) {
     if (!fusing(a.st)) return;
     node_body(a, r);
-}
-__device__ __forceinline__ void table_clear_body(const SegArgs &a, int r) {
-    const unsigned long long ts = table_size(list_in_count(a, r));
-    SV_FOR(i, ts) a.table[i] = DEAD;
-}
-__global__ void table_clear_kernel(SegArgs a, int r) {
-    if (!fusing(a.st)) return;
-    table_clear_body(a, r);
 }
 // Round r's list from round r - 1's (FROM_KNN: from the neighbour lists themselves, rounds 0 and 1), and its active edges.
 // Round 0 has nothing to re-point or merge: only the active edges are picked.
@@ -503,6 +537,7 @@ __device__ __forceinline__ void build_body(const SegArgs &a, int r) {
     unsigned long long *__restrict__ lout = list_of(a, r);
     const float *__restrict__ xyz = a.xyz;
     const unsigned int ts32 = (unsigned int)ts;
+    const unsigned long long stamp = round_stamp(r);  // (what this round leaves in the device-wide filter is its own)
     // the distance term of the metric alone against lambda, c * d * sizes[v] > lambda, first in float with a margin a thousand
     // times the float error (the few edges inside the margin take the exact test in double)
     const float cfs = (float)(0.4 / resolution) * quant_of(st).step, lambda_hi = (float)(lambda * 1.001);  // (cfs: c times the quantisation step)
@@ -532,13 +567,14 @@ __device__ __forceinline__ void build_body(const SegArgs &a, int r) {
             u[j] = v[j] = 0;
             if (live[j]) {
                 const unsigned long long old = lin[e];
-                u[j] = (int32_t)(old >> 32);
-                v[j] = (int32_t)(old & 0xffffffffULL);
+                u[j] = key_u(old);
+                v[j] = key_v(old);
             }
         }
         // ... re-pointed (the records of the round: one load per end gives representative, size and position)
         int32_t szu[BUILD_ITEMS];
         float d2low[BUILD_ITEMS];
+        unsigned int elig[BUILD_ITEMS];  // the sub-rounds in which the edge can make an offer (none: it is never active)
         {
             Node nu[BUILD_ITEMS], nv[BUILD_ITEMS];
 #pragma unroll
@@ -548,6 +584,7 @@ __device__ __forceinline__ void build_body(const SegArgs &a, int r) {
                 u[j] = nu[j].root; v[j] = nv[j].root;
                 szu[j] = nu[j].size; szv[j] = nv[j].size;
                 d2low[j] = node_dist2_low(nu[j], nv[j]);
+                elig[j] = edge_eligible(nu[j], nv[j]);
             }
         }
         // ... merged.  First by the wave's own filter in LDS (direct mapped: an edge that finds itself in its slot is parallel to
@@ -571,10 +608,10 @@ __device__ __forceinline__ void build_body(const SegArgs &a, int r) {
                     live[j] = __hip_atomic_exchange(&wf[h >> 24], key[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != key[j];
                 fresh[j] = live[j] && (!emit || (szu[j] == 1 && szv[j] == 1));
                 old[j] = DEAD;
-                if (live[j] && !fresh[j]) old[j] = atomicExch(&a.table[__umulhi(h * 0x9E3779B1u, ts32)], key[j]);
+                if (live[j] && !fresh[j]) old[j] = atomicExch(&a.table[__umulhi(h * 0x9E3779B1u, ts32)], key[j] | stamp);
             }
 #pragma unroll
-            for (int j = 0; j < BUILD_ITEMS; ++j) fresh[j] = fresh[j] || (live[j] && old[j] != key[j]);
+            for (int j = 0; j < BUILD_ITEMS; ++j) fresh[j] = fresh[j] || (live[j] && old[j] != (key[j] | stamp));
         }
         // ... and the active ones among the fresh: those the criterion `lambda - sizes[v] * metric(u, v) > 0` (:147-149) accepts
         // with the size v has NOW -- sizes only grow, so no other edge can be accepted in this round.  The distance term of the
@@ -585,7 +622,7 @@ __device__ __forceinline__ void build_body(const SegArgs &a, int r) {
 #pragma unroll
             for (int j = 0; j < BUILD_ITEMS; ++j) {
                 const float fs = cfs * (float)szv[j];
-                near[j] = fresh[j] && !(fs * fs * d2low[j] > lambda_hi * lambda_hi);
+                near[j] = fresh[j] && elig[j] != 0u && !(fs * fs * d2low[j] > lambda_hi * lambda_hi);
                 // (exactly: the distance term against lambda / sizes[v], without the division)
                 if (near[j]) near[j] = !sv_metric_at_least_sized(xyz, u[j], v[j], cd * (double)szv[j], lambda * 1.000001 + (double)szv[j] * 1e-15);
             }
@@ -596,7 +633,7 @@ __device__ __forceinline__ void build_body(const SegArgs &a, int r) {
                     act[j] = lambda - (double)szv[j] * m[j] > 0.0;
                     // (a round without a list: its few active edges pass the device-wide filter here, or the active list of round 2
                     //  would hold every edge four times over -- one per member pair of the two supervoxels)
-                    if (act[j] && !emit && r > 0) act[j] = atomicExch(&a.table[__umulhi(hsh[j] * 0x9E3779B1u, ts32)], key[j]) != key[j];
+                    if (act[j] && !emit && r > 0) act[j] = atomicExch(&a.table[__umulhi(hsh[j] * 0x9E3779B1u, ts32)], key[j] | stamp) != (key[j] | stamp);
                 }
                 listed[j] = fresh[j] && r > 0;  // (counted from round 1 on: an empty list means a disconnected graph; written from round KNN_ROUNDS on)
             }
@@ -612,7 +649,7 @@ __device__ __forceinline__ void build_body(const SegArgs &a, int r) {
 #pragma unroll
         for (int j = 0; j < BUILD_ITEMS; ++j) {
             if (listed[j] && emit) lout[at0[j]] = key[j];
-            if (act[j]) { a.akey[at1[j]] = key[j]; a.am[at1[j]] = m[j]; }
+            if (act[j]) { a.akey[at1[j]] = key[j] | ((unsigned long long)elig[j] << 60); a.am[at1[j]] = m[j]; }
         }
     }
 }
@@ -671,6 +708,11 @@ __device__ __forceinline__ unsigned int edge_slot(int32_t u, int32_t v, unsigned
 constexpr int ROW_FILTER = 2048;  // slots (16 KB of LDS)
 constexpr int ROW_SEEN = 8;
 constexpr int ROW_CHUNK = 10;
+#ifndef SVX_NEAR_BATCH
+#define SVX_NEAR_BATCH 4
+#endif
+constexpr int NEAR_BATCH = SVX_NEAR_BATCH;  // near edges of a row that are measured together
+constexpr int LIST_BATCH = 5;  // listed edges of a row whose representatives are fetched together
 constexpr int SWEEP_CHUNK = 10;  // representatives a lane remembers having met in its row (most of a row's edges lead to a few supervoxels)
 __device__ __forceinline__ void rows_body(const SegArgs &a, int r) {
     State *st = a.st;
@@ -679,10 +721,15 @@ __device__ __forceinline__ void rows_body(const SegArgs &a, int r) {
     const bool emit = r >= KNN_ROUNDS;  // this round writes a list (and passes the device-wide filter)
     const double lambda = lambda_of(st, r), lambda0 = st->lambda0, resolution = a.resolution;
     const unsigned int ts32 = (unsigned int)table_size((unsigned long long)n * (unsigned long long)k);
+    const unsigned long long stamp = round_stamp(r);  // (what this round leaves in the device-wide filter is its own)
     // the distance term of the metric alone against lambda, c * d * sizes[v] > lambda, first in float with a margin a thousand
     // times the float error (the few edges inside the margin take the exact test in double)
     const float cfs = (float)(0.4 / resolution) * quant_of(st).step, lambda_hi = (float)(lambda * 1.001);  // (cfs: c times the quantisation step)
     const double cd = 0.4 / resolution;
+    // Round 0: every point is its own representative and its list is in ascending order of distance (what a neighbour search
+    // returns; min_metric_kernel checked it), so the first neighbour the distance term rules out ends the row -- at lambda0, the
+    // median of the smallest metrics, that is among the first few, and whole waves leave after the first chunk.
+    const bool stop_early = r == 0 && !st->unsorted;
     unsigned long long *__restrict__ lout = list_of(a, r);
     const float *__restrict__ xyz = a.xyz;
     const int32_t *__restrict__ knnT = a.knnT;
@@ -698,6 +745,11 @@ __device__ __forceinline__ void rows_body(const SegArgs &a, int r) {
         unsigned long long listmask = 0ULL, actmask = 0ULL;
         int n_fresh = 0;
         int32_t u = 0;
+        int kept_j[NEAR_BATCH];  // the first batch of the row's near edges that turned out active: slot, key (with its sub-round bits), metric
+        unsigned long long kept_key[NEAR_BATCH];
+        double kept_m[NEAR_BATCH];
+#pragma unroll
+        for (int t = 0; t < NEAR_BATCH; ++t) { kept_j[t] = -1; kept_key[t] = 0ULL; kept_m[t] = 0.0; }
         // (round 0: a point whose smallest metric is not below lambda0 has no active edge -- half of the points)
         const bool row = i < n && !(r == 0 && !(a.dis[i] < lambda0));
         if (row) {
@@ -713,16 +765,21 @@ __device__ __forceinline__ void rows_body(const SegArgs &a, int r) {
             int at_seen = 0;
             // (the neighbours ROW_CHUNK at a time: their indices, then their records, are loaded together -- one after the other
             //  a row would wait for sixty memory round trips in turn, and the pass is bound by exactly that wait)
+            int32_t qn[ROW_CHUNK];  // the NEXT chunk's indices: requested together with the current chunk's records
+#pragma unroll
+            for (int c = 0; c < ROW_CHUNK; ++c) qn[c] = c < k ? knnT[(int64_t)c * n + i] : -1;
             for (int j0 = 0; j0 < k; j0 += ROW_CHUNK) {
                 int32_t q[ROW_CHUNK];
                 Node nq[ROW_CHUNK];
 #pragma unroll
                 for (int c = 0; c < ROW_CHUNK; ++c) {
-                    q[c] = j0 + c < k ? knnT[(int64_t)(j0 + c) * n + i] : -1;
+                    q[c] = qn[c];
                     if (q[c] < 0 || (int64_t)q[c] >= n) q[c] = (int32_t)i;  // (its own record: the edge is dropped as a self loop)
                 }
 #pragma unroll
                 for (int c = 0; c < ROW_CHUNK; ++c) nq[c] = a.node[q[c]];
+#pragma unroll
+                for (int c = 0; c < ROW_CHUNK; ++c) qn[c] = j0 + ROW_CHUNK + c < k ? knnT[(int64_t)(j0 + ROW_CHUNK + c) * n + i] : -1;
                 // new to this row?  (its own supervoxel, or one this row has just met, is not)
                 bool fresh[ROW_CHUNK], asked[ROW_CHUNK];
 #pragma unroll
@@ -753,53 +810,123 @@ __device__ __forceinline__ void rows_body(const SegArgs &a, int r) {
 #pragma unroll
                 for (int c = 0; c < ROW_CHUNK; ++c) {
                     const unsigned long long key = ((unsigned long long)(unsigned int)u << 32) | (unsigned int)nq[c].root;
-                    found[c] = asked[c] ? atomicExch(&a.table[edge_slot(u, nq[c].root, ts32)], key) : DEAD;
+                    found[c] = asked[c] ? atomicExch(&a.table[edge_slot(u, nq[c].root, ts32)], key | stamp) : DEAD;
                 }
+                bool far_last = false;
 #pragma unroll
                 for (int c = 0; c < ROW_CHUNK; ++c) {
                     const int j = j0 + c;
                     const unsigned long long key = ((unsigned long long)(unsigned int)u << 32) | (unsigned int)nq[c].root;
-                    if (fresh[c] && found[c] != key) {
+                    if (fresh[c] && found[c] != (key | stamp)) {
                         ++n_fresh;
                         if (emit) listmask |= 1ULL << j;
                         const float fs = cfs * (float)nq[c].size;
-                        if (!(fs * fs * node_dist2_low(nu, nq[c]) > lambda_hi * lambda_hi)) nearmask |= 1ULL << j;
+                        const bool far = fs * fs * node_dist2_low(nu, nq[c]) > lambda_hi * lambda_hi;
+                        // (an edge that can make no offer in any of the round's sub-rounds -- u tails or v heads in all three -- is never active)
+                        if (!far && edge_eligible(nu, nq[c]) != 0u) nearmask |= 1ULL << j;
+                        far_last = far;  // (of the last REAL neighbour of the chunk: padding and "no neighbour here" are not fresh)
                     }
                 }
+                if (stop_early && far_last) break;
             }
-            while (nearmask) {
-                const int j = __ffsll((long long)nearmask) - 1;
-                nearmask &= nearmask - 1ULL;
-                const Node nv = a.node[knnT[(int64_t)j * n + i]];
-                const int32_t v = nv.root;
-                if (sv_metric_at_least_sized(xyz, u, v, cd * (double)nv.size, lambda * 1.000001 + (double)nv.size * 1e-15)) continue;
-                const double m = sv_metric(xyz, a.nrm, u, v, resolution);
-                if (!(lambda - (double)nv.size * m > 0.0)) continue;
-                // (a round without a list: its few active edges pass the device-wide filter here)
-                const unsigned long long key = ((unsigned long long)(unsigned int)u << 32) | (unsigned int)v;
-                if (!emit && r > 0 && atomicExch(&a.table[edge_slot(u, v, ts32)], key) == key) continue;
-                actmask |= 1ULL << j;
+            // The near edges (a row has one or two): exact distance test, metric, criterion -- NEAR_BATCH at a time, so that the
+            // loads of a batch (neighbour index -> its record -> its representative's position and normal) are three round trips
+            // for the batch, not four for every edge in turn (round 4: this loop and the recomputation at the writes below were
+            // most of the rounds' time; the row's own position and normal are the same for all of its edges).
+            if (nearmask) {
+                float pu[3];
+                double nu_[3];
+#pragma unroll
+                for (int d = 0; d < 3; ++d) { pu[d] = xyz[3 * (int64_t)u + d]; nu_[d] = a.nrm[3 * (int64_t)u + d]; }
+                bool first = true;
+                while (nearmask) {
+                    int js[NEAR_BATCH];
+                    bool on[NEAR_BATCH];
+                    int32_t qv[NEAR_BATCH];
+                    Node nv[NEAR_BATCH];
+                    float pv[NEAR_BATCH][3];
+                    double nn[NEAR_BATCH][3];
+#pragma unroll
+                    for (int t = 0; t < NEAR_BATCH; ++t) {
+                        on[t] = nearmask != 0ULL;
+                        js[t] = on[t] ? __ffsll((long long)nearmask) - 1 : 0;
+                        nearmask &= nearmask - 1ULL;  // (0 stays 0)
+                    }
+#pragma unroll
+                    for (int t = 0; t < NEAR_BATCH; ++t) qv[t] = on[t] ? knnT[(int64_t)js[t] * n + i] : (int32_t)i;
+#pragma unroll
+                    for (int t = 0; t < NEAR_BATCH; ++t) nv[t] = a.node[qv[t]];
+#pragma unroll
+                    for (int t = 0; t < NEAR_BATCH; ++t)
+#pragma unroll
+                        for (int d = 0; d < 3; ++d) { pv[t][d] = xyz[3 * (int64_t)nv[t].root + d]; nn[t][d] = a.nrm[3 * (int64_t)nv[t].root + d]; }
+#pragma unroll
+                    for (int t = 0; t < NEAR_BATCH; ++t) {
+                        if (!on[t]) continue;
+                        const int32_t v = nv[t].root;
+                        // sv_metric_at_least_sized(xyz, u, v, cd * size, lambda * 1.000001 + size * 1e-15) on the values already here
+                        const double t1 = (double)pu[0] - pv[t][0], t2 = (double)pu[1] - pv[t][1], t3 = (double)pu[2] - pv[t][2];
+                        const double cs = cd * (double)nv[t].size, bound = lambda * 1.000001 + (double)nv[t].size * 1e-15;
+                        if (cs * cs * (t1 * t1 + t2 * t2 + t3 * t3) > bound * bound) continue;
+                        const double m = sv_metric_vals(pu, nu_, pv[t], nn[t], resolution);
+                        if (!(lambda - (double)nv[t].size * m > 0.0)) continue;
+                        // (a round without a list: its few active edges pass the device-wide filter here)
+                        const unsigned long long key = ((unsigned long long)(unsigned int)u << 32) | (unsigned int)v;
+                        if (!emit && r > 0 && atomicExch(&a.table[edge_slot(u, v, ts32)], key | stamp) == (key | stamp)) continue;
+                        actmask |= 1ULL << js[t];
+                        if (first) {  // (the first batch's results are kept for the writes below)
+                            kept_j[t] = js[t];
+                            kept_key[t] = key | ((unsigned long long)edge_eligible(nu, nv[t]) << 60);
+                            kept_m[t] = m;
+                        }
+                    }
+                    first = false;
+                }
             }
         }
         // (the list's length is counted from round 1 on -- an empty list means a disconnected graph -- and written from round KNN_ROUNDS on)
         unsigned long long at0, at1;
         block_reserve2(&st->ne[r], r > 0 ? n_fresh : 0, &st->na[r], (int)__popcll(actmask), at0, at1, scratch);
-        while (listmask) {
-            const int j = __ffsll((long long)listmask) - 1;
-            listmask &= listmask - 1ULL;
-            const int32_t v = a.node[knnT[(int64_t)j * n + i]].root;
-            lout[at0++] = ((unsigned long long)(unsigned int)u << 32) | (unsigned int)v;
+        while (listmask) {  // (LIST_BATCH edges at a time: index, then record, are two round trips per batch)
+            int32_t ql[LIST_BATCH], vl[LIST_BATCH];
+            bool on[LIST_BATCH];
+#pragma unroll
+            for (int t = 0; t < LIST_BATCH; ++t) {
+                on[t] = listmask != 0ULL;
+                const int j = on[t] ? __ffsll((long long)listmask) - 1 : 0;
+                listmask &= listmask - 1ULL;
+                ql[t] = on[t] ? knnT[(int64_t)j * n + i] : (int32_t)i;
+            }
+#pragma unroll
+            for (int t = 0; t < LIST_BATCH; ++t) vl[t] = a.node[ql[t]].root;
+#pragma unroll
+            for (int t = 0; t < LIST_BATCH; ++t)
+                if (on[t]) lout[at0++] = ((unsigned long long)(unsigned int)u << 32) | (unsigned int)vl[t];
         }
         while (actmask) {
             const int j = __ffsll((long long)actmask) - 1;
             actmask &= actmask - 1ULL;
-            const int32_t v = a.node[knnT[(int64_t)j * n + i]].root;
-            a.akey[at1] = ((unsigned long long)(unsigned int)u << 32) | (unsigned int)v;
-            a.am[at1++] = sv_metric(xyz, a.nrm, u, v, resolution);
+            unsigned long long key = 0ULL;
+            double m = 0.0;
+            bool have = false;
+#pragma unroll
+            for (int t = 0; t < NEAR_BATCH; ++t)
+                if (kept_j[t] == j) { key = kept_key[t]; m = kept_m[t]; have = true; }
+            if (!have) {  // (a row with more active edges than one batch holds: measured again)
+                const Node nv = a.node[knnT[(int64_t)j * n + i]];
+                const int32_t v = nv.root;
+                key = ((unsigned long long)(unsigned int)u << 32) | (unsigned int)v | ((unsigned long long)edge_eligible(a.node[i], nv) << 60);
+                m = sv_metric(xyz, a.nrm, u, v, resolution);
+            }
+            a.akey[at1] = key;
+            a.am[at1++] = m;
         }
     }
 }
-__global__ __launch_bounds__(256) void rows_kernel(SegArgs a, int r) {
+#ifndef SVX_ROWS_WPE
+#define SVX_ROWS_WPE 1
+#endif
+__global__ __launch_bounds__(256, SVX_ROWS_WPE) void rows_kernel(SegArgs a, int r) {
     if (!fusing(a.st)) return;
     rows_body(a, r);
 }
@@ -812,11 +939,13 @@ __global__ __launch_bounds__(256) void rows_kernel(SegArgs a, int r) {
 // apply:  Link(v, bestu[v]) for every proposal -- unless there are more proposals than representatives to spare: then nothing
 //         is applied here, every later pass of the fusion returns at once, and the overflow passes after the schedule apply
 //         the best (the sub-round's bestm / bestu stay as they are until then).
-__device__ __forceinline__ bool offer_of(const SegArgs &a, unsigned long long e, int rho, double lambda, int32_t &u, int32_t &v, double &m) {
+__device__ __forceinline__ bool offer_of(const SegArgs &a, unsigned long long e, int s, double lambda, int32_t &u, int32_t &v, double &m) {
     const unsigned long long key = a.akey[e];
-    u = (int32_t)(key >> 32);
-    v = (int32_t)(key & 0xffffffffULL);
-    if (!heads(a.orig[u], rho) || heads(a.orig[v], rho)) return false;  // (the coins are drawn on the CALLER's indices)
+    // u heads and v tails in sub-round s: bit 60 + s of the key, set when the edge was picked (the coins of the round's
+    // representatives travel in their records); three quarters of the edges end here, with one coalesced load
+    if (!((key >> (60 + s)) & 1ULL)) return false;
+    u = key_u(key);
+    v = key_v(key);
     const int32_t pu = a.parent[u], pv = a.parent[v], sz = a.size[v];  // (loaded together, not one behind the other)
     m = a.am[e];
     return pu == u && pv == v && lambda - (double)sz * m > 0.0;  // :147-149 `improvement > 0.0`
@@ -847,7 +976,7 @@ __device__ __forceinline__ void cand_body(const SegArgs &a, int r, int s) {
             e[j] = e0 + (unsigned long long)j * blockDim.x + threadIdx.x;
             int32_t u = 0, v = 0;
             double m = 0.0;
-            off[j] = e[j] < na && offer_of(a, e[j], rho, lambda, u, v, m);
+            off[j] = e[j] < na && offer_of(a, e[j], s, lambda, u, v, m);
             none[j] = false;
             if (off[j]) atomicMin(&a.bestm[v], d2ord(m));
         }
@@ -865,7 +994,7 @@ __device__ __forceinline__ void cand2_body(const SegArgs &a, int r, int s) {
     int first = 0;
     SV_FOR(i, n_off) {
         const unsigned long long e = offers[i], key = a.akey[e];
-        const int32_t u = (int32_t)(key >> 32), v = (int32_t)(key & 0xffffffffULL);
+        const int32_t u = key_u(key), v = key_v(key);
         if (a.bestm[v] == d2ord(a.am[e])) first += atomicMin(&a.bestu[v], a.orig[u]) == NONE ? 1 : 0;  // (ties: the smallest index of the caller's)
     }
     block_add(&st->n_prop[rho], first, false);
@@ -882,7 +1011,7 @@ __device__ __forceinline__ void apply_body(const SegArgs &a, int r, int s) {
     int dropped = 0;
     SV_FOR(i, n_off) {
         const unsigned long long e = offers[i], key = a.akey[e];
-        const int32_t u = (int32_t)(key >> 32), v = (int32_t)(key & 0xffffffffULL);
+        const int32_t u = key_u(key), v = key_v(key);
         const int32_t ou = a.orig[u];
         if (a.bestu[v] == ou && a.bestm[v] == d2ord(a.am[e]) &&
             atomicCAS(&a.bestu[v], ou, NONE) == ou) {  // (the claim lets one of several equal edges through, and leaves bestu clean for the next sub-round)
@@ -925,8 +1054,8 @@ __global__ __launch_bounds__(1024) void overflow_collect_kernel(SegArgs a) {
         bool has = false;
         if (i < n_off) {
             const unsigned long long e = offers[i], key = a.akey[e];
-            u = (int32_t)(key >> 32);
-            v = (int32_t)(key & 0xffffffffULL);
+            u = key_u(key);
+            v = key_v(key);
             m = a.am[e];
             // (the list may hold an edge twice: the claim lets one of them through)
             const int32_t ou = a.orig[u];
@@ -1154,7 +1283,6 @@ __global__ __launch_bounds__(1024) void segment_rest_kernel(SegArgs a, int first
         for (int r = first_round; r < LAMBDA_ROUNDS; ++r) {
             if (!wg_fusing(st)) break;
             node_body(a, r);
-            if (r >= 1) table_clear_body(a, r);
             wg_sync();
             if (r <= KNN_ROUNDS) rows_body(a, r);
             else build_body(a, r);
@@ -1267,7 +1395,7 @@ extern "C" int f4l_supervoxel_segment_device(const float *xyz, const double *nor
     using namespace f4l;
     using namespace f4l::svg;
     if (!xyz || !normals || !knn || n <= 0 || k < 1 || !(resolution > 0.0) || !labels_out || !workspace) return F4L_EINVAL;
-    if (k > F4L_MAX_K || n > 0x7fffffffLL) return F4L_EUNSUPPORTED;  // (the transpose tile holds rows of up to 64 neighbours)
+    if (k > F4L_MAX_K || n >= MAX_PLACES) return F4L_EUNSUPPORTED;  // (the transpose tile holds rows of up to 64 neighbours; edge keys keep 28 bits per end)
     GridBox box;
     box.given = grid_bbox_host ? 1 : 0;
     for (int d = 0; d < 3; ++d) {
@@ -1294,14 +1422,15 @@ extern "C" int f4l_supervoxel_segment_device(const float *xyz, const double *nor
     hipLaunchKernelGGL(order_apply_kernel, g, b, 0, st, xyz, normals, w.orig, n, w.xyz_p, w.nrm_p, w.pos_of);
     xyz = w.xyz_p;  // (from here on: the sorted copies)
     normals = w.nrm_p;
-    hipLaunchKernelGGL(grid_key_kernel, g, b, 0, st, xyz, n, resolution, w.st, w.keys_a);
-    F4L_LAUNCH_CHECK();
-    tb = w.prim_bytes;
-    F4L_HIP_CHECK(rocprim::radix_sort_keys(w.prim, tb, w.keys_a, w.keys_b, (size_t)n, 0, 64, st, false));
-    hipLaunchKernelGGL(count_distinct_kernel, dim3(256), b, 0, st, w.keys_b, n, w.st);
+    {   // K: the distinct cells of the resolution grid, through a hash set in the (still idle) filter table: two slots per point
+        const unsigned long long slots = 2ULL * (unsigned long long)n + 1024ULL;  // (layout: the table holds at least that many words)
+        F4L_HIP_CHECK(hipMemsetAsync(w.keys_a, 0xff, (size_t)slots * 8, st));
+        hipLaunchKernelGGL(grid_count_kernel, g, b, 0, st, xyz, n, resolution, w.st, w.keys_a, slots);
+        F4L_LAUNCH_CHECK();
+    }
     // lambda0
     hipLaunchKernelGGL(knn_transpose_kernel, g, b, 0, st, knn, w.orig, w.pos_of, n, k, w.knnT);
-    hipLaunchKernelGGL(min_metric_kernel, g, b, 0, st, xyz, normals, w.knnT, n, k, resolution, w.dis);
+    hipLaunchKernelGGL(min_metric_kernel, g, b, 0, st, xyz, normals, w.knnT, n, k, resolution, w.dis, w.st);
     F4L_LAUNCH_CHECK();
     {   // the median of the smallest neighbour metrics: one order statistic, no sort
         const int64_t rank = n / 2;
@@ -1326,9 +1455,10 @@ extern "C" int f4l_supervoxel_segment_device(const float *xyz, const double *nor
     sa.edges_a = w.edges_a; sa.edges_b = w.edges_b; sa.table = w.table; sa.akey = w.akey; sa.am = w.am; sa.bestm = w.bestm;
     sa.prop_key = w.prop_key; sa.parent = w.parent; sa.size = w.size; sa.bestu = w.bestu; sa.prop_u = w.prop_u; sa.prop_v = w.flag; sa.la = w.la;
     sa.lb = w.lb; sa.dis = w.dis; sa.d0 = w.d0; sa.d1 = w.d1; sa.node = w.node;
+    // the device-wide filter of parallel edges: cleared ONCE -- every entry carries the number of the round that wrote it (round_stamp)
+    F4L_HIP_CHECK(hipMemsetAsync(w.table, 0xff, (size_t)table_size((unsigned long long)n * (unsigned long long)k) * 8, st));
     for (int r = 0; r < sched_rounds; ++r) {
         hipLaunchKernelGGL(node_kernel, g, b, 0, st, sa, r);
-        if (r >= 1) hipLaunchKernelGGL(table_clear_kernel, g, b, 0, st, sa, r);
         if (r <= KNN_ROUNDS) hipLaunchKernelGGL(rows_kernel, g, b, 0, st, sa, r);
         else hipLaunchKernelGGL(build_kernel, g, dim3(BUILD_BLOCK), 0, st, sa, r);
         for (int s = 0; s < SUBROUNDS; ++s) {
@@ -1373,7 +1503,7 @@ extern "C" int f4l_supervoxel_parallel(const float *xyz, int64_t n, int k, doubl
                                        int32_t *reps_out, int32_t *info_out, int32_t *knn_out, double *normals_out,
                                        void *workspace, size_t workspace_bytes, void *stream) {
     if (!xyz || n <= 0 || k < 1 || k >= n || !(resolution > 0.0) || !labels_out || !workspace) return F4L_EINVAL;  // supervoxel.cpp:100
-    if (k > F4L_MAX_K || n > 0x7fffffffLL) return F4L_EUNSUPPORTED;
+    if (k > F4L_MAX_K || n >= f4l::svg::MAX_PLACES) return F4L_EUNSUPPORTED;
     if (workspace_bytes < f4l_supervoxel_parallel_workspace_bytes(n, k)) return F4L_EWORKSPACE;
     const size_t a = f4l_knn_workspace_bytes(n, k), s = f4l_supervoxel_segment_device_workspace_bytes(n, k);
     const size_t shared = a > s ? a : s;

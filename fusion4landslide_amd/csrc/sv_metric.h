@@ -14,4 +14,12 @@ __device__ __forceinline__ double sv_metric(const float *__restrict__ xyz, const
                  t3 = (double)xyz[3 * a + 2] - xyz[3 * b + 2];
     return 1.0 - fabs(dot) + sqrt(t1 * t1 + t2 * t2 + t3 * t3) / resolution * 0.4;
 }
+// the same value from coordinates and normals already in registers (a: float xyz + double normal, b likewise)
+__device__ __forceinline__ double sv_metric_vals(const float (&pa)[3], const double (&na)[3], const float (&pb)[3], const double (&nb)[3],
+                                                 double resolution) {
+#pragma clang fp contract(off)
+    const double dot = na[0] * nb[0] + na[1] * nb[1] + na[2] * nb[2];
+    const double t1 = (double)pa[0] - pb[0], t2 = (double)pa[1] - pb[1], t3 = (double)pa[2] - pb[2];
+    return 1.0 - fabs(dot) + sqrt(t1 * t1 + t2 * t2 + t3 * t3) / resolution * 0.4;
+}
 }  // namespace f4l
