@@ -56,6 +56,9 @@ SIGNATURES = {
     "f4l_supervoxel": (C.c_int, [_P, _I64, _I, _D, _P, _P, _P, _P, _P, _SZ, _P]),
     "f4l_supervoxel_segment_device_workspace_bytes": (_SZ, [_I64, _I]),
     "f4l_supervoxel_segment_device": (C.c_int, [_P, _P, _P, _I64, _I, _D, _P, _P, _P, _P, _P, _SZ, _P]),
+    "f4l_partition_workspace_bytes": (_SZ, [_I64, _I]),
+    "f4l_partition_neighbours": (C.c_int, [_P, _I64, _I, _P, _P, _SZ, _P]),
+    "f4l_partition_segment": (C.c_int, [_I64, _I, _D, _P, _P, _P, _P, _P, _SZ, _P]),
     "f4l_supervoxel_parallel_workspace_bytes": (_SZ, [_I64, _I]),
     "f4l_supervoxel_parallel": (C.c_int, [_P, _I64, _I, _D, _P, _P, _P, _P, _P, _P, _SZ, _P]),
     "f4l_supervoxel_segment_host": (C.c_int, [_P, _P, _P, _I64, _I, _D, _P, _P]),

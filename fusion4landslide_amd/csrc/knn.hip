@@ -231,6 +231,11 @@ struct KnnArgs {
     double *d2_out;
     double *nn1_out = nullptr;        // [n] squared distance to the nearest OTHER point (slot 1 of the row), or null
     const DevGrid *dg;                // non-null: grid, cell counts and the dense-table switch come from the device (see DevGrid)
+    // POSITION mode (the partition's own neighbour search, f4l_partition_neighbours): a point is named by its position in the
+    // cell-sorted array, not by the caller's index -- neighbours, ties between equal distances, the rows of nn1_out and of the
+    // normals -- and idx_out is TRANSPOSED, idx_out[j * n + position]: 64 consecutive queries of a wave write 256 contiguous
+    // bytes per neighbour slot, and the segmentation works in this order as it stands (no relabelling pass, no transpose)
+    int pos_mode = 0;
 };
 __device__ __forceinline__ void adopt_device_grid(KnnArgs &a) {
     if (!a.dg) return;
@@ -307,7 +312,7 @@ __device__ __forceinline__ void knn_query_wave(const KnnArgs &a, const float4 qp
                     if (ci < e) {
                         const float4 cp = a.sorted[ci];
                         cd = dist2_exact(cp.x, cp.y, cp.z, qp.x, qp.y, qp.z);
-                        cid = __float_as_int(cp.w);
+                        cid = a.pos_mode ? ci : __float_as_int(cp.w);
                     }
                     if (first) { best.fill_sorted(cd, cid); first = false; }
                     else best.offer(cd, cid, k);
@@ -383,9 +388,14 @@ __global__ __launch_bounds__(KNN_NW * 64) void knn_listed_kernel(KnnArgs a, cons
         WaveTopK best;
         knn_query_wave(a, qp, cx, cy, cz, row_lo1, row_hi1, best);
         if (lane < k) {
-            a.idx_out[(int64_t)qid * k + lane] = best.i;
-            if (a.d2_out) a.d2_out[(int64_t)qid * k + lane] = best.d;
-            if (a.nn1_out && lane == 1) a.nn1_out[qid] = best.d;
+            if (a.pos_mode) {
+                a.idx_out[(int64_t)lane * a.n + list[i]] = best.i;
+                if (a.nn1_out && lane == 1) a.nn1_out[list[i]] = best.d;
+            } else {
+                a.idx_out[(int64_t)qid * k + lane] = best.i;
+                if (a.d2_out) a.d2_out[(int64_t)qid * k + lane] = best.d;
+                if (a.nn1_out && lane == 1) a.nn1_out[qid] = best.d;
+            }
         }
     }
 }
@@ -688,6 +698,7 @@ __device__ __forceinline__ void kr_walk(const float4 *__restrict__ sorted, float
     }
 }
 
+template <bool POS>
 __global__ __launch_bounds__(KR_NW * 64, 2) void knn_lanes_kernel(KnnLanesArgs ra) {
     __shared__ unsigned int s_hist[KR_NW][KR_NB * 64];
     __shared__ unsigned int s_list[KR_NW][(KR_CAP + 1) * 64];  // (+ 1: the row predicated-off writes of pass 2 land in)
@@ -828,7 +839,7 @@ __global__ __launch_bounds__(KR_NW * 64, 2) void knn_lanes_kernel(KnnLanesArgs r
         const float4 p = a.sorted[slot];
         const double d = dist2_exact(p.x, p.y, p.z, qp.x, qp.y, qp.z);
         key[j] = ok ? d : __builtin_inf();
-        pay[j] = ok ? __float_as_int(p.w) : 0x7fffffff;
+        pay[j] = ok ? (POS ? (int)slot : __float_as_int(p.w)) : 0x7fffffff;
     }
     KR_TICK(4);
     // bitonic network of 64 with ascending comparators only (per merge size one mirrored stage, then the half-cleaners).
@@ -903,6 +914,28 @@ __global__ __launch_bounds__(KR_NW * 64, 2) void knn_lanes_kernel(KnnLanesArgs r
         }
     }
     KR_TICK(6);
+    if (POS) {  // transposed lists in position space: lane = position, 256 contiguous bytes per neighbour slot and wave
+        if (valid && !fb) {
+#pragma unroll
+            for (int j = 0; j < KR_MAX_K; ++j)
+                if (j < k) a.idx_out[(int64_t)j * a.n + q] = pay[j];
+            if (a.nn1_out && k > 1) a.nn1_out[q] = key[1];
+            if (ra.normals_out) {
+                float px[KR_MAX_K], py[KR_MAX_K], pz[KR_MAX_K];
+#pragma unroll
+                for (int j = 0; j < KR_MAX_K; ++j) {
+                    const float4 c = a.sorted[j < k ? pay[j] : pay[0]];
+                    px[j] = c.x; py[j] = c.y; pz[j] = c.z;
+                }
+                double nx, ny, nz;
+                pca_normal_regs<KR_MAX_K>(px, py, pz, k, nx, ny, nz);
+                double *o = ra.normals_out + 3 * q;
+                o[0] = nx; o[1] = ny; o[2] = nz;
+            }
+        }
+        KR_TICK(7);
+        return;
+    }
     {   // neighbour rows: staged in LDS (the list's space) and written out two rows per instruction, 120 contiguous bytes each
         // at k = 30, instead of 64 scattered dwords per instruction
         unsigned int *stage = s_list[wave];
@@ -1002,6 +1035,62 @@ __global__ void normals_listed_kernel(const float *__restrict__ xyz, const float
     for (int i = (int)(blockIdx.x * blockDim.x + threadIdx.x); i < m; i += (int)(gridDim.x * blockDim.x)) {
         const int64_t id = __float_as_int(q_sorted[list[i]].w);
         pca_normal_row(xyz, knn + id * k, k, normals + 3 * id);
+    }
+}
+
+// position mode: the same from the transposed lists and the sorted array
+__global__ void normals_listed_pos_kernel(const float4 *__restrict__ sorted, int64_t n, const int32_t *__restrict__ list,
+                                          const int32_t *__restrict__ count, const int32_t *__restrict__ knnT, int k,
+                                          double *__restrict__ normals) {
+#pragma clang fp contract(off)
+    const int m = *count;
+    for (int i = (int)(blockIdx.x * blockDim.x + threadIdx.x); i < m; i += (int)(gridDim.x * blockDim.x)) {
+        const int64_t pos = list[i];
+        float px[F4L_MAX_K], py[F4L_MAX_K], pz[F4L_MAX_K];
+        for (int j = 0; j < k; ++j) {
+            const float4 c = sorted[knnT[(int64_t)j * n + pos]];
+            px[j] = c.x; py[j] = c.y; pz[j] = c.z;
+        }
+        // pca_normal_row on gathered coordinates (same arithmetic and order)
+        double cx = 0.0, cy = 0.0, cz = 0.0, sum = 0.0;
+        for (int j = 0; j < k; ++j) { cx += (double)px[j]; cy += (double)py[j]; cz += (double)pz[j]; sum += 1.0; }
+        const double inv = 1.0 / sum;
+        cx *= inv; cy *= inv; cz *= inv;
+        double a00 = 0, a01 = 0, a02 = 0, a11 = 0, a12 = 0, a22 = 0, ws = 0;
+        for (int j = 0; j < k; ++j) {
+            const double x = (double)px[j] - cx, y = (double)py[j] - cy, z = (double)pz[j] - cz;
+            a00 += x * x; a01 += x * y; a02 += x * z; a11 += y * y; a12 += y * z; a22 += z * z;
+            ws += 1.0;
+        }
+        const double t = 1.0 / ws;
+        a00 *= t; a01 *= t; a02 *= t; a11 *= t; a12 *= t; a22 *= t;
+        const double q = (a00 + a11 + a22) / 3.0;
+        double pq = (a00 - q) * (a00 - q) + (a11 - q) * (a11 - q) + (a22 - q) * (a22 - q) + 2.0 * (a01 * a01 + a02 * a02 + a12 * a12);
+        pq = sqrt(pq / 6.0);
+        const double mpq = pow(1.0 / pq, 3.0);
+        const double det_b = mpq * ((a00 - q) * ((a11 - q) * (a22 - q) - a12 * a12) - a01 * (a01 * (a22 - q) - a12 * a02) +
+                                    a02 * (a01 * a12 - (a11 - q) * a02));
+        const double r = 0.5 * det_b;
+        double phi;
+        if (r <= -1.0) phi = 3.14159265358979323846 / 3.0;
+        else if (r >= 1.0) phi = 0.0;
+        else phi = acos(r) / 3.0;
+        const double eig = q + 2.0 * pq * cos(phi + 3.14159265358979323846 * (2.0 / 3.0));
+        double nx = a01 * a12 - a02 * (a11 - eig);
+        double ny = a01 * a02 - a12 * (a00 - eig);
+        double nz = (a00 - eig) * (a11 - eig) - a01 * a01;
+        const double norm = sqrt(nx * nx + ny * ny + nz * nz);
+        if (norm == 0.0) { nx = 0.0; ny = 0.0; nz = 1.0; }
+        else { const double sc = 1.0 / norm; nx *= sc; ny *= sc; nz *= sc; }
+        normals[3 * pos] = nx; normals[3 * pos + 1] = ny; normals[3 * pos + 2] = nz;
+    }
+}
+// the sorted array {x, y, z, id} as packed coordinates and the caller's index of every position
+__global__ void unpack_sorted_kernel(const float4 *__restrict__ sorted, int64_t n, float *__restrict__ xyz_p, int32_t *__restrict__ orig) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float4 c = sorted[i];
+        xyz_p[3 * i] = c.x; xyz_p[3 * i + 1] = c.y; xyz_p[3 * i + 2] = c.z;
+        orig[i] = __float_as_int(c.w);
     }
 }
 
@@ -1305,9 +1394,14 @@ __global__ void normals_listed_kernel(const float *__restrict__ xyz, const float
                                       const int32_t *__restrict__ count, const int32_t *__restrict__ knn, int k,
                                       double *__restrict__ normals);
 
+// `pos` (position mode, see KnnArgs): idx_out receives the TRANSPOSED lists in position space, normals_out / nn1_out rows in
+// position order, and pos->xyz_p / pos->orig the cloud in that order and the caller's index of every position.  Only the
+// lane-per-query search has the mode (k <= KR_MAX_K): F4L_EUNSUPPORTED otherwise, the caller then takes the ordinary path.
+struct KnnPosOut { float *xyz_p; int32_t *orig; };
 static int knn_self(const float *xyz, int64_t n, int k, int32_t *idx_out, double *d2_out, double *normals_out, void *workspace,
-                    size_t workspace_bytes, hipStream_t st, double *nn1_out = nullptr) {
+                    size_t workspace_bytes, hipStream_t st, double *nn1_out = nullptr, const KnnPosOut *pos = nullptr) {
     if (!xyz || n <= 0 || k < 1 || k > n || !idx_out || !workspace) return F4L_EINVAL;
+    if (pos && (k > KR_MAX_K || getenv("F4L_KNN_WAVE_PER_QUERY") || d2_out)) return F4L_EUNSUPPORTED;
     if (k > F4L_MAX_K || n > 0x7fffffffLL) return F4L_EUNSUPPORTED;
     KnnWs w;
     int rc = knn_ws_layout(n, w, (unsigned char *)workspace);
@@ -1340,7 +1434,8 @@ static int knn_self(const float *xyz, int64_t n, int k, int32_t *idx_out, double
     a.dense = w.has_dense ? w.dense : nullptr;
     a.q_sorted = w.sorted; a.q_cell_keys = w.cell_keys; a.q_cell_start = w.cell_start; a.Mq = M;
     a.idx_out = idx_out; a.d2_out = d2_out; a.dg = dg; a.nn1_out = nn1_out;
-    if (k <= KS_MAX_K && !normals_out && !nn1_out && !getenv("F4L_KNN_WAVE_PER_QUERY") && !getenv("F4L_KNN_NO_SMALL")) {
+    a.pos_mode = pos ? 1 : 0;
+    if (k <= KS_MAX_K && !pos && !normals_out && !nn1_out && !getenv("F4L_KNN_WAVE_PER_QUERY") && !getenv("F4L_KNN_NO_SMALL")) {
         hipLaunchKernelGGL(nn_small_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a, (int)n, (const int32_t *)nullptr, (const int32_t *)nullptr);
         F4L_LAUNCH_CHECK();
         return F4L_OK;
@@ -1379,7 +1474,8 @@ static int knn_self(const float *xyz, int64_t n, int k, int32_t *idx_out, double
         memcpy(&bits, &top, 4);
         ra.bin_base = (int)(bits >> 21) - (KR_NB - 1);
     }
-    hipLaunchKernelGGL(knn_lanes_kernel, dim3((unsigned)((n + KR_NW * 64 - 1) / (KR_NW * 64))), dim3(KR_NW * 64), 0, st, ra);
+    if (pos) hipLaunchKernelGGL(knn_lanes_kernel<true>, dim3((unsigned)((n + KR_NW * 64 - 1) / (KR_NW * 64))), dim3(KR_NW * 64), 0, st, ra);
+    else hipLaunchKernelGGL(knn_lanes_kernel<false>, dim3((unsigned)((n + KR_NW * 64 - 1) / (KR_NW * 64))), dim3(KR_NW * 64), 0, st, ra);
     F4L_LAUNCH_CHECK();
     hipLaunchKernelGGL(knn_listed_kernel, dim3(2048), dim3(KNN_NW * 64), 0, st, a, w.fb_list, w.fb_count);
     F4L_LAUNCH_CHECK();
@@ -1396,10 +1492,21 @@ static int knn_self(const float *xyz, int64_t n, int k, int32_t *idx_out, double
     }
 #endif
     if (normals_out) {
-        hipLaunchKernelGGL(normals_listed_kernel, dim3(256), dim3(256), 0, st, xyz, w.sorted, w.fb_list, w.fb_count, idx_out, k, normals_out);
+        if (pos) hipLaunchKernelGGL(normals_listed_pos_kernel, dim3(256), dim3(256), 0, st, w.sorted, n, w.fb_list, w.fb_count, idx_out, k, normals_out);
+        else hipLaunchKernelGGL(normals_listed_kernel, dim3(256), dim3(256), 0, st, xyz, w.sorted, w.fb_list, w.fb_count, idx_out, k, normals_out);
+        F4L_LAUNCH_CHECK();
+    }
+    if (pos) {
+        hipLaunchKernelGGL(unpack_sorted_kernel, dim3(grid_for(n)), dim3(256), 0, st, w.sorted, n, pos->xyz_p, pos->orig);
         F4L_LAUNCH_CHECK();
     }
     return F4L_OK;
+}
+// (the partition's entry: supervoxel_gpu.hip)
+int knn_position_mode(const float *xyz, int64_t n, int k, int32_t *knnT_out, double *normals_p_out, double *nn1_p_out, float *xyz_p_out,
+                      int32_t *orig_out, void *workspace, size_t workspace_bytes, void *stream) {
+    const KnnPosOut pos{xyz_p_out, orig_out};
+    return knn_self(xyz, n, k, knnT_out, nullptr, normals_p_out, workspace, workspace_bytes, (hipStream_t)stream, nn1_p_out, &pos);
 }
 }  // namespace f4l
 
@@ -1521,7 +1628,7 @@ extern "C" int f4l_nn_query(const float *cloud, int64_t n, const float *queries,
         memcpy(&bits, &top, 4);
         ra.bin_base = (int)(bits >> 21) - (KR_NB - 1);
     }
-    hipLaunchKernelGGL(knn_lanes_kernel, dim3((unsigned)((m + KR_NW * 64 - 1) / (KR_NW * 64))), dim3(KR_NW * 64), 0, st, ra);
+    hipLaunchKernelGGL(knn_lanes_kernel<false>, dim3((unsigned)((m + KR_NW * 64 - 1) / (KR_NW * 64))), dim3(KR_NW * 64), 0, st, ra);
     F4L_LAUNCH_CHECK();
     a.n = n;
     hipLaunchKernelGGL(knn_listed_kernel, dim3(2048), dim3(KNN_NW * 64), 0, st, a, wq.fb_list, wq.fb_count);

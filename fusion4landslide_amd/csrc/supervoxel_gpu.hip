@@ -70,7 +70,7 @@ constexpr unsigned long long DEAD = ~0ULL;
 // the fly); round KNN_ROUNDS builds the first list, when three quarters of a point's 30 edges have become parallel to one another
 // and fall to the filter a wave keeps in LDS.
 #ifndef SVX_KNN_ROUNDS
-#define SVX_KNN_ROUNDS 3
+#define SVX_KNN_ROUNDS 4
 #endif
 constexpr int KNN_ROUNDS = SVX_KNN_ROUNDS;
 constexpr int WAVE_FILTER = 256;  // slots of a wave's own filter (2 KB of LDS)
@@ -713,7 +713,8 @@ constexpr int ROW_CHUNK = 10;
 #endif
 constexpr int NEAR_BATCH = SVX_NEAR_BATCH;  // near edges of a row that are measured together
 constexpr int LIST_BATCH = 5;  // listed edges of a row whose representatives are fetched together
-constexpr int SWEEP_CHUNK = 10;  // representatives a lane remembers having met in its row (most of a row's edges lead to a few supervoxels)
+constexpr int SWEEP_CHUNK = 10;  // neighbours of a point whose labels are fetched together
+constexpr int FOREIGN = 3;       // foreign labels of a point that are measured together
 __device__ __forceinline__ void rows_body(const SegArgs &a, int r) {
     State *st = a.st;
     const int64_t n = a.n;
@@ -1188,28 +1189,69 @@ __device__ __forceinline__ void sweep_body(const SegArgs &a, int s) {
         din[i] = 0;
         if (look) {
             double best = dis[i];
-            // (several neighbours carry the same foreign label: the last two labels found no better are not measured again --
-            //  the best only decreases, so a label that lost once has lost for good)
-            int32_t r0 = own, r1 = own;
-            // (the neighbours SWEEP_CHUNK at a time: their indices, then their labels, are loaded together -- the pass is bound by
-            //  the wait for these loads, see rows_body)
-            for (int j0 = 0; j0 < k; j0 += SWEEP_CHUNK) {
-                int32_t q[SWEEP_CHUNK], lab[SWEEP_CHUNK];
+            // The foreign labels of the row, first in list order, FOREIGN at a time: their representatives' positions and normals
+            // are requested together and measured together, then folded in list order with the reference's strict `<` (:219-223:
+            // the first of several equal minima wins, the point's own label wins a tie).  A label met again is either the best so
+            // far or has lost for good (the best only decreases).  Round 4 measured them one behind the other, two dependent
+            // round trips each, with a pre-test on the distance term in between.
+            int32_t fb[FOREIGN];
+            int nf = 0;
 #pragma unroll
-                for (int c = 0; c < SWEEP_CHUNK; ++c) q[c] = j0 + c < k ? knnT[(int64_t)(j0 + c) * n + i] : -1;
+            for (int t = 0; t < FOREIGN; ++t) fb[t] = own;
+            float pi_[3];
+            double ni_[3];
+            bool mine = false;  // (the point's own position and normal: fetched when the first foreign label shows up)
+            auto flush = [&]() {
+                if (!mine) {
 #pragma unroll
-                for (int c = 0; c < SWEEP_CHUNK; ++c) lab[c] = lin[q[c] >= 0 ? q[c] : (int32_t)i];
-#pragma unroll
-                for (int c = 0; c < SWEEP_CHUNK; ++c) {
-                    const int32_t b = lab[c];
-                    if (b == own || b == bl || b == r0 || b == r1) continue;
-                    r1 = r0;
-                    if (sv_metric_at_least(xyz, i, (int64_t)b, resolution, best)) { r0 = b; continue; }
-                    const double d = sv_metric(xyz, nrm, i, (int64_t)b, resolution);
-                    if (d < best) { r0 = bl; best = d; bl = b; }
-                    else r0 = b;
+                    for (int d = 0; d < 3; ++d) { pi_[d] = xyz[3 * i + d]; ni_[d] = nrm[3 * i + d]; }
+                    mine = true;
                 }
+                float pb[FOREIGN][3];
+                double nb[FOREIGN][3];
+#pragma unroll
+                for (int t = 0; t < FOREIGN; ++t)
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) { pb[t][d] = xyz[3 * (int64_t)fb[t] + d]; nb[t][d] = nrm[3 * (int64_t)fb[t] + d]; }
+#pragma unroll
+                for (int t = 0; t < FOREIGN; ++t) {
+                    if (t >= nf) continue;
+                    const double d = sv_metric_vals(pi_, ni_, pb[t], nb[t], resolution);
+                    if (d < best) { best = d; bl = fb[t]; }
+                }
+                nf = 0;
+            };
+            int32_t qn[SWEEP_CHUNK];  // the NEXT chunk's indices: requested together with the current chunk's labels
+#pragma unroll
+            for (int c = 0; c < SWEEP_CHUNK; ++c) qn[c] = c < k ? knnT[(int64_t)c * n + i] : -1;
+            for (int j0 = 0; j0 < k; j0 += SWEEP_CHUNK) {
+                int32_t lab[SWEEP_CHUNK];
+#pragma unroll
+                for (int c = 0; c < SWEEP_CHUNK; ++c) lab[c] = lin[qn[c] >= 0 ? qn[c] : (int32_t)i];
+#pragma unroll
+                for (int c = 0; c < SWEEP_CHUNK; ++c) qn[c] = j0 + SWEEP_CHUNK + c < k ? knnT[(int64_t)(j0 + SWEEP_CHUNK + c) * n + i] : -1;
+                bool again;
+                unsigned int settled = 0u;  // places of the chunk that are dealt with (every walk settles at least one: the walks end)
+                do {  // (a chunk that meets more new labels than the buffer has room for is walked again after a flush)
+                    again = false;
+#pragma unroll
+                    for (int c = 0; c < SWEEP_CHUNK; ++c) {
+                        if (settled & (1u << c)) continue;
+                        const int32_t b = lab[c];
+                        bool known = b == own || b == bl;
+#pragma unroll
+                        for (int t = 0; t < FOREIGN; ++t) known = known || fb[t] == b;
+                        if (!known && nf == FOREIGN) { again = true; continue; }  // (full: this label and the ones after it wait for the next walk)
+                        settled |= 1u << c;
+                        if (known) continue;
+#pragma unroll
+                        for (int t = 0; t < FOREIGN; ++t) fb[t] = t == nf ? b : fb[t];
+                        ++nf;
+                    }
+                    if (again) flush();
+                } while (again);
             }
+            if (nf > 0) flush();
             if (bl != own) {
                 dis[i] = best;
                 any = true;
@@ -1388,14 +1430,16 @@ extern "C" size_t f4l_supervoxel_segment_device_workspace_bytes(int64_t n, int k
 }
 
 // Enqueues the whole segmentation on `stream`; never synchronises, never touches host memory.
-extern "C" int f4l_supervoxel_segment_device(const float *xyz, const double *normals, const int32_t *knn, int64_t n, int k,
-                                             double resolution, const float *grid_bbox_host, int32_t *labels_out,
-                                             int32_t *reps_out, int32_t *info_out, void *workspace, size_t workspace_bytes,
-                                             void *stream) {
+// The whole segmentation, enqueued on `st`.  presorted: the neighbour search ran in POSITION mode (knn.hip) and left, inside this
+// workspace, the cloud and its normals in the search's own cell order (w.xyz_p, w.nrm_p), the caller's index of every position
+// (w.orig) and the TRANSPOSED neighbour lists in position space (w.knnT): the segmentation works in that order as it stands --
+// no ordering sort, no gather of the cloud, no transpose (rounds 3-4 paid 2.3 ms and 8.5 GB per 10 M points for the three).
+static int segment_enqueue(const float *xyz, const double *normals, const int32_t *knn, int64_t n, int k, double resolution,
+                           const float *grid_bbox_host, int32_t *labels_out, int32_t *reps_out, int32_t *info_out, f4l::svg::Ws &w,
+                           hipStream_t st, bool presorted) {
     using namespace f4l;
     using namespace f4l::svg;
-    if (!xyz || !normals || !knn || n <= 0 || k < 1 || !(resolution > 0.0) || !labels_out || !workspace) return F4L_EINVAL;
-    if (k > F4L_MAX_K || n >= MAX_PLACES) return F4L_EUNSUPPORTED;  // (the transpose tile holds rows of up to 64 neighbours; edge keys keep 28 bits per end)
+    int rc = F4L_OK;
     GridBox box;
     box.given = grid_bbox_host ? 1 : 0;
     for (int d = 0; d < 3; ++d) {
@@ -1403,25 +1447,26 @@ extern "C" int f4l_supervoxel_segment_device(const float *xyz, const double *nor
         box.mx[d] = grid_bbox_host ? grid_bbox_host[3 + d] : 0.f;
         if (grid_bbox_host && !(box.mx[d] >= box.mn[d])) return F4L_EINVAL;
     }
-    Ws w;
-    int rc = layout(n, k, w, (unsigned char *)workspace);
-    if (rc != F4L_OK) return rc;
-    if (workspace_bytes < w.total) return F4L_EWORKSPACE;
-    hipStream_t st = (hipStream_t)stream;
     const dim3 g(GRID), ga(GRID_ACTIVE), b(BLOCK), one(1);
 
     F4L_HIP_CHECK(hipMemsetAsync(w.st, 0, sizeof(State), st));
     hipLaunchKernelGGL(init_state_kernel, one, one, 0, st, w.st, (int32_t)n, box);
-    // K
-    hipLaunchKernelGGL(svg::bbox_kernel, dim3(256), b, 0, st, xyz, n, w.st, box.given);
-    // the segmentation's own order of the points (F4L_SV_NO_REORDER: the caller's, for measurements)
-    hipLaunchKernelGGL(order_key_kernel, g, b, 0, st, xyz, n, resolution, w.st, getenv("F4L_SV_NO_REORDER") ? 1 : 0, w.okey_a, w.ids_in);
-    F4L_LAUNCH_CHECK();
     size_t tb = w.prim_bytes;
-    F4L_HIP_CHECK(rocprim::radix_sort_pairs(w.prim, tb, w.okey_a, w.okey_b, w.ids_in, w.orig, (size_t)n, 0, 32, st, false));
-    hipLaunchKernelGGL(order_apply_kernel, g, b, 0, st, xyz, normals, w.orig, n, w.xyz_p, w.nrm_p, w.pos_of);
-    xyz = w.xyz_p;  // (from here on: the sorted copies)
-    normals = w.nrm_p;
+    if (presorted) {
+        xyz = w.xyz_p;
+        normals = w.nrm_p;
+        hipLaunchKernelGGL(svg::bbox_kernel, dim3(256), b, 0, st, xyz, n, w.st, box.given);
+    } else {
+        // K
+        hipLaunchKernelGGL(svg::bbox_kernel, dim3(256), b, 0, st, xyz, n, w.st, box.given);
+        // the segmentation's own order of the points (F4L_SV_NO_REORDER: the caller's, for measurements)
+        hipLaunchKernelGGL(order_key_kernel, g, b, 0, st, xyz, n, resolution, w.st, getenv("F4L_SV_NO_REORDER") ? 1 : 0, w.okey_a, w.ids_in);
+        F4L_LAUNCH_CHECK();
+        F4L_HIP_CHECK(rocprim::radix_sort_pairs(w.prim, tb, w.okey_a, w.okey_b, w.ids_in, w.orig, (size_t)n, 0, 32, st, false));
+        hipLaunchKernelGGL(order_apply_kernel, g, b, 0, st, xyz, normals, w.orig, n, w.xyz_p, w.nrm_p, w.pos_of);
+        xyz = w.xyz_p;  // (from here on: the sorted copies)
+        normals = w.nrm_p;
+    }
     {   // K: the distinct cells of the resolution grid, through a hash set in the (still idle) filter table: two slots per point
         const unsigned long long slots = 2ULL * (unsigned long long)n + 1024ULL;  // (layout: the table holds at least that many words)
         F4L_HIP_CHECK(hipMemsetAsync(w.keys_a, 0xff, (size_t)slots * 8, st));
@@ -1429,7 +1474,7 @@ extern "C" int f4l_supervoxel_segment_device(const float *xyz, const double *nor
         F4L_LAUNCH_CHECK();
     }
     // lambda0
-    hipLaunchKernelGGL(knn_transpose_kernel, g, b, 0, st, knn, w.orig, w.pos_of, n, k, w.knnT);
+    if (!presorted) hipLaunchKernelGGL(knn_transpose_kernel, g, b, 0, st, knn, w.orig, w.pos_of, n, k, w.knnT);
     hipLaunchKernelGGL(min_metric_kernel, g, b, 0, st, xyz, normals, w.knnT, n, k, resolution, w.dis, w.st);
     F4L_LAUNCH_CHECK();
     {   // the median of the smallest neighbour metrics: one order statistic, no sort
@@ -1487,24 +1532,104 @@ extern "C" int f4l_supervoxel_segment_device(const float *xyz, const double *nor
     F4L_HIP_CHECK(rocprim::exclusive_scan(w.prim, tb, w.flag, w.rank, 0, (size_t)n, rocprim::plus<int32_t>(), st, false));
     hipLaunchKernelGGL(relabel_kernel, g, b, 0, st, w.st, n, w.la, w.lb, w.orig, w.flag, w.rank, labels_out, reps_out, info_out);
     F4L_LAUNCH_CHECK();
-    return F4L_OK;
+    return rc;
+}
+
+extern "C" int f4l_supervoxel_segment_device(const float *xyz, const double *normals, const int32_t *knn, int64_t n, int k,
+                                             double resolution, const float *grid_bbox_host, int32_t *labels_out,
+                                             int32_t *reps_out, int32_t *info_out, void *workspace, size_t workspace_bytes,
+                                             void *stream) {
+    using namespace f4l;
+    using namespace f4l::svg;
+    if (!xyz || !normals || !knn || n <= 0 || k < 1 || !(resolution > 0.0) || !labels_out || !workspace) return F4L_EINVAL;
+    if (k > F4L_MAX_K || n >= MAX_PLACES) return F4L_EUNSUPPORTED;  // (the transpose tile holds rows of up to 64 neighbours; edge keys keep 28 bits per end)
+    for (int d = 0; d < 3 && grid_bbox_host; ++d)
+        if (!(grid_bbox_host[3 + d] >= grid_bbox_host[d])) return F4L_EINVAL;
+    Ws w;
+    const int rc = layout(n, k, w, (unsigned char *)workspace);
+    if (rc != F4L_OK) return rc;
+    if (workspace_bytes < w.total) return F4L_EWORKSPACE;
+    return segment_enqueue(xyz, normals, knn, n, k, resolution, grid_bbox_host, labels_out, reps_out, info_out, w, (hipStream_t)stream, false);
+}
+
+// ---- the partition in two calls: neighbours (position mode), then the segmentation on what they left in the workspace -----------
+// The neighbour search does not depend on the resolution: a caller that derives the resolution from the point spacing
+// (src/coarse_to_fine_matching_base.py:2668-2671: sqrt(3) * 10 * median spacing) runs it first, takes the nearest-neighbour
+// distances from it (nn1_d2_out, position order: good for a median), and then segments.  The search's scratch lives in the
+// segmentation's edge buffers (idle until the fourth round), or behind the segmentation's workspace where those are too small.
+namespace f4l {
+int knn_position_mode(const float *xyz, int64_t n, int k, int32_t *knnT_out, double *normals_p_out, double *nn1_p_out, float *xyz_p_out,
+                      int32_t *orig_out, void *workspace, size_t workspace_bytes, void *stream);
+namespace svg {
+static size_t partition_knn_offset(int64_t n, int k, const Ws &w, size_t &total) {
+    const size_t need = f4l_knn_workspace_bytes(n, k);
+    const size_t room = 2 * align_up((size_t)n * (size_t)k * 8);  // edges_a + edges_b, carved one behind the other
+    if (need <= room) { total = w.total; return (size_t)((unsigned char *)w.edges_a - (unsigned char *)w.st); }
+    total = w.total + need;
+    return w.total;
+}
+}  // namespace svg
+}  // namespace f4l
+extern "C" size_t f4l_partition_workspace_bytes(int64_t n, int k) {
+    if (n <= 0 || k < 1) return 0;
+    f4l::svg::Ws w;
+    if (f4l::svg::layout(n, k, w, (unsigned char *)256) != F4L_OK) return 0;  // (a non-null base: the offsets are wanted)
+    size_t total = 0;
+    (void)f4l::svg::partition_knn_offset(n, k, w, total);
+    return total;
+}
+extern "C" int f4l_partition_neighbours(const float *xyz, int64_t n, int k, double *nn1_d2_out, void *workspace, size_t workspace_bytes,
+                                        void *stream) {
+    using namespace f4l::svg;
+    if (!xyz || n <= 0 || k < 1 || k >= n || !workspace) return F4L_EINVAL;  // supervoxel.cpp:100
+    if (k > F4L_MAX_K || n >= MAX_PLACES) return F4L_EUNSUPPORTED;
+    Ws w;
+    int rc = layout(n, k, w, (unsigned char *)workspace);
+    if (rc != F4L_OK) return rc;
+    size_t total = 0;
+    const size_t at = partition_knn_offset(n, k, w, total);
+    if (workspace_bytes < total) return F4L_EWORKSPACE;
+    return f4l::knn_position_mode(xyz, n, k, w.knnT, w.nrm_p, nn1_d2_out, w.xyz_p, w.orig, (unsigned char *)workspace + at,
+                                  f4l_knn_workspace_bytes(n, k), stream);
+}
+extern "C" int f4l_partition_segment(int64_t n, int k, double resolution, const float *grid_bbox_host, int32_t *labels_out,
+                                     int32_t *reps_out, int32_t *info_out, void *workspace, size_t workspace_bytes, void *stream) {
+    using namespace f4l::svg;
+    if (n <= 0 || k < 1 || !(resolution > 0.0) || !labels_out || !workspace) return F4L_EINVAL;
+    if (k > F4L_MAX_K || n >= MAX_PLACES) return F4L_EUNSUPPORTED;
+    for (int d = 0; d < 3 && grid_bbox_host; ++d)
+        if (!(grid_bbox_host[3 + d] >= grid_bbox_host[d])) return F4L_EINVAL;
+    Ws w;
+    const int rc = layout(n, k, w, (unsigned char *)workspace);
+    if (rc != F4L_OK) return rc;
+    if (workspace_bytes < w.total) return F4L_EWORKSPACE;
+    return segment_enqueue(nullptr, nullptr, nullptr, n, k, resolution, grid_bbox_host, labels_out, reps_out, info_out, w, (hipStream_t)stream, true);
 }
 
 extern "C" size_t f4l_supervoxel_parallel_workspace_bytes(int64_t n, int k) {
     if (n <= 0 || k < 1) return 0;
     const size_t a = f4l_knn_workspace_bytes(n, k), s = f4l_supervoxel_segment_device_workspace_bytes(n, k);
     const size_t idx = ((size_t)n * k * 4 + 255) / 256 * 256, nrm = ((size_t)n * 24 + 255) / 256 * 256;
-    return (a > s ? a : s) + idx + nrm;  // the kNN workspace is dead when the segmentation starts
+    const size_t two_step = (a > s ? a : s) + idx + nrm;  // the kNN workspace is dead when the segmentation starts
+    const size_t fused = f4l_partition_workspace_bytes(n, k);
+    return two_step > fused ? two_step : fused;
 }
 
 // kNN + normals + segmentation, all on the device.  f4l_knn synchronises `stream` once while it sizes its grid (bounding
-// box and cell count are read back); nothing after that does.
+// box and cell count are read back); nothing after that does.  Without a caller who wants the neighbour lists or the normals
+// (caller's order) the search runs in position mode and the segmentation takes its order over (f4l_partition_neighbours +
+// f4l_partition_segment); with one, or for k beyond the lane-per-query search, the two stages run as before.
 extern "C" int f4l_supervoxel_parallel(const float *xyz, int64_t n, int k, double resolution, int32_t *labels_out,
                                        int32_t *reps_out, int32_t *info_out, int32_t *knn_out, double *normals_out,
                                        void *workspace, size_t workspace_bytes, void *stream) {
     if (!xyz || n <= 0 || k < 1 || k >= n || !(resolution > 0.0) || !labels_out || !workspace) return F4L_EINVAL;  // supervoxel.cpp:100
     if (k > F4L_MAX_K || n >= f4l::svg::MAX_PLACES) return F4L_EUNSUPPORTED;
     if (workspace_bytes < f4l_supervoxel_parallel_workspace_bytes(n, k)) return F4L_EWORKSPACE;
+    if (!knn_out && !normals_out && !getenv("F4L_SV_TWO_STEP")) {
+        const int rc = f4l_partition_neighbours(xyz, n, k, nullptr, workspace, workspace_bytes, stream);
+        if (rc == F4L_OK) return f4l_partition_segment(n, k, resolution, nullptr, labels_out, reps_out, info_out, workspace, workspace_bytes, stream);
+        if (rc != F4L_EUNSUPPORTED) return rc;
+    }
     const size_t a = f4l_knn_workspace_bytes(n, k), s = f4l_supervoxel_segment_device_workspace_bytes(n, k);
     const size_t shared = a > s ? a : s;
     const size_t idx_b = ((size_t)n * k * 4 + 255) / 256 * 256;

@@ -652,6 +652,43 @@ def supervoxel_parallel(xyz, k, resolution, return_intermediates=False, read_cou
     return labels, K
 
 
+class PartitionNeighbours:
+    """What f4l_partition_neighbours left for f4l_partition_segment: the workspace (neighbour lists, normals and the cloud in the
+    search's own order, inside it) and, when asked for, every point's squared distance to its nearest other point."""
+    def __init__(self, ws, nbytes, n, k, nn1_d2):
+        self.ws, self.nbytes, self.n, self.k, self.nn1_d2 = ws, nbytes, n, k, nn1_d2
+
+
+def partition_neighbours(xyz, k, return_nn1=False):
+    """First half of the partition (f4l_partition_neighbours): the neighbour search and the normals, which do not depend on the
+    resolution -- `_compute_median_resolution` (src/coarse_to_fine_matching_base.py:2716-2754) can take its nearest-neighbour
+    distances from `.nn1_d2` (n,) float64, in the search's order, before `partition_segment` is given the resolution."""
+    torch = require_gpu()
+    xyz = _dev(xyz, torch.float32, "xyz", (3,))
+    n = xyz.shape[0]
+    nbytes = lib().f4l_partition_workspace_bytes(n, int(k))
+    ws = torch.empty((max(int(nbytes), 1),), dtype=torch.uint8, device=xyz.device)
+    nn1 = torch.empty((n,), dtype=torch.float64, device=xyz.device) if return_nn1 else None
+    check(lib().f4l_partition_neighbours(ptr(xyz), n, int(k), ptr(nn1), ptr(ws), C.c_size_t(nbytes), stream_ptr()), "f4l_partition_neighbours")
+    return PartitionNeighbours(ws, nbytes, n, int(k), nn1)
+
+
+def partition_segment(nb, resolution, return_reps=False, grid_bbox=None):
+    """Second half (f4l_partition_segment): labels (n,) int32 in the caller's order and info (8,) int32 on the device (see
+    supervoxel_segment_device)[, reps]."""
+    torch = require_gpu()
+    dev = nb.ws.device
+    labels = torch.empty((nb.n,), dtype=torch.int32, device=dev)
+    info = torch.zeros((8,), dtype=torch.int32, device=dev)
+    reps = torch.empty((nb.n,), dtype=torch.int32, device=dev) if return_reps else None
+    box = None
+    if grid_bbox is not None:
+        box = (C.c_float * 6)(*[float(v) for v in grid_bbox])
+    check(lib().f4l_partition_segment(nb.n, nb.k, float(resolution), box, ptr(labels), ptr(reps), ptr(info), ptr(nb.ws),
+                                      C.c_size_t(nb.nbytes), stream_ptr()), "f4l_partition_segment")
+    return (labels, info, reps) if return_reps else (labels, info)
+
+
 def labels_to_csr(labels, K):
     """Sort-by-label -> (order (n,) int32, off (K+1,) int64); replaces prepare_pts2spt_dict's mask loop
     (src/coarse_to_fine_matching_base.py:1327-1332)."""

@@ -39,17 +39,27 @@ def full_path(src, tgt, k=30, icp_threshold=0.1, voxel_size=0.0, partition="para
     if resolution is None and partition == "parallel" and k >= 2:
         # the partition's neighbour search does not depend on the resolution: run it first and let it serve the median point
         # spacing of the source epoch too (slot 1 of every row), instead of a 2-NN pass of its own over the same cloud
-        knn_idx, nrm, nn1 = engine.knn_normals(src, k, return_nn1=True)
+        # (f4l_partition_neighbours / f4l_partition_segment: the segmentation adopts the search's order; k beyond the lane-per-query
+        #  search falls back to the two ordinary calls)
+        nb = knn_idx = None
+        if k <= 36:
+            nb = engine.partition_neighbours(src, k, return_nn1=True)
+            nn1 = nb.nn1_d2
+        else:
+            knn_idx, nrm, nn1 = engine.knn_normals(src, k, return_nn1=True)
         mark("neighbours")
         med = engine.median_resolution(src, tgt, src_nn1_d2=nn1)
         resolution = max(np.sqrt(3.0) * 10.0 * med, float(voxel_size), 1e-6)  # base:2668-2671
         mark("median_resolution")
-        labels, info = engine.supervoxel_segment_device(src, nrm, knn_idx, float(resolution))
+        if nb is not None:
+            labels, info = engine.partition_segment(nb, float(resolution))
+        else:
+            labels, info = engine.supervoxel_segment_device(src, nrm, knn_idx, float(resolution))
         info_h = info.cpu()
         K = int(info_h[0])
         if int(info_h[2]) & 6:
-            raise RuntimeError(f"f4l_supervoxel_segment_device: the segmentation did not finish (status bits {int(info_h[2])})")
-        del knn_idx, nrm, nn1
+            raise RuntimeError(f"f4l_partition_segment: the segmentation did not finish (status bits {int(info_h[2])})")
+        del nb, knn_idx, nn1
         mark("supervoxel_partition")
     else:
         if resolution is None:

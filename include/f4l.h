@@ -326,6 +326,24 @@ int f4l_supervoxel_parallel(const float *xyz, int64_t n, int k, double resolutio
                             int32_t *info_out, int32_t *knn_out, double *normals_out, void *workspace,
                             size_t workspace_bytes, void *stream);
 
+/* The same partition in TWO calls sharing one workspace, for a caller who derives the resolution from the point spacing
+ * (src/coarse_to_fine_matching_base.py:2668-2671: resolution = max(sqrt(3) * 10 * median spacing, voxel); the neighbour search
+ * of cpp_core/supervoxel_segmentation/supervoxel.cpp:105-113 does not depend on it):
+ *   f4l_partition_neighbours  kNN-k + PCA normals of the cloud in the search's own cell order ("position mode": neighbours named
+ *       by position, lists transposed), left INSIDE the workspace; nn1_d2_out (device double [n], or NULL): every point's squared
+ *       distance to its nearest other point, in that order -- good for the median of `_compute_median_resolution`
+ *       (:2716-2754).  k <= 36 (the lane-per-query search); F4L_EUNSUPPORTED beyond: use f4l_knn_normals +
+ *       f4l_supervoxel_segment_device.  Synchronises `stream` once like f4l_knn (not under graph capture / F4L_KNN_ASYNC).
+ *   f4l_partition_segment     f4l_supervoxel_segment_device on what the first call left: the segmentation adopts the search's
+ *       order as it stands (no ordering sort, no gather of the cloud, no transpose of the lists); outputs in the CALLER's order
+ *       as always.  The workspace must not be touched between the two calls; n and k must be the same.
+ * f4l_supervoxel_parallel runs the pair when neither knn_out nor normals_out is asked for. */
+size_t f4l_partition_workspace_bytes(int64_t n, int k);
+int f4l_partition_neighbours(const float *xyz, int64_t n, int k, double *nn1_d2_out, void *workspace, size_t workspace_bytes,
+                             void *stream);
+int f4l_partition_segment(int64_t n, int k, double resolution, const float *grid_bbox_host, int32_t *labels_out,
+                          int32_t *reps_out, int32_t *info_out, void *workspace, size_t workspace_bytes, void *stream);
+
 /* Host-only helper (no device work): the sequential segmentation stage on host arrays.  Exposed so the
  * Python shim can re-segment cached kNN/normals; same semantics as inside f4l_supervoxel. */
 int f4l_supervoxel_segment_host(const float *xyz_host, const double *normals_host, const int32_t *knn_host,
