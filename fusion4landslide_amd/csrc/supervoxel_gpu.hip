@@ -75,6 +75,9 @@ constexpr unsigned long long DEAD = ~0ULL;
 constexpr int KNN_ROUNDS = SVX_KNN_ROUNDS;
 constexpr int WAVE_FILTER = 256;  // slots of a wave's own filter (2 KB of LDS)
 constexpr int32_t NONE = 0x7fffffff;
+#ifndef SVX_WIDE_ROUNDS
+#define SVX_WIDE_ROUNDS 6
+#endif
 
 struct State {
     double lambda0;
@@ -82,6 +85,7 @@ struct State {
     unsigned long long ne[LAMBDA_ROUNDS + 1];    // ne[r]: edges of round r's list, r >= 1 (round 0's list is the neighbour lists)
     unsigned long long na[LAMBDA_ROUNDS + 1];    // na[r]: active edges of round r
     unsigned long long n_off[LAMBDA_ROUNDS * SUBROUNDS];  // offers of sub-round rho
+    unsigned long long nrep[LAMBDA_ROUNDS + 2];  // nrep[r], r > KNN_ROUNDS: points whose record round r refreshes (node_body)
     unsigned long long n_list;                   // (overflow path) proposals collected
     unsigned int bb[6];                          // the box of the resolution grid as order-preserving unsigned images of the floats (min x,y,z, max x,y,z)
     unsigned int pb[6];                          // the points' own bounding box (the frame of the quantised positions)
@@ -90,6 +94,7 @@ struct State {
     int32_t stalled;                             // the graph of representatives has no edges left but live > K
     int32_t rounds;                              // lambda rounds entered
     int32_t sweeps_done;
+    int32_t overflow_offers;                     // a sub-round made more offers than its list holds (refused: status bit 3)
     int32_t unsorted;                            // some neighbour list is not in ascending order of distance (round 0 then reads every list to its end)
     int32_t n_prop[LAMBDA_ROUNDS * SUBROUNDS];   // proposals of sub-round rho
     int32_t sw_on[SWEEPS + 1], sw_full[SWEEPS + 1], sw_changed[SWEEPS + 1];  // per sweep: ran / looked at every point / changed a label
@@ -370,14 +375,54 @@ __device__ __forceinline__ bool sv_distance_at_least(const float (&pa)[3], const
 
 // ---- lambda0 -----------------------------------------------------------------------------------------------------
 #pragma clang fp contract(off)
+// SORTED: the lists are known to be in ascending order of distance (the library's own search, position mode): the metric is at
+// least its distance term, so the first neighbour whose distance term reaches the smallest metric so far ends the row -- the
+// minimum sits among the first few neighbours, and a row reads a chunk or two of its list instead of all of it.  Positions AND
+// normals of a chunk are requested together (one round trip per chunk).
+template <bool SORTED>
 __global__ void min_metric_kernel(const float *__restrict__ xyz, const double *__restrict__ nrm, const int32_t *__restrict__ knnT,
                                   int64_t n, int k, double resolution, double *__restrict__ dis0, State *st) {
     constexpr int CH = 6;  // neighbours whose indices and coordinates are loaded together (see rows_body)
     bool unsorted = false;  // (a list that is NOT in ascending order of distance: round 0 may then not stop at the first far neighbour)
     SV_FOR(i, n) {
         double best = DBL_MAX, d2_before = 0.0;
-        const double xi = xyz[3 * i], yi = xyz[3 * i + 1], zi = xyz[3 * i + 2];
         const double c = 0.4 / resolution;
+        if (SORTED) {
+            float pi_[3];
+            double ni_[3];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) { pi_[d] = xyz[3 * i + d]; ni_[d] = nrm[3 * i + d]; }
+            int64_t qn[CH];  // the NEXT chunk's indices
+#pragma unroll
+            for (int t = 0; t < CH; ++t) qn[t] = t < k ? knnT[(int64_t)t * n + i] : -1;
+            for (int j0 = 0; j0 < k; j0 += CH) {
+                int64_t q[CH];
+                float p[CH][3];
+                double nn[CH][3];
+#pragma unroll
+                for (int t = 0; t < CH; ++t) q[t] = qn[t] < 0 ? i : qn[t];
+#pragma unroll
+                for (int t = 0; t < CH; ++t)
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) { p[t][d] = xyz[3 * q[t] + d]; nn[t][d] = nrm[3 * q[t] + d]; }
+#pragma unroll
+                for (int t = 0; t < CH; ++t) qn[t] = j0 + CH + t < k ? knnT[(int64_t)(j0 + CH + t) * n + i] : -1;
+                bool done = false;
+#pragma unroll
+                for (int t = 0; t < CH; ++t) {
+                    if (q[t] == i || done) continue;
+                    const double t1 = (double)pi_[0] - p[t][0], t2 = (double)pi_[1] - p[t][1], t3 = (double)pi_[2] - p[t][2];
+                    const double bound = best * 1.000001 + 1e-15;
+                    if (c * c * (t1 * t1 + t2 * t2 + t3 * t3) > bound * bound) { done = true; continue; }  // (and so is every neighbour after it)
+                    const double m = sv_metric_vals(pi_, ni_, p[t], nn[t], resolution);
+                    best = m < best ? m : best;
+                }
+                if (done) break;
+            }
+            dis0[i] = best;
+            continue;
+        }
+        const double xi = xyz[3 * i], yi = xyz[3 * i + 1], zi = xyz[3 * i + 2];
         for (int j0 = 0; j0 < k; j0 += CH) {
             int64_t q[CH];
             float p[CH][3];
@@ -403,7 +448,7 @@ __global__ void min_metric_kernel(const float *__restrict__ xyz, const double *_
         }
         dis0[i] = best;
     }
-    if (__ballot(unsorted) != 0ULL && lane_id() == 0) atomicOr(&st->unsorted, 1);
+    if (!SORTED && __ballot(unsorted) != 0ULL && lane_id() == 0) atomicOr(&st->unsorted, 1);
 }
 __global__ void start_kernel(State *st, const double *__restrict__ median) {
     const double med = median[0];  // median.h:27-30: nth_element at size / 2 (the element of that rank: select.hip)
@@ -480,11 +525,12 @@ struct SegArgs {
     unsigned long long *edges_a, *edges_b, *table, *akey, *bestm, *prop_key;
     double *am, *dis;
     int32_t *parent, *size, *bestu, *prop_u, *prop_v, *la, *lb;
+    int32_t *reps_a, *reps_b;  // the lists of node_body (idle arrays: the overflow pass's proposals, the relabelling's ranks)
     Node *node;
     unsigned char *d0, *d1;
 };
 
-__device__ __forceinline__ bool fusing(const State *st) { return st->live > st->K && !st->stalled && !st->overflow; }
+__device__ __forceinline__ bool fusing(const State *st) { return st->live > st->K && !st->stalled && !st->overflow && !st->overflow_offers; }
 __device__ __forceinline__ double lambda_of(const State *st, int r) { return ldexp(st->lambda0, r); }  // :117 `lambda *= 2.0`, exact
 // the list of round r (r >= 1) alternates between the two edge buffers
 __device__ __forceinline__ unsigned long long *list_of(const SegArgs &a, int r) { return (r & 1) ? a.edges_a : a.edges_b; }
@@ -501,21 +547,47 @@ __host__ __device__ __forceinline__ unsigned long long table_size(unsigned long 
 __device__ __forceinline__ void node_body(const SegArgs &a, int r) {
     int32_t *__restrict__ parent = a.parent;
     // a round that reads a LIST only meets the representatives of the round before as end points: a point that was absorbed
-    // earlier (its record of the last pass names another point) is never looked up again
-    const bool reps_only = r > KNN_ROUNDS;
+    // earlier (its record of the last pass names another point) is never looked up again.  Those points are kept in a list of
+    // their own from the last all-points pass on (round 4 read all n records every round to find them: 160 MB per round and
+    // 10 M points): every pass writes the list of the next, the points it finds still their own representative.
+    const bool from_list = r > KNN_ROUNDS, to_list = r >= KNN_ROUNDS;
+    const int32_t *__restrict__ lin = (r & 1) ? a.reps_a : a.reps_b;
+    int32_t *__restrict__ lout = (r & 1) ? a.reps_b : a.reps_a;
+    const int64_t count = from_list ? (int64_t)a.st->nrep[r] : a.n;
     const Quant qt = quant_of(a.st);
-    SV_FOR(i, a.n) {
-        if (reps_only && a.node[i].root != (int32_t)i) continue;
-        int32_t q = parent[i];
-        while (parent[q] != q) q = parent[q];  // (roots are stable while this pass runs)
-        if (q != parent[i]) parent[i] = q;
-        Node nd;
-        nd.root = q;
-        nd.size = a.size[q];
-        const int32_t oq = a.orig[q];  // (the coins are drawn on the CALLER's indices)
-        const unsigned int coins = (heads(oq, SUBROUNDS * r) ? 1u : 0u) | (heads(oq, SUBROUNDS * r + 1) ? 2u : 0u) | (heads(oq, SUBROUNDS * r + 2) ? 4u : 0u);
-        node_pack(nd, qt, a.xyz[3 * (int64_t)q], a.xyz[3 * (int64_t)q + 1], a.xyz[3 * (int64_t)q + 2], coins);
-        a.node[i] = nd;
+    __shared__ AppendScratch scratch;
+    constexpr int NI = 4;  // points per thread and trip: four independent chains of loads, a quarter of the barriers of the append
+    const int64_t step = (int64_t)blockDim.x * NI, stride = (int64_t)gridDim.x * step;
+    for (int64_t i0 = (int64_t)blockIdx.x * step; i0 < count; i0 += stride) {  // whole workgroups iterate together
+        bool keep[NI], none[NI];
+        int32_t i[NI];
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int64_t t = i0 + (int64_t)j * blockDim.x + threadIdx.x;
+            keep[j] = none[j] = false;
+            i[j] = 0;
+            if (t < count) {
+                i[j] = from_list ? lin[t] : (int32_t)t;
+                int32_t q = parent[i[j]];
+                while (parent[q] != q) q = parent[q];  // (roots are stable while this pass runs)
+                if (q != parent[i[j]]) parent[i[j]] = q;
+                Node nd;
+                nd.root = q;
+                nd.size = a.size[q];
+                const int32_t oq = a.orig[q];  // (the coins are drawn on the CALLER's indices)
+                const unsigned int coins = (heads(oq, SUBROUNDS * r) ? 1u : 0u) | (heads(oq, SUBROUNDS * r + 1) ? 2u : 0u) | (heads(oq, SUBROUNDS * r + 2) ? 4u : 0u);
+                node_pack(nd, qt, a.xyz[3 * (int64_t)q], a.xyz[3 * (int64_t)q + 1], a.xyz[3 * (int64_t)q + 2], coins);
+                a.node[i[j]] = nd;
+                keep[j] = q == i[j];
+            }
+        }
+        if (to_list) {  // (uniform)
+            unsigned long long at[NI], unused[NI];
+            block_append2<NI>(&a.st->nrep[r + 1], keep, &a.st->nrep[r + 1], none, at, unused, scratch);
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+                if (keep[j]) lout[at[j]] = i[j];
+        }
     }
 }
 __global__ void node_kernel(SegArgs a, int r) {
@@ -966,12 +1038,13 @@ __device__ __forceinline__ void cand_body(const SegArgs &a, int r, int s) {
     // the offers (their places in the active list) go to the edge buffer that is idle until the next round's list is built:
     // the two passes after this one walk the sub-round's offers, a twentieth of the active edges, not the active edges again
     unsigned long long *__restrict__ offers = list_of(a, r + 1);
+    const unsigned long long cap = (unsigned long long)a.n * (unsigned long long)a.k;
     __shared__ AppendScratch scratch;
     constexpr int ITEMS = 4;
     const unsigned long long step = (unsigned long long)blockDim.x * ITEMS, stride = (unsigned long long)gridDim.x * step;
     for (unsigned long long e0 = (unsigned long long)blockIdx.x * step; e0 < na; e0 += stride) {  // whole workgroups iterate together
         bool off[ITEMS], none[ITEMS];
-        unsigned long long e[ITEMS], at[ITEMS], unused[ITEMS];
+        unsigned long long e[ITEMS], at[ITEMS], unused[ITEMS], mo[ITEMS];
 #pragma unroll
         for (int j = 0; j < ITEMS; ++j) {
             e[j] = e0 + (unsigned long long)j * blockDim.x + threadIdx.x;
@@ -979,12 +1052,20 @@ __device__ __forceinline__ void cand_body(const SegArgs &a, int r, int s) {
             double m = 0.0;
             off[j] = e[j] < na && offer_of(a, e[j], s, lambda, u, v, m);
             none[j] = false;
-            if (off[j]) atomicMin(&a.bestm[v], d2ord(m));
+            mo[j] = d2ord(m);
+            if (off[j]) atomicMin(&a.bestm[v], mo[j]);
         }
         block_append2<ITEMS>(&st->n_off[rho], off, &st->n_off[rho], none, at, unused, scratch);
+        // (an offer is listed with its edge and its metric's ordered image: the two passes below read the list front to back
+        //  and need no look-up of the edge)
 #pragma unroll
         for (int j = 0; j < ITEMS; ++j)
-            if (off[j]) offers[at[j]] = e[j];
+            if (off[j]) {
+                // (two words per offer in a buffer of n k words: offers are a few per cent of n k on any real cloud; a cloud that
+                //  offered more than half of its neighbour edges at once is refused -- status bit 3 -- not written past the end)
+                if (2 * at[j] + 1 < cap) { offers[2 * at[j]] = a.akey[e[j]]; offers[2 * at[j] + 1] = mo[j]; }
+                else st->overflow_offers = 1;
+            }
     }
 }
 __device__ __forceinline__ void cand2_body(const SegArgs &a, int r, int s) {
@@ -994,9 +1075,9 @@ __device__ __forceinline__ void cand2_body(const SegArgs &a, int r, int s) {
     const unsigned long long n_off = st->n_off[rho];
     int first = 0;
     SV_FOR(i, n_off) {
-        const unsigned long long e = offers[i], key = a.akey[e];
+        const unsigned long long key = offers[2 * i], mo = offers[2 * i + 1];
         const int32_t u = key_u(key), v = key_v(key);
-        if (a.bestm[v] == d2ord(a.am[e])) first += atomicMin(&a.bestu[v], a.orig[u]) == NONE ? 1 : 0;  // (ties: the smallest index of the caller's)
+        if (a.bestm[v] == mo) first += atomicMin(&a.bestu[v], a.orig[u]) == NONE ? 1 : 0;  // (ties: the smallest index of the caller's)
     }
     block_add(&st->n_prop[rho], first, false);
 }
@@ -1011,10 +1092,10 @@ __device__ __forceinline__ void apply_body(const SegArgs &a, int r, int s) {
     const unsigned long long n_off = st->n_off[rho];
     int dropped = 0;
     SV_FOR(i, n_off) {
-        const unsigned long long e = offers[i], key = a.akey[e];
+        const unsigned long long key = offers[2 * i], mo = offers[2 * i + 1];
         const int32_t u = key_u(key), v = key_v(key);
         const int32_t ou = a.orig[u];
-        if (a.bestu[v] == ou && a.bestm[v] == d2ord(a.am[e]) &&
+        if (a.bestu[v] == ou && a.bestm[v] == mo &&
             atomicCAS(&a.bestu[v], ou, NONE) == ou) {  // (the claim lets one of several equal edges through, and leaves bestu clean for the next sub-round)
             a.bestm[v] = ~0ULL;
             a.parent[v] = u;                   // Link(v, u), disjoint_set.h:77-85
@@ -1054,13 +1135,13 @@ __global__ __launch_bounds__(1024) void overflow_collect_kernel(SegArgs a) {
         double m = 0.0;
         bool has = false;
         if (i < n_off) {
-            const unsigned long long e = offers[i], key = a.akey[e];
+            const unsigned long long key = offers[2 * i], mo = offers[2 * i + 1];
             u = key_u(key);
             v = key_v(key);
-            m = a.am[e];
+            m = ord2d(mo);
             // (the list may hold an edge twice: the claim lets one of them through)
             const int32_t ou = a.orig[u];
-            has = a.bestu[v] == ou && a.bestm[v] == d2ord(m) && atomicCAS(&a.bestu[v], ou, NONE) == ou;
+            has = a.bestu[v] == ou && a.bestm[v] == mo && atomicCAS(&a.bestu[v], ou, NONE) == ou;
         }
         const bool t0[1] = {has}, t1[1] = {false};
         unsigned long long at_[1], unused[1];
@@ -1284,7 +1365,7 @@ __global__ void relabel_kernel(State *st, int64_t n, const int32_t *__restrict__
         sweep_state(st, st->sweeps_done, on, full);  // would another sweep run? (only the budget can have stopped it)
         info_out[0] = rank[n - 1] + flag[n - 1];  // supervoxels produced
         info_out[1] = st->K;                      // occupied grid cells (the target)
-        info_out[2] = (st->stalled ? 1 : 0) | (st->live > st->K && !st->stalled ? 2 : 0) | (on ? 4 : 0);
+        info_out[2] = (st->stalled ? 1 : 0) | (st->live > st->K && !st->stalled ? 2 : 0) | (on ? 4 : 0) | (st->overflow_offers ? 8 : 0);
         info_out[3] = st->sweeps_done;
         const unsigned long long lb = (unsigned long long)__double_as_longlong(st->lambda0);
         info_out[4] = (int32_t)(unsigned int)(lb & 0xffffffffULL);  // the fusion's starting lambda (:105-113), the double's two words
@@ -1475,7 +1556,8 @@ static int segment_enqueue(const float *xyz, const double *normals, const int32_
     }
     // lambda0
     if (!presorted) hipLaunchKernelGGL(knn_transpose_kernel, g, b, 0, st, knn, w.orig, w.pos_of, n, k, w.knnT);
-    hipLaunchKernelGGL(min_metric_kernel, g, b, 0, st, xyz, normals, w.knnT, n, k, resolution, w.dis, w.st);
+    if (presorted) hipLaunchKernelGGL(min_metric_kernel<true>, g, b, 0, st, xyz, normals, w.knnT, n, k, resolution, w.dis, w.st);
+    else hipLaunchKernelGGL(min_metric_kernel<false>, g, b, 0, st, xyz, normals, w.knnT, n, k, resolution, w.dis, w.st);
     F4L_LAUNCH_CHECK();
     {   // the median of the smallest neighbour metrics: one order statistic, no sort
         const int64_t rank = n / 2;
@@ -1500,16 +1582,18 @@ static int segment_enqueue(const float *xyz, const double *normals, const int32_
     sa.edges_a = w.edges_a; sa.edges_b = w.edges_b; sa.table = w.table; sa.akey = w.akey; sa.am = w.am; sa.bestm = w.bestm;
     sa.prop_key = w.prop_key; sa.parent = w.parent; sa.size = w.size; sa.bestu = w.bestu; sa.prop_u = w.prop_u; sa.prop_v = w.flag; sa.la = w.la;
     sa.lb = w.lb; sa.dis = w.dis; sa.d0 = w.d0; sa.d1 = w.d1; sa.node = w.node;
+    sa.reps_a = w.prop_u; sa.reps_b = w.rank;
     // the device-wide filter of parallel edges: cleared ONCE -- every entry carries the number of the round that wrote it (round_stamp)
     F4L_HIP_CHECK(hipMemsetAsync(w.table, 0xff, (size_t)table_size((unsigned long long)n * (unsigned long long)k) * 8, st));
     for (int r = 0; r < sched_rounds; ++r) {
         hipLaunchKernelGGL(node_kernel, g, b, 0, st, sa, r);
         if (r <= KNN_ROUNDS) hipLaunchKernelGGL(rows_kernel, g, b, 0, st, sa, r);
         else hipLaunchKernelGGL(build_kernel, g, dim3(BUILD_BLOCK), 0, st, sa, r);
+        const dim3 gs = r < SVX_WIDE_ROUNDS ? g : ga;  // (the first rounds' lists are millions of edges: every pass is a handful of dependent loads per edge, and more threads in flight are fewer trips)
         for (int s = 0; s < SUBROUNDS; ++s) {
-            hipLaunchKernelGGL(cand_kernel, ga, b, 0, st, sa, r, s);
-            hipLaunchKernelGGL(cand2_kernel, ga, b, 0, st, sa, r, s);
-            hipLaunchKernelGGL(apply_kernel, ga, b, 0, st, sa, r, s);
+            hipLaunchKernelGGL(cand_kernel, gs, b, 0, st, sa, r, s);
+            hipLaunchKernelGGL(cand2_kernel, gs, b, 0, st, sa, r, s);
+            hipLaunchKernelGGL(apply_kernel, gs, b, 0, st, sa, r, s);
         }
         F4L_LAUNCH_CHECK();
     }

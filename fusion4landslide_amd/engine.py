@@ -644,7 +644,7 @@ def supervoxel_parallel(xyz, k, resolution, return_intermediates=False, read_cou
         return (labels, info, knn_out, nrm_out, reps) if return_intermediates else (labels, info)
     info_h = info.cpu()
     K = int(info_h[0])
-    if int(info_h[2]) & 6:  # (bit 0, a disconnected neighbour graph that stops above its target, leaves a valid partition)
+    if int(info_h[2]) & 14:  # (bit 0, a disconnected neighbour graph that stops above its target, leaves a valid partition)
         raise RuntimeError(f"f4l_supervoxel_parallel: the segmentation did not finish (status bits {int(info_h[2])}: 2 = lambda "
                            "schedule exhausted above K, 4 = exchange stopped by its sweep budget)")
     if return_intermediates:

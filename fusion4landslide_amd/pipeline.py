@@ -57,7 +57,7 @@ def full_path(src, tgt, k=30, icp_threshold=0.1, voxel_size=0.0, partition="para
             labels, info = engine.supervoxel_segment_device(src, nrm, knn_idx, float(resolution))
         info_h = info.cpu()
         K = int(info_h[0])
-        if int(info_h[2]) & 6:
+        if int(info_h[2]) & 14:
             raise RuntimeError(f"f4l_partition_segment: the segmentation did not finish (status bits {int(info_h[2])})")
         del nb, knn_idx, nn1
         mark("supervoxel_partition")

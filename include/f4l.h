@@ -314,7 +314,9 @@ int f4l_supervoxel(const float *xyz, int64_t n, int k, double resolution, int32_
  *   starting lambda (supervoxel_segmentation.h:105-113) as the low and the high word of the double, lambda rounds entered,
  *   1 + the number of the sub-round whose proposals were cut to reach K exactly (0: none)};
  *   status bit 0: the graph of representatives ran out of edges above K (disconnected cloud; the reference would not
- *   return), bit 1: lambda schedule exhausted above K, bit 2: exchange stopped by the sweep budget before its fixed point.
+ *   return), bit 1: lambda schedule exhausted above K, bit 2: exchange stopped by the sweep budget before its fixed point,
+ *   bit 3: one sub-round offered more than half of the cloud's n k neighbour edges at once (no real cloud does; refused, with bit 1).
+ *   n must be below 2^28 (edge keys keep 28 bits per end; the workspace of that many points exceeds one MI355X anyway).
  * f4l_supervoxel_parallel = f4l_knn + f4l_normals + this (f4l_knn synchronises while it sizes its grid -- unless the stream is
  * being captured into a HIP graph or F4L_KNN_ASYNC is set: then the grid is sized on the device and the call only enqueues). */
 size_t f4l_supervoxel_segment_device_workspace_bytes(int64_t n, int k);
