@@ -56,6 +56,8 @@ SIGNATURES = {
     "f4l_supervoxel": (C.c_int, [_P, _I64, _I, _D, _P, _P, _P, _P, _P, _SZ, _P]),
     "f4l_supervoxel_segment_device_workspace_bytes": (_SZ, [_I64, _I]),
     "f4l_supervoxel_segment_device": (C.c_int, [_P, _P, _P, _I64, _I, _D, _P, _P, _P, _P, _P, _SZ, _P]),
+    "f4l_supervoxel_segment_exact_workspace_bytes": (_SZ, [_I64, _I]),
+    "f4l_supervoxel_segment_exact": (C.c_int, [_P, _P, _P, _I64, _I, _D, _P, _P, _P, _P, _SZ, _P]),
     "f4l_partition_workspace_bytes": (_SZ, [_I64, _I]),
     "f4l_partition_neighbours": (C.c_int, [_P, _I64, _I, _P, _P, _SZ, _P]),
     "f4l_partition_segment": (C.c_int, [_I64, _I, _D, _P, _P, _P, _P, _P, _SZ, _P]),

@@ -82,11 +82,19 @@ static void boundary_on_device(const int32_t *labels, uint8_t *flag, double *dis
 }
 }  // namespace f4l
 
+extern "C" size_t f4l_supervoxel_segment_exact_workspace_bytes(int64_t n, int k);
+extern "C" int f4l_supervoxel_segment_exact(const float *xyz, const double *normals, const int32_t *knn, int64_t n, int k,
+                                            double resolution, int32_t *labels_out, int32_t *n_supervoxels_host, int32_t *stats_host,
+                                            void *workspace, size_t workspace_bytes, void *stream);
+static size_t sv_shared_bytes(int64_t n, int k) {  // the kNN's workspace, reused by the device segmentation once the search is over
+    const size_t a = f4l_knn_workspace_bytes(n, k), x = f4l_supervoxel_segment_exact_workspace_bytes(n, k);
+    return a > x ? a : x;
+}
 extern "C" size_t f4l_supervoxel_workspace_bytes(int64_t n, int k) {
     if (n <= 0 || k < 1) return 0;
     // kNN workspace + (when the caller does not want the intermediates) room for idx and normals + the two sweeps of
     // the segmentation that run on the device (8 n of metric values, n of flags)
-    const size_t a = f4l_knn_workspace_bytes(n, k);
+    const size_t a = sv_shared_bytes(n, k);
     const size_t idx = ((size_t)n * k * 4 + 255) / 256 * 256, nrm = ((size_t)n * 24 + 255) / 256 * 256;
     const size_t dis = ((size_t)n * 8 + 255) / 256 * 256, flag = ((size_t)n + 255) / 256 * 256;
     return a + idx + nrm + dis + flag;
@@ -100,7 +108,7 @@ extern "C" int f4l_supervoxel(const float *xyz, int64_t n, int k, double resolut
     if (k > F4L_MAX_K || n > 0x7fffffffLL) return F4L_EUNSUPPORTED;
     if (workspace_bytes < f4l_supervoxel_workspace_bytes(n, k)) return F4L_EWORKSPACE;
     hipStream_t st = (hipStream_t)stream;
-    const size_t knn_ws = f4l_knn_workspace_bytes(n, k);
+    const size_t knn_ws = sv_shared_bytes(n, k);
     unsigned char *base = (unsigned char *)workspace;
     const size_t idx_b = ((size_t)n * k * 4 + 255) / 256 * 256, nrm_b = ((size_t)n * 24 + 255) / 256 * 256,
                  dis_b = ((size_t)n * 8 + 255) / 256 * 256;
@@ -110,6 +118,19 @@ extern "C" int f4l_supervoxel(const float *xyz, int64_t n, int k, double resolut
     uint8_t *d_flag = (uint8_t *)(base + knn_ws + idx_b + nrm_b + dis_b);
     int rc = f4l_knn_normals(xyz, n, k, idx, nullptr, nrm, workspace, knn_ws, stream);
     if (rc != F4L_OK) return rc;
+    // The reference's segmentation, label for label, ON THE DEVICE (supervoxel_exact.hip: its sequential fusion and its FIFO
+    // exchange as fixed points of parallel passes).  F4L_SV_EXACT_HOST=1, or a cloud whose closures outgrow the device's
+    // buffers (F4L_EUNSUPPORTED), replays the sequence on one host core instead: the same labels.
+    if (!getenv("F4L_SV_EXACT_HOST")) {
+        int32_t nsv_d = 0;
+        rc = f4l_supervoxel_segment_exact(xyz, nrm, idx, n, k, resolution, labels_out, &nsv_d, nullptr, workspace, knn_ws, stream);
+        if (rc == F4L_OK) {
+            if (n_supervoxels_host) *n_supervoxels_host = nsv_d;
+            return F4L_OK;
+        }
+        if (rc != F4L_EUNSUPPORTED) return rc;
+        if (getenv("F4L_SV_EXACT_DEBUG")) fprintf(stderr, "[sv exact] device buffers outgrown: replaying on the host\n");
+    }
     // the starting lambda's sweep (smallest metric to a neighbour, per point) on the device
     hipLaunchKernelGGL(f4l::sv_min_metric_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, xyz, nrm, idx, n, k,
                        resolution, d_dis);

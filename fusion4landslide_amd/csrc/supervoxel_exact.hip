@@ -1,0 +1,770 @@
+// supervoxel_exact.hip -- the reference's OWN supervoxel labels on the device.
+//
+// codelibrary/geometry/point_cloud/supervoxel_segmentation.h:65-248 is sequential twice over: the fusion (:117-176) visits the
+// representatives in index order, each absorbing what its closure offers under the state its predecessors left (mutable ordered
+// adjacency lists, a disjoint set, a `break` when the count reaches K), and the boundary exchange (:186-237) is a FIFO work list.
+// Rounds 1-4 replayed both on one host core (csrc/supervoxel_host.cpp: 1.07 s per 1 M points) and offered a parallel VARIANT
+// with other labels (csrc/supervoxel_gpu.hip).  This file computes the sequential result itself, in parallel, as a FIXED POINT:
+//
+//   fusion    What centre i does is a function of the round's starting state and of what the centres BEFORE it (lower index) did.
+//             Every centre is evaluated at once against an ESTIMATE of that -- per node: who absorbed it (abs), and per centre:
+//             its size and its ordered list of rejected neighbours after its turn (ns, kept) -- seen through the eyes of centre i:
+//             an absorption by centre c counts iff c < i and c itself was not absorbed before its turn (abs[c] < c); a root j has
+//             its new size and list iff j < i.  The evaluations give the next estimate; centre i is right as soon as all centres
+//             below it are, so the iteration reaches THE sequential result (the unique fixed point of a recursion on the index)
+//             after as many passes as the longest chain of real dependencies: 6-20 per lambda round on 100 k - 1 M point clouds
+//             in patch, row-major and random order (tools/experiments/fixed_point_fusion_proto.cpp, every label equal).  The
+//             `break` at K representatives is one more dependency on lower centres: a centre's budget is what the absorptions of
+//             the centres before it (a prefix sum of the estimate) leave of (live - K).
+//   exchange  The queue is processed in GENERATIONS (the entries it holds when a generation starts; what they push is the next
+//             generation, in (position of the pusher, neighbour slot) order).  Inside a generation an entry sees the labels its
+//             EARLIER entries leave: the same fixed-point iteration, 3-4 generations and ~10 passes in all.
+//
+// Queue order, visited sets, list order, the strict `<` of the exchange and the position of the break are the reference's, so the
+// labels are the reference's (tests: every label of the reference-compiled fixtures and of fresh clouds through the live
+// reference, and of the host replay on random clouds).  One wavefront evaluates one centre (its queue in LDS).  A closure beyond
+// the queue's capacity, or lists beyond the pools, are reported (F4L_EUNSUPPORTED): f4l_supervoxel then replays on the host.
+#include <cfloat>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include <rocprim/rocprim.hpp>
+
+#include "f4l_device.h"
+#include "select.h"
+#include "sv_metric.h"
+
+namespace f4l {
+namespace svx {
+
+constexpr unsigned int NONE = 0xffffffffu;
+constexpr int QCAP = 512;                 // distinct nodes one centre's closure may visit (its queue, in LDS)
+constexpr int EVAL_WAVES = 4;             // centres per workgroup
+constexpr int SUBPOOLS = 1024;            // bump pointers of a list pool (one address would serialise a million allocations)
+constexpr unsigned long long KEY_INF = (1ULL << 40) - 1ULL;
+constexpr int32_t POS_INF = 0x7fffffff;
+constexpr int MAX_ROUNDS = 64, MAX_ITERS = 4096, MAX_GENERATIONS = 100000;
+
+struct State {
+    unsigned int bb[6];
+    int K;
+    int overflow;          // 1: a closure beyond QCAP, 2: a list pool full
+    int changed[8];        // per pass (slot = pass % 8): something differed from the estimate before
+    int m;                 // entries of the exchange's current generation
+    unsigned long long sub[2][SUBPOOLS];  // bump pointers of the two estimate pools
+};
+
+__device__ __forceinline__ unsigned int f2ord(float f) {
+    const unsigned int u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ord2f(unsigned int o) { return __uint_as_float((o & 0x80000000u) ? (o & 0x7fffffffu) : ~o); }
+__device__ __forceinline__ unsigned long long mix64(unsigned long long x) {
+    x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
+    return x;
+}
+#define SVX_FOR(i, n) for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (int64_t)(n); i += (int64_t)gridDim.x * blockDim.x)
+
+// ---- K = occupied cells of the resolution grid (grid_sample.h:48-68), lambda0's metric sweep ------------------------------------
+__global__ void bbox_kernel(const float *__restrict__ xyz, int64_t n, State *st) {
+    unsigned int mn[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, mx[3] = {0u, 0u, 0u};
+    SVX_FOR(i, n) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const unsigned int o = f2ord(xyz[3 * i + d]);
+            mn[d] = o < mn[d] ? o : mn[d];
+            mx[d] = o > mx[d] ? o : mx[d];
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            const unsigned int a = (unsigned int)__shfl_xor((int)mn[d], m, 64), b = (unsigned int)__shfl_xor((int)mx[d], m, 64);
+            mn[d] = a < mn[d] ? a : mn[d];
+            mx[d] = b > mx[d] ? b : mx[d];
+        }
+    if (lane_id() == 0) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) { atomicMin(&st->bb[d], mn[d]); atomicMax(&st->bb[3 + d], mx[d]); }
+    }
+}
+__global__ void grid_count_kernel(const float *__restrict__ xyz, int64_t n, double resolution, State *st,
+                                  unsigned long long *__restrict__ set, unsigned long long slots) {
+#pragma clang fp contract(off)
+    double mn[3];
+    int size[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        mn[d] = (double)ord2f(st->bb[d]);
+        size[d] = (int)(((double)ord2f(st->bb[3 + d]) - mn[d]) / resolution + 1);
+    }
+    int cnt = 0;
+    SVX_FOR(i, n) {
+        int c[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            c[d] = (int)(((double)xyz[3 * i + d] - mn[d]) / resolution);
+            c[d] = c[d] < 0 ? 0 : (c[d] > size[d] - 1 ? size[d] - 1 : c[d]);
+        }
+        const unsigned long long key = ((unsigned long long)c[0] * (unsigned long long)size[1] + (unsigned long long)c[1]) * (unsigned long long)size[2] +
+                                       (unsigned long long)c[2];
+        unsigned long long slot = __umul64hi(mix64(key), slots);
+        for (;;) {
+            const unsigned long long old = atomicCAS(&set[slot], ~0ULL, key);
+            if (old == ~0ULL) { ++cnt; break; }
+            if (old == key) break;
+            slot = slot + 1ULL == slots ? 0ULL : slot + 1ULL;
+        }
+    }
+    cnt = wave_sum(cnt);
+    if (lane_id() == 0 && cnt) atomicAdd(&st->K, cnt);
+}
+#pragma clang fp contract(off)
+__global__ void min_metric_kernel(const float *__restrict__ xyz, const double *__restrict__ nrm, const int32_t *__restrict__ knn, int64_t n,
+                                  int k, double resolution, double *__restrict__ dis0) {
+    SVX_FOR(i, n) {
+        double best = DBL_MAX;
+        for (int j = 0; j < k; ++j) {
+            const int64_t q = knn[i * k + j];
+            if (q != i) {
+                const double m = sv_metric(xyz, nrm, i, q, resolution);
+                best = m < best ? m : best;
+            }
+        }
+        dis0[i] = best;
+    }
+}
+
+// ---- fusion -------------------------------------------------------------------------------------------------------------
+struct Est {                     // one estimate of "what the centres of this round do" (two of them: read / written)
+    unsigned int *abs;           // [n] the centre that absorbs the node, NONE
+    int32_t *ns, *cnt;           // [n] a centre's size after its turn, the nodes it absorbs
+    int64_t *off;                // [n] its list of rejected neighbours after its turn: offset into `lists` ...
+    int32_t *len;                //     ... and length
+    unsigned long long *hash;    // [n] order-sensitive hash of that list (what "the list did not change" is read from)
+    int32_t *cnt_slot;           // [nreps] cnt in the order of the centres (the budget's prefix sum runs over it)
+};
+struct FuseArgs {
+    const float *xyz;
+    const double *nrm;
+    const int32_t *lists;        // the neighbour table followed by the three list pools: one address space
+    int64_t n;
+    int k;
+    double resolution;
+    State *st;
+    const int32_t *reps;         // the round's centres, ascending
+    int nreps;
+    const int32_t *root;         // [n] round-start representative of every node
+    const int32_t *sz0;          // [n] round-start sizes
+    const int64_t *adj_off;      // [n] round-start lists
+    const int32_t *adj_len;
+    const int64_t *before;       // [nreps] absorptions by the centres before each centre (previous estimate), or null
+    int64_t pool_base, sub_cap;  // where this pass writes lists: SUBPOOLS regions of sub_cap entries from pool_base
+    int pool_sel;                // which set of bump pointers
+    Est rd, wr;
+};
+
+__global__ void iota_kernel(int32_t *a, int32_t *b, int32_t *sz, int64_t *off, int32_t *len, int64_t n, int k) {
+    SVX_FOR(i, n) { a[i] = (int32_t)i; b[i] = (int32_t)i; sz[i] = 1; off[i] = i * k; len[i] = k; }
+}
+__global__ void round_init_kernel(FuseArgs a) {
+    SVX_FOR(s, a.nreps) {
+        const int32_t i = a.reps[s];
+        a.rd.abs[i] = NONE;
+        a.rd.ns[i] = a.sz0[i];
+        a.rd.cnt[i] = 0;
+        a.rd.off[i] = a.adj_off[i];
+        a.rd.len[i] = a.adj_len[i];
+        a.rd.hash[i] = ~0ULL;   // ("the round-start list": no evaluation writes this value twice in a row unless nothing changes)
+        a.rd.cnt_slot[s] = 0;
+    }
+}
+__global__ void sub_reset_kernel(State *st, int sel) {
+    for (int t = (int)threadIdx.x; t < SUBPOOLS; t += (int)blockDim.x) st->sub[sel][t] = 0ULL;
+}
+
+// One wavefront = one centre.  Q: the closure's queue = its visited set, in the reference's order (:125-134, 151-157).
+__global__ __launch_bounds__(EVAL_WAVES * 64) void eval_kernel(FuseArgs a, double lambda, long long budget_total, int pass) {
+    __shared__ int32_t q_all[EVAL_WAVES][QCAP];
+    __shared__ unsigned int acc_all[EVAL_WAVES][QCAP / 32];
+    const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
+    const int64_t s = (int64_t)blockIdx.x * EVAL_WAVES + wave;
+    if (s >= a.nreps) return;  // (whole wave)
+    int32_t *Q = q_all[wave];
+    unsigned int *ACC = acc_all[wave];
+    const int32_t i = a.reps[s];
+    const unsigned int ui = (unsigned int)i;
+    const unsigned int *__restrict__ abs_rd = a.rd.abs;
+    const unsigned int absi = abs_rd[i];
+    const bool dead = absi != NONE && absi < ui;  // absorbed before its turn: adjacents[i] is empty by then (:121)
+    const int64_t off0 = a.adj_off[i];
+    const int len0 = a.adj_len[i];
+    long long budget = a.before ? budget_total - (long long)a.before[s] : 0x7fffffffffffLL;
+    const bool run = !dead && len0 > 0 && budget > 0;
+    int nsz = a.sz0[i], cnt = 0;
+    int head = 0, tail = 0;
+    bool overflow = false;
+    // this centre's own position and normal (the metric's first argument, :142)
+    float pi_[3];
+    double ni_[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { pi_[d] = a.xyz[3 * (int64_t)i + d]; ni_[d] = a.nrm[3 * (int64_t)i + d]; }
+
+    // appends Find(list entries) that are not yet visited, in list order (:126-133 / :151-157)
+    auto append_list = [&](int64_t off, int len) {
+        for (int c0 = 0; c0 < len && !overflow; c0 += 64) {
+            const bool have = c0 + lane < len;
+            unsigned int r = NONE;
+            if (have) {
+                r = (unsigned int)a.root[a.lists[off + c0 + lane]];
+                // Find as centre i sees it (set.Find, :127/:152): every absorption by a centre that ran BEFORE i and was alive at its
+                // own turn; honoured claims lead to ever higher centres, so the walk ends
+                for (;;) {
+                    const unsigned int c = abs_rd[r];
+                    if (c == NONE || !(c < ui)) break;
+                    const unsigned int cc = abs_rd[c];
+                    if (cc != NONE && cc < c) break;
+                    r = c;
+                }
+            }
+            // visited already? (the queue so far; four entries per LDS read)
+            bool fresh = have;
+            for (int e = 0; e < tail; e += 4) {
+                const int4 v = *reinterpret_cast<const int4 *>(Q + e);  // (entries past `tail` hold -1)
+                fresh = fresh && (unsigned int)v.x != r && (unsigned int)v.y != r && (unsigned int)v.z != r && (unsigned int)v.w != r;
+            }
+            // ... or by a lower lane of this chunk (the first occurrence wins)
+            unsigned long long cand = __ballot(fresh), news = 0ULL;
+            while (cand) {
+                const int l = __ffsll((long long)cand) - 1;
+                const unsigned int rl = (unsigned int)__shfl((int)r, l, 64);
+                const unsigned long long same = __ballot(fresh && r == rl);
+                news |= 1ULL << l;
+                cand &= ~same;
+            }
+            const int nn = (int)__popcll(news);
+            if (tail + nn > QCAP) { overflow = true; break; }
+            if ((news >> lane) & 1ULL) Q[tail + (int)__popcll(news & ((1ULL << lane) - 1ULL))] = (int32_t)r;
+            tail += nn;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+    };
+
+    if (run) {
+        for (int e = lane; e < QCAP; e += 64) Q[e] = -1;
+        for (int e = lane; e < QCAP / 32; e += 64) ACC[e] = 0u;
+        if (lane == 0) Q[0] = i;  // visited[i] = true; queue[front++] = i (:123-125)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        head = tail = 1;
+        append_list(off0, len0);
+        bool stop = false;
+        while (head < tail && !stop && !overflow) {  // :137-163, 64 entries of the queue at a time
+            const int m = tail - head < 64 ? tail - head : 64;
+            const bool mine = lane < m;
+            const int32_t j = mine ? Q[head + lane] : i;
+            // sizes[j] as centre i finds it: j ran before i (and grew) iff j < i
+            const int sj = mine ? ((unsigned int)j < ui ? a.rd.ns[j] : a.sz0[j]) : 0;
+            bool acc = false;
+            if (mine) {
+                float pj[3];
+                double nj[3];
+#pragma unroll
+                for (int d = 0; d < 3; ++d) { pj[d] = a.xyz[3 * (int64_t)j + d]; nj[d] = a.nrm[3 * (int64_t)j + d]; }
+                const double loss = (double)sj * sv_metric_vals(pi_, ni_, pj, nj, a.resolution);  // :142 `sizes[j] * metric(points[i], points[j])`
+                acc = lambda - loss > 0.0;                                                        // :143-144
+            }
+            // adjacents[j] as centre i finds it (:151): j's list after its turn iff j < i
+            const int64_t joff = mine ? ((unsigned int)j < ui ? a.rd.off[j] : a.adj_off[j]) : 0;
+            const int jlen = mine ? ((unsigned int)j < ui ? a.rd.len[j] : a.adj_len[j]) : 0;
+            unsigned long long accm = __ballot(acc);
+            int done = m;  // entries of this chunk that the reference's loop reaches
+            if ((long long)__popcll(accm) >= budget) {  // `if (--number_of_supervoxels == n_supervoxels) break;` (:160) inside this chunk
+                unsigned long long t = accm;
+                for (long long b = 1; b < budget; ++b) t &= t - 1ULL;
+                const int last = __ffsll((long long)t) - 1;  // lane of the absorption that reaches K
+                done = last + 1;
+                accm &= (last == 63) ? ~0ULL : ((1ULL << (last + 1)) - 1ULL);
+                stop = true;
+            }
+            const bool take = mine && ((accm >> lane) & 1ULL);
+            if (take) {
+                atomicMin(&a.wr.abs[j], ui);  // set.Link(j, i) (:145); of several centres that claim j in an estimate the lowest counts
+                atomicOr(&ACC[(head + lane) >> 5], 1u << ((head + lane) & 31));
+            }
+            nsz += wave_sum(take ? sj : 0);   // sizes[i] += sizes[j] (:147)
+            const int na = (int)__popcll(accm);
+            cnt += na;
+            budget -= na;
+            // the absorbed nodes' lists join the queue, in the queue's order (:149-157)
+            unsigned long long mm = accm;
+            while (mm && !overflow) {
+                const int l = __ffsll((long long)mm) - 1;
+                mm &= mm - 1ULL;
+                const long long o = __shfl((long long)joff, l, 64);
+                append_list((int64_t)o, __shfl(jlen, l, 64));
+            }
+            head += done;
+        }
+    }
+    // the centre's list after its turn (:164 `adjacents[i].swap(adjacent)`): the entries it looked at and did not absorb, in order
+    int64_t out_off = dead ? 0 : off0;
+    int out_len = dead ? 0 : len0;  // (a centre that did not run keeps its list; an absorbed one's is cleared, :158)
+    unsigned long long hash = dead ? 1ULL : ~0ULL;
+    if (run && !overflow) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        int kept = 0;
+        for (int e0 = 1; e0 < head; e0 += 64) {
+            const int e = e0 + lane;
+            kept += (int)__popcll(__ballot(e < head && !((ACC[e >> 5] >> (e & 31)) & 1u)));
+        }
+        out_len = kept;
+        out_off = 0;
+        unsigned long long base = 0ULL;
+        if (kept > 0) {
+            const int sp = (int)(s & (SUBPOOLS - 1));
+            if (lane == 0) base = atomicAdd(&a.st->sub[a.pool_sel][sp], (unsigned long long)kept);
+            base = (unsigned long long)__shfl((long long)base, 0, 64);
+            if ((long long)base + kept > a.sub_cap) overflow = true;
+            out_off = a.pool_base + (int64_t)sp * a.sub_cap + (int64_t)base;
+        }
+        unsigned long long h = 0ULL;
+        int at = 0;
+        if (!overflow) {
+            int32_t *__restrict__ dst = const_cast<int32_t *>(a.lists) + out_off;
+            for (int e0 = 1; e0 < head; e0 += 64) {
+                const int e = e0 + lane;
+                const bool keep = e < head && !((ACC[e >> 5] >> (e & 31)) & 1u);
+                const unsigned long long km = __ballot(keep);
+                if (keep) {
+                    const int p = at + (int)__popcll(km & ((1ULL << lane) - 1ULL));
+                    dst[p] = Q[e];
+                    h += mix64(((unsigned long long)(unsigned int)Q[e] << 32) | (unsigned int)p);
+                }
+                at += (int)__popcll(km);
+            }
+        }
+        hash = 2ULL + (wave_sum((int)(h & 0x7fffffffULL)) + (unsigned long long)wave_sum((int)((h >> 31) & 0x7fffffffULL)) * 0x9E3779B1ULL +
+                       (unsigned long long)kept * 0x85EBCA6BULL);
+    }
+    if (overflow && lane == 0) atomicOr(&a.st->overflow, tail + 64 > QCAP ? 1 : 2);
+    if (lane == 0) {
+        const bool same = a.rd.ns[i] == nsz && a.rd.cnt[i] == cnt && a.rd.len[i] == out_len && a.rd.hash[i] == hash;
+        a.wr.ns[i] = nsz; a.wr.cnt[i] = cnt; a.wr.off[i] = out_off; a.wr.len[i] = out_len; a.wr.hash[i] = hash;
+        a.wr.cnt_slot[s] = cnt;
+        if (!same) a.st->changed[pass & 7] = 1;
+    }
+}
+// (the claims: compared after the pass, when all of them are in)
+__global__ void abs_changed_kernel(FuseArgs a, int pass) {
+    bool ch = false;
+    SVX_FOR(s, a.nreps) { const int32_t i = a.reps[s]; ch = ch || a.rd.abs[i] != a.wr.abs[i]; }
+    if (__ballot(ch) != 0ULL && lane_id() == 0) a.st->changed[pass & 7] = 1;
+}
+__global__ void abs_clear_kernel(unsigned int *abs, const int32_t *reps, int nreps) {
+    SVX_FOR(s, nreps) abs[reps[s]] = NONE;
+}
+// the converged estimate becomes the state: survivors keep size and list, everybody follows its absorber
+__global__ void commit_kernel(FuseArgs a, int32_t *sz0, int64_t *adj_off, int32_t *adj_len, int32_t *keep_flag) {
+    SVX_FOR(s, a.nreps) {
+        const int32_t i = a.reps[s];
+        const bool survives = a.rd.abs[i] == NONE;
+        keep_flag[s] = survives ? 1 : 0;
+        if (survives) { sz0[i] = a.rd.ns[i]; adj_off[i] = a.rd.off[i]; adj_len[i] = a.rd.len[i]; }
+        else adj_len[i] = 0;
+    }
+}
+__global__ void reroot_kernel(int32_t *root, const unsigned int *__restrict__ abs, int64_t n) {
+    SVX_FOR(x, n) {
+        unsigned int r = (unsigned int)root[x];
+        while (abs[r] != NONE) r = abs[r];  // (a converged estimate: every claim real, chains ascend in time)
+        root[x] = (int32_t)r;
+    }
+}
+__global__ void compact_kernel(const int32_t *reps, const int32_t *keep_flag, const int32_t *keep_pos, int nreps, int32_t *reps_out) {
+    SVX_FOR(s, nreps) if (keep_flag[s]) reps_out[keep_pos[s]] = reps[s];
+}
+
+// ---- exchange -----------------------------------------------------------------------------------------------------------
+struct XchArgs {
+    const float *xyz;
+    const double *nrm;
+    const int32_t *knn;
+    int64_t n;
+    int k;
+    double resolution;
+    State *st;
+    int32_t *lab;                 // [n] label = representative point (the generation's starting state)
+    double *dis;                  // [n] metric to it
+    int32_t *pos;                 // [n] position in the current generation, POS_INF
+    unsigned long long *key;      // [n] (pusher position, slot) that first pushes the node into the next generation, KEY_INF
+    const int32_t *Q;             // the generation's entries
+    int32_t *out_rd, *out_wr;     // [n] an entry's label after its turn (estimate read / written)
+    double *dis_wr;
+    unsigned char *ch_rd, *ch_wr; // [n] `change` of :214-226
+};
+#pragma clang fp contract(off)
+__global__ void xch_init_kernel(XchArgs a, const int32_t *__restrict__ root) {
+    SVX_FOR(i, a.n) {
+        const int32_t l = root[i];
+        a.lab[i] = l;
+        a.dis[i] = sv_metric(a.xyz, a.nrm, i, (int64_t)l, a.resolution);  // :186-189
+        a.pos[i] = POS_INF;
+        a.key[i] = KEY_INF;
+    }
+}
+// the scan of :194-207: a point enters the queue at the first event that touches it
+__global__ void xch_first_keys_kernel(XchArgs a, const int32_t *__restrict__ root) {
+    SVX_FOR(i, a.n) {
+        const int32_t li = root[i];
+        for (int j = 0; j < a.k; ++j) {
+            const int32_t q = a.knn[i * a.k + j];
+            if (li != root[q]) {
+                const unsigned long long e = ((unsigned long long)i * 64ULL + (unsigned long long)j) * 2ULL;
+                atomicMin(&a.key[i], e);
+                atomicMin(&a.key[q], e + 1ULL);
+            }
+        }
+    }
+}
+__global__ void xch_pairs_kernel(const unsigned long long *__restrict__ key, int64_t n, unsigned long long *__restrict__ k_out, int32_t *__restrict__ v_out) {
+    SVX_FOR(i, n) { k_out[i] = key[i]; v_out[i] = (int32_t)i; }
+}
+// after the sort: the entries with a finite key are the generation; their positions; the keys are cleared for the next one
+__global__ void xch_generation_kernel(XchArgs a, const unsigned long long *__restrict__ sorted_keys, const int32_t *__restrict__ sorted_nodes) {
+    SVX_FOR(t, a.n) {
+        const bool in = sorted_keys[t] != KEY_INF;
+        if (in) {
+            const int32_t i = sorted_nodes[t];
+            a.pos[i] = (int32_t)t;
+            a.out_rd[i] = a.lab[i];
+            a.ch_rd[i] = 0;
+            a.key[i] = KEY_INF;
+            if (t + 1 == a.n || sorted_keys[t + 1] == KEY_INF) a.st->m = (int)(t + 1);
+        } else if (t == 0) a.st->m = 0;
+    }
+}
+// one entry's turn (:214-226) with the labels its earlier entries leave
+__global__ void xch_eval_kernel(XchArgs a, int m, int pass) {
+    bool differs = false;
+    SVX_FOR(t, m) {
+        const int32_t i = a.Q[t];
+        int32_t la = a.lab[i];
+        double d0 = a.dis[i];
+        bool ch = false;
+        for (int j = 0; j < a.k; ++j) {
+            const int32_t q = a.knn[(int64_t)i * a.k + j];
+            if (q == i) continue;
+            const int32_t b = a.pos[q] < (int32_t)t ? a.out_rd[q] : a.lab[q];
+            if (la == b) continue;
+            const double d = sv_metric(a.xyz, a.nrm, (int64_t)i, (int64_t)b, a.resolution);
+            if (d < d0) { la = b; d0 = d; ch = true; }
+        }
+        differs = differs || a.out_rd[i] != la || (a.ch_rd[i] != 0) != ch;
+        a.out_wr[i] = la;
+        a.dis_wr[i] = d0;
+        a.ch_wr[i] = ch ? 1 : 0;
+    }
+    if (__ballot(differs) != 0ULL && lane_id() == 0) a.st->changed[pass & 7] = 1;
+}
+// the pushes of the generation (:228-236) and its labels
+__global__ void xch_push_kernel(XchArgs a, int m) {
+    SVX_FOR(t, m) {
+        const int32_t i = a.Q[t];
+        const int32_t li = a.out_rd[i];
+        if (!a.ch_rd[i]) continue;
+        for (int j = 0; j < a.k; ++j) {
+            const int32_t q = a.knn[(int64_t)i * a.k + j];
+            if (q == i) continue;
+            const int32_t pq = a.pos[q];
+            const int32_t b = pq < (int32_t)t ? a.out_rd[q] : a.lab[q];
+            if (li != b && !(pq != POS_INF && pq > (int32_t)t)) atomicMin(&a.key[q], (unsigned long long)t * 64ULL + (unsigned long long)j);
+        }
+    }
+}
+__global__ void xch_commit_kernel(XchArgs a, int m, const double *__restrict__ dis_rd) {
+    SVX_FOR(t, m) {
+        const int32_t i = a.Q[t];
+        a.lab[i] = a.out_rd[i];
+        a.dis[i] = dis_rd[i];
+        a.pos[i] = POS_INF;
+    }
+}
+__global__ void rank_kernel(const int32_t *__restrict__ reps, int nreps, int32_t *__restrict__ rank) {
+    SVX_FOR(s, nreps) rank[reps[s]] = (int32_t)s;
+}
+__global__ void relabel_kernel(const int32_t *__restrict__ lab, const int32_t *__restrict__ rank, int64_t n, int32_t *__restrict__ labels_out) {
+    SVX_FOR(i, n) labels_out[i] = rank[lab[i]];  // :241-247
+}
+
+static inline size_t align_up(size_t v) { return (v + 255) / 256 * 256; }
+struct Ws {
+    State *st;
+    int32_t *lists;  // [n k] the neighbour table (a copy: one address space with the pools) + 3 pools
+    int64_t pool_off[3], pool_cap;
+    int32_t *root, *sz0, *adj_len, *reps_a, *reps_b, *keep_flag, *keep_pos;
+    int64_t *adj_off, *before;
+    unsigned int *abs[2];
+    int32_t *ns[2], *cnt[2], *len[2], *cnt_slot[2];
+    int64_t *off[2];
+    unsigned long long *hash[2];
+    double *dis, *dis2[2], *median;
+    void *sel;
+    unsigned long long *key, *key_s_in, *key_s_out;
+    int32_t *node_s_in, *node_s_out, *pos, *lab, *out[2], *rank;
+    unsigned char *ch[2];
+    void *prim;
+    size_t prim_bytes, total;
+};
+static int layout(int64_t n, int k, Ws &w, unsigned char *base) {
+    size_t sort_b = 0, scan_b = 0, scan64_b = 0;
+    unsigned long long *k0 = nullptr;
+    int32_t *i0 = nullptr;
+    int64_t *l0 = nullptr;
+    if (rocprim::radix_sort_pairs(nullptr, sort_b, k0, k0, i0, i0, (size_t)n, 0, 40, 0, false) != hipSuccess) return F4L_EHIP;
+    if (rocprim::exclusive_scan(nullptr, scan_b, i0, i0, 0, (size_t)n, rocprim::plus<int32_t>(), 0, false) != hipSuccess) return F4L_EHIP;
+    if (rocprim::exclusive_scan(nullptr, scan64_b, i0, l0, (int64_t)0, (size_t)n, rocprim::plus<int64_t>(), 0, false) != hipSuccess) return F4L_EHIP;
+    size_t prim = sort_b > scan_b ? sort_b : scan_b;
+    prim = prim > scan64_b ? prim : scan64_b;
+    size_t o = 0;
+    auto carve = [&](size_t bytes) { size_t at = o; o += align_up(bytes); return base ? base + at : (unsigned char *)nullptr; };
+    const size_t nk = (size_t)n * (size_t)k;
+    w.st = (State *)carve(sizeof(State));
+    // the pools: a centre's list is inherited by ONE absorber in a consistent estimate, so the lists of a pass sum to at most the
+    // lists before it (n k at the start); an inconsistent estimate may count some twice: room for 2 n k, in SUBPOOLS slices
+    w.pool_cap = (int64_t)((2 * nk / SUBPOOLS + 64) * SUBPOOLS);
+    w.lists = (int32_t *)carve((nk + 3 * (size_t)w.pool_cap) * 4);
+    for (int p = 0; p < 3; ++p) w.pool_off[p] = (int64_t)nk + (int64_t)p * w.pool_cap;
+    w.root = (int32_t *)carve((size_t)n * 4); w.sz0 = (int32_t *)carve((size_t)n * 4); w.adj_len = (int32_t *)carve((size_t)n * 4);
+    w.reps_a = (int32_t *)carve((size_t)n * 4); w.reps_b = (int32_t *)carve((size_t)n * 4);
+    w.keep_flag = (int32_t *)carve((size_t)n * 4); w.keep_pos = (int32_t *)carve((size_t)n * 4);
+    w.adj_off = (int64_t *)carve((size_t)n * 8); w.before = (int64_t *)carve((size_t)n * 8);
+    for (int e = 0; e < 2; ++e) {
+        w.abs[e] = (unsigned int *)carve((size_t)n * 4); w.ns[e] = (int32_t *)carve((size_t)n * 4); w.cnt[e] = (int32_t *)carve((size_t)n * 4);
+        w.len[e] = (int32_t *)carve((size_t)n * 4); w.cnt_slot[e] = (int32_t *)carve((size_t)n * 4);
+        w.off[e] = (int64_t *)carve((size_t)n * 8); w.hash[e] = (unsigned long long *)carve((size_t)n * 8);
+    }
+    w.dis = (double *)carve((size_t)n * 8);
+    w.dis2[0] = (double *)carve((size_t)n * 8); w.dis2[1] = (double *)carve((size_t)n * 8);
+    w.median = (double *)carve(16);
+    w.sel = carve(select_workspace_bytes());
+    // (the exchange's arrays alias the fusion's estimates: the fusion is over when the exchange starts)
+    w.key = (unsigned long long *)w.off[0]; w.key_s_in = (unsigned long long *)w.off[1]; w.key_s_out = (unsigned long long *)w.hash[0];
+    w.node_s_in = w.ns[0]; w.node_s_out = w.ns[1]; w.pos = w.cnt[0]; w.lab = w.cnt[1]; w.out[0] = w.len[0]; w.out[1] = w.len[1];
+    w.rank = w.cnt_slot[0];
+    w.ch[0] = (unsigned char *)w.abs[0]; w.ch[1] = (unsigned char *)w.abs[1];
+    w.prim = carve(prim);
+    w.prim_bytes = prim;
+    w.total = o;
+    return F4L_OK;
+}
+}  // namespace svx
+}  // namespace f4l
+
+extern "C" size_t f4l_supervoxel_segment_exact_workspace_bytes(int64_t n, int k) {
+    if (n <= 0 || k < 1) return 0;
+    f4l::svx::Ws w;
+    if (f4l::svx::layout(n, k, w, nullptr) != F4L_OK) return 0;
+    return w.total;
+}
+
+// The reference's segmentation (supervoxel_segmentation.h:65-248) of device arrays, label for label.  SYNCHRONISES `stream` (a
+// few times per lambda round and exchange generation: whether the estimate still changes, how many representatives are left).
+// F4L_EUNSUPPORTED: a closure or the lists outgrew the device buffers (nothing was written to labels_out): replay on the host.
+extern "C" int f4l_supervoxel_segment_exact(const float *xyz, const double *normals, const int32_t *knn, int64_t n, int k,
+                                            double resolution, int32_t *labels_out, int32_t *n_supervoxels_host, int32_t *stats_host,
+                                            void *workspace, size_t workspace_bytes, void *stream) {
+    using namespace f4l;
+    using namespace f4l::svx;
+    if (!xyz || !normals || !knn || n <= 0 || k < 1 || !(resolution > 0.0) || !labels_out || !workspace) return F4L_EINVAL;
+    if (k > F4L_MAX_K || n > 0x3fffffffLL) return F4L_EUNSUPPORTED;
+    Ws w;
+    int rc = layout(n, k, w, (unsigned char *)workspace);
+    if (rc != F4L_OK) return rc;
+    if (workspace_bytes < w.total) return F4L_EWORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 g(2048), b(256), one(1);
+    State hs;
+    auto read_state = [&]() -> int {
+        F4L_HIP_CHECK(hipMemcpyAsync(&hs, w.st, sizeof(int) * 12 + sizeof(unsigned int) * 6, hipMemcpyDeviceToHost, st));
+        F4L_HIP_CHECK(hipStreamSynchronize(st));
+        return F4L_OK;
+    };
+    F4L_HIP_CHECK(hipMemsetAsync(w.st, 0, sizeof(State), st));
+    {
+        State init;
+        memset(&init, 0, sizeof(init));
+        for (int d = 0; d < 3; ++d) { init.bb[d] = 0xffffffffu; init.bb[3 + d] = 0u; }
+        F4L_HIP_CHECK(hipMemcpyAsync(w.st, &init, sizeof(unsigned int) * 6, hipMemcpyHostToDevice, st));
+    }
+    // K (grid_sample.h:48-68): the hash set lives in the first pool, idle until the first pass writes lists
+    hipLaunchKernelGGL(svx::bbox_kernel, dim3(256), b, 0, st, xyz, n, w.st);
+    {
+        const unsigned long long slots = 2ULL * (unsigned long long)n + 1024ULL;
+        unsigned long long *set = (unsigned long long *)(w.lists + ((w.pool_off[1] + 1) & ~(int64_t)1));  // (an even entry of a 256-byte aligned array: 8-byte aligned)
+        if (((size_t)w.pool_cap - 1) * 4 < (size_t)slots * 8) return F4L_EUNSUPPORTED;  // (k = 1: replay on the host)
+        F4L_HIP_CHECK(hipMemsetAsync(set, 0xff, (size_t)slots * 8, st));
+        hipLaunchKernelGGL(svx::grid_count_kernel, g, b, 0, st, xyz, n, resolution, w.st, set, slots);
+    }
+    // lambda0 (:105-113)
+    hipLaunchKernelGGL(svx::min_metric_kernel, g, b, 0, st, xyz, normals, knn, n, k, resolution, w.dis);
+    F4L_LAUNCH_CHECK();
+    {
+        const int64_t rank = n / 2;
+        rc = select_ranks_f64(w.dis, n, 1, 1, &rank, w.median, w.sel, st);
+        if (rc != F4L_OK) return rc;
+    }
+    double lambda0 = 0.0;
+    F4L_HIP_CHECK(hipMemcpyAsync(&lambda0, w.median, 8, hipMemcpyDeviceToHost, st));
+    F4L_HIP_CHECK(hipMemcpyAsync(w.lists, knn, (size_t)n * k * 4, hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(svx::iota_kernel, g, b, 0, st, w.root, w.reps_a, w.sz0, w.adj_off, w.adj_len, n, k);
+    rc = read_state();
+    if (rc != F4L_OK) return rc;
+    const int K = hs.K;
+    double lambda = lambda0 > DBL_EPSILON ? lambda0 : DBL_EPSILON;
+
+    FuseArgs fa;
+    fa.xyz = xyz; fa.nrm = normals; fa.lists = w.lists; fa.n = n; fa.k = k; fa.resolution = resolution; fa.st = w.st;
+    fa.root = w.root; fa.sz0 = w.sz0; fa.adj_off = w.adj_off; fa.adj_len = w.adj_len; fa.sub_cap = w.pool_cap / SUBPOOLS;
+    int32_t *reps = w.reps_a, *reps_next = w.reps_b;
+    int nreps = (int)n, live = (int)n;
+    int committed_pool = -1;  // (the pool the round-start lists live in; -1: the neighbour table)
+    int rounds = 0, passes = 0;
+    auto est = [&](int e) { Est x; x.abs = w.abs[e]; x.ns = w.ns[e]; x.cnt = w.cnt[e]; x.off = w.off[e]; x.len = w.len[e]; x.hash = w.hash[e]; x.cnt_slot = w.cnt_slot[e]; return x; };
+    for (; rounds < MAX_ROUNDS; lambda *= 2.0, ++rounds) {
+        if (nreps <= 1) break;  // :118
+        fa.reps = reps; fa.nreps = nreps;
+        int rd = 0;
+        fa.rd = est(0); fa.wr = est(1);
+        hipLaunchKernelGGL(svx::round_init_kernel, g, b, 0, st, fa);
+        const long long budget_total = (long long)live - K;
+        // the two pools the estimates' lists alternate between: the ones the round-start lists are not in
+        int pe[2], np = 0;
+        for (int p = 0; p < 3; ++p) if (p != committed_pool && np < 2) pe[np++] = p;
+        long long prev_total = 0;
+        bool converged = false;
+        int it = 0;
+        while (!converged) {
+            for (int batch = 0; batch < 4; ++batch, ++it, ++passes) {
+                if (it >= MAX_ITERS) return F4L_EUNSUPPORTED;
+                fa.rd = est(rd); fa.wr = est(rd ^ 1);
+                fa.pool_sel = it & 1; fa.pool_base = w.pool_off[pe[it & 1]];
+                hipLaunchKernelGGL(svx::sub_reset_kernel, one, b, 0, st, w.st, it & 1);
+                hipLaunchKernelGGL(svx::abs_clear_kernel, g, b, 0, st, fa.wr.abs, reps, nreps);
+                // the budget only binds in the round that reaches K: the prefix sum of the absorptions is taken once a pass has
+                // absorbed as much as the budget
+                fa.before = nullptr;
+                if (prev_total >= budget_total) {
+                    size_t tb = w.prim_bytes;
+                    F4L_HIP_CHECK(rocprim::exclusive_scan(w.prim, tb, fa.rd.cnt_slot, w.before, (int64_t)0, (size_t)nreps, rocprim::plus<int64_t>(), st, false));
+                    fa.before = w.before;
+                }
+                F4L_HIP_CHECK(hipMemsetAsync(&w.st->changed[it & 7], 0, 4, st));
+                hipLaunchKernelGGL(svx::eval_kernel, dim3((unsigned)((nreps + EVAL_WAVES - 1) / EVAL_WAVES)), dim3(EVAL_WAVES * 64), 0, st, fa, lambda, budget_total, it);
+                hipLaunchKernelGGL(svx::abs_changed_kernel, g, b, 0, st, fa, it);
+                F4L_LAUNCH_CHECK();
+                rd ^= 1;
+            }
+            rc = read_state();
+            if (rc != F4L_OK) return rc;
+            if (hs.overflow) return F4L_EUNSUPPORTED;
+            // total absorptions of the last estimate (for the budget's switch): from the counts, on the device -> one number
+            {
+                size_t tb = w.prim_bytes;
+                F4L_HIP_CHECK(rocprim::exclusive_scan(w.prim, tb, est(rd).cnt_slot, w.before, (int64_t)0, (size_t)nreps, rocprim::plus<int64_t>(), st, false));
+                int64_t last_before = 0;
+                int32_t last_cnt = 0;
+                F4L_HIP_CHECK(hipMemcpyAsync(&last_before, w.before + (nreps - 1), 8, hipMemcpyDeviceToHost, st));
+                F4L_HIP_CHECK(hipMemcpyAsync(&last_cnt, est(rd).cnt_slot + (nreps - 1), 4, hipMemcpyDeviceToHost, st));
+                F4L_HIP_CHECK(hipStreamSynchronize(st));
+                const long long total = (long long)last_before + last_cnt;
+                const bool budget_was_on = prev_total >= budget_total;
+                prev_total = total;
+                // converged: the last pass of the batch changed nothing -- and it ran with the budget if the budget binds
+                converged = hs.changed[(it - 1) & 7] == 0 && (budget_was_on || total < budget_total);
+            }
+        }
+        // commit (the estimate `rd` = the last one written; its lists are in pool pe[(it - 1) & 1])
+        fa.rd = est(rd);
+        hipLaunchKernelGGL(svx::commit_kernel, g, b, 0, st, fa, w.sz0, w.adj_off, w.adj_len, w.keep_flag);
+        hipLaunchKernelGGL(svx::reroot_kernel, g, b, 0, st, w.root, (const unsigned int *)fa.rd.abs, n);
+        {
+            size_t tb = w.prim_bytes;
+            F4L_HIP_CHECK(rocprim::exclusive_scan(w.prim, tb, w.keep_flag, w.keep_pos, 0, (size_t)nreps, rocprim::plus<int32_t>(), st, false));
+        }
+        hipLaunchKernelGGL(svx::compact_kernel, g, b, 0, st, reps, w.keep_flag, w.keep_pos, nreps, reps_next);
+        F4L_LAUNCH_CHECK();
+        int32_t lastp = 0, lastf = 0;
+        F4L_HIP_CHECK(hipMemcpyAsync(&lastp, w.keep_pos + (nreps - 1), 4, hipMemcpyDeviceToHost, st));
+        F4L_HIP_CHECK(hipMemcpyAsync(&lastf, w.keep_flag + (nreps - 1), 4, hipMemcpyDeviceToHost, st));
+        F4L_HIP_CHECK(hipStreamSynchronize(st));
+        committed_pool = pe[(it - 1) & 1];
+        nreps = lastp + lastf;
+        live = nreps;
+        { int32_t *t = reps; reps = reps_next; reps_next = t; }
+        if (getenv("F4L_SV_EXACT_DEBUG")) fprintf(stderr, "[sv exact] round %d lambda %.6g: %d passes, %d representatives left (K %d)\n", rounds, lambda, it, nreps, K);
+        if (nreps == K) { ++rounds; break; }  // :175
+    }
+    if (rounds >= MAX_ROUNDS && nreps != K && nreps > 1) return F4L_EUNSUPPORTED;
+
+    // ---- the exchange (:186-237)
+    XchArgs xa;
+    xa.xyz = xyz; xa.nrm = normals; xa.knn = knn; xa.n = n; xa.k = k; xa.resolution = resolution; xa.st = w.st;
+    xa.lab = w.lab; xa.dis = w.dis; xa.pos = w.pos; xa.key = w.key;
+    hipLaunchKernelGGL(svx::xch_init_kernel, g, b, 0, st, xa, (const int32_t *)w.root);
+    hipLaunchKernelGGL(svx::xch_first_keys_kernel, g, b, 0, st, xa, (const int32_t *)w.root);
+    F4L_LAUNCH_CHECK();
+    int generations = 0, xpasses = 0;
+    for (;; ++generations) {
+        if (generations >= MAX_GENERATIONS) return F4L_EUNSUPPORTED;
+        // the next generation: the nodes with a key, in key order
+        hipLaunchKernelGGL(svx::xch_pairs_kernel, g, b, 0, st, (const unsigned long long *)w.key, n, w.key_s_in, w.node_s_in);
+        {
+            size_t tb = w.prim_bytes;
+            F4L_HIP_CHECK(rocprim::radix_sort_pairs(w.prim, tb, w.key_s_in, w.key_s_out, w.node_s_in, w.node_s_out, (size_t)n, 0, 40, st, false));
+        }
+        xa.Q = w.node_s_out;
+        int rd = 0;
+        xa.out_rd = w.out[0]; xa.out_wr = w.out[1]; xa.ch_rd = w.ch[0]; xa.ch_wr = w.ch[1]; xa.dis_wr = w.dis2[1];
+        hipLaunchKernelGGL(svx::xch_generation_kernel, g, b, 0, st, xa, (const unsigned long long *)w.key_s_out, (const int32_t *)w.node_s_out);
+        F4L_LAUNCH_CHECK();
+        rc = read_state();
+        if (rc != F4L_OK) return rc;
+        const int m = hs.m;
+        if (m == 0) break;
+        bool converged = false;
+        int it = 0;
+        while (!converged) {
+            for (int batch = 0; batch < 2; ++batch, ++it, ++xpasses) {
+                if (it >= MAX_ITERS) return F4L_EUNSUPPORTED;
+                xa.out_rd = w.out[rd]; xa.out_wr = w.out[rd ^ 1]; xa.ch_rd = w.ch[rd]; xa.ch_wr = w.ch[rd ^ 1]; xa.dis_wr = w.dis2[rd ^ 1];
+                F4L_HIP_CHECK(hipMemsetAsync(&w.st->changed[it & 7], 0, 4, st));
+                hipLaunchKernelGGL(svx::xch_eval_kernel, g, b, 0, st, xa, m, it);
+                F4L_LAUNCH_CHECK();
+                rd ^= 1;
+            }
+            rc = read_state();
+            if (rc != F4L_OK) return rc;
+            converged = hs.changed[(it - 1) & 7] == 0;
+        }
+        xa.out_rd = w.out[rd]; xa.ch_rd = w.ch[rd];
+        hipLaunchKernelGGL(svx::xch_push_kernel, g, b, 0, st, xa, m);
+        hipLaunchKernelGGL(svx::xch_commit_kernel, g, b, 0, st, xa, m, (const double *)w.dis2[rd]);
+        F4L_LAUNCH_CHECK();
+    }
+    // ---- relabel (:241-247)
+    hipLaunchKernelGGL(svx::rank_kernel, g, b, 0, st, (const int32_t *)reps, nreps, w.rank);
+    hipLaunchKernelGGL(svx::relabel_kernel, g, b, 0, st, (const int32_t *)w.lab, (const int32_t *)w.rank, n, labels_out);
+    F4L_LAUNCH_CHECK();
+    F4L_HIP_CHECK(hipStreamSynchronize(st));
+    if (n_supervoxels_host) *n_supervoxels_host = nreps;
+    if (stats_host) { stats_host[0] = rounds; stats_host[1] = passes; stats_host[2] = generations; stats_host[3] = xpasses; }
+    return F4L_OK;
+}

@@ -62,7 +62,10 @@ constexpr int SWEEPS = 1024;  // (the reference sweeps until nothing changes; a 
 // what the schedule of LAUNCHES covers (the rest runs in segment_rest_kernel): a 1 M-point terrain tile at the reference's
 // resolutions needs 11-14 rounds and 5-15 sweeps
 constexpr int SCHED_ROUNDS = 16, SCHED_SWEEPS = 16;
-constexpr unsigned GRID = 2048, BLOCK = 256, GRID_ACTIVE = 512, BUILD_BLOCK = 1024;
+#ifndef SVX_GRID
+#define SVX_GRID 2048
+#endif
+constexpr unsigned GRID = SVX_GRID, BLOCK = 256, GRID_ACTIVE = 512, BUILD_BLOCK = 1024;
 constexpr unsigned long long DEAD = ~0ULL;
 // The first rounds work straight from the neighbour lists: while the representatives are a handful of points each, a list of
 // their edges would be nearly as long as the neighbour lists (18 M of 30 M edges after round 0 of a 1 M-point tile), and writing
@@ -779,13 +782,19 @@ __device__ __forceinline__ unsigned int edge_slot(int32_t u, int32_t v, unsigned
 // dropped; what another edge displaced is forgotten (it then meets the device-wide filter: nothing is lost but a slot).
 constexpr int ROW_FILTER = 2048;  // slots (16 KB of LDS)
 constexpr int ROW_SEEN = 8;
-constexpr int ROW_CHUNK = 10;
+#ifndef SVX_ROW_CHUNK
+#define SVX_ROW_CHUNK 10
+#endif
+constexpr int ROW_CHUNK = SVX_ROW_CHUNK;
 #ifndef SVX_NEAR_BATCH
 #define SVX_NEAR_BATCH 4
 #endif
 constexpr int NEAR_BATCH = SVX_NEAR_BATCH;  // near edges of a row that are measured together
 constexpr int LIST_BATCH = 5;  // listed edges of a row whose representatives are fetched together
-constexpr int SWEEP_CHUNK = 10;  // neighbours of a point whose labels are fetched together
+#ifndef SVX_SWEEP_CHUNK
+#define SVX_SWEEP_CHUNK 10
+#endif
+constexpr int SWEEP_CHUNK = SVX_SWEEP_CHUNK;  // neighbours of a point whose labels are fetched together
 constexpr int FOREIGN = 3;       // foreign labels of a point that are measured together
 __device__ __forceinline__ void rows_body(const SegArgs &a, int r) {
     State *st = a.st;

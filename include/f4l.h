@@ -346,6 +346,21 @@ int f4l_partition_neighbours(const float *xyz, int64_t n, int k, double *nn1_d2_
 int f4l_partition_segment(int64_t n, int k, double resolution, const float *grid_bbox_host, int32_t *labels_out,
                           int32_t *reps_out, int32_t *info_out, void *workspace, size_t workspace_bytes, void *stream);
 
+/* The reference's segmentation (supervoxel_segmentation.h:65-248) ON THE DEVICE, LABEL FOR LABEL: its sequential fusion
+ * (:117-176: representatives in index order, ordered adjacency lists, the `break` at K) and its FIFO boundary exchange
+ * (:186-237) computed as fixed points of parallel passes (csrc/supervoxel_exact.hip: what a representative does depends on the
+ * round's start and on what LOWER-indexed ones did; every one is evaluated against an estimate of that until nothing changes --
+ * the unique fixed point is the sequential result; 6-20 passes per lambda round).  xyz, normals, knn as for
+ * f4l_supervoxel_segment_device (device arrays, the CALLER's order; knn rows in the order the search returned them: the
+ * reference's queue order follows it).  labels_out int32 [n] (device), n_supervoxels_host (host), stats_host int32 [4] or NULL:
+ * lambda rounds, fusion passes, exchange generations, exchange passes.  SYNCHRONISES `stream`.  F4L_EUNSUPPORTED when a
+ * representative's closure or the lists outgrow the device buffers (k = 1, degenerate clouds): f4l_supervoxel then replays the
+ * sequence on the host (f4l_supervoxel_segment_host) -- the same labels either way. */
+size_t f4l_supervoxel_segment_exact_workspace_bytes(int64_t n, int k);
+int f4l_supervoxel_segment_exact(const float *xyz, const double *normals, const int32_t *knn, int64_t n, int k, double resolution,
+                                 int32_t *labels_out, int32_t *n_supervoxels_host, int32_t *stats_host, void *workspace,
+                                 size_t workspace_bytes, void *stream);
+
 /* Host-only helper (no device work): the sequential segmentation stage on host arrays.  Exposed so the
  * Python shim can re-segment cached kNN/normals; same semantics as inside f4l_supervoxel. */
 int f4l_supervoxel_segment_host(const float *xyz_host, const double *normals_host, const int32_t *knn_host,
