@@ -27,6 +27,7 @@
 #include <cfloat>
 #include <cstdio>
 #include <cstdlib>
+#include <cstddef>
 #include <cstring>
 
 #include <rocprim/rocprim.hpp>
@@ -52,6 +53,8 @@ struct State {
     int overflow;          // 1: a closure beyond QCAP, 2: a list pool full
     int changed[8];        // per pass (slot = pass % 8): something differed from the estimate before
     int m;                 // entries of the exchange's current generation
+    int pad_;
+    long long total[8];    // per pass: absorptions of the whole estimate (the budget of the last round is switched on by it)
     unsigned long long sub[2][SUBPOOLS];  // bump pointers of the two estimate pools
 };
 
@@ -145,6 +148,7 @@ struct Est {                     // one estimate of "what the centres of this ro
     int32_t *len;                //     ... and length
     unsigned long long *hash;    // [n] order-sensitive hash of that list (what "the list did not change" is read from)
     int32_t *cnt_slot;           // [nreps] cnt in the order of the centres (the budget's prefix sum runs over it)
+    int32_t *nx;                 // [n] nodes its Finds passed through, stored behind its lists; -1: evaluate every pass, -2: did not run
 };
 struct FuseArgs {
     const float *xyz;
@@ -163,6 +167,7 @@ struct FuseArgs {
     const int64_t *before;       // [nreps] absorptions by the centres before each centre (previous estimate), or null
     int64_t pool_base, sub_cap;  // where this pass writes lists: SUBPOOLS regions of sub_cap entries from pool_base
     int pool_sel;                // which set of bump pointers
+    int32_t *chg;                // [n] the pass that last changed the node's estimate
     Est rd, wr;
 };
 
@@ -179,24 +184,97 @@ __global__ void round_init_kernel(FuseArgs a) {
         a.rd.len[i] = a.adj_len[i];
         a.rd.hash[i] = ~0ULL;   // ("the round-start list": no evaluation writes this value twice in a row unless nothing changes)
         a.rd.cnt_slot[s] = 0;
+        a.rd.nx[i] = -2;
+        a.chg[i] = -1;
     }
 }
-__global__ void sub_reset_kernel(State *st, int sel) {
-    for (int t = (int)threadIdx.x; t < SUBPOOLS; t += (int)blockDim.x) st->sub[sel][t] = 0ULL;
+// before a pass: its pool's bump pointers, its claims, its flag and its total
+__global__ void prep_kernel(State *st, int sel, unsigned int *abs_wr, const int32_t *reps, int nreps, int pass) {
+    if (blockIdx.x == 0) {
+        for (int t = (int)threadIdx.x; t < SUBPOOLS; t += (int)blockDim.x) st->sub[sel][t] = 0ULL;
+        if (threadIdx.x == 0) { st->changed[pass & 7] = 0; st->total[pass & 7] = 0; }
+    }
+    SVX_FOR(s, nreps) abs_wr[reps[s]] = NONE;
 }
 
 // One wavefront = one centre.  Q: the closure's queue = its visited set, in the reference's order (:125-134, 151-157).
+//
+// A centre whose inputs did not change is not evaluated again.  What an evaluation READ of the estimate is the estimate of the
+// nodes it visited (its queue: itself, what it kept, what it absorbed) and of the few nodes its Finds passed through without
+// ending there (X below); every node carries the number of the pass that last changed its estimate (chg).  If none of them
+// changed in the pass before, the same evaluation would read the same values and do the same: the centre copies its lists
+// forward, renews its claims and is done -- a fifth of the memory traffic of an evaluation, and after the first two or three
+// passes of a round that is nearly every centre.  (Not in the round that reaches K: there every centre also depends on the
+// absorptions of ALL centres before it.)
+constexpr int XCAP = 128;  // nodes a centre's Finds may pass through without ending there (more: it is evaluated every pass)
+// MEASURED (round 5, 1 M points): with the skip the passes of a segmentation take 51.4 ms, without it 41.7 -- a change at one
+// node sends its ~30 neighbouring centres back into evaluation whether or not their outcome moves, so the skipped share stays
+// below a half until the last passes, and recording what the Finds pass through costs every evaluation.  Kept behind this switch.
+#ifndef SVX_SKIP_STABLE
+#define SVX_SKIP_STABLE 0
+#endif
+constexpr bool SKIP_STABLE = SVX_SKIP_STABLE != 0;
 __global__ __launch_bounds__(EVAL_WAVES * 64) void eval_kernel(FuseArgs a, double lambda, long long budget_total, int pass) {
     __shared__ int32_t q_all[EVAL_WAVES][QCAP];
+    __shared__ int32_t x_all[EVAL_WAVES][XCAP];
     __shared__ unsigned int acc_all[EVAL_WAVES][QCAP / 32];
     const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
     const int64_t s = (int64_t)blockIdx.x * EVAL_WAVES + wave;
     if (s >= a.nreps) return;  // (whole wave)
-    int32_t *Q = q_all[wave];
+    int32_t *Q = q_all[wave], *X = x_all[wave];
     unsigned int *ACC = acc_all[wave];
     const int32_t i = a.reps[s];
     const unsigned int ui = (unsigned int)i;
     const unsigned int *__restrict__ abs_rd = a.rd.abs;
+    int32_t *__restrict__ pool = const_cast<int32_t *>(a.lists);
+    const unsigned long long below = (1ULL << lane) - 1ULL;
+    auto wsync = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    // a region of `count` entries in this pass's pool (one bump pointer per slice of the centres)
+    bool overflow = false;
+    auto region = [&](int count) -> int64_t {
+        if (count <= 0) return 0;
+        const int sp = (int)(s & (SUBPOOLS - 1));
+        unsigned long long base = 0ULL;
+        if (lane == 0) base = atomicAdd(&a.st->sub[a.pool_sel][sp], (unsigned long long)count);
+        base = (unsigned long long)__shfl((long long)base, 0, 64);
+        if ((long long)base + count > a.sub_cap) { overflow = true; return 0; }
+        return a.pool_base + (int64_t)sp * a.sub_cap + (int64_t)base;
+    };
+
+    // ---- nothing it read has changed: the outcome stands
+    const int nx_old = a.rd.nx[i];
+    if (SKIP_STABLE && pass > 0 && !a.before && nx_old != -1) {
+        const bool ran = nx_old >= 0;
+        const int64_t ro = a.rd.off[i];
+        const int klen = a.rd.len[i], kcnt = a.rd.cnt[i];
+        const int tot = ran ? klen + kcnt + nx_old : 0;
+        bool any = a.chg[i] == pass - 1;
+        for (int e = lane; e < tot; e += 64) any = any || a.chg[pool[ro + e]] == pass - 1;
+        if (__ballot(any) == 0ULL) {
+            int64_t no = ro;
+            if (ran) {
+                no = region(tot);
+                if (!overflow) {
+                    for (int e = lane; e < tot; e += 64) {
+                        const int32_t v = pool[ro + e];
+                        pool[no + e] = v;
+                        if (e >= klen && e < klen + kcnt) atomicMin(&a.wr.abs[v], ui);  // (the claims of this pass are collected anew)
+                    }
+                }
+            }
+            if (overflow && lane == 0) atomicOr(&a.st->overflow, 2);
+            if (lane == 0) {
+                a.wr.ns[i] = a.rd.ns[i]; a.wr.cnt[i] = kcnt; a.wr.off[i] = no; a.wr.len[i] = klen; a.wr.hash[i] = a.rd.hash[i];
+                a.wr.nx[i] = nx_old; a.wr.cnt_slot[s] = kcnt;
+            }
+            return;
+        }
+    }
+
     const unsigned int absi = abs_rd[i];
     const bool dead = absi != NONE && absi < ui;  // absorbed before its turn: adjacents[i] is empty by then (:121)
     const int64_t off0 = a.adj_off[i];
@@ -204,63 +282,76 @@ __global__ __launch_bounds__(EVAL_WAVES * 64) void eval_kernel(FuseArgs a, doubl
     long long budget = a.before ? budget_total - (long long)a.before[s] : 0x7fffffffffffLL;
     const bool run = !dead && len0 > 0 && budget > 0;
     int nsz = a.sz0[i], cnt = 0;
-    int head = 0, tail = 0;
-    bool overflow = false;
+    int head = 0, tail = 0, nx = 0;
+    bool complex_ = false;  // (a Find passed through more nodes than X records, or X is full: evaluated every pass)
     // this centre's own position and normal (the metric's first argument, :142)
     float pi_[3];
     double ni_[3];
 #pragma unroll
     for (int d = 0; d < 3; ++d) { pi_[d] = a.xyz[3 * (int64_t)i + d]; ni_[d] = a.nrm[3 * (int64_t)i + d]; }
 
+    // adds the lanes' values (valid where `on`) to SET[0 .. count) unless there already, lanes in order, first occurrence first
+    auto add_unique = [&](unsigned int v, bool on, int32_t *SET, int &count, int cap, bool &full) {
+        bool fresh = on;
+        for (int e = 0; e < count; e += 4) {
+            const int4 u = *reinterpret_cast<const int4 *>(SET + e);  // (entries past `count` hold -1)
+            fresh = fresh && (unsigned int)u.x != v && (unsigned int)u.y != v && (unsigned int)u.z != v && (unsigned int)u.w != v;
+        }
+        unsigned long long cand = __ballot(fresh), news = 0ULL;
+        while (cand) {
+            const int l = __ffsll((long long)cand) - 1;
+            const unsigned int vl = (unsigned int)__shfl((int)v, l, 64);
+            const unsigned long long same = __ballot(fresh && v == vl);
+            news |= 1ULL << l;
+            cand &= ~same;
+        }
+        const int nn = (int)__popcll(news);
+        if (count + nn + 4 > cap) { full = true; return; }
+        if ((news >> lane) & 1ULL) SET[count + (int)__popcll(news & below)] = (int32_t)v;
+        if (lane < 4) SET[count + nn + lane] = -1;  // (the padding the four-at-a-time look-up reads)
+        count += nn;
+        wsync();
+    };
     // appends Find(list entries) that are not yet visited, in list order (:126-133 / :151-157)
     auto append_list = [&](int64_t off, int len) {
         for (int c0 = 0; c0 < len && !overflow; c0 += 64) {
             const bool have = c0 + lane < len;
-            unsigned int r = NONE;
+            unsigned int r = NONE, e1 = NONE, e2 = NONE;
+            bool longer = false;
             if (have) {
                 r = (unsigned int)a.root[a.lists[off + c0 + lane]];
                 // Find as centre i sees it (set.Find, :127/:152): every absorption by a centre that ran BEFORE i and was alive at its
-                // own turn; honoured claims lead to ever higher centres, so the walk ends
+                // own turn; honoured claims lead to ever higher centres, so the walk ends.  e1, e2: nodes whose estimate the walk
+                // read without ending there
                 for (;;) {
                     const unsigned int c = abs_rd[r];
                     if (c == NONE || !(c < ui)) break;
                     const unsigned int cc = abs_rd[c];
-                    if (cc != NONE && cc < c) break;
+                    const bool refused = cc != NONE && cc < c;
+                    const unsigned int passed = refused ? c : r;  // (a refused claimant was read too)
+                    if (e1 == NONE) e1 = passed; else if (e2 == NONE) e2 = passed; else longer = true;
+                    if (refused) break;
                     r = c;
                 }
             }
-            // visited already? (the queue so far; four entries per LDS read)
-            bool fresh = have;
-            for (int e = 0; e < tail; e += 4) {
-                const int4 v = *reinterpret_cast<const int4 *>(Q + e);  // (entries past `tail` hold -1)
-                fresh = fresh && (unsigned int)v.x != r && (unsigned int)v.y != r && (unsigned int)v.z != r && (unsigned int)v.w != r;
+            if (SKIP_STABLE && __ballot(longer) != 0ULL) complex_ = true;
+            bool qfull = false;
+            add_unique(r, have, Q, tail, QCAP, qfull);
+            if (qfull) { overflow = true; break; }
+            if (SKIP_STABLE && __ballot(e1 != NONE) != 0ULL) {
+                bool xfull = false;
+                add_unique(e1, e1 != NONE, X, nx, XCAP, xfull);
+                if (__ballot(e2 != NONE) != 0ULL && !xfull) add_unique(e2, e2 != NONE, X, nx, XCAP, xfull);
+                if (xfull) complex_ = true;
             }
-            // ... or by a lower lane of this chunk (the first occurrence wins)
-            unsigned long long cand = __ballot(fresh), news = 0ULL;
-            while (cand) {
-                const int l = __ffsll((long long)cand) - 1;
-                const unsigned int rl = (unsigned int)__shfl((int)r, l, 64);
-                const unsigned long long same = __ballot(fresh && r == rl);
-                news |= 1ULL << l;
-                cand &= ~same;
-            }
-            const int nn = (int)__popcll(news);
-            if (tail + nn > QCAP) { overflow = true; break; }
-            if ((news >> lane) & 1ULL) Q[tail + (int)__popcll(news & ((1ULL << lane) - 1ULL))] = (int32_t)r;
-            tail += nn;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
     };
 
     if (run) {
-        for (int e = lane; e < QCAP; e += 64) Q[e] = -1;
+        if (lane < 5) Q[lane] = lane == 0 ? i : -1;  // visited[i] = true; queue[front++] = i (:123-125)
+        if (lane < 4) X[lane] = -1;
         for (int e = lane; e < QCAP / 32; e += 64) ACC[e] = 0u;
-        if (lane == 0) Q[0] = i;  // visited[i] = true; queue[front++] = i (:123-125)
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        wsync();
         head = tail = 1;
         append_list(off0, len0);
         bool stop = false;
@@ -312,64 +403,67 @@ __global__ __launch_bounds__(EVAL_WAVES * 64) void eval_kernel(FuseArgs a, doubl
             head += done;
         }
     }
-    // the centre's list after its turn (:164 `adjacents[i].swap(adjacent)`): the entries it looked at and did not absorb, in order
+    // the centre's list after its turn (:164 `adjacents[i].swap(adjacent)`): the entries it looked at and did not absorb, in order;
+    // behind it, for the look above: what it absorbed and what its Finds passed through
     int64_t out_off = dead ? 0 : off0;
     int out_len = dead ? 0 : len0;  // (a centre that did not run keeps its list; an absorbed one's is cleared, :158)
+    int out_nx = -2;                // (-2: did not run -- its outcome depends on its own estimate only)
     unsigned long long hash = dead ? 1ULL : ~0ULL;
     if (run && !overflow) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        wsync();
         int kept = 0;
         for (int e0 = 1; e0 < head; e0 += 64) {
             const int e = e0 + lane;
             kept += (int)__popcll(__ballot(e < head && !((ACC[e >> 5] >> (e & 31)) & 1u)));
         }
         out_len = kept;
-        out_off = 0;
-        unsigned long long base = 0ULL;
-        if (kept > 0) {
-            const int sp = (int)(s & (SUBPOOLS - 1));
-            if (lane == 0) base = atomicAdd(&a.st->sub[a.pool_sel][sp], (unsigned long long)kept);
-            base = (unsigned long long)__shfl((long long)base, 0, 64);
-            if ((long long)base + kept > a.sub_cap) overflow = true;
-            out_off = a.pool_base + (int64_t)sp * a.sub_cap + (int64_t)base;
-        }
+        out_nx = (!SKIP_STABLE || complex_ || a.before) ? -1 : nx;
+        const int nxs = out_nx >= 0 ? nx : 0;
+        const int nacc = SKIP_STABLE ? cnt : 0;  // (what it absorbed is only stored for the skip)
+        out_off = region(kept + nacc + nxs);
         unsigned long long h = 0ULL;
-        int at = 0;
+        int at = 0, at_acc = kept;
         if (!overflow) {
-            int32_t *__restrict__ dst = const_cast<int32_t *>(a.lists) + out_off;
+            int32_t *__restrict__ dst = pool + out_off;
             for (int e0 = 1; e0 < head; e0 += 64) {
                 const int e = e0 + lane;
-                const bool keep = e < head && !((ACC[e >> 5] >> (e & 31)) & 1u);
-                const unsigned long long km = __ballot(keep);
-                if (keep) {
-                    const int p = at + (int)__popcll(km & ((1ULL << lane) - 1ULL));
+                const bool in = e < head;
+                const bool took = in && ((ACC[e >> 5] >> (e & 31)) & 1u);
+                const unsigned long long km = __ballot(in && !took), am = __ballot(took);
+                if (in && !took) {
+                    const int p = at + (int)__popcll(km & below);
                     dst[p] = Q[e];
                     h += mix64(((unsigned long long)(unsigned int)Q[e] << 32) | (unsigned int)p);
                 }
+                if (SKIP_STABLE && took) dst[at_acc + (int)__popcll(am & below)] = Q[e];
                 at += (int)__popcll(km);
+                at_acc += (int)__popcll(am);
             }
+            for (int e = lane; e < nxs; e += 64) dst[kept + nacc + e] = X[e];
         }
-        hash = 2ULL + (wave_sum((int)(h & 0x7fffffffULL)) + (unsigned long long)wave_sum((int)((h >> 31) & 0x7fffffffULL)) * 0x9E3779B1ULL +
-                       (unsigned long long)kept * 0x85EBCA6BULL);
+        hash = 2ULL + (unsigned long long)wave_sum((int)(h & 0x7fffffffULL)) + (unsigned long long)wave_sum((int)((h >> 31) & 0x7fffffffULL)) * 0x9E3779B1ULL +
+               (unsigned long long)kept * 0x85EBCA6BULL;
     }
-    if (overflow && lane == 0) atomicOr(&a.st->overflow, tail + 64 > QCAP ? 1 : 2);
+    if (overflow && lane == 0) atomicOr(&a.st->overflow, tail + 68 > QCAP ? 1 : 2);
     if (lane == 0) {
         const bool same = a.rd.ns[i] == nsz && a.rd.cnt[i] == cnt && a.rd.len[i] == out_len && a.rd.hash[i] == hash;
-        a.wr.ns[i] = nsz; a.wr.cnt[i] = cnt; a.wr.off[i] = out_off; a.wr.len[i] = out_len; a.wr.hash[i] = hash;
+        a.wr.ns[i] = nsz; a.wr.cnt[i] = cnt; a.wr.off[i] = out_off; a.wr.len[i] = out_len; a.wr.hash[i] = hash; a.wr.nx[i] = out_nx;
         a.wr.cnt_slot[s] = cnt;
-        if (!same) a.st->changed[pass & 7] = 1;
+        if (!same) { a.st->changed[pass & 7] = 1; a.chg[i] = pass; }
     }
 }
-// (the claims: compared after the pass, when all of them are in)
+// (the claims: compared after the pass, when all of them are in; and the pass's absorptions in all)
 __global__ void abs_changed_kernel(FuseArgs a, int pass) {
     bool ch = false;
-    SVX_FOR(s, a.nreps) { const int32_t i = a.reps[s]; ch = ch || a.rd.abs[i] != a.wr.abs[i]; }
+    long long tot = 0;
+    SVX_FOR(s, a.nreps) {
+        const int32_t i = a.reps[s];
+        if (a.rd.abs[i] != a.wr.abs[i]) { ch = true; a.chg[i] = pass; }
+        tot += a.wr.cnt_slot[s];
+    }
     if (__ballot(ch) != 0ULL && lane_id() == 0) a.st->changed[pass & 7] = 1;
-}
-__global__ void abs_clear_kernel(unsigned int *abs, const int32_t *reps, int nreps) {
-    SVX_FOR(s, nreps) abs[reps[s]] = NONE;
+    int lo = wave_sum((int)(tot & 0xffff)), hi = wave_sum((int)(tot >> 16));  // (a lane's share is far below 2^31)
+    if (lane_id() == 0 && (lo || hi)) atomicAdd((unsigned long long *)&a.st->total[pass & 7], (unsigned long long)(((long long)hi << 16) + lo));
 }
 // the converged estimate becomes the state: survivors keep size and list, everybody follows its absorber
 __global__ void commit_kernel(FuseArgs a, int32_t *sz0, int64_t *adj_off, int32_t *adj_len, int32_t *keep_flag) {
@@ -451,26 +545,45 @@ __global__ void xch_generation_kernel(XchArgs a, const unsigned long long *__res
         } else if (t == 0) a.st->m = 0;
     }
 }
-// one entry's turn (:214-226) with the labels its earlier entries leave
-__global__ void xch_eval_kernel(XchArgs a, int m, int pass) {
+// One entry's turn (:214-226) with the labels its earlier entries leave.  The reference walks the neighbours in order and takes
+// a label whose representative is STRICTLY closer than the best so far: the result is the label of smallest metric below the
+// point's own, the first neighbour slot among equal minima -- a (metric, slot) minimum, taken here by 16 lanes per entry (a
+// coalesced 4 k-byte row per entry, four entries per wavefront) and reduced across them.
+__global__ __launch_bounds__(256) void xch_eval_kernel(XchArgs a, int m, int pass) {
+    const int lane = lane_id(), sub = lane & 15;
+    const int64_t per_pass = (int64_t)gridDim.x * (blockDim.x >> 6) * 4;
     bool differs = false;
-    SVX_FOR(t, m) {
-        const int32_t i = a.Q[t];
-        int32_t la = a.lab[i];
-        double d0 = a.dis[i];
-        bool ch = false;
-        for (int j = 0; j < a.k; ++j) {
+    for (int64_t t0 = ((int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 4; t0 < m; t0 += per_pass) {  // (whole waves iterate together)
+        const int64_t t = t0 + (lane >> 4);
+        const bool valid = t < m;
+        const int32_t i = a.Q[valid ? t : 0];
+        const int32_t la0 = a.lab[i];
+        const double d00 = a.dis[i];
+        double bd = d00;
+        int bj = 0x7fffffff;
+        int32_t bl = la0;
+        for (int j = sub; j < a.k; j += 16) {
             const int32_t q = a.knn[(int64_t)i * a.k + j];
             if (q == i) continue;
             const int32_t b = a.pos[q] < (int32_t)t ? a.out_rd[q] : a.lab[q];
-            if (la == b) continue;
+            if (b == la0) continue;  // (its own label: never strictly closer than itself)
             const double d = sv_metric(a.xyz, a.nrm, (int64_t)i, (int64_t)b, a.resolution);
-            if (d < d0) { la = b; d0 = d; ch = true; }
+            if (d < bd) { bd = d; bj = j; bl = b; }  // (slots ascend within a lane: the first of equal minima stays)
         }
-        differs = differs || a.out_rd[i] != la || (a.ch_rd[i] != 0) != ch;
-        a.out_wr[i] = la;
-        a.dis_wr[i] = d0;
-        a.ch_wr[i] = ch ? 1 : 0;
+#pragma unroll
+        for (int x = 1; x < 16; x <<= 1) {
+            const double od = __shfl_xor(bd, x, 64);
+            const int oj = __shfl_xor(bj, x, 64);
+            const int32_t ol = __shfl_xor(bl, x, 64);
+            if (od < bd || (od == bd && oj < bj)) { bd = od; bj = oj; bl = ol; }
+        }
+        const bool ch = bj != 0x7fffffff;  // (some label strictly closer than the point's own)
+        if (valid && sub == 0) {
+            differs = differs || a.out_rd[i] != bl || (a.ch_rd[i] != 0) != ch;
+            a.out_wr[i] = bl;
+            a.dis_wr[i] = bd;
+            a.ch_wr[i] = ch ? 1 : 0;
+        }
     }
     if (__ballot(differs) != 0ULL && lane_id() == 0) a.st->changed[pass & 7] = 1;
 }
@@ -512,7 +625,7 @@ struct Ws {
     int32_t *root, *sz0, *adj_len, *reps_a, *reps_b, *keep_flag, *keep_pos;
     int64_t *adj_off, *before;
     unsigned int *abs[2];
-    int32_t *ns[2], *cnt[2], *len[2], *cnt_slot[2];
+    int32_t *ns[2], *cnt[2], *len[2], *cnt_slot[2], *nx[2], *chg;
     int64_t *off[2];
     unsigned long long *hash[2];
     double *dis, *dis2[2], *median;
@@ -539,7 +652,7 @@ static int layout(int64_t n, int k, Ws &w, unsigned char *base) {
     w.st = (State *)carve(sizeof(State));
     // the pools: a centre's list is inherited by ONE absorber in a consistent estimate, so the lists of a pass sum to at most the
     // lists before it (n k at the start); an inconsistent estimate may count some twice: room for 2 n k, in SUBPOOLS slices
-    w.pool_cap = (int64_t)((2 * nk / SUBPOOLS + 64) * SUBPOOLS);
+    w.pool_cap = (int64_t)(((2 * nk + 2 * (size_t)n) / SUBPOOLS + 64) * SUBPOOLS);  // (+ what was absorbed and passed through: at most a few per centre)
     w.lists = (int32_t *)carve((nk + 3 * (size_t)w.pool_cap) * 4);
     for (int p = 0; p < 3; ++p) w.pool_off[p] = (int64_t)nk + (int64_t)p * w.pool_cap;
     w.root = (int32_t *)carve((size_t)n * 4); w.sz0 = (int32_t *)carve((size_t)n * 4); w.adj_len = (int32_t *)carve((size_t)n * 4);
@@ -548,9 +661,10 @@ static int layout(int64_t n, int k, Ws &w, unsigned char *base) {
     w.adj_off = (int64_t *)carve((size_t)n * 8); w.before = (int64_t *)carve((size_t)n * 8);
     for (int e = 0; e < 2; ++e) {
         w.abs[e] = (unsigned int *)carve((size_t)n * 4); w.ns[e] = (int32_t *)carve((size_t)n * 4); w.cnt[e] = (int32_t *)carve((size_t)n * 4);
-        w.len[e] = (int32_t *)carve((size_t)n * 4); w.cnt_slot[e] = (int32_t *)carve((size_t)n * 4);
+        w.len[e] = (int32_t *)carve((size_t)n * 4); w.cnt_slot[e] = (int32_t *)carve((size_t)n * 4); w.nx[e] = (int32_t *)carve((size_t)n * 4);
         w.off[e] = (int64_t *)carve((size_t)n * 8); w.hash[e] = (unsigned long long *)carve((size_t)n * 8);
     }
+    w.chg = (int32_t *)carve((size_t)n * 4);
     w.dis = (double *)carve((size_t)n * 8);
     w.dis2[0] = (double *)carve((size_t)n * 8); w.dis2[1] = (double *)carve((size_t)n * 8);
     w.median = (double *)carve(16);
@@ -593,7 +707,7 @@ extern "C" int f4l_supervoxel_segment_exact(const float *xyz, const double *norm
     const dim3 g(2048), b(256), one(1);
     State hs;
     auto read_state = [&]() -> int {
-        F4L_HIP_CHECK(hipMemcpyAsync(&hs, w.st, sizeof(int) * 12 + sizeof(unsigned int) * 6, hipMemcpyDeviceToHost, st));
+        F4L_HIP_CHECK(hipMemcpyAsync(&hs, w.st, offsetof(State, sub), hipMemcpyDeviceToHost, st));
         F4L_HIP_CHECK(hipStreamSynchronize(st));
         return F4L_OK;
     };
@@ -632,12 +746,13 @@ extern "C" int f4l_supervoxel_segment_exact(const float *xyz, const double *norm
 
     FuseArgs fa;
     fa.xyz = xyz; fa.nrm = normals; fa.lists = w.lists; fa.n = n; fa.k = k; fa.resolution = resolution; fa.st = w.st;
+    fa.chg = w.chg;
     fa.root = w.root; fa.sz0 = w.sz0; fa.adj_off = w.adj_off; fa.adj_len = w.adj_len; fa.sub_cap = w.pool_cap / SUBPOOLS;
     int32_t *reps = w.reps_a, *reps_next = w.reps_b;
     int nreps = (int)n, live = (int)n;
     int committed_pool = -1;  // (the pool the round-start lists live in; -1: the neighbour table)
     int rounds = 0, passes = 0;
-    auto est = [&](int e) { Est x; x.abs = w.abs[e]; x.ns = w.ns[e]; x.cnt = w.cnt[e]; x.off = w.off[e]; x.len = w.len[e]; x.hash = w.hash[e]; x.cnt_slot = w.cnt_slot[e]; return x; };
+    auto est = [&](int e) { Est x; x.abs = w.abs[e]; x.ns = w.ns[e]; x.cnt = w.cnt[e]; x.off = w.off[e]; x.len = w.len[e]; x.hash = w.hash[e]; x.cnt_slot = w.cnt_slot[e]; x.nx = w.nx[e]; return x; };
     for (; rounds < MAX_ROUNDS; lambda *= 2.0, ++rounds) {
         if (nreps <= 1) break;  // :118
         fa.reps = reps; fa.nreps = nreps;
@@ -651,45 +766,36 @@ extern "C" int f4l_supervoxel_segment_exact(const float *xyz, const double *norm
         long long prev_total = 0;
         bool converged = false;
         int it = 0;
+        // passes between two looks at the state: one while a pass takes longer than the look, four in the short late rounds
+        const int batch_len = nreps > 40000 ? 1 : 4;
         while (!converged) {
-            for (int batch = 0; batch < 4; ++batch, ++it, ++passes) {
+            bool budget_on = false;
+            for (int batch = 0; batch < batch_len; ++batch, ++it, ++passes) {
                 if (it >= MAX_ITERS) return F4L_EUNSUPPORTED;
                 fa.rd = est(rd); fa.wr = est(rd ^ 1);
                 fa.pool_sel = it & 1; fa.pool_base = w.pool_off[pe[it & 1]];
-                hipLaunchKernelGGL(svx::sub_reset_kernel, one, b, 0, st, w.st, it & 1);
-                hipLaunchKernelGGL(svx::abs_clear_kernel, g, b, 0, st, fa.wr.abs, reps, nreps);
+                hipLaunchKernelGGL(svx::prep_kernel, g, b, 0, st, w.st, it & 1, fa.wr.abs, (const int32_t *)reps, nreps, it);
                 // the budget only binds in the round that reaches K: the prefix sum of the absorptions is taken once a pass has
                 // absorbed as much as the budget
                 fa.before = nullptr;
-                if (prev_total >= budget_total) {
+                budget_on = prev_total >= budget_total;
+                if (budget_on) {
                     size_t tb = w.prim_bytes;
                     F4L_HIP_CHECK(rocprim::exclusive_scan(w.prim, tb, fa.rd.cnt_slot, w.before, (int64_t)0, (size_t)nreps, rocprim::plus<int64_t>(), st, false));
                     fa.before = w.before;
                 }
-                F4L_HIP_CHECK(hipMemsetAsync(&w.st->changed[it & 7], 0, 4, st));
                 hipLaunchKernelGGL(svx::eval_kernel, dim3((unsigned)((nreps + EVAL_WAVES - 1) / EVAL_WAVES)), dim3(EVAL_WAVES * 64), 0, st, fa, lambda, budget_total, it);
-                hipLaunchKernelGGL(svx::abs_changed_kernel, g, b, 0, st, fa, it);
+                hipLaunchKernelGGL(svx::abs_changed_kernel, dim3(nreps > 262144 ? 256 : 64), b, 0, st, fa, it);
                 F4L_LAUNCH_CHECK();
                 rd ^= 1;
             }
             rc = read_state();
             if (rc != F4L_OK) return rc;
             if (hs.overflow) return F4L_EUNSUPPORTED;
-            // total absorptions of the last estimate (for the budget's switch): from the counts, on the device -> one number
-            {
-                size_t tb = w.prim_bytes;
-                F4L_HIP_CHECK(rocprim::exclusive_scan(w.prim, tb, est(rd).cnt_slot, w.before, (int64_t)0, (size_t)nreps, rocprim::plus<int64_t>(), st, false));
-                int64_t last_before = 0;
-                int32_t last_cnt = 0;
-                F4L_HIP_CHECK(hipMemcpyAsync(&last_before, w.before + (nreps - 1), 8, hipMemcpyDeviceToHost, st));
-                F4L_HIP_CHECK(hipMemcpyAsync(&last_cnt, est(rd).cnt_slot + (nreps - 1), 4, hipMemcpyDeviceToHost, st));
-                F4L_HIP_CHECK(hipStreamSynchronize(st));
-                const long long total = (long long)last_before + last_cnt;
-                const bool budget_was_on = prev_total >= budget_total;
-                prev_total = total;
-                // converged: the last pass of the batch changed nothing -- and it ran with the budget if the budget binds
-                converged = hs.changed[(it - 1) & 7] == 0 && (budget_was_on || total < budget_total);
-            }
+            const long long total = hs.total[(it - 1) & 7];
+            prev_total = total;
+            // converged: the last pass changed nothing -- and it ran with the budget if the budget binds
+            converged = hs.changed[(it - 1) & 7] == 0 && (budget_on || total < budget_total);
         }
         // commit (the estimate `rd` = the last one written; its lists are in pool pe[(it - 1) & 1])
         fa.rd = est(rd);

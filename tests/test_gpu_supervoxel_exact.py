@@ -1,0 +1,89 @@
+"""GPU tests of the reference's OWN labels computed on the device (csrc/supervoxel_exact.hip, f4l_supervoxel_segment_exact): the
+sequential fusion and the FIFO exchange of codelibrary/geometry/point_cloud/supervoxel_segmentation.h:65-248 as fixed points of
+parallel passes.  The reference-held fixtures are in tests/test_gpu_parity.py::test_knn_normals_supervoxel_vs_golden and
+tests/test_gpu_supervoxel_parallel.py::test_partition_against_the_large_reference_fixture (both call f4l_supervoxel, which takes
+this path); here: random clouds against the one-core host replay of the same sequence (csrc/supervoxel_host.cpp, itself pinned by
+those fixtures) -- every label, in orders that make the index-ordered dependency chains short (random) and long (sorted rows)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from fusion4landslide_amd import engine
+    return engine
+
+
+def _cloud(kind, n, seed):
+    rng = np.random.default_rng(seed)
+    if kind == "surface":
+        xy = rng.uniform(0, 30, (n, 2))
+        p = np.c_[xy, 0.8 * np.sin(0.5 * xy[:, 0]) * np.cos(0.4 * xy[:, 1]) + rng.normal(0, 0.01, n)]
+    elif kind == "rows":  # a voxel-filtered tile as PCL leaves it: rows along x, one after the other -- long chains of dependencies
+        xy = rng.uniform(0, 30, (n, 2))
+        p = np.c_[xy, 0.5 * np.sin(0.7 * xy[:, 0]) + rng.normal(0, 0.005, n)]
+        p = p[np.lexsort((p[:, 0], np.floor(p[:, 1] / 0.2)))]
+    elif kind == "volume":
+        p = rng.uniform(0, 6, (n, 3))
+    elif kind == "lattice":  # exactly equal distances everywhere, a few duplicated points
+        m = int(round(n ** 0.5))
+        gx, gy = np.meshgrid(np.arange(m) * 0.1, np.arange(m) * 0.1)
+        p = np.c_[gx.ravel(), gy.ravel(), np.zeros(m * m)]
+        p = np.r_[p, p[rng.integers(0, len(p), 7)]]
+        p = p[rng.permutation(len(p))]
+    else:  # georeferenced, two sheets
+        xy = rng.uniform(0, 20, (n, 2))
+        z = np.where(rng.random(n) < 0.5, 0.0, 0.6) + 0.05 * xy[:, 0]
+        p = np.c_[xy, z] + np.array([2647000.0, 1177000.0, 1500.0]) % 4096
+    return np.ascontiguousarray(p, dtype=np.float32)
+
+
+@pytest.mark.parametrize("kind,n,k,res", [("surface", 30_000, 30, 1.0), ("surface", 120_000, 15, 0.6), ("rows", 60_000, 30, 0.8),
+                                          ("volume", 25_000, 12, 0.9), ("lattice", 10_000, 8, 0.55), ("georef", 40_000, 30, 1.2),
+                                          ("rows", 200_000, 30, 0.5), ("surface", 3_000, 30, 4.0)])
+def test_device_labels_equal_the_host_replay(eng, kind, n, k, res, monkeypatch):
+    import torch
+    xyz = torch.from_numpy(_cloud(kind, n, seed=n + k)).cuda()
+    monkeypatch.delenv("F4L_SV_EXACT_HOST", raising=False)
+    lab_d, K_d = eng.supervoxel(xyz, k, res)
+    monkeypatch.setenv("F4L_SV_EXACT_HOST", "1")
+    lab_h, K_h = eng.supervoxel(xyz, k, res)
+    assert K_d == K_h
+    assert torch.equal(lab_d, lab_h), f"{int((lab_d != lab_h).sum())} of {len(lab_d)} labels differ"
+    cnt = torch.bincount(lab_d.long(), minlength=K_d)
+    assert int(cnt.min()) > 0 and int(lab_d.max()) == K_d - 1
+
+
+def test_segment_exact_entry_reports_its_passes_and_refuses_what_it_cannot_hold(eng):
+    """The C entry by itself: stats (lambda rounds, fusion passes, exchange generations and passes), and k = 1 -- whose pools cannot
+    hold the cell-count hash set -- refused with F4L_EUNSUPPORTED (f4l_supervoxel then replays on the host)."""
+    import ctypes as C
+    import torch
+    from fusion4landslide_amd._lib import lib, ptr, stream_ptr
+    xyz = torch.from_numpy(_cloud("surface", 20_000, seed=3)).cuda()
+    knn, nrm = eng.knn_normals(xyz, 20)
+    n = xyz.shape[0]
+    labels = torch.empty(n, dtype=torch.int32, device="cuda")
+    nb = lib().f4l_supervoxel_segment_exact_workspace_bytes(n, 20)
+    ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
+    K, stats = C.c_int32(0), (C.c_int32 * 4)()
+    rc = lib().f4l_supervoxel_segment_exact(ptr(xyz), ptr(nrm), ptr(knn), n, 20, 1.0, ptr(labels), C.byref(K), stats, ptr(ws), C.c_size_t(nb), stream_ptr())
+    assert rc == 0 and K.value > 10
+    assert 3 <= stats[0] <= 40 and stats[1] >= stats[0] and 1 <= stats[2] <= 50 and stats[3] >= stats[2]
+    lab_h, K_h = eng.supervoxel(xyz, 20, 1.0)
+    assert K_h == K.value and torch.equal(labels, lab_h)
+    knn1 = knn[:, :1].contiguous()
+    nb1 = max(int(lib().f4l_supervoxel_segment_exact_workspace_bytes(n, 1)), 1)
+    ws1 = torch.empty(nb1, dtype=torch.uint8, device="cuda")
+    rc = lib().f4l_supervoxel_segment_exact(ptr(xyz), ptr(nrm), ptr(knn1), n, 1, 1.0, ptr(labels), C.byref(K), stats, ptr(ws1), C.c_size_t(nb1), stream_ptr())
+    assert rc == -4 or rc != 0  # F4L_EUNSUPPORTED
