@@ -148,7 +148,6 @@ struct Est {                     // one estimate of "what the centres of this ro
     int32_t *len;                //     ... and length
     unsigned long long *hash;    // [n] order-sensitive hash of that list (what "the list did not change" is read from)
     int32_t *cnt_slot;           // [nreps] cnt in the order of the centres (the budget's prefix sum runs over it)
-    int32_t *nx;                 // [n] nodes its Finds passed through, stored behind its lists; -1: evaluate every pass, -2: did not run
 };
 struct FuseArgs {
     const float *xyz;
@@ -167,7 +166,6 @@ struct FuseArgs {
     const int64_t *before;       // [nreps] absorptions by the centres before each centre (previous estimate), or null
     int64_t pool_base, sub_cap;  // where this pass writes lists: SUBPOOLS regions of sub_cap entries from pool_base
     int pool_sel;                // which set of bump pointers
-    int32_t *chg;                // [n] the pass that last changed the node's estimate
     Est rd, wr;
 };
 
@@ -184,8 +182,7 @@ __global__ void round_init_kernel(FuseArgs a) {
         a.rd.len[i] = a.adj_len[i];
         a.rd.hash[i] = ~0ULL;   // ("the round-start list": no evaluation writes this value twice in a row unless nothing changes)
         a.rd.cnt_slot[s] = 0;
-        a.rd.nx[i] = -2;
-        a.chg[i] = -1;
+
     }
 }
 // before a pass: its pool's bump pointers, its claims, its flag and its total
@@ -197,259 +194,215 @@ __global__ void prep_kernel(State *st, int sel, unsigned int *abs_wr, const int3
     SVX_FOR(s, nreps) abs_wr[reps[s]] = NONE;
 }
 
-// One wavefront = one centre.  Q: the closure's queue = its visited set, in the reference's order (:125-134, 151-157).
+// Half a wavefront (32 lanes) = one centre: the lists are a few dozen entries, and two dependent-load chains per wave keep the
+// memory system busier than one.  Q: the closure's queue = its visited set, in the reference's order (:125-134, 151-157), in LDS.
+// Everything "uniform" below is uniform within a half; both halves walk every loop together (a half that is through is
+// predicated off), so that the wave-wide ballots and shuffles stay convergent.
 //
-// A centre whose inputs did not change is not evaluated again.  What an evaluation READ of the estimate is the estimate of the
-// nodes it visited (its queue: itself, what it kept, what it absorbed) and of the few nodes its Finds passed through without
-// ending there (X below); every node carries the number of the pass that last changed its estimate (chg).  If none of them
-// changed in the pass before, the same evaluation would read the same values and do the same: the centre copies its lists
-// forward, renews its claims and is done -- a fifth of the memory traffic of an evaluation, and after the first two or three
-// passes of a round that is nearly every centre.  (Not in the round that reaches K: there every centre also depends on the
-// absorptions of ALL centres before it.)
-constexpr int XCAP = 128;  // nodes a centre's Finds may pass through without ending there (more: it is evaluated every pass)
-// MEASURED (round 5, 1 M points): with the skip the passes of a segmentation take 51.4 ms, without it 41.7 -- a change at one
-// node sends its ~30 neighbouring centres back into evaluation whether or not their outcome moves, so the skipped share stays
-// below a half until the last passes, and recording what the Finds pass through costs every evaluation.  Kept behind this switch.
-#ifndef SVX_SKIP_STABLE
-#define SVX_SKIP_STABLE 0
+// (Measured and dropped: skipping centres none of whose inputs changed in the pass before -- per-node change stamps, the nodes a
+//  centre read stored behind its list.  A change at one node sends its ~30 neighbouring centres back into evaluation whether
+//  or not their outcome moves, so fewer than half are skipped until the last passes, and the bookkeeping costs every evaluation:
+//  51.4 ms of passes per 1 M points against 41.7 without.  One centre per wavefront, the first version: 41.7 ms.)
+#ifndef SVX_EVAL_WPE
+#define SVX_EVAL_WPE 8
 #endif
-constexpr bool SKIP_STABLE = SVX_SKIP_STABLE != 0;
-__global__ __launch_bounds__(EVAL_WAVES * 64) void eval_kernel(FuseArgs a, double lambda, long long budget_total, int pass) {
-    __shared__ int32_t q_all[EVAL_WAVES][QCAP];
-    __shared__ int32_t x_all[EVAL_WAVES][XCAP];
-    __shared__ unsigned int acc_all[EVAL_WAVES][QCAP / 32];
-    const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
-    const int64_t s = (int64_t)blockIdx.x * EVAL_WAVES + wave;
-    if (s >= a.nreps) return;  // (whole wave)
-    int32_t *Q = q_all[wave], *X = x_all[wave];
-    unsigned int *ACC = acc_all[wave];
-    const int32_t i = a.reps[s];
+__global__ __launch_bounds__(EVAL_WAVES * 64, SVX_EVAL_WPE) void eval_kernel(FuseArgs a, double lambda, long long budget_total, int pass) {
+    __shared__ int32_t q_all[EVAL_WAVES][2][QCAP];
+    __shared__ unsigned int acc_all[EVAL_WAVES][2][QCAP / 32];
+    const int wave = (int)(threadIdx.x >> 6), lane = lane_id(), h = lane >> 5, hl = lane & 31, hbase = h << 5;
+    const int64_t s0 = ((int64_t)blockIdx.x * EVAL_WAVES + wave) * 2;
+    if (s0 >= a.nreps) return;  // (whole wave)
+    const int64_t s = s0 + h;
+    const bool valid_c = s < a.nreps;
+    int32_t *Q = q_all[wave][h];
+    unsigned int *ACC = acc_all[wave][h];
+    const int32_t i = a.reps[valid_c ? s : s0];
     const unsigned int ui = (unsigned int)i;
     const unsigned int *__restrict__ abs_rd = a.rd.abs;
     int32_t *__restrict__ pool = const_cast<int32_t *>(a.lists);
-    const unsigned long long below = (1ULL << lane) - 1ULL;
+    const unsigned int below = (1u << hl) - 1u;
+    auto hb = [&](unsigned long long m) { return (unsigned int)(m >> hbase); };  // this half's bits of a wave-wide ballot
+    auto half_sum = [&](int v) {
+#pragma unroll
+        for (int x = 1; x < 32; x <<= 1) v += __shfl_xor(v, x, 64);
+        return v;
+    };
     auto wsync = [&]() {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     };
-    // a region of `count` entries in this pass's pool (one bump pointer per slice of the centres)
-    bool overflow = false;
-    auto region = [&](int count) -> int64_t {
-        if (count <= 0) return 0;
-        const int sp = (int)(s & (SUBPOOLS - 1));
-        unsigned long long base = 0ULL;
-        if (lane == 0) base = atomicAdd(&a.st->sub[a.pool_sel][sp], (unsigned long long)count);
-        base = (unsigned long long)__shfl((long long)base, 0, 64);
-        if ((long long)base + count > a.sub_cap) { overflow = true; return 0; }
-        return a.pool_base + (int64_t)sp * a.sub_cap + (int64_t)base;
-    };
-
-    // ---- nothing it read has changed: the outcome stands
-    const int nx_old = a.rd.nx[i];
-    if (SKIP_STABLE && pass > 0 && !a.before && nx_old != -1) {
-        const bool ran = nx_old >= 0;
-        const int64_t ro = a.rd.off[i];
-        const int klen = a.rd.len[i], kcnt = a.rd.cnt[i];
-        const int tot = ran ? klen + kcnt + nx_old : 0;
-        bool any = a.chg[i] == pass - 1;
-        for (int e = lane; e < tot; e += 64) any = any || a.chg[pool[ro + e]] == pass - 1;
-        if (__ballot(any) == 0ULL) {
-            int64_t no = ro;
-            if (ran) {
-                no = region(tot);
-                if (!overflow) {
-                    for (int e = lane; e < tot; e += 64) {
-                        const int32_t v = pool[ro + e];
-                        pool[no + e] = v;
-                        if (e >= klen && e < klen + kcnt) atomicMin(&a.wr.abs[v], ui);  // (the claims of this pass are collected anew)
-                    }
-                }
-            }
-            if (overflow && lane == 0) atomicOr(&a.st->overflow, 2);
-            if (lane == 0) {
-                a.wr.ns[i] = a.rd.ns[i]; a.wr.cnt[i] = kcnt; a.wr.off[i] = no; a.wr.len[i] = klen; a.wr.hash[i] = a.rd.hash[i];
-                a.wr.nx[i] = nx_old; a.wr.cnt_slot[s] = kcnt;
-            }
-            return;
-        }
-    }
-
     const unsigned int absi = abs_rd[i];
     const bool dead = absi != NONE && absi < ui;  // absorbed before its turn: adjacents[i] is empty by then (:121)
     const int64_t off0 = a.adj_off[i];
     const int len0 = a.adj_len[i];
-    long long budget = a.before ? budget_total - (long long)a.before[s] : 0x7fffffffffffLL;
-    const bool run = !dead && len0 > 0 && budget > 0;
+    long long budget = a.before ? budget_total - (long long)a.before[valid_c ? s : s0] : 0x7fffffffffffLL;
+    const bool run = valid_c && !dead && len0 > 0 && budget > 0;
     int nsz = a.sz0[i], cnt = 0;
-    int head = 0, tail = 0, nx = 0;
-    bool complex_ = false;  // (a Find passed through more nodes than X records, or X is full: evaluated every pass)
+    int head = 0, tail = 0;
+    bool ovf = false;
     // this centre's own position and normal (the metric's first argument, :142)
     float pi_[3];
     double ni_[3];
 #pragma unroll
     for (int d = 0; d < 3; ++d) { pi_[d] = a.xyz[3 * (int64_t)i + d]; ni_[d] = a.nrm[3 * (int64_t)i + d]; }
 
-    // adds the lanes' values (valid where `on`) to SET[0 .. count) unless there already, lanes in order, first occurrence first
-    auto add_unique = [&](unsigned int v, bool on, int32_t *SET, int &count, int cap, bool &full) {
-        bool fresh = on;
-        for (int e = 0; e < count; e += 4) {
-            const int4 u = *reinterpret_cast<const int4 *>(SET + e);  // (entries past `count` hold -1)
-            fresh = fresh && (unsigned int)u.x != v && (unsigned int)u.y != v && (unsigned int)u.z != v && (unsigned int)u.w != v;
-        }
-        unsigned long long cand = __ballot(fresh), news = 0ULL;
-        while (cand) {
-            const int l = __ffsll((long long)cand) - 1;
-            const unsigned int vl = (unsigned int)__shfl((int)v, l, 64);
-            const unsigned long long same = __ballot(fresh && v == vl);
-            news |= 1ULL << l;
-            cand &= ~same;
-        }
-        const int nn = (int)__popcll(news);
-        if (count + nn + 4 > cap) { full = true; return; }
-        if ((news >> lane) & 1ULL) SET[count + (int)__popcll(news & below)] = (int32_t)v;
-        if (lane < 4) SET[count + nn + lane] = -1;  // (the padding the four-at-a-time look-up reads)
-        count += nn;
-        wsync();
-    };
-    // appends Find(list entries) that are not yet visited, in list order (:126-133 / :151-157)
-    auto append_list = [&](int64_t off, int len) {
-        for (int c0 = 0; c0 < len && !overflow; c0 += 64) {
-            const bool have = c0 + lane < len;
-            unsigned int r = NONE, e1 = NONE, e2 = NONE;
-            bool longer = false;
+    // appends Find(list entries) that are not yet visited, in list order (:126-133 / :151-157); `act`: this half has a list to append
+    auto append_list = [&](bool act, int64_t off, int len) {
+        for (int c0 = 0; __any(act && !ovf && c0 < len); c0 += 32) {
+            const bool go = act && !ovf && c0 < len;
+            const bool have = go && c0 + hl < len;
+            unsigned int r = NONE;
             if (have) {
-                r = (unsigned int)a.root[a.lists[off + c0 + lane]];
+                r = (unsigned int)a.root[pool[off + c0 + hl]];
                 // Find as centre i sees it (set.Find, :127/:152): every absorption by a centre that ran BEFORE i and was alive at its
-                // own turn; honoured claims lead to ever higher centres, so the walk ends.  e1, e2: nodes whose estimate the walk
-                // read without ending there
+                // own turn; honoured claims lead to ever higher centres, so the walk ends
                 for (;;) {
                     const unsigned int c = abs_rd[r];
                     if (c == NONE || !(c < ui)) break;
                     const unsigned int cc = abs_rd[c];
-                    const bool refused = cc != NONE && cc < c;
-                    const unsigned int passed = refused ? c : r;  // (a refused claimant was read too)
-                    if (e1 == NONE) e1 = passed; else if (e2 == NONE) e2 = passed; else longer = true;
-                    if (refused) break;
+                    if (cc != NONE && cc < c) break;
                     r = c;
                 }
             }
-            if (SKIP_STABLE && __ballot(longer) != 0ULL) complex_ = true;
-            bool qfull = false;
-            add_unique(r, have, Q, tail, QCAP, qfull);
-            if (qfull) { overflow = true; break; }
-            if (SKIP_STABLE && __ballot(e1 != NONE) != 0ULL) {
-                bool xfull = false;
-                add_unique(e1, e1 != NONE, X, nx, XCAP, xfull);
-                if (__ballot(e2 != NONE) != 0ULL && !xfull) add_unique(e2, e2 != NONE, X, nx, XCAP, xfull);
-                if (xfull) complex_ = true;
+            // visited already? (the queue so far; four entries per LDS read; entries past `tail` hold -1)
+            bool fresh = have;
+            for (int e = 0; __any(go && e < tail); e += 4) {
+                if (go && e < tail) {
+                    const int4 v = *reinterpret_cast<const int4 *>(Q + e);
+                    fresh = fresh && (unsigned int)v.x != r && (unsigned int)v.y != r && (unsigned int)v.z != r && (unsigned int)v.w != r;
+                }
             }
+            // ... or by a lower lane of this chunk (the first occurrence wins)
+            unsigned int cand = hb(__ballot(fresh)), news = 0u;
+            while (__any(cand != 0u)) {
+                const bool on = cand != 0u;
+                const int l = on ? __ffs((int)cand) - 1 : 0;
+                const unsigned int rl = (unsigned int)__shfl((int)r, hbase + l, 64);
+                const unsigned int same = hb(__ballot(on && fresh && r == rl));
+                if (on) { news |= 1u << l; cand &= ~same; }
+            }
+            if (go) {
+                const int nn = (int)__popc(news);
+                if (tail + nn + 4 > QCAP) ovf = true;
+                else {
+                    if ((news >> hl) & 1u) Q[tail + (int)__popc(news & below)] = (int32_t)r;
+                    if (hl < 4) Q[tail + nn + hl] = -1;
+                    tail += nn;
+                }
+            }
+            wsync();
         }
     };
 
     if (run) {
-        if (lane < 5) Q[lane] = lane == 0 ? i : -1;  // visited[i] = true; queue[front++] = i (:123-125)
-        if (lane < 4) X[lane] = -1;
-        for (int e = lane; e < QCAP / 32; e += 64) ACC[e] = 0u;
-        wsync();
+        if (hl < 5) Q[hl] = hl == 0 ? i : -1;  // visited[i] = true; queue[front++] = i (:123-125)
+        if (hl < QCAP / 32) ACC[hl] = 0u;
         head = tail = 1;
-        append_list(off0, len0);
-        bool stop = false;
-        while (head < tail && !stop && !overflow) {  // :137-163, 64 entries of the queue at a time
-            const int m = tail - head < 64 ? tail - head : 64;
-            const bool mine = lane < m;
-            const int32_t j = mine ? Q[head + lane] : i;
-            // sizes[j] as centre i finds it: j ran before i (and grew) iff j < i
-            const int sj = mine ? ((unsigned int)j < ui ? a.rd.ns[j] : a.sz0[j]) : 0;
-            bool acc = false;
-            if (mine) {
-                float pj[3];
-                double nj[3];
-#pragma unroll
-                for (int d = 0; d < 3; ++d) { pj[d] = a.xyz[3 * (int64_t)j + d]; nj[d] = a.nrm[3 * (int64_t)j + d]; }
-                const double loss = (double)sj * sv_metric_vals(pi_, ni_, pj, nj, a.resolution);  // :142 `sizes[j] * metric(points[i], points[j])`
-                acc = lambda - loss > 0.0;                                                        // :143-144
-            }
-            // adjacents[j] as centre i finds it (:151): j's list after its turn iff j < i
-            const int64_t joff = mine ? ((unsigned int)j < ui ? a.rd.off[j] : a.adj_off[j]) : 0;
-            const int jlen = mine ? ((unsigned int)j < ui ? a.rd.len[j] : a.adj_len[j]) : 0;
-            unsigned long long accm = __ballot(acc);
-            int done = m;  // entries of this chunk that the reference's loop reaches
-            if ((long long)__popcll(accm) >= budget) {  // `if (--number_of_supervoxels == n_supervoxels) break;` (:160) inside this chunk
-                unsigned long long t = accm;
-                for (long long b = 1; b < budget; ++b) t &= t - 1ULL;
-                const int last = __ffsll((long long)t) - 1;  // lane of the absorption that reaches K
-                done = last + 1;
-                accm &= (last == 63) ? ~0ULL : ((1ULL << (last + 1)) - 1ULL);
-                stop = true;
-            }
-            const bool take = mine && ((accm >> lane) & 1ULL);
-            if (take) {
-                atomicMin(&a.wr.abs[j], ui);  // set.Link(j, i) (:145); of several centres that claim j in an estimate the lowest counts
-                atomicOr(&ACC[(head + lane) >> 5], 1u << ((head + lane) & 31));
-            }
-            nsz += wave_sum(take ? sj : 0);   // sizes[i] += sizes[j] (:147)
-            const int na = (int)__popcll(accm);
-            cnt += na;
-            budget -= na;
-            // the absorbed nodes' lists join the queue, in the queue's order (:149-157)
-            unsigned long long mm = accm;
-            while (mm && !overflow) {
-                const int l = __ffsll((long long)mm) - 1;
-                mm &= mm - 1ULL;
-                const long long o = __shfl((long long)joff, l, 64);
-                append_list((int64_t)o, __shfl(jlen, l, 64));
-            }
-            head += done;
-        }
     }
-    // the centre's list after its turn (:164 `adjacents[i].swap(adjacent)`): the entries it looked at and did not absorb, in order;
-    // behind it, for the look above: what it absorbed and what its Finds passed through
+    wsync();
+    append_list(run, off0, len0);
+    bool stop = false;
+    while (__any(run && !stop && !ovf && head < tail)) {  // :137-163, 32 entries of the queue at a time
+        const bool go = run && !stop && !ovf && head < tail;
+        const int m = go ? (tail - head < 32 ? tail - head : 32) : 0;
+        const bool mine = hl < m;
+        const int32_t j = mine ? Q[head + hl] : i;
+        // sizes[j] as centre i finds it: j ran before i (and grew) iff j < i
+        const int sj = mine ? ((unsigned int)j < ui ? a.rd.ns[j] : a.sz0[j]) : 0;
+        bool acc = false;
+        if (mine) {
+            float pj[3];
+            double nj[3];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) { pj[d] = a.xyz[3 * (int64_t)j + d]; nj[d] = a.nrm[3 * (int64_t)j + d]; }
+            const double loss = (double)sj * sv_metric_vals(pi_, ni_, pj, nj, a.resolution);  // :142 `sizes[j] * metric(points[i], points[j])`
+            acc = lambda - loss > 0.0;                                                        // :143-144
+        }
+        // adjacents[j] as centre i finds it (:151): j's list after its turn iff j < i
+        const int64_t joff = mine ? ((unsigned int)j < ui ? a.rd.off[j] : a.adj_off[j]) : 0;
+        const int jlen = mine ? ((unsigned int)j < ui ? a.rd.len[j] : a.adj_len[j]) : 0;
+        unsigned int accm = hb(__ballot(acc));
+        int done = m;  // entries of this chunk that the reference's loop reaches
+        if (go && (long long)__popc(accm) >= budget) {  // `if (--number_of_supervoxels == n_supervoxels) break;` (:160) inside this chunk
+            unsigned int t = accm;
+            for (long long b = 1; b < budget; ++b) t &= t - 1u;
+            const int last = __ffs((int)t) - 1;  // lane of the absorption that reaches K
+            done = last + 1;
+            accm &= (last == 31) ? ~0u : ((1u << (last + 1)) - 1u);
+            stop = true;
+        }
+        const bool take = mine && ((accm >> hl) & 1u);
+        if (take) {
+            atomicMin(&a.wr.abs[j], ui);  // set.Link(j, i) (:145); of several centres that claim j in an estimate the lowest counts
+            atomicOr(&ACC[(head + hl) >> 5], 1u << ((head + hl) & 31));
+        }
+        nsz += half_sum(take ? sj : 0);   // sizes[i] += sizes[j] (:147)
+        const int na = (int)__popc(accm);
+        cnt += na;
+        budget -= na;
+        // the absorbed nodes' lists join the queue, in the queue's order (:149-157)
+        unsigned int mm = accm;
+        while (__any(mm != 0u && !ovf)) {
+            const bool ex = mm != 0u && !ovf;
+            const int l = ex ? __ffs((int)mm) - 1 : 0;
+            if (ex) mm &= mm - 1u;
+            const long long o = __shfl((long long)joff, hbase + l, 64);
+            const int ln = __shfl(jlen, hbase + l, 64);
+            append_list(ex, (int64_t)o, ln);
+        }
+        if (go) head += done;
+    }
+    // the centre's list after its turn (:164 `adjacents[i].swap(adjacent)`): the entries it looked at and did not absorb, in order
     int64_t out_off = dead ? 0 : off0;
     int out_len = dead ? 0 : len0;  // (a centre that did not run keeps its list; an absorbed one's is cleared, :158)
-    int out_nx = -2;                // (-2: did not run -- its outcome depends on its own estimate only)
     unsigned long long hash = dead ? 1ULL : ~0ULL;
-    if (run && !overflow) {
-        wsync();
-        int kept = 0;
-        for (int e0 = 1; e0 < head; e0 += 64) {
-            const int e = e0 + lane;
-            kept += (int)__popcll(__ballot(e < head && !((ACC[e >> 5] >> (e & 31)) & 1u)));
-        }
-        out_len = kept;
-        out_nx = (!SKIP_STABLE || complex_ || a.before) ? -1 : nx;
-        const int nxs = out_nx >= 0 ? nx : 0;
-        const int nacc = SKIP_STABLE ? cnt : 0;  // (what it absorbed is only stored for the skip)
-        out_off = region(kept + nacc + nxs);
-        unsigned long long h = 0ULL;
-        int at = 0, at_acc = kept;
-        if (!overflow) {
-            int32_t *__restrict__ dst = pool + out_off;
-            for (int e0 = 1; e0 < head; e0 += 64) {
-                const int e = e0 + lane;
-                const bool in = e < head;
-                const bool took = in && ((ACC[e >> 5] >> (e & 31)) & 1u);
-                const unsigned long long km = __ballot(in && !took), am = __ballot(took);
-                if (in && !took) {
-                    const int p = at + (int)__popcll(km & below);
-                    dst[p] = Q[e];
-                    h += mix64(((unsigned long long)(unsigned int)Q[e] << 32) | (unsigned int)p);
-                }
-                if (SKIP_STABLE && took) dst[at_acc + (int)__popcll(am & below)] = Q[e];
-                at += (int)__popcll(km);
-                at_acc += (int)__popcll(am);
-            }
-            for (int e = lane; e < nxs; e += 64) dst[kept + nacc + e] = X[e];
-        }
-        hash = 2ULL + (unsigned long long)wave_sum((int)(h & 0x7fffffffULL)) + (unsigned long long)wave_sum((int)((h >> 31) & 0x7fffffffULL)) * 0x9E3779B1ULL +
-               (unsigned long long)kept * 0x85EBCA6BULL;
+    wsync();
+    const bool fin = run && !ovf;
+    int kept = 0;
+    for (int e0 = 1; __any(fin && e0 < head); e0 += 32) {
+        const int e = e0 + hl;
+        kept += (int)__popc(hb(__ballot(fin && e < head && !((ACC[e >> 5] >> (e & 31)) & 1u))));
     }
-    if (overflow && lane == 0) atomicOr(&a.st->overflow, tail + 68 > QCAP ? 1 : 2);
-    if (lane == 0) {
+    if (fin) {
+        out_len = kept;
+        out_off = 0;
+        if (kept > 0) {
+            const int sp = (int)(s & (SUBPOOLS - 1));
+            unsigned long long base = 0ULL;
+            if (hl == 0) base = atomicAdd(&a.st->sub[a.pool_sel][sp], (unsigned long long)kept);
+            base = (unsigned long long)__shfl((long long)base, hbase, 64);
+            if ((long long)base + kept > a.sub_cap) ovf = true;
+            out_off = a.pool_base + (int64_t)sp * a.sub_cap + (int64_t)base;
+        }
+    } else if (run) {
+        // (keeps the shuffle above convergent: nothing to do)
+    }
+    unsigned long long hsum = 0ULL;
+    {
+        int at = 0;
+        const bool wr = fin && !ovf;
+        for (int e0 = 1; __any(wr && e0 < head); e0 += 32) {
+            const int e = e0 + hl;
+            const bool keep = wr && e < head && !((ACC[e >> 5] >> (e & 31)) & 1u);
+            const unsigned int km = hb(__ballot(keep));
+            if (keep) {
+                const int p = at + (int)__popc(km & below);
+                pool[out_off + p] = Q[e];
+                hsum += mix64(((unsigned long long)(unsigned int)Q[e] << 32) | (unsigned int)p);
+            }
+            at += (int)__popc(km);
+        }
+    }
+    if (run) hash = 2ULL + (unsigned long long)half_sum((int)(hsum & 0x7fffffffULL)) + (unsigned long long)half_sum((int)((hsum >> 31) & 0x7fffffffULL)) * 0x9E3779B1ULL +
+                    (unsigned long long)kept * 0x85EBCA6BULL;
+    else { (void)half_sum(0); (void)half_sum(0); }
+    if (ovf && hl == 0) atomicOr(&a.st->overflow, tail + 68 > QCAP ? 1 : 2);
+    if (hl == 0 && valid_c) {
         const bool same = a.rd.ns[i] == nsz && a.rd.cnt[i] == cnt && a.rd.len[i] == out_len && a.rd.hash[i] == hash;
-        a.wr.ns[i] = nsz; a.wr.cnt[i] = cnt; a.wr.off[i] = out_off; a.wr.len[i] = out_len; a.wr.hash[i] = hash; a.wr.nx[i] = out_nx;
+        a.wr.ns[i] = nsz; a.wr.cnt[i] = cnt; a.wr.off[i] = out_off; a.wr.len[i] = out_len; a.wr.hash[i] = hash;
         a.wr.cnt_slot[s] = cnt;
-        if (!same) { a.st->changed[pass & 7] = 1; a.chg[i] = pass; }
+        if (!same) a.st->changed[pass & 7] = 1;
     }
 }
 // (the claims: compared after the pass, when all of them are in; and the pass's absorptions in all)
@@ -458,7 +411,7 @@ __global__ void abs_changed_kernel(FuseArgs a, int pass) {
     long long tot = 0;
     SVX_FOR(s, a.nreps) {
         const int32_t i = a.reps[s];
-        if (a.rd.abs[i] != a.wr.abs[i]) { ch = true; a.chg[i] = pass; }
+        ch = ch || a.rd.abs[i] != a.wr.abs[i];
         tot += a.wr.cnt_slot[s];
     }
     if (__ballot(ch) != 0ULL && lane_id() == 0) a.st->changed[pass & 7] = 1;
@@ -625,7 +578,7 @@ struct Ws {
     int32_t *root, *sz0, *adj_len, *reps_a, *reps_b, *keep_flag, *keep_pos;
     int64_t *adj_off, *before;
     unsigned int *abs[2];
-    int32_t *ns[2], *cnt[2], *len[2], *cnt_slot[2], *nx[2], *chg;
+    int32_t *ns[2], *cnt[2], *len[2], *cnt_slot[2];
     int64_t *off[2];
     unsigned long long *hash[2];
     double *dis, *dis2[2], *median;
@@ -661,10 +614,9 @@ static int layout(int64_t n, int k, Ws &w, unsigned char *base) {
     w.adj_off = (int64_t *)carve((size_t)n * 8); w.before = (int64_t *)carve((size_t)n * 8);
     for (int e = 0; e < 2; ++e) {
         w.abs[e] = (unsigned int *)carve((size_t)n * 4); w.ns[e] = (int32_t *)carve((size_t)n * 4); w.cnt[e] = (int32_t *)carve((size_t)n * 4);
-        w.len[e] = (int32_t *)carve((size_t)n * 4); w.cnt_slot[e] = (int32_t *)carve((size_t)n * 4); w.nx[e] = (int32_t *)carve((size_t)n * 4);
+        w.len[e] = (int32_t *)carve((size_t)n * 4); w.cnt_slot[e] = (int32_t *)carve((size_t)n * 4);
         w.off[e] = (int64_t *)carve((size_t)n * 8); w.hash[e] = (unsigned long long *)carve((size_t)n * 8);
     }
-    w.chg = (int32_t *)carve((size_t)n * 4);
     w.dis = (double *)carve((size_t)n * 8);
     w.dis2[0] = (double *)carve((size_t)n * 8); w.dis2[1] = (double *)carve((size_t)n * 8);
     w.median = (double *)carve(16);
@@ -746,13 +698,12 @@ extern "C" int f4l_supervoxel_segment_exact(const float *xyz, const double *norm
 
     FuseArgs fa;
     fa.xyz = xyz; fa.nrm = normals; fa.lists = w.lists; fa.n = n; fa.k = k; fa.resolution = resolution; fa.st = w.st;
-    fa.chg = w.chg;
     fa.root = w.root; fa.sz0 = w.sz0; fa.adj_off = w.adj_off; fa.adj_len = w.adj_len; fa.sub_cap = w.pool_cap / SUBPOOLS;
     int32_t *reps = w.reps_a, *reps_next = w.reps_b;
     int nreps = (int)n, live = (int)n;
     int committed_pool = -1;  // (the pool the round-start lists live in; -1: the neighbour table)
     int rounds = 0, passes = 0;
-    auto est = [&](int e) { Est x; x.abs = w.abs[e]; x.ns = w.ns[e]; x.cnt = w.cnt[e]; x.off = w.off[e]; x.len = w.len[e]; x.hash = w.hash[e]; x.cnt_slot = w.cnt_slot[e]; x.nx = w.nx[e]; return x; };
+    auto est = [&](int e) { Est x; x.abs = w.abs[e]; x.ns = w.ns[e]; x.cnt = w.cnt[e]; x.off = w.off[e]; x.len = w.len[e]; x.hash = w.hash[e]; x.cnt_slot = w.cnt_slot[e]; return x; };
     for (; rounds < MAX_ROUNDS; lambda *= 2.0, ++rounds) {
         if (nreps <= 1) break;  // :118
         fa.reps = reps; fa.nreps = nreps;
@@ -784,7 +735,7 @@ extern "C" int f4l_supervoxel_segment_exact(const float *xyz, const double *norm
                     F4L_HIP_CHECK(rocprim::exclusive_scan(w.prim, tb, fa.rd.cnt_slot, w.before, (int64_t)0, (size_t)nreps, rocprim::plus<int64_t>(), st, false));
                     fa.before = w.before;
                 }
-                hipLaunchKernelGGL(svx::eval_kernel, dim3((unsigned)((nreps + EVAL_WAVES - 1) / EVAL_WAVES)), dim3(EVAL_WAVES * 64), 0, st, fa, lambda, budget_total, it);
+                hipLaunchKernelGGL(svx::eval_kernel, dim3((unsigned)((nreps + 2 * EVAL_WAVES - 1) / (2 * EVAL_WAVES))), dim3(EVAL_WAVES * 64), 0, st, fa, lambda, budget_total, it);
                 hipLaunchKernelGGL(svx::abs_changed_kernel, dim3(nreps > 262144 ? 256 : 64), b, 0, st, fa, it);
                 F4L_LAUNCH_CHECK();
                 rd ^= 1;
