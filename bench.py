@@ -524,7 +524,23 @@ def cpu_baseline_supervoxel(torch, engine, src, n=200_000, k=30):
         out[name] = {"value": round(len(xyz) / gpu_s / 1e6, 4), "unit": "Mpts/s", "seconds": round(gpu_s, 4), "n_supervoxels": int(K),
                      "labels_identical_to_the_port": bool(np.array_equal(labels.cpu().numpy(), ref["labels"])) and K == ref["n_supervoxels"],
                      "note": ("everything on the device; same count and invariants as the reference's algorithm, not its labels" if "parallel" in name
-                              else "kNN + normals on the device, the reference's sequential segmentation replayed on one host core")}
+                              else "everything on the device: the reference's sequential fusion and FIFO exchange as fixed points of parallel "
+                                   "passes (csrc/supervoxel_exact.hip); rounds 1-4 replayed them on one host core")}
+    # the same at the size of one of the reference's tiles (<= 1 M points, fusion_brienz.yaml:25-26): the sample above is small
+    # enough for the one-core port, and too small to fill the device
+    big = src[:1_000_000]
+    if big.shape[0] >= 1_000_000:
+        out["this_repo_identical_1M"] = {}
+        for name, fn in (("identical", engine.supervoxel), ("parallel", engine.supervoxel_parallel)):
+            fn(big, k, res)
+            ts = []
+            for _ in range(3):
+                torch.cuda.synchronize()
+                t = time.perf_counter()
+                labels, K = fn(big, k, res)
+                torch.cuda.synchronize()
+                ts.append(time.perf_counter() - t)
+            out["this_repo_identical_1M"][name] = {"value": round(1.0 / min(ts), 3), "unit": "Mpts/s", "ms": round(1e3 * min(ts), 2), "n_supervoxels": int(K)}
     return out
 
 

@@ -40,8 +40,11 @@ namespace f4l {
 namespace svx {
 
 constexpr unsigned int NONE = 0xffffffffu;
-constexpr int QCAP = 512;                 // distinct nodes one centre's closure may visit (its queue, in LDS)
-constexpr int EVAL_WAVES = 4;             // centres per workgroup
+constexpr int QCAP_WIDE = 1024;                 // distinct nodes one centre's closure may visit (its queue, in LDS)
+#ifndef SVX_EVAL_WAVES
+#define SVX_EVAL_WAVES 4
+#endif
+constexpr int EVAL_WAVES = SVX_EVAL_WAVES;  // wavefronts per workgroup
 constexpr int SUBPOOLS = 1024;            // bump pointers of a list pool (one address would serialise a million allocations)
 constexpr unsigned long long KEY_INF = (1ULL << 40) - 1ULL;
 constexpr int32_t POS_INF = 0x7fffffff;
@@ -53,7 +56,7 @@ struct State {
     int overflow;          // 1: a closure beyond QCAP, 2: a list pool full
     int changed[8];        // per pass (slot = pass % 8): something differed from the estimate before
     int m;                 // entries of the exchange's current generation
-    int pad_;
+    int max_tail;          // the largest closure (visited set) any centre had
     long long total[8];    // per pass: absorptions of the whole estimate (the budget of the last round is switched on by it)
     unsigned long long sub[2][SUBPOOLS];  // bump pointers of the two estimate pools
 };
@@ -206,11 +209,17 @@ __global__ void prep_kernel(State *st, int sel, unsigned int *abs_wr, const int3
 #ifndef SVX_EVAL_WPE
 #define SVX_EVAL_WPE 8
 #endif
+// G lanes per centre (64 / G centres per wavefront), QCAP entries of queue: <16, 256> is the shape clouds normally take (closures
+// of 45-76 nodes on surfaces, up to 216 in volumes; 16 KB of LDS per workgroup: full occupancy; 31 ms per 1 M points against 37
+// for <32, 512>); a closure beyond it restarts the segmentation in the wide shape <32, 1024>, one beyond that replays on the host.
+template <int G, int QCAP>
 __global__ __launch_bounds__(EVAL_WAVES * 64, SVX_EVAL_WPE) void eval_kernel(FuseArgs a, double lambda, long long budget_total, int pass) {
-    __shared__ int32_t q_all[EVAL_WAVES][2][QCAP];
-    __shared__ unsigned int acc_all[EVAL_WAVES][2][QCAP / 32];
-    const int wave = (int)(threadIdx.x >> 6), lane = lane_id(), h = lane >> 5, hl = lane & 31, hbase = h << 5;
-    const int64_t s0 = ((int64_t)blockIdx.x * EVAL_WAVES + wave) * 2;
+    constexpr int CPW = 64 / G;  // centres per wavefront
+    constexpr unsigned int GMASK = G == 32 ? 0xffffffffu : ((1u << (G & 31)) - 1u);
+    __shared__ int32_t q_all[EVAL_WAVES][CPW][QCAP];
+    __shared__ unsigned int acc_all[EVAL_WAVES][CPW][QCAP / 32];
+    const int wave = (int)(threadIdx.x >> 6), lane = lane_id(), h = lane / G, hl = lane % G, hbase = h * G;
+    const int64_t s0 = ((int64_t)blockIdx.x * EVAL_WAVES + wave) * CPW;
     if (s0 >= a.nreps) return;  // (whole wave)
     const int64_t s = s0 + h;
     const bool valid_c = s < a.nreps;
@@ -221,10 +230,10 @@ __global__ __launch_bounds__(EVAL_WAVES * 64, SVX_EVAL_WPE) void eval_kernel(Fus
     const unsigned int *__restrict__ abs_rd = a.rd.abs;
     int32_t *__restrict__ pool = const_cast<int32_t *>(a.lists);
     const unsigned int below = (1u << hl) - 1u;
-    auto hb = [&](unsigned long long m) { return (unsigned int)(m >> hbase); };  // this half's bits of a wave-wide ballot
+    auto hb = [&](unsigned long long m) { return (unsigned int)(m >> hbase) & GMASK; };  // this half's bits of a wave-wide ballot
     auto half_sum = [&](int v) {
 #pragma unroll
-        for (int x = 1; x < 32; x <<= 1) v += __shfl_xor(v, x, 64);
+        for (int x = 1; x < G; x <<= 1) v += __shfl_xor(v, x, 64);
         return v;
     };
     auto wsync = [&]() {
@@ -249,7 +258,7 @@ __global__ __launch_bounds__(EVAL_WAVES * 64, SVX_EVAL_WPE) void eval_kernel(Fus
 
     // appends Find(list entries) that are not yet visited, in list order (:126-133 / :151-157); `act`: this half has a list to append
     auto append_list = [&](bool act, int64_t off, int len) {
-        for (int c0 = 0; __any(act && !ovf && c0 < len); c0 += 32) {
+        for (int c0 = 0; __any(act && !ovf && c0 < len); c0 += G) {
             const bool go = act && !ovf && c0 < len;
             const bool have = go && c0 + hl < len;
             unsigned int r = NONE;
@@ -297,7 +306,7 @@ __global__ __launch_bounds__(EVAL_WAVES * 64, SVX_EVAL_WPE) void eval_kernel(Fus
 
     if (run) {
         if (hl < 5) Q[hl] = hl == 0 ? i : -1;  // visited[i] = true; queue[front++] = i (:123-125)
-        if (hl < QCAP / 32) ACC[hl] = 0u;
+        for (int e = hl; e < QCAP / 32; e += G) ACC[e] = 0u;
         head = tail = 1;
     }
     wsync();
@@ -305,7 +314,7 @@ __global__ __launch_bounds__(EVAL_WAVES * 64, SVX_EVAL_WPE) void eval_kernel(Fus
     bool stop = false;
     while (__any(run && !stop && !ovf && head < tail)) {  // :137-163, 32 entries of the queue at a time
         const bool go = run && !stop && !ovf && head < tail;
-        const int m = go ? (tail - head < 32 ? tail - head : 32) : 0;
+        const int m = go ? (tail - head < G ? tail - head : G) : 0;
         const bool mine = hl < m;
         const int32_t j = mine ? Q[head + hl] : i;
         // sizes[j] as centre i finds it: j ran before i (and grew) iff j < i
@@ -360,7 +369,7 @@ __global__ __launch_bounds__(EVAL_WAVES * 64, SVX_EVAL_WPE) void eval_kernel(Fus
     wsync();
     const bool fin = run && !ovf;
     int kept = 0;
-    for (int e0 = 1; __any(fin && e0 < head); e0 += 32) {
+    for (int e0 = 1; __any(fin && e0 < head); e0 += G) {
         const int e = e0 + hl;
         kept += (int)__popc(hb(__ballot(fin && e < head && !((ACC[e >> 5] >> (e & 31)) & 1u))));
     }
@@ -382,7 +391,7 @@ __global__ __launch_bounds__(EVAL_WAVES * 64, SVX_EVAL_WPE) void eval_kernel(Fus
     {
         int at = 0;
         const bool wr = fin && !ovf;
-        for (int e0 = 1; __any(wr && e0 < head); e0 += 32) {
+        for (int e0 = 1; __any(wr && e0 < head); e0 += G) {
             const int e = e0 + hl;
             const bool keep = wr && e < head && !((ACC[e >> 5] >> (e & 31)) & 1u);
             const unsigned int km = hb(__ballot(keep));
@@ -398,6 +407,7 @@ __global__ __launch_bounds__(EVAL_WAVES * 64, SVX_EVAL_WPE) void eval_kernel(Fus
                     (unsigned long long)kept * 0x85EBCA6BULL;
     else { (void)half_sum(0); (void)half_sum(0); }
     if (ovf && hl == 0) atomicOr(&a.st->overflow, tail + 68 > QCAP ? 1 : 2);
+    if (hl == 0 && tail > a.st->max_tail) atomicMax(&a.st->max_tail, tail);  // (a statistic: rarely more than a few updates per pass)
     if (hl == 0 && valid_c) {
         const bool same = a.rd.ns[i] == nsz && a.rd.cnt[i] == cnt && a.rd.len[i] == out_len && a.rd.hash[i] == hash;
         a.wr.ns[i] = nsz; a.wr.cnt[i] = cnt; a.wr.off[i] = out_off; a.wr.len[i] = out_len; a.wr.hash[i] = hash;
@@ -644,11 +654,12 @@ extern "C" size_t f4l_supervoxel_segment_exact_workspace_bytes(int64_t n, int k)
 // The reference's segmentation (supervoxel_segmentation.h:65-248) of device arrays, label for label.  SYNCHRONISES `stream` (a
 // few times per lambda round and exchange generation: whether the estimate still changes, how many representatives are left).
 // F4L_EUNSUPPORTED: a closure or the lists outgrew the device buffers (nothing was written to labels_out): replay on the host.
-extern "C" int f4l_supervoxel_segment_exact(const float *xyz, const double *normals, const int32_t *knn, int64_t n, int k,
-                                            double resolution, int32_t *labels_out, int32_t *n_supervoxels_host, int32_t *stats_host,
-                                            void *workspace, size_t workspace_bytes, void *stream) {
+static int segment_exact_run(const float *xyz, const double *normals, const int32_t *knn, int64_t n, int k, double resolution,
+                             int32_t *labels_out, int32_t *n_supervoxels_host, int32_t *stats_host, void *workspace, size_t workspace_bytes,
+                             void *stream, bool wide, bool &queue_outgrown) {
     using namespace f4l;
     using namespace f4l::svx;
+    queue_outgrown = false;
     if (!xyz || !normals || !knn || n <= 0 || k < 1 || !(resolution > 0.0) || !labels_out || !workspace) return F4L_EINVAL;
     if (k > F4L_MAX_K || n > 0x3fffffffLL) return F4L_EUNSUPPORTED;
     Ws w;
@@ -735,14 +746,15 @@ extern "C" int f4l_supervoxel_segment_exact(const float *xyz, const double *norm
                     F4L_HIP_CHECK(rocprim::exclusive_scan(w.prim, tb, fa.rd.cnt_slot, w.before, (int64_t)0, (size_t)nreps, rocprim::plus<int64_t>(), st, false));
                     fa.before = w.before;
                 }
-                hipLaunchKernelGGL(svx::eval_kernel, dim3((unsigned)((nreps + 2 * EVAL_WAVES - 1) / (2 * EVAL_WAVES))), dim3(EVAL_WAVES * 64), 0, st, fa, lambda, budget_total, it);
+                if (wide) hipLaunchKernelGGL((svx::eval_kernel<32, QCAP_WIDE>), dim3((unsigned)((nreps + 2 * EVAL_WAVES - 1) / (2 * EVAL_WAVES))), dim3(EVAL_WAVES * 64), 0, st, fa, lambda, budget_total, it);
+                else hipLaunchKernelGGL((svx::eval_kernel<16, 256>), dim3((unsigned)((nreps + 4 * EVAL_WAVES - 1) / (4 * EVAL_WAVES))), dim3(EVAL_WAVES * 64), 0, st, fa, lambda, budget_total, it);
                 hipLaunchKernelGGL(svx::abs_changed_kernel, dim3(nreps > 262144 ? 256 : 64), b, 0, st, fa, it);
                 F4L_LAUNCH_CHECK();
                 rd ^= 1;
             }
             rc = read_state();
             if (rc != F4L_OK) return rc;
-            if (hs.overflow) return F4L_EUNSUPPORTED;
+            if (hs.overflow) { queue_outgrown = (hs.overflow & 1) != 0; return F4L_EUNSUPPORTED; }
             const long long total = hs.total[(it - 1) & 7];
             prev_total = total;
             // converged: the last pass changed nothing -- and it ran with the budget if the budget binds
@@ -822,6 +834,21 @@ extern "C" int f4l_supervoxel_segment_exact(const float *xyz, const double *norm
     F4L_LAUNCH_CHECK();
     F4L_HIP_CHECK(hipStreamSynchronize(st));
     if (n_supervoxels_host) *n_supervoxels_host = nreps;
-    if (stats_host) { stats_host[0] = rounds; stats_host[1] = passes; stats_host[2] = generations; stats_host[3] = xpasses; }
+    if (stats_host) { stats_host[0] = rounds; stats_host[1] = passes; stats_host[2] = generations; stats_host[3] = xpasses; stats_host[4] = hs.max_tail; }
+    if (getenv("F4L_SV_EXACT_DEBUG")) fprintf(stderr, "[sv exact] %d rounds, %d passes, %d generations, %d exchange passes; largest closure %d of %d\n", rounds, passes, generations, xpasses, hs.max_tail, wide ? QCAP_WIDE : 256);
     return F4L_OK;
+}
+
+extern "C" int f4l_supervoxel_segment_exact(const float *xyz, const double *normals, const int32_t *knn, int64_t n, int k,
+                                            double resolution, int32_t *labels_out, int32_t *n_supervoxels_host, int32_t *stats_host,
+                                            void *workspace, size_t workspace_bytes, void *stream) {
+    bool outgrown = false;
+    int rc = segment_exact_run(xyz, normals, knn, n, k, resolution, labels_out, n_supervoxels_host, stats_host, workspace, workspace_bytes,
+                               stream, getenv("F4L_SV_EXACT_WIDE") != nullptr, outgrown);
+    if (rc == F4L_EUNSUPPORTED && outgrown && !getenv("F4L_SV_EXACT_WIDE")) {  // a closure beyond the narrow queue: once more, wide
+        if (getenv("F4L_SV_EXACT_DEBUG")) fprintf(stderr, "[sv exact] a closure beyond 256 nodes: restarting with the wide queue\n");
+        rc = segment_exact_run(xyz, normals, knn, n, k, resolution, labels_out, n_supervoxels_host, stats_host, workspace, workspace_bytes, stream,
+                               true, outgrown);
+    }
+    return rc;
 }

@@ -352,8 +352,8 @@ int f4l_partition_segment(int64_t n, int k, double resolution, const float *grid
  * round's start and on what LOWER-indexed ones did; every one is evaluated against an estimate of that until nothing changes --
  * the unique fixed point is the sequential result; 6-20 passes per lambda round).  xyz, normals, knn as for
  * f4l_supervoxel_segment_device (device arrays, the CALLER's order; knn rows in the order the search returned them: the
- * reference's queue order follows it).  labels_out int32 [n] (device), n_supervoxels_host (host), stats_host int32 [4] or NULL:
- * lambda rounds, fusion passes, exchange generations, exchange passes.  SYNCHRONISES `stream`.  F4L_EUNSUPPORTED when a
+ * reference's queue order follows it).  labels_out int32 [n] (device), n_supervoxels_host (host), stats_host int32 [5] or NULL:
+ * lambda rounds, fusion passes, exchange generations, exchange passes, the largest closure a representative had.  SYNCHRONISES `stream`.  F4L_EUNSUPPORTED when a
  * representative's closure or the lists outgrow the device buffers (k = 1, degenerate clouds): f4l_supervoxel then replays the
  * sequence on the host (f4l_supervoxel_segment_host) -- the same labels either way. */
 size_t f4l_supervoxel_segment_exact_workspace_bytes(int64_t n, int k);

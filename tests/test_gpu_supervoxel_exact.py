@@ -64,6 +64,36 @@ def test_device_labels_equal_the_host_replay(eng, kind, n, k, res, monkeypatch):
     assert int(cnt.min()) > 0 and int(lab_d.max()) == K_d - 1
 
 
+def test_wide_queue_and_restart_give_the_same_labels(eng, monkeypatch):
+    """The evaluation kernel has two shapes: 16 lanes and a queue of 256 nodes per representative (the normal one), 32 lanes and 1024
+    (F4L_SV_EXACT_WIDE, and the automatic restart when a closure outgrows the narrow queue: a dense VOLUME at a coarse resolution,
+    where a representative's closure visits several hundred others).  Both equal the host replay."""
+    import ctypes as C
+    import torch
+    from fusion4landslide_amd._lib import lib, ptr, stream_ptr
+    xyz = torch.from_numpy(_cloud("surface", 50_000, seed=9)).cuda()
+    monkeypatch.setenv("F4L_SV_EXACT_HOST", "1")
+    lab_h, K_h = eng.supervoxel(xyz, 30, 1.0)
+    monkeypatch.delenv("F4L_SV_EXACT_HOST")
+    monkeypatch.setenv("F4L_SV_EXACT_WIDE", "1")
+    lab_w, K_w = eng.supervoxel(xyz, 30, 1.0)
+    monkeypatch.delenv("F4L_SV_EXACT_WIDE")
+    assert K_w == K_h and torch.equal(lab_w, lab_h)
+    # a closure beyond the narrow queue: the entry restarts wide by itself (stats[4] = the largest closure of the run that finished)
+    vol = torch.from_numpy(_cloud("volume", 150_000, seed=2)).cuda()
+    knn, nrm = eng.knn_normals(vol, 40)
+    n = vol.shape[0]
+    labels = torch.empty(n, dtype=torch.int32, device="cuda")
+    nb = lib().f4l_supervoxel_segment_exact_workspace_bytes(n, 40)
+    ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
+    K, stats = C.c_int32(0), (C.c_int32 * 5)()
+    rc = lib().f4l_supervoxel_segment_exact(ptr(vol), ptr(nrm), ptr(knn), n, 40, 2.5, ptr(labels), C.byref(K), stats, ptr(ws), C.c_size_t(nb), stream_ptr())
+    assert rc == 0 and stats[4] > 252, stats[4]   # (beyond the narrow queue: this run was the wide one)
+    monkeypatch.setenv("F4L_SV_EXACT_HOST", "1")
+    lab_h2, K_h2 = eng.supervoxel(vol, 40, 2.5)
+    assert K_h2 == K.value and torch.equal(labels, lab_h2)
+
+
 def test_segment_exact_entry_reports_its_passes_and_refuses_what_it_cannot_hold(eng):
     """The C entry by itself: stats (lambda rounds, fusion passes, exchange generations and passes), and k = 1 -- whose pools cannot
     hold the cell-count hash set -- refused with F4L_EUNSUPPORTED (f4l_supervoxel then replays on the host)."""
@@ -76,10 +106,10 @@ def test_segment_exact_entry_reports_its_passes_and_refuses_what_it_cannot_hold(
     labels = torch.empty(n, dtype=torch.int32, device="cuda")
     nb = lib().f4l_supervoxel_segment_exact_workspace_bytes(n, 20)
     ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
-    K, stats = C.c_int32(0), (C.c_int32 * 4)()
+    K, stats = C.c_int32(0), (C.c_int32 * 5)()
     rc = lib().f4l_supervoxel_segment_exact(ptr(xyz), ptr(nrm), ptr(knn), n, 20, 1.0, ptr(labels), C.byref(K), stats, ptr(ws), C.c_size_t(nb), stream_ptr())
     assert rc == 0 and K.value > 10
-    assert 3 <= stats[0] <= 40 and stats[1] >= stats[0] and 1 <= stats[2] <= 50 and stats[3] >= stats[2]
+    assert 3 <= stats[0] <= 40 and stats[1] >= stats[0] and 1 <= stats[2] <= 50 and stats[3] >= stats[2] and 20 <= stats[4] <= 252
     lab_h, K_h = eng.supervoxel(xyz, 20, 1.0)
     assert K_h == K.value and torch.equal(labels, lab_h)
     knn1 = knn[:, :1].contiguous()
