@@ -570,8 +570,9 @@ def normals(xyz, knn_idx):
 def supervoxel(xyz, k, resolution, return_intermediates=False):
     """Whole partition (supervoxel.cpp:92-133 without file I/O). Returns labels (n,) int32 on the GPU and K.
 
-    kNN and normals run on the GPU; the order-dependent segmentation runs on the host inside the library,
-    so this call synchronises the current stream."""
+    The reference's own labels: kNN, normals AND the order-dependent segmentation run on the GPU (csrc/supervoxel_exact.hip: the
+    sequential fusion and the FIFO exchange as fixed points of parallel passes; the one-core host replay is the fall-back and
+    F4L_SV_EXACT_HOST=1).  The call synchronises the current stream (it looks at the convergence of the passes)."""
     torch = require_gpu()
     xyz = _dev(xyz, torch.float32, "xyz", (3,))
     n = xyz.shape[0]

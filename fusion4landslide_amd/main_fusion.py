@@ -3,10 +3,10 @@ once -> per tile `Coarse2Fine(cfg).implement_c2f_matching()` (:134-148) -> `resu
 
     python -m fusion4landslide_amd.main_fusion --config configs/landslide/fusion_3d_brienz.yaml [--partition identical]
 
-The supervoxel partition of this entry is the REFERENCE's own (`identical`: f4l_supervoxel -- kNN and normals on the device, the
-sequential fusion of supervoxel_segmentation.h:117-176 replayed label for label), so a drop-in run writes the partition and
-`c2f_*_tile` files the reference writes.  `--partition parallel` -- or F4L_SV_MODE=parallel -- opts into the all-device
-segmentation (f4l_supervoxel_parallel: the reference's K, criteria and partition quality at 200x the speed, not its labels).
+The supervoxel partition of this entry is the REFERENCE's own (`identical`: f4l_supervoxel -- kNN, normals and the sequential
+fusion / FIFO exchange of supervoxel_segmentation.h:117-237 on the device, label for label: 30 ms per 1 M-point tile), so a
+drop-in run writes the partition and `c2f_*_tile` files the reference writes.  `--partition parallel` -- or F4L_SV_MODE=parallel --
+opts into the parallel variant (f4l_supervoxel_parallel: the reference's K, criteria and partition quality in 4 ms, not its labels).
 The mode is validated before anything runs and logged at start-up.
 
 The config keys are the reference's (path_name / data / method / parameter_setting / misc).  What the reference computes with
