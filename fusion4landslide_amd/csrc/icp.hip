@@ -1076,6 +1076,9 @@ __global__ void icp_bin_patches(const int64_t *__restrict__ src_off, const int64
 
 template <int MODE, int NW, typename F, bool WIDE = false>
 static int launch_icp_one(const IcpArgs &a, size_t lds, hipStream_t st) {
+    // (measurement only: F4L_ICP_LDS_PAD = bytes of LDS asked for and never used -- fewer workgroups per CU, nothing else changes:
+    //  what ONE workgroup per CU is worth, profiles/r5_*_occupancy_slope*.log)
+    if (const char *e = getenv("F4L_ICP_LDS_PAD")) lds += (size_t)atoi(e);
     if (lds > 64 * 1024)  // opt in to > 64 KiB of dynamic LDS
         F4L_HIP_CHECK(hipFuncSetAttribute((const void *)icp_kernel<MODE, NW, F, WIDE>,
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
