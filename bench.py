@@ -490,7 +490,16 @@ def extras(torch, engine, synthetic, prob, dev, args):
         r = pipeline.full_path(src, tgt, max_iter=MAX_ITER, fixed_iters=True)
         out[f"full_path_{n_pts // 1_000_000}M"] = {"value": round(n_pts / r["stage_ms"]["total"] / 1e3, 3), "unit": "Mpts/s", "supervoxels": int(r["K"]),
                                                     "resolution_m": round(r["resolution"], 4), "stage_ms": {k: round(v, 3) for k, v in r["stage_ms"].items()},
-                                                    "mean_fitness": round(float(r["fitness"].mean().item()), 4)}
+                                                    "mean_fitness": round(float(r["fitness"].mean().item()), 4),
+                                                    "partition": "parallel variant (f4l_partition_neighbours + f4l_partition_segment)"}
+        if n_pts <= 10_000_000:  # the same path on the REFERENCE's own partition (its labels, computed on the device: supervoxel_exact.hip)
+            pipeline.full_path(src, tgt, max_iter=MAX_ITER, fixed_iters=True, partition="identical")
+            ri = pipeline.full_path(src, tgt, max_iter=MAX_ITER, fixed_iters=True, partition="identical")
+            out[f"full_path_{n_pts // 1_000_000}M_identical_partition"] = {
+                "value": round(n_pts / ri["stage_ms"]["total"] / 1e3, 3), "unit": "Mpts/s", "supervoxels": int(ri["K"]),
+                "stage_ms": {k: round(v, 3) for k, v in ri["stage_ms"].items()}, "mean_fitness": round(float(ri["fitness"].mean().item()), 4),
+                "partition": "the reference's labels (f4l_supervoxel)"}
+            del ri
         del src, tgt, r
         torch.cuda.empty_cache()
     return out

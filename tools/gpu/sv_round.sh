@@ -9,6 +9,6 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python3 tools
 cp $OUT/kt/*/*_kernel_stats.csv $OUT/partition_10M_kernel_stats.csv
 python3 tools/gpu/sv_trace_view.py $OUT/kt/*/*_kernel_trace.csv 12 > $OUT/timeline_10M.log 2>&1; rm -rf $OUT/kt
 if [ "$2" = "pmc" ]; then
-  python3 tools/gpu/pmc_passes.py --counters "FETCH_SIZE;WRITE_SIZE" --sum-all --calls 3 $OUT/svp_bytes.json "f4l::,rocprim::ROCPRIM_400200" -- python3 tools/gpu/svp_only.py 10000000 3 > $OUT/pmc.log 2>&1
+  python3 tools/gpu/pmc_passes.py --counters "FETCH_SIZE;WRITE_SIZE" --sum-all --calls 3 $OUT/svp_bytes.json "f4l::,rocprim::,fillBuffer" -- python3 tools/gpu/svp_only.py 10000000 3 > $OUT/pmc.log 2>&1
 fi
 ls $OUT
