@@ -69,6 +69,9 @@ SIGNATURES = {
     "f4l_median_f64": (C.c_int, [_P, _I64, _I64, _P, _P, _SZ, _P]),
     "f4l_labels_to_csr_workspace_bytes": (_SZ, [_I64, _I64]),
     "f4l_labels_to_csr": (C.c_int, [_P, _I64, _I64, _P, _P, _P, _SZ, _P]),
+    "f4l_labels_to_csr_via": (C.c_int, [_P, _I64, _P, _I64, _I64, _P, _P, _P, _SZ, _P]),
+    "f4l_epoch_join_workspace_bytes": (_SZ, [_I64, _I64]),
+    "f4l_epoch_join": (C.c_int, [_P, _I64, _P, _I64, _P, _P, _P, _SZ, _P]),
     "f4l_gather_points": (C.c_int, [_P, _P, _I64, _P, _P]),
 }
 

@@ -411,6 +411,27 @@ __global__ __launch_bounds__(KNN_NW * 64) void knn_listed_kernel(KnnArgs a, cons
 // a quarter of them displaced: 0.25 ms (lane kernel + one wave per uncertified query: 0.40 + 2.9 ms in round 2b).
 // `list` = nullptr: all nq queries of q_sorted; else the listed ones.
 constexpr int KS_MAX_K = 4;
+// Round 5: the walk is two-stage.  Every candidate used to cost an exact double distance and an insertion by (d2, index) into four
+// slots (~150 SIMD cycles a candidate and wave: 2.2 ms per 10 M queries whatever k).  Now the block is scanned in float32 -- the
+// differences of neighbouring float coordinates are exact, three roundings remain: d2 to 2e-7 of itself -- keeping the KK + 1
+// smallest approximate d2 with the candidates' positions; when the (k + 1)-th approximate d2 lies beyond the k-th by more than
+// that error can explain (a factor 1 + 2e-6, and 1e-30 for the flush-to-zero range), the k nearest ARE the first k slots as a set,
+// and only they are measured exactly and ordered by (d2, index).  A lane whose slots k and k + 1 are closer than that -- duplicates,
+// lattices, genuine near-ties -- walks its block again the old way; results are those of the exact walk in every case.
+// KK = slots kept (1, 2 or 4 >= k).
+template <int KK>
+__device__ __forceinline__ void ks_insert_exact(double (&bd)[KK], int (&bi)[KK], double d, int id) {
+#pragma unroll
+    for (int t = 0; t < KK; ++t) {  // insertion, ascending by (d2, index); the last falls off
+        const bool lt = d < bd[t] || (d == bd[t] && id < bi[t]);
+        const double dn = lt ? bd[t] : d;
+        const int in = lt ? bi[t] : id;
+        bd[t] = lt ? d : bd[t];
+        bi[t] = lt ? id : bi[t];
+        d = dn; id = in;
+    }
+}
+template <int KK>
 __global__ __launch_bounds__(256) void nn_small_kernel(KnnArgs a, int nq, const int32_t *__restrict__ list, const int32_t *__restrict__ count) {
     adopt_device_grid(a);
     const int n_q = list ? *count : nq;
@@ -425,36 +446,70 @@ __global__ __launch_bounds__(256) void nn_small_kernel(KnnArgs a, int nq, const 
         cell_of(g, qp.x, qp.y, qp.z, cx, cy, cz);
         const double fx = ((double)qp.x - g.minx) - (double)cx * g.h, fy = ((double)qp.y - g.miny) - (double)cy * g.h,
                      fz = ((double)qp.z - g.minz) - (double)cz * g.h;
-        double bd[KS_MAX_K];
-        int bi[KS_MAX_K];
+        double bd[KK];
+        int bi[KK];
         for (int R = 1;;) {
-#pragma unroll
-            for (int j = 0; j < KS_MAX_K; ++j) { bd[j] = __builtin_inf(); bi[j] = 0x7fffffff; }
             const int x0 = cx - R < 0 ? 0 : cx - R, x1 = cx + R >= g.nx ? g.nx - 1 : cx + R;
             const int y0 = cy - R < 0 ? 0 : cy - R, y1 = cy + R >= g.ny ? g.ny - 1 : cy + R;
             const int z0 = cz - R < 0 ? 0 : cz - R, z1 = cz + R >= g.nz ? g.nz - 1 : cz + R;
+            // stage 1: the KK + 1 smallest approximate d2 of the block, with their positions in the sorted array
+            float fd[KK + 1];
+            int fj[KK + 1];
+#pragma unroll
+            for (int t = 0; t <= KK; ++t) { fd[t] = __builtin_inff(); fj[t] = -1; }
             for (int zz = z0; zz <= z1; ++zz)
                 for (int yy = y0; yy <= y1; ++yy) {
                     int lo, hi;
                     cell_range(a.dense, a.cell_keys, a.cell_start, a.M, key_of(g, x0, yy, zz), key_of(g, x1, yy, zz), lo, hi);
                     for (int j = lo; j < hi; ++j) {
                         const float4 cp = a.sorted[j];
-                        double d = dist2_exact(cp.x, cp.y, cp.z, qp.x, qp.y, qp.z);
-                        int id = __float_as_int(cp.w);
+                        const float dx = cp.x - qp.x, dy = cp.y - qp.y, dz = cp.z - qp.z;
+                        float d = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+                        int jj = j;
 #pragma unroll
-                        for (int t = 0; t < KS_MAX_K; ++t) {  // insertion, ascending by (d2, index); the last falls off
-                            const bool lt = d < bd[t] || (d == bd[t] && id < bi[t]);
-                            const double dn = lt ? bd[t] : d;
-                            const int in = lt ? bi[t] : id;
-                            bd[t] = lt ? d : bd[t];
-                            bi[t] = lt ? id : bi[t];
-                            d = dn; id = in;
+                        for (int t = 0; t <= KK; ++t) {
+                            const bool lt = d < fd[t];
+                            const float dn = lt ? fd[t] : d;
+                            const int jn = lt ? fj[t] : jj;
+                            fd[t] = lt ? d : fd[t];
+                            fj[t] = lt ? jj : fj[t];
+                            d = dn; jj = jn;
                         }
                     }
                 }
+            // slots k - 1 and k (0-based): is the gap between them more than the float32 error of either?
+            float f_k1 = fd[0], f_k = fd[KK];
+#pragma unroll
+            for (int t = 0; t < KK; ++t) {
+                if (t == k - 1) f_k1 = fd[t];
+                if (t == k) f_k = fd[t];
+            }
+#pragma unroll
+            for (int j = 0; j < KK; ++j) { bd[j] = __builtin_inf(); bi[j] = 0x7fffffff; }
+            const bool separated = f_k1 == __builtin_inff() || !(f_k <= f_k1 * 1.000002f + 1e-30f);  // (fewer than k candidates: nothing to order)
+            if (separated) {
+                // stage 2: the first k slots measured exactly, ordered by (d2, index)
+#pragma unroll
+                for (int t = 0; t < KK; ++t)
+                    if (t < k && fj[t] >= 0) {
+                        const float4 cp = a.sorted[fj[t]];
+                        ks_insert_exact<KK>(bd, bi, dist2_exact(cp.x, cp.y, cp.z, qp.x, qp.y, qp.z), __float_as_int(cp.w));
+                    }
+            } else {
+                // near-ties around the k-th neighbour: the exact walk
+                for (int zz = z0; zz <= z1; ++zz)
+                    for (int yy = y0; yy <= y1; ++yy) {
+                        int lo, hi;
+                        cell_range(a.dense, a.cell_keys, a.cell_start, a.M, key_of(g, x0, yy, zz), key_of(g, x1, yy, zz), lo, hi);
+                        for (int j = lo; j < hi; ++j) {
+                            const float4 cp = a.sorted[j];
+                            ks_insert_exact<KK>(bd, bi, dist2_exact(cp.x, cp.y, cp.z, qp.x, qp.y, qp.z), __float_as_int(cp.w));
+                        }
+                    }
+            }
             double dk = bd[0];
 #pragma unroll
-            for (int t = 1; t < KS_MAX_K; ++t)
+            for (int t = 1; t < KK; ++t)
                 if (t == k - 1) dk = bd[t];
             // exactness: the k-th distance lies strictly inside the searched block (faces at the grid border do not count)
             double margin = __builtin_inf();
@@ -472,13 +527,25 @@ __global__ __launch_bounds__(256) void nn_small_kernel(KnnArgs a, int nq, const 
                 R = Rj > R + 1 ? Rj : R + 1;
             }
         }
+        if (a.nn1_out) {  // (f4l_epoch_join: only the distance to the nearest other point is wanted; k = 2 there)
+            if constexpr (KK >= 2) a.nn1_out[qid] = bd[1];
+        }
+        if (a.idx_out) {
 #pragma unroll
-        for (int t = 0; t < KS_MAX_K; ++t)
-            if (t < k) {
-                a.idx_out[(int64_t)qid * k + t] = bi[t];
-                if (a.d2_out) a.d2_out[(int64_t)qid * k + t] = bd[t];
-            }
+            for (int t = 0; t < KK; ++t)
+                if (t < k) {
+                    a.idx_out[(int64_t)qid * k + t] = bi[t];
+                    if (a.d2_out) a.d2_out[(int64_t)qid * k + t] = bd[t];
+                }
+        }
     }
+}
+static void launch_nn_small(const KnnArgs &a, int64_t m, hipStream_t st) {
+    const dim3 grid((unsigned)((m + 255) / 256)), block(256);
+    const int32_t *none = nullptr;
+    if (a.k == 1) hipLaunchKernelGGL(nn_small_kernel<1>, grid, block, 0, st, a, (int)m, none, none);
+    else if (a.k == 2) hipLaunchKernelGGL(nn_small_kernel<2>, grid, block, 0, st, a, (int)m, none, none);
+    else hipLaunchKernelGGL(nn_small_kernel<KS_MAX_K>, grid, block, 0, st, a, (int)m, none, none);
 }
 
 // ---- fast path of f4l_knn: one LANE per query -------------------------------------------------------------------------
@@ -1100,10 +1167,15 @@ __global__ void iota_kernel(int32_t *v, int64_t n) {
 // Sort keys of f4l_labels_to_csr: the label itself, or K for a label outside [0, K) (an "unlabelled" -1, a label beyond the
 // caller's count): those points sort behind every patch -- order[off[K] ..) -- and belong to none, as the histogram this path
 // replaced skipped them.  (Sorting the raw labels over the low bits of K only would place them by their low bits.)
+// `via` (f4l_labels_to_csr_via): row i takes the label of row via[i] of another cloud (a via outside [0, n_labels) = no patch).
 __global__ void label_keys_kernel(const int32_t *__restrict__ labels, int64_t n, int64_t K, int32_t *__restrict__ keys,
-                                  int32_t *__restrict__ iota) {
+                                  int32_t *__restrict__ iota, const int32_t *__restrict__ via = nullptr, int64_t n_labels = 0) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const int32_t l = labels[i];
+        int32_t l;
+        if (via) {
+            const int32_t v = via[i];
+            l = (v >= 0 && (int64_t)v < n_labels) ? labels[v] : -1;
+        } else l = labels[i];
         keys[i] = (l >= 0 && (int64_t)l < K) ? l : (int32_t)K;
         iota[i] = (int32_t)i;
     }
@@ -1140,7 +1212,9 @@ struct KnnWs {
     size_t prim_bytes, total;
 };
 
-static int knn_ws_layout(int64_t n, KnnWs &w, unsigned char *base) {
+// `small_k`: the layout for the lane-per-query walk of k <= KS_MAX_K alone (nn_small_kernel: no candidate runs, no redo list) --
+// f4l_epoch_join's two clouds; 80 bytes per point less.
+static int knn_ws_layout(int64_t n, KnnWs &w, unsigned char *base, bool small_k = false) {
     size_t sort_b = 0, rle_b = 0, scan_b = 0;
     unsigned long long *k0 = nullptr;
     int32_t *i0 = nullptr;
@@ -1173,11 +1247,11 @@ static int knn_ws_layout(int64_t n, KnnWs &w, unsigned char *base) {
     w.cell_start = (int32_t *)carve(((size_t)n + 1) * 4);
     w.n_cells = (int32_t *)carve(256);
     w.sorted = (float4 *)carve((size_t)n * 16);
-    w.fb_list = (int32_t *)carve((size_t)n * 4);
+    w.fb_list = (int32_t *)carve(small_k ? 256 : (size_t)n * 4);
     w.fb_count = (int32_t *)carve(256);
-    w.run_lo = (int32_t *)carve((size_t)n * 9 * 4);
-    w.run_hi = (int32_t *)carve((size_t)n * 9 * 4);
-    w.pcell = (int32_t *)carve((size_t)n * 4);
+    w.run_lo = (int32_t *)carve(small_k ? 256 : (size_t)n * 9 * 4);
+    w.run_hi = (int32_t *)carve(small_k ? 256 : (size_t)n * 9 * 4);
+    w.pcell = (int32_t *)carve(small_k ? 256 : (size_t)n * 4);
     w.dense = (int32_t *)carve((2 * (size_t)n + 4) * 4);
     w.has_dense = false;
     w.bbox_partial = (float *)carve(256 * 6 * 4);
@@ -1436,7 +1510,7 @@ static int knn_self(const float *xyz, int64_t n, int k, int32_t *idx_out, double
     a.idx_out = idx_out; a.d2_out = d2_out; a.dg = dg; a.nn1_out = nn1_out;
     a.pos_mode = pos ? 1 : 0;
     if (k <= KS_MAX_K && !pos && !normals_out && !nn1_out && !getenv("F4L_KNN_WAVE_PER_QUERY") && !getenv("F4L_KNN_NO_SMALL")) {
-        hipLaunchKernelGGL(nn_small_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a, (int)n, (const int32_t *)nullptr, (const int32_t *)nullptr);
+        launch_nn_small(a, n, st);
         F4L_LAUNCH_CHECK();
         return F4L_OK;
     }
@@ -1587,7 +1661,7 @@ extern "C" int f4l_nn_query(const float *cloud, int64_t n, const float *queries,
         a.dense = w.has_dense ? w.dense : nullptr;
         a.q_sorted = wq.sorted; a.q_cell_keys = nullptr; a.q_cell_start = nullptr; a.Mq = 0;
         a.idx_out = idx_out; a.d2_out = d2_out; a.dg = nullptr;
-        hipLaunchKernelGGL(nn_small_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, a, (int)m, (const int32_t *)nullptr, (const int32_t *)nullptr);
+        launch_nn_small(a, m, st);
         F4L_LAUNCH_CHECK();
         return F4L_OK;
     }
@@ -1640,6 +1714,56 @@ extern "C" int f4l_nn_query(const float *cloud, int64_t n, const float *queries,
         fprintf(stderr, "[nn_query] n %lld m %lld k %d: h %.4f grid %d x %d x %d, %d cells (%d with queries), %d queries to the wave-per-query search\n",
                 (long long)n, (long long)m, k, g.h, g.nx, g.ny, g.nz, M, Mq, fbc);
     }
+    return F4L_OK;
+}
+
+// ---- the two searches over the SECOND epoch of a tile, with one binning of it -------------------------------------------------
+// `_compute_median_resolution` (src/coarse_to_fine_matching_base.py:2716-2754) wants every target point's distance to its nearest
+// other target point; the patches of the second epoch (a target point joins the patch of its nearest source point: what stands in
+// for the learned patch matches, pipeline.py) want every target point's nearest SOURCE point.  f4l_knn(tgt, 2) + f4l_nn_query(src,
+// tgt, 1) bin the target cloud twice -- once in its own grid, once (64-bit keys) in the source's; the order only matters for the
+// locality of neighbouring lanes, so here the target is binned ONCE, in its own grid, and both searches walk it in that order.
+extern "C" size_t f4l_epoch_join_workspace_bytes(int64_t n, int64_t m) {
+    if (n <= 0 || m <= 0) return 0;
+    f4l::KnnWs w, wq;
+    if (f4l::knn_ws_layout(n, w, nullptr, true) != F4L_OK || f4l::knn_ws_layout(m, wq, nullptr, true) != F4L_OK) return 0;
+    return w.total + wq.total;
+}
+
+// Synchronises `stream` (both grids are sized with the host in the loop).  tgt_nn1_d2_out [m] may be null (no median wanted).
+extern "C" int f4l_epoch_join(const float *src, int64_t n, const float *tgt, int64_t m, double *tgt_nn1_d2_out, int32_t *tgt_to_src_out,
+                              void *workspace, size_t workspace_bytes, void *stream) {
+    using namespace f4l;
+    if (m == 0) return F4L_OK;
+    if (!src || !tgt || n <= 0 || m < 0 || !tgt_to_src_out || !workspace || (tgt_nn1_d2_out && m < 2)) return F4L_EINVAL;
+    if (n > 0x7fffffffLL || m > 0x7fffffffLL) return F4L_EUNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    KnnWs w, wq;
+    int rc = knn_ws_layout(n, w, (unsigned char *)workspace, true);
+    if (rc != F4L_OK) return rc;
+    rc = knn_ws_layout(m, wq, (unsigned char *)workspace + w.total, true);
+    if (rc != F4L_OK) return rc;
+    if (workspace_bytes < w.total + wq.total) return F4L_EWORKSPACE;
+    GridSpec g, gq;
+    int M = 0, Mq = 0;
+    rc = knn_build_grid(tgt, m, 2, wq, st, gq, Mq);  // (rejects NaN / inf coordinates)
+    if (rc != F4L_OK) return rc;
+    rc = knn_build_grid(src, n, 1, w, st, g, M);
+    if (rc != F4L_OK) return rc;
+    KnnArgs a;
+    a.d2_out = nullptr; a.dg = nullptr; a.q_cell_keys = nullptr; a.q_cell_start = nullptr; a.Mq = 0; a.q_sorted = wq.sorted;
+    if (tgt_nn1_d2_out) {  // the target cloud against itself, k = 2: slot 1 of every row
+        a.sorted = wq.sorted; a.cell_keys = wq.cell_keys; a.cell_start = wq.cell_start; a.M = Mq; a.n = m; a.k = 2; a.g = gq;
+        a.dense = wq.has_dense ? wq.dense : nullptr;
+        a.idx_out = nullptr; a.nn1_out = tgt_nn1_d2_out;
+        launch_nn_small(a, m, st);
+        F4L_LAUNCH_CHECK();
+    }
+    a.sorted = w.sorted; a.cell_keys = w.cell_keys; a.cell_start = w.cell_start; a.M = M; a.n = n; a.k = 1; a.g = g;
+    a.dense = w.has_dense ? w.dense : nullptr;
+    a.idx_out = tgt_to_src_out; a.nn1_out = nullptr;
+    launch_nn_small(a, m, st);
+    F4L_LAUNCH_CHECK();
     return F4L_OK;
 }
 
@@ -1830,8 +1954,24 @@ extern "C" size_t f4l_labels_to_csr_workspace_bytes(int64_t n, int64_t K) {
     return w.total;
 }
 
+namespace f4l {
+static int labels_to_csr_impl(const int32_t *labels, int64_t n_labels, const int32_t *via, int64_t n, int64_t K, int32_t *order_out,
+                              int64_t *off_out, void *workspace, size_t workspace_bytes, void *stream);
+}
 extern "C" int f4l_labels_to_csr(const int32_t *labels, int64_t n, int64_t K, int32_t *order_out, int64_t *off_out,
                                  void *workspace, size_t workspace_bytes, void *stream) {
+    return f4l::labels_to_csr_impl(labels, n, nullptr, n, K, order_out, off_out, workspace, workspace_bytes, stream);
+}
+// The same for a cloud whose rows take their labels from ANOTHER cloud's rows: row i of the m rows belongs to patch
+// labels[via[i]] (the second epoch's points joining the patch of their nearest first-epoch point: `labels[nn]` followed by
+// f4l_labels_to_csr, without materialising the gathered labels).  A `via` outside [0, n_labels) is "no patch".
+extern "C" int f4l_labels_to_csr_via(const int32_t *labels, int64_t n_labels, const int32_t *via, int64_t m, int64_t K, int32_t *order_out,
+                                     int64_t *off_out, void *workspace, size_t workspace_bytes, void *stream) {
+    if (m > 0 && (!via || n_labels <= 0)) return F4L_EINVAL;
+    return f4l::labels_to_csr_impl(labels, n_labels, via, m, K, order_out, off_out, workspace, workspace_bytes, stream);
+}
+static int f4l::labels_to_csr_impl(const int32_t *labels, int64_t n_labels, const int32_t *via, int64_t n, int64_t K, int32_t *order_out,
+                                   int64_t *off_out, void *workspace, size_t workspace_bytes, void *stream) {
     using namespace f4l;
     if (n < 0 || K <= 0 || !off_out || (n > 0 && (!labels || !order_out || !workspace))) return F4L_EINVAL;
     if (n > 0x7fffffffLL || K >= 0x7fffffffLL) return F4L_EUNSUPPORTED;
@@ -1844,7 +1984,7 @@ extern "C" int f4l_labels_to_csr(const int32_t *labels, int64_t n, int64_t K, in
     int rc = csr_ws_layout(n, K, w, (unsigned char *)workspace);
     if (rc != F4L_OK) return rc;
     if (workspace_bytes < w.total) return F4L_EWORKSPACE;
-    hipLaunchKernelGGL(label_keys_kernel, dim3(grid_for(n)), dim3(256), 0, st, labels, n, K, w.keys_in, w.iota);
+    hipLaunchKernelGGL(label_keys_kernel, dim3(grid_for(n)), dim3(256), 0, st, labels, n, K, w.keys_in, w.iota, via, n_labels);
     F4L_LAUNCH_CHECK();
     int end_bit = 1;
     while (end_bit < 31 && (1LL << end_bit) <= K) ++end_bit;  // the keys run 0 .. K inclusive

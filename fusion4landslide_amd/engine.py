@@ -118,11 +118,11 @@ def _median_of_sqrt(d2):
     return out
 
 
-def median_resolution(src, tgt=None, src_nn1_d2=None):
+def median_resolution(src, tgt=None, src_nn1_d2=None, tgt_nn1_d2=None):
     """`_compute_median_resolution` (src/coarse_to_fine_matching_base.py:2716-2754): median distance of every point to
     its nearest other point (exact 2-NN on the GPU, f4l_knn), the larger of the two clouds' medians when `tgt` is given.
     `src_nn1_d2`: the squared nearest-neighbour distances of `src` when a neighbour search of it has run already
-    (`knn_normals(..., return_nn1=True)`): its 2-NN pass is skipped.  Returns a Python float."""
+    (`knn_normals(..., return_nn1=True)`): its 2-NN pass is skipped; `tgt_nn1_d2` likewise (`epoch_join`).  Returns a Python float."""
     torch = require_gpu()
 
     def one(xyz):
@@ -132,7 +132,8 @@ def median_resolution(src, tgt=None, src_nn1_d2=None):
     r = one(src) if src_nn1_d2 is None else _median_of_sqrt(_dev(src_nn1_d2, torch.float64, "src_nn1_d2"))
     if tgt is None:
         return float(r.item())
-    return float(torch.maximum(r, one(tgt)).item())  # one read-back for both clouds
+    rt = one(tgt) if tgt_nn1_d2 is None else _median_of_sqrt(_dev(tgt_nn1_d2, torch.float64, "tgt_nn1_d2"))  # (epoch_join's)
+    return float(torch.maximum(r, rt).item())  # one read-back for both clouds
 
 
 def kabsch_residuals(src, ref, off, R, t):
@@ -703,6 +704,39 @@ def labels_to_csr(labels, K):
     check(lib().f4l_labels_to_csr(ptr(labels), n, int(K), ptr(order), ptr(off), ptr(ws), C.c_size_t(nbytes),
                                   stream_ptr()), "f4l_labels_to_csr")
     return order, off
+
+
+def labels_to_csr_via(labels, via, K):
+    """`labels_to_csr(labels[via], K)` without the gathered labels: row i of `via` (int32 rows of `labels`; outside = no patch)
+    belongs to patch labels[via[i]] -> (order (m,) int32, off (K+1,) int64).  f4l_labels_to_csr_via."""
+    torch = require_gpu()
+    labels = _dev(labels, torch.int32, "labels")
+    via = _dev(via, torch.int32, "via")
+    m = via.shape[0]
+    order = torch.empty((m,), dtype=torch.int32, device=labels.device)
+    off = torch.empty((K + 1,), dtype=torch.int64, device=labels.device)
+    nbytes = lib().f4l_labels_to_csr_workspace_bytes(m, K)
+    ws = torch.empty((max(int(nbytes), 1),), dtype=torch.uint8, device=labels.device)
+    check(lib().f4l_labels_to_csr_via(ptr(labels), labels.shape[0], ptr(via), m, int(K), ptr(order), ptr(off), ptr(ws),
+                                      C.c_size_t(nbytes), stream_ptr()), "f4l_labels_to_csr_via")
+    return order, off
+
+
+def epoch_join(src, tgt, return_nn1=True):
+    """The two searches over the second epoch with ONE binning of it (f4l_epoch_join): -> (tgt_to_src (m,) int32 = every target
+    point's nearest source point, the `nn_query(src, tgt, 1)` of the label transfer; tgt_nn1_d2 (m,) float64 = its squared
+    distance to the nearest other target point, what `_compute_median_resolution` (src/coarse_to_fine_matching_base.py:2716-2754)
+    takes the median of -- or None)."""
+    torch = require_gpu()
+    src = _dev(src, torch.float32, "src", (3,))
+    tgt = _dev(tgt, torch.float32, "tgt", (3,))
+    n, m = src.shape[0], tgt.shape[0]
+    idx = torch.empty((m,), dtype=torch.int32, device=src.device)
+    nn1 = torch.empty((m,), dtype=torch.float64, device=src.device) if return_nn1 else None
+    nbytes = lib().f4l_epoch_join_workspace_bytes(n, m)
+    ws = torch.empty((max(int(nbytes), 1),), dtype=torch.uint8, device=src.device)
+    check(lib().f4l_epoch_join(ptr(src), n, ptr(tgt), m, ptr(nn1), ptr(idx), ptr(ws), C.c_size_t(nbytes), stream_ptr()), "f4l_epoch_join")
+    return idx, nn1
 
 
 def gather_points(pts, order):

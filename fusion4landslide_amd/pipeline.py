@@ -48,8 +48,12 @@ def full_path(src, tgt, k=30, icp_threshold=0.1, voxel_size=0.0, partition="para
         else:
             knn_idx, nrm, nn1 = engine.knn_normals(src, k, return_nn1=True)
         mark("neighbours")
-        med = engine.median_resolution(src, tgt, src_nn1_d2=nn1)
+        # the second epoch is binned once for both of its searches: nearest other target point (the median) and nearest source
+        # point (the patch it joins once the labels exist) -- f4l_epoch_join
+        tgt_nn, tgt_nn1 = engine.epoch_join(src, tgt)
+        med = engine.median_resolution(src, tgt, src_nn1_d2=nn1, tgt_nn1_d2=tgt_nn1)
         resolution = max(np.sqrt(3.0) * 10.0 * med, float(voxel_size), 1e-6)  # base:2668-2671
+        del tgt_nn1
         mark("median_resolution")
         if nb is not None:
             labels, info = engine.partition_segment(nb, float(resolution))
@@ -62,6 +66,7 @@ def full_path(src, tgt, k=30, icp_threshold=0.1, voxel_size=0.0, partition="para
         del nb, knn_idx, nn1
         mark("supervoxel_partition")
     else:
+        tgt_nn = None
         if resolution is None:
             med = engine.median_resolution(src, tgt)
             resolution = max(np.sqrt(3.0) * 10.0 * med, float(voxel_size), 1e-6)  # base:2668-2671
@@ -70,7 +75,7 @@ def full_path(src, tgt, k=30, icp_threshold=0.1, voxel_size=0.0, partition="para
         mark("median_resolution")
         labels, K = (engine.supervoxel_parallel if partition == "parallel" else engine.supervoxel)(src, k, float(resolution))
         mark("supervoxel_partition")
-    st = _patches_and_registration(torch, src, tgt, labels, None, K, med, icp_threshold, max_iter, fixed_iters, search, mark, keep_inputs)
+    st = _patches_and_registration(torch, src, tgt, labels, tgt_nn, K, med, icp_threshold, max_iter, fixed_iters, search, mark, keep_inputs)
     torch.cuda.synchronize()
     ms = {stages[i]: marks[i - 1].elapsed_time(marks[i]) for i in range(1, len(stages))}
     ms["total"] = marks[0].elapsed_time(marks[-1])
@@ -79,11 +84,15 @@ def full_path(src, tgt, k=30, icp_threshold=0.1, voxel_size=0.0, partition="para
 
 def _patches_and_registration(torch, src, tgt, labels, tgt_nn, K, med, icp_threshold, max_iter, fixed_iters, search, mark, keep_inputs=False):
     """The stages after the partition, on one device: patches of both epochs (a target point joins the patch of its nearest
-    source point: `tgt_nn` (m,) int64 indices into `src` when the caller has them already, else f4l_nn_query), point matches,
+    source point: `tgt_nn` (m,) int32 / int64 indices into `src` when the caller has them already, else f4l_nn_query), point matches,
     the per-patch loop, the refinement.  Returns dict(rows, sparse, T, fitness, rmse, iters, order, src_off, tgt_off)."""
     order_s, off_s = engine.labels_to_csr(labels, K)
-    nn = engine.nn_query(src, tgt, 1)[:, 0].to(torch.int64) if tgt_nn is None else tgt_nn
-    order_t, off_t = engine.labels_to_csr(labels[nn], K)
+    if tgt_nn is None:
+        tgt_nn = engine.nn_query(src, tgt, 1)[:, 0]
+    if tgt_nn.dtype == torch.int32:
+        order_t, off_t = engine.labels_to_csr_via(labels, tgt_nn.contiguous(), K)
+    else:
+        order_t, off_t = engine.labels_to_csr(labels[tgt_nn], K)
     ps, pt = engine.gather_points(src, order_s), engine.gather_points(tgt, order_t)
     mark("patches")
     P = K

@@ -380,6 +380,21 @@ int f4l_write_partition_txt(const char *path, const float *xyz_host, const int32
 size_t f4l_labels_to_csr_workspace_bytes(int64_t n, int64_t K);
 int f4l_labels_to_csr(const int32_t *labels, int64_t n, int64_t K, int32_t *order_out, int64_t *off_out,
                       void *workspace, size_t workspace_bytes, void *stream);
+/* The same for a cloud whose m rows take their labels from ANOTHER cloud's rows: row i belongs to patch labels[via[i]]
+ * (`labels[nn]` followed by f4l_labels_to_csr without materialising the gathered labels: how the second epoch's points join the
+ * patch of their nearest first-epoch point, via = f4l_epoch_join's tgt_to_src_out).  A via outside [0, n_labels) is "no patch".
+ * Workspace: f4l_labels_to_csr_workspace_bytes(m, K). */
+int f4l_labels_to_csr_via(const int32_t *labels, int64_t n_labels, const int32_t *via, int64_t m, int64_t K, int32_t *order_out,
+                          int64_t *off_out, void *workspace, size_t workspace_bytes, void *stream);
+
+/* The two searches the path runs over the SECOND epoch of a tile, with one binning of it: tgt_nn1_d2_out double [m] (nullable) =
+ * every target point's squared distance to its nearest other target point -- what `_compute_median_resolution`
+ * (src/coarse_to_fine_matching_base.py:2716-2754) takes the median of; tgt_to_src_out int32 [m] = index of its nearest SOURCE
+ * point (ties by index) -- f4l_knn(tgt, 2) and f4l_nn_query(src, n, tgt, m, 1) in one call: same values, the target cloud
+ * sorted once instead of twice.  Synchronises `stream` (grid sizing).  Non-finite coordinates: F4L_EINVAL. */
+size_t f4l_epoch_join_workspace_bytes(int64_t n, int64_t m);
+int f4l_epoch_join(const float *src, int64_t n, const float *tgt, int64_t m, double *tgt_nn1_d2_out, int32_t *tgt_to_src_out,
+                   void *workspace, size_t workspace_bytes, void *stream);
 
 /* Median of n doubles values[i * stride] as numpy.median computes it (the middle element, or the mean of the middle pair) --
  * the last step of `_compute_median_resolution` (src/coarse_to_fine_matching_base.py:2716-2754: median of the nearest-

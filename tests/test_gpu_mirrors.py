@@ -302,6 +302,53 @@ def test_nn_query_vs_kdtree():
     assert engine.nn_query(torch.from_numpy(cloud).cuda(), torch.zeros((0, 3)).cuda(), 1).shape == (0, 1)
 
 
+def test_epoch_join_is_the_two_searches_it_replaces():
+    """f4l_epoch_join: the second epoch binned once for its two searches.  Bit-equal to f4l_knn(tgt, 2)[:, 1] (what
+    `_compute_median_resolution`, src/coarse_to_fine_matching_base.py:2716-2754, takes the median of) and to
+    f4l_nn_query(src, tgt, 1) (the label transfer), both checked against a KD-tree above; targets inside, at the border of
+    and far outside the source's box; f4l_labels_to_csr_via = f4l_labels_to_csr of the gathered labels."""
+    from scipy.spatial import cKDTree
+    from fusion4landslide_amd import engine, synthetic
+    rng = np.random.default_rng(43)
+    c = synthetic.two_epoch_cloud(80_000, 9, 1.386, seed=8)
+    src = c["src"]
+    tgt = np.concatenate([c["tgt"][:50_000], src[:300], rng.uniform(-30, 40, (300, 3)).astype(np.float32),
+                          src[:200] + np.float32([0, 0, 25.0]), c["tgt"][:7]])      # (exact duplicates inside tgt: nn1 = 0)
+    s_d, t_d = torch.from_numpy(src).cuda(), torch.from_numpy(tgt).cuda()
+    idx, nn1 = engine.epoch_join(s_d, t_d)
+    _, d2 = engine.knn(t_d, 2, return_d2=True)
+    assert torch.equal(nn1, d2[:, 1].contiguous())
+    assert torch.equal(idx, engine.nn_query(s_d, t_d, 1)[:, 0].contiguous())
+    dref, _ = cKDTree(src.astype(np.float64)).query(tgt.astype(np.float64), k=1)
+    got = np.sqrt(((src[idx.cpu().numpy()].astype(np.float64) - tgt.astype(np.float64)) ** 2).sum(1))
+    assert np.abs(got - dref).max() <= 1e-12 * max(1.0, dref.max())
+    assert engine.median_resolution(s_d, t_d) == engine.median_resolution(s_d, t_d, tgt_nn1_d2=nn1)
+    idx_only, none = engine.epoch_join(s_d, t_d, return_nn1=False)
+    assert none is None and torch.equal(idx_only, idx)
+    # labels through the join
+    K = 53
+    labels = rng.integers(0, K, len(src)).astype(np.int32)
+    labels[rng.choice(len(src), 500, replace=False)] = -1
+    l_d = torch.from_numpy(labels).cuda()
+    o1, f1 = engine.labels_to_csr(l_d[idx.to(torch.int64)], K)
+    o2, f2 = engine.labels_to_csr_via(l_d, idx, K)
+    assert torch.equal(o1, o2) and torch.equal(f1, f2)
+    via = idx.clone()
+    via[::97] = -1
+    via[5::101] = len(src) + 3                                                       # outside the labelled cloud: no patch
+    lab_of = np.where((via.cpu().numpy() >= 0) & (via.cpu().numpy() < len(src)), labels[np.clip(via.cpu().numpy(), 0, len(src) - 1)], -1)
+    o3, f3 = engine.labels_to_csr_via(l_d, via, K)
+    o4, f4 = engine.labels_to_csr(torch.from_numpy(lab_of.astype(np.int32)).cuda(), K)
+    assert torch.equal(o3, o4) and torch.equal(f3, f4)
+    # two points per cloud, one target
+    i2, n2 = engine.epoch_join(s_d[:2], t_d[:2])
+    assert i2.shape == (2,) and n2.shape == (2,) and abs(float(n2[0]) - float(((tgt[0].astype(np.float64) - tgt[1]) ** 2).sum())) <= 1e-12
+    with pytest.raises(Exception):
+        engine.epoch_join(s_d, t_d[:1])                                              # (no "other" target point: EINVAL)
+    i1, _ = engine.epoch_join(s_d, t_d[:1], return_nn1=False)
+    assert int(i1[0]) == int(idx[0])
+
+
 def test_voxel_downsample_and_subsampling_vs_oracle():
     """f4l_voxel_downsample against the numpy restatement of Open3D's voxel grid filter, and the whole
     `_voxel_subsampling` bookkeeping (src/coarse_to_fine_matching_base.py:1012-1057) against numpy + a KD-tree."""

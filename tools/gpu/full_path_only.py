@@ -18,5 +18,6 @@ for _ in range(reps):
     r = pipeline.full_path(src, tgt, max_iter=20, fixed_iters=True)
     torch.cuda.synchronize()
     wall = 1e3 * (time.perf_counter() - t)
-    print(f"wall {wall:.2f} ms  " + "  ".join(f"{k} {v:.2f}" for k, v in r["stage_ms"].items()), flush=True)
+    print(f"wall {wall:.2f} ms  " + "  ".join(f"{k} {v:.2f}" for k, v in r["stage_ms"].items())
+          + f"  [reserved {torch.cuda.memory_reserved() / 2**30:.1f} GiB, peak allocated {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB]", flush=True)
 print("K", int(r["K"]), "mean fitness", float(r["fitness"].mean()))
