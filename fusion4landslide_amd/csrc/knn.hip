@@ -410,7 +410,7 @@ __global__ __launch_bounds__(KNN_NW * 64) void knn_listed_kernel(KnnArgs a, cons
 // second epoch: 0.2-0.5 m against cells of 0.125 m) ends with a block of ~11 x 11 cells = ~500 candidates.  1 M queries, k = 1,
 // a quarter of them displaced: 0.25 ms (lane kernel + one wave per uncertified query: 0.40 + 2.9 ms in round 2b).
 // `list` = nullptr: all nq queries of q_sorted; else the listed ones.
-constexpr int KS_MAX_K = 4;
+constexpr int KS_MAX_K = 4, KS_BATCH = 4;
 // Round 5: the walk is two-stage.  Every candidate used to cost an exact double distance and an insertion by (d2, index) into four
 // slots (~150 SIMD cycles a candidate and wave: 2.2 ms per 10 M queries whatever k).  Now the block is scanned in float32 -- the
 // differences of neighbouring float coordinates are exact, three roundings remain: d2 to 2e-7 of itself -- keeping the KK + 1
@@ -448,35 +448,68 @@ __global__ __launch_bounds__(256) void nn_small_kernel(KnnArgs a, int nq, const 
                      fz = ((double)qp.z - g.minz) - (double)cz * g.h;
         double bd[KK];
         int bi[KK];
+        // From the second round on the previous round's k-th distance bounds the answer: only the cells a ball of that radius around
+        // the query reaches are walked -- rows of cells farther than it in y / z are skipped, the others clipped in x (a query displaced
+        // against the cloud by a few cells, a moving slope's second epoch, used to walk the whole square block again: 9 x 9 cells
+        // where the disc covers a fifth of them).  What lies in the block outside the ball is farther than the k candidates already
+        // known, so the walk's result is that of the whole block, and the block's certificate below stands.
+        double lim = __builtin_inf();
+        const double qxr = fx + (double)cx * g.h;  // the query's x in the grid's frame
+        auto gap = [&](double f, int c, int cc) {  // distance along one axis from the query (offset f in its cell c) to cell cc
+            const double d = cc > c ? (double)(cc - c) * g.h - f : (cc < c ? f - (double)(cc + 1 - c) * g.h : 0.0);
+            return d > 0.0 ? d : 0.0;
+        };
         for (int R = 1;;) {
             const int x0 = cx - R < 0 ? 0 : cx - R, x1 = cx + R >= g.nx ? g.nx - 1 : cx + R;
             const int y0 = cy - R < 0 ? 0 : cy - R, y1 = cy + R >= g.ny ? g.ny - 1 : cy + R;
             const int z0 = cz - R < 0 ? 0 : cz - R, z1 = cz + R >= g.nz ? g.nz - 1 : cz + R;
+            auto walk = [&](auto &&visit) {
+                for (int zz = z0; zz <= z1; ++zz) {
+                    const double gz = g.nz > 1 ? gap(fz, cz, zz) : 0.0;
+                    if (gz * gz > lim) continue;
+                    for (int yy = y0; yy <= y1; ++yy) {
+                        const double gy = gap(fy, cy, yy);
+                        const double rem = lim - gz * gz - gy * gy;
+                        if (rem < 0.0) continue;
+                        int xa = x0, xb = x1;
+                        if (lim < __builtin_inf()) {
+                            const double w = sqrt(rem) + eps;
+                            const double lo_c = floor((qxr - w) * g.inv_h), hi_c = floor((qxr + w) * g.inv_h);
+                            xa = lo_c > (double)x0 ? (int)lo_c : x0;
+                            xb = hi_c < (double)x1 ? (int)hi_c : x1;
+                            if (xa > xb) continue;
+                        }
+                        int lo, hi;
+                        cell_range(a.dense, a.cell_keys, a.cell_start, a.M, key_of(g, xa, yy, zz), key_of(g, xb, yy, zz), lo, hi);
+                        for (int j = lo; j < hi; j += KS_BATCH) {  // (KS_BATCH loads in flight per lane instead of one dependent chain)
+                            float4 c[KS_BATCH];
+#pragma unroll
+                            for (int u = 0; u < KS_BATCH; ++u) c[u] = a.sorted[j + u < hi ? j + u : hi - 1];
+#pragma unroll
+                            for (int u = 0; u < KS_BATCH; ++u) visit(c[u], j + u, j + u < hi);
+                        }
+                    }
+                }
+            };
             // stage 1: the KK + 1 smallest approximate d2 of the block, with their positions in the sorted array
             float fd[KK + 1];
             int fj[KK + 1];
 #pragma unroll
             for (int t = 0; t <= KK; ++t) { fd[t] = __builtin_inff(); fj[t] = -1; }
-            for (int zz = z0; zz <= z1; ++zz)
-                for (int yy = y0; yy <= y1; ++yy) {
-                    int lo, hi;
-                    cell_range(a.dense, a.cell_keys, a.cell_start, a.M, key_of(g, x0, yy, zz), key_of(g, x1, yy, zz), lo, hi);
-                    for (int j = lo; j < hi; ++j) {
-                        const float4 cp = a.sorted[j];
-                        const float dx = cp.x - qp.x, dy = cp.y - qp.y, dz = cp.z - qp.z;
-                        float d = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
-                        int jj = j;
+            walk([&](const float4 &cp, int j, bool real) {
+                const float dx = cp.x - qp.x, dy = cp.y - qp.y, dz = cp.z - qp.z;
+                float d = real ? __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx)) : __builtin_inff();
+                int jj = j;
 #pragma unroll
-                        for (int t = 0; t <= KK; ++t) {
-                            const bool lt = d < fd[t];
-                            const float dn = lt ? fd[t] : d;
-                            const int jn = lt ? fj[t] : jj;
-                            fd[t] = lt ? d : fd[t];
-                            fj[t] = lt ? jj : fj[t];
-                            d = dn; jj = jn;
-                        }
-                    }
+                for (int t = 0; t <= KK; ++t) {
+                    const bool lt = d < fd[t];
+                    const float dn = lt ? fd[t] : d;
+                    const int jn = lt ? fj[t] : jj;
+                    fd[t] = lt ? d : fd[t];
+                    fj[t] = lt ? jj : fj[t];
+                    d = dn; jj = jn;
                 }
+            });
             // slots k - 1 and k (0-based): is the gap between them more than the float32 error of either?
             float f_k1 = fd[0], f_k = fd[KK];
 #pragma unroll
@@ -497,15 +530,10 @@ __global__ __launch_bounds__(256) void nn_small_kernel(KnnArgs a, int nq, const 
                     }
             } else {
                 // near-ties around the k-th neighbour: the exact walk
-                for (int zz = z0; zz <= z1; ++zz)
-                    for (int yy = y0; yy <= y1; ++yy) {
-                        int lo, hi;
-                        cell_range(a.dense, a.cell_keys, a.cell_start, a.M, key_of(g, x0, yy, zz), key_of(g, x1, yy, zz), lo, hi);
-                        for (int j = lo; j < hi; ++j) {
-                            const float4 cp = a.sorted[j];
-                            ks_insert_exact<KK>(bd, bi, dist2_exact(cp.x, cp.y, cp.z, qp.x, qp.y, qp.z), __float_as_int(cp.w));
-                        }
-                    }
+                walk([&](const float4 &cp, int, bool real) {
+                    ks_insert_exact<KK>(bd, bi, real ? dist2_exact(cp.x, cp.y, cp.z, qp.x, qp.y, qp.z) : __builtin_inf(),
+                                        real ? __float_as_int(cp.w) : 0x7fffffff);
+                });
             }
             double dk = bd[0];
 #pragma unroll
@@ -525,6 +553,7 @@ __global__ __launch_bounds__(256) void nn_small_kernel(KnnArgs a, int nq, const 
                 const double need = (sqrt(dk) + eps) * g.inv_h + 1.0;
                 const int Rj = need < (double)max_dim ? (int)need : max_dim;
                 R = Rj > R + 1 ? Rj : R + 1;
+                lim = dk * (1.0 + 1e-12);
             }
         }
         if (a.nn1_out) {  // (f4l_epoch_join: only the distance to the nearest other point is wanted; k = 2 there)
@@ -1193,6 +1222,7 @@ __global__ void label_bounds_kernel(const int32_t *__restrict__ sorted, int64_t 
     }
 }
 
+constexpr int BBOX_BLOCKS = 2048;  // partial boxes of bbox_kernel (256 workgroups -- one per CU -- read at a third of the bandwidth)
 static inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
 static inline unsigned grid_for(int64_t n, int block = 256, int cap = 4096) {
     int64_t b = (n + block - 1) / block;
@@ -1254,7 +1284,7 @@ static int knn_ws_layout(int64_t n, KnnWs &w, unsigned char *base, bool small_k 
     w.pcell = (int32_t *)carve(small_k ? 256 : (size_t)n * 4);
     w.dense = (int32_t *)carve((2 * (size_t)n + 4) * 4);
     w.has_dense = false;
-    w.bbox_partial = (float *)carve(256 * 6 * 4);
+    w.bbox_partial = (float *)carve(BBOX_BLOCKS * 6 * 4);
     w.prim_temp = carve(prim);
     w.prim_bytes = prim;
     w.total = o;
@@ -1275,10 +1305,10 @@ namespace f4l {
 // Steps 1-4 of f4l_knn: bounding box, cell size for ~k/2 points per occupied cell, points sorted by cell, occupied-cell
 // table.  Synchronises `st`.
 static int bbox_to_host(const float *xyz, int64_t n, float *partial, hipStream_t st, double *mn, double *mx) {
-    const unsigned bb_grid = grid_for(n, 256, 256);
+    const unsigned bb_grid = grid_for(n, 256, BBOX_BLOCKS);
     hipLaunchKernelGGL(bbox_kernel, dim3(bb_grid), dim3(256), 0, st, xyz, n, partial);
     F4L_LAUNCH_CHECK();
-    float hb[256 * 6];
+    float hb[BBOX_BLOCKS * 6];
     F4L_HIP_CHECK(hipMemcpyAsync(hb, partial, (size_t)bb_grid * 6 * 4, hipMemcpyDeviceToHost, st));
     F4L_HIP_CHECK(hipStreamSynchronize(st));
     for (int d = 0; d < 3; ++d) { mn[d] = 1e300; mx[d] = -1e300; }
@@ -1338,7 +1368,7 @@ __global__ void grid_init_kernel(const float *__restrict__ partial, int nb, int6
 __global__ void grid_finish_kernel(DevGrid *dg, const int32_t *__restrict__ n_cells) { dg->M = *n_cells; }
 
 static int knn_build_grid_async(const float *xyz, int64_t n, int k, KnnWs &w, hipStream_t st, DevGrid *dg) {
-    const unsigned bb_grid = grid_for(n, 256, 256);
+    const unsigned bb_grid = grid_for(n, 256, BBOX_BLOCKS);
     hipLaunchKernelGGL(bbox_kernel, dim3(bb_grid), dim3(256), 0, st, xyz, n, w.bbox_partial);
     hipLaunchKernelGGL(grid_init_kernel, dim3(1), dim3(1), 0, st, w.bbox_partial, (int)bb_grid, n, k, dg);
     F4L_LAUNCH_CHECK();
