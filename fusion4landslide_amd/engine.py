@@ -344,6 +344,10 @@ def merge_tiles(tiles):
         return torch.cat(parts)
     m = {k: cat_pts(k) for k in ("src", "tgt", "corr_src", "corr_ref", "corr_weights", "rows_src")}
     m.update({k: cat_off(k, v) for k, v in (("src_off", "src"), ("tgt_off", "tgt"), ("corr_off", "corr_src"), ("rows_off", "rows_src"))})
+    # (the fine matching registers the mutual points themselves: its tiles pass the same arrays as cloud and as matches)
+    for dup, of in (("corr_src", "src"), ("corr_ref", "tgt"), ("corr_off", "src_off"), ("tgt_off", "src_off")):
+        if all(t.get(dup) is t.get(of) for t in tiles):
+            m[dup] = m[of]
     for key, name in (("max_src", "max_src_patch"), ("max_tgt", "max_tgt_patch")):
         if all(key in t for t in tiles):
             m[name] = max(int(t[key]) for t in tiles)

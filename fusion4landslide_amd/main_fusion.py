@@ -25,6 +25,7 @@ import os
 import os.path as osp
 import time
 
+from . import engine
 from .src.coarse_to_fine_matching import Coarse2Fine
 from .utils.common import AttrDict, access_device, get_logger, load_yaml, setup_seed
 from .utils.tiles import for_each_tile, prepare_tiles
@@ -44,8 +45,10 @@ def build_config(path, log_prefix='coarse2fine_matching'):
     return cfg, log_path
 
 
-def run(cfg, first_tile=0):
-    """main_fusion.py:106-148 on a prepared cfg (also the entry for callers that attach the matching hooks)."""
+def run(cfg, first_tile=0, tiles_per_launch=8):
+    """main_fusion.py:106-148 on a prepared cfg (also the entry for callers that attach the matching hooks).  `tiles_per_launch`
+    tiles share one per-patch launch (engine.patch_loop_tiles; 1 = the reference's tile-by-tile order of work; results agree to
+    rounding, 1e-9 m in a transform, whatever the batch)."""
     import torch
     tile_dir = cfg.path_name.tile_dir = osp.join(cfg.path_name.output_root, 'tiled_data')
 
@@ -58,7 +61,13 @@ def run(cfg, first_tile=0):
 
     with torch.no_grad():
         tiles = prepare_tiles(tile_dir, tiling_config, cfg.logging)
-        for_each_tile(cfg, tiles, lambda c: Coarse2Fine(c).implement_c2f_matching(), cfg.logging, first=first_tile)
+        def launch(states):
+            kw = states[0].fine_state["loop_kw"]
+            assert all(s.fine_state["loop_kw"] == kw for s in states)  # (one config: one set of loop parameters)
+            return engine.patch_loop_tiles([s.fine_state["loop_args"] for s in states], **kw)
+
+        for_each_tile(cfg, tiles, lambda c: Coarse2Fine(c).implement_c2f_matching(), cfg.logging, first=first_tile, batch=int(tiles_per_launch),
+                      stages=(lambda c: Coarse2Fine(c).prepare_c2f(), launch, lambda s, out: s.finish_c2f(out)))
     return tiles
 
 
@@ -69,6 +78,8 @@ def main(argv=None):
     parser.add_argument('--partition', type=str, default=None, choices=['identical', 'parallel'],
                         help="supervoxel segmentation: the reference's labels (default) or the all-device segmentation")
     parser.add_argument('--first-tile', type=int, default=0)
+    parser.add_argument('--tiles-per-launch', type=int, default=8,
+                        help="tiles whose per-patch loops run as ONE launch (results agree to rounding; 1 = tile by tile like the reference)")
     args = parser.parse_args(argv)
     mode = args.partition or os.environ.get("F4L_SV_MODE", "identical")
     if mode not in ("identical", "parallel"):  # (before tiling starts, not inside the first computeSupervoxel)
@@ -82,7 +93,7 @@ def main(argv=None):
                      "(device segmentation: the reference's K and criteria, NOT its labels; partition files differ from the reference's)"))
     start = time.time()
     try:
-        run(cfg, args.first_tile)
+        run(cfg, args.first_tile, args.tiles_per_launch)
     finally:
         supervoxel.SEGMENTATION = mode_before  # (the module's own default is its callers' business, not this entry's)
     if cfg.verbose:

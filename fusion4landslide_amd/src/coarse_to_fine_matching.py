@@ -30,7 +30,7 @@ from .. import engine
 from ..cpp_core.supervoxel_segmentation.build import supervoxel as supervoxel_partition
 from ..utils.common import AttrDict, dir_exist
 from ..utils.ply import read_ply
-from .fine_matching import fine_matching_3d
+from .fine_matching import fine_matching_3d, fine_matching_finish, fine_matching_prepare  # noqa: F401
 
 
 def _get(d, key, default=None):
@@ -121,6 +121,7 @@ class Coarse2Fine:
         self.logging = config.logging
         self.output_root = config.path_name.output_root
         self.device = _get(config, "device")
+        self.tile_id = _get(config, "tile_id", 0)  # (captured now: the tile loop moves the config on before a batched tile is finished)
         self.data_input_3d, self.data_interim, self.data_output = AttrDict(), AttrDict(), AttrDict()
         if self.method.partition_type != "supervoxel":
             raise NotImplementedError(f"partition_type {self.method.partition_type!r}: only 'supervoxel' is built here (the superpoint "
@@ -168,7 +169,7 @@ class Coarse2Fine:
         self.data_interim.svl_radius = float(svl_radius)
         partition_path = osp.join(self.output_root, f"{self.method.partition_type}_partition")
         dir_exist(partition_path)
-        tag = f"_tile_{self.config.tile_id}" if self.data.multiple_case else ""
+        tag = f"_tile_{self.tile_id}" if self.data.multiple_case else ""
         save = bool(_get(self.method, "save_partition", True))
         labels = []
         for which, path in (("src", self.src_pcd_path), ("tgt", self.tgt_pcd_path)):
@@ -259,11 +260,20 @@ class Coarse2Fine:
 
     # ---- base:3236-3436 --------------------------------------------------------------------------------------------------------
     def fine_matching_with_different_types(self):
+        self.fine_matching_prepare()
+        a = self.fine_state["loop_args"]
+        out = engine.patch_loop(a["src"], a["src_off"], a["tgt"], a["tgt_off"], a["corr_src"], a["corr_ref"], a["corr_off"], a["corr_weights"],
+                                0.0, 1e-6, rows_src=a["rows_src"], rows_off=a["rows_off"], **self.fine_state["loop_kw"])
+        self.fine_matching_finish(out)
+
+    def fine_matching_prepare(self):
+        """Everything of base:3236-3436 before the per-patch loop; leaves `self.fine_state` (fine_matching.fine_matching_prepare), whose
+        `loop_args` / `loop_kw` one f4l_patch_loop launch takes -- this tile's alone, or several tiles' merged (main_fusion)."""
         I, O, m = self.data_interim, self.data_output, self.method
         if not _get(m, "icp_refine", True):
             raise NotImplementedError("icp_refine: False leaves the reference without an output (base:3441-3442)")
         c2d = None if I.corres_3d_from_2d_idx is None else I.corres_3d_from_2d_idx[:, 1]
-        res = fine_matching_3d(
+        self.fine_state = fine_matching_prepare(
             self.data_input_3d.src_pts, self.data_input_3d.tgt_pts, O.spt_corres_src_ids, O.spt_corres_src_off, O.spt_corres_tgt_ids,
             O.spt_corres_tgt_off, I.corres_3d_voxel_from_3d_idx[:, 1], corr_tgt_2d=c2d, matching=self.matching,
             weighting_svd=bool(_get(m, "weighting_svd", False)), num_min_fine_match=int(m.num_min_fine_match),
@@ -272,6 +282,11 @@ class Coarse2Fine:
             thres_inlier_ratio=float(_get(m, "thres_inlier_ratio", 0.5)), assign_type=m.assign_type, output_tgt2src=bool(_get(m, "output_tgt2src", False)),
             median_max_resolution=float(self.para.median_max_resolution),
             rigidity_precision=str(_get(m, "rigidity_precision", "f64")))  # (this build's key; the reference has no such choice)
+
+    def fine_matching_finish(self, out):
+        O = self.data_output
+        res = fine_matching_finish(self.fine_state, out)
+        self.fine_state = None
         O.fine = res
         O.corres_3d_refine_apply_icp = res["dense"]
         O.corres_3d_refine_apply_icp_discrete = res["sparse"]
@@ -281,12 +296,21 @@ class Coarse2Fine:
 
     def save_process_dvf(self):
         O = self.data_output
-        return save_process_dvf(self.output_root, _get(self.config, "tile_id", 0), self.data.dataset, O.corres_3d_refine_apply_icp,
+        return save_process_dvf(self.output_root, self.tile_id, self.data.dataset, O.corres_3d_refine_apply_icp,
                                 O.corres_3d_refine_apply_icp_discrete, O.corres_3d_refine_apply_icp_tgt2src,
                                 multiple_case=bool(self.data.multiple_case), voxel_size=_get(self.method, "voxel_size"))
 
     # ---- src/coarse_to_fine_matching.py:201-290 -------------------------------------------------------------------------------
     def implement_c2f_matching(self):
+        self.prepare_c2f()
+        a = self.fine_state["loop_args"]
+        return self.finish_c2f(engine.patch_loop(a["src"], a["src_off"], a["tgt"], a["tgt_off"], a["corr_src"], a["corr_ref"], a["corr_off"],
+                                                 a["corr_weights"], 0.0, 1e-6, rows_src=a["rows_src"], rows_off=a["rows_off"],
+                                                 **self.fine_state["loop_kw"]))
+
+    # The same in two halves around the per-patch loop, so that the loop of SEVERAL tiles can be one launch (a <= 1 M-point tile's
+    # ~2000 patch matches are two rounds of workgroups on an MI355X: main_fusion's tile loop merges them, utils/tiles.py).
+    def prepare_c2f(self):
         if self.verbose:
             self.logging.info("Skip 2d matching!" if self.matching == "only_3d" else
                               "2d matching is not run here: its lifted matches come in as cfg.point_matches_from_2d")
@@ -296,7 +320,11 @@ class Coarse2Fine:
         self.prepare_pts2spt_dict()
         self.global_matches_from_3d()
         self.coarse_matching_with_different_types()
-        self.fine_matching_with_different_types()
+        self.fine_matching_prepare()
+        return self
+
+    def finish_c2f(self, out):
+        self.fine_matching_finish(out)
         if self.data_output.corres_3d_refine_apply_icp.shape[0]:
             self.written = self.save_process_dvf()
         return self.data_output

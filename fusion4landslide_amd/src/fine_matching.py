@@ -22,11 +22,21 @@ Patch matches are CSR: match i pairs the source points `src_ids[src_off[i]:src_o
 from .. import engine
 
 
-def fine_matching_3d(src_pts, tgt_pts, src_ids, src_off, tgt_ids, tgt_off, corr_tgt, *, corr_tgt_2d=None, matching="only_3d",
-                     weighting_svd=False, num_min_fine_match=3, icp_threshold=0.1, remove_low_quality_patch_matches=False,
-                     num_min_matches_for_quality_check=10, thres_dist_diff=0.05, thres_inlier_ratio=0.5, assign_type="assign_all_src",
-                     output_tgt2src=False, median_max_resolution=0.0, icp_type="point2point", init_round_f32=True,
-                     rigidity_precision="f64"):
+def fine_matching_3d(src_pts, tgt_pts, src_ids, src_off, tgt_ids, tgt_off, corr_tgt, **kw):
+    """prepare -> ONE f4l_patch_loop launch -> finish; see :func:`fine_matching_prepare` for the arguments and the result.  The two
+    halves are separate so that the launches of SEVERAL tiles can be one (main_fusion's tile loop: engine.patch_loop_tiles)."""
+    st = fine_matching_prepare(src_pts, tgt_pts, src_ids, src_off, tgt_ids, tgt_off, corr_tgt, **kw)
+    a = st["loop_args"]
+    out = engine.patch_loop(a["src"], a["src_off"], a["tgt"], a["tgt_off"], a["corr_src"], a["corr_ref"], a["corr_off"], a["corr_weights"],
+                            0.0, 1e-6, rows_src=a["rows_src"], rows_off=a["rows_off"], **st["loop_kw"])
+    return fine_matching_finish(st, out)
+
+
+def fine_matching_prepare(src_pts, tgt_pts, src_ids, src_off, tgt_ids, tgt_off, corr_tgt, *, corr_tgt_2d=None, matching="only_3d",
+                          weighting_svd=False, num_min_fine_match=3, icp_threshold=0.1, remove_low_quality_patch_matches=False,
+                          num_min_matches_for_quality_check=10, thres_dist_diff=0.05, thres_inlier_ratio=0.5, assign_type="assign_all_src",
+                          output_tgt2src=False, median_max_resolution=0.0, icp_type="point2point", init_round_f32=True,
+                          rigidity_precision="f64"):
     """corr_tgt (n_src_points,) int64: `corres_3d_voxel_from_3d_idx[:, 1]`, the target point matched to each source point, -1 for
     none; corr_tgt_2d: `corres_3d_from_2d_idx[:, 1]` likewise (needed for matching = "only_2d" / "fusion").
     matching: "only_3d" | "only_2d" | "fusion" -- `method.fine_matching_only_3d / _only_2d / _fusion` (:3257-3276); in "fusion" a
@@ -38,7 +48,8 @@ def fine_matching_3d(src_pts, tgt_pts, src_ids, src_off, tgt_ids, tgt_off, corr_
     init_round_f32: ICP starts from the float32 values of the Kabsch transform (the reference's float32 4 x 4, :3360).
     rigidity_precision: "f64" | "f32", the pair arithmetic of the quality check (engine.rigidity_check).
 
-    Returns a dict:
+    Returns the state :func:`fine_matching_finish` completes once the per-patch loop has run on `loop_args` (the tile dict of
+    engine.merge_tiles / the arguments of engine.patch_loop) with `loop_kw`.  fine_matching_finish returns a dict:
       dense        (m, 6) float32 [s, T s] for every point of every registered match's source patch, in match order (:3408)
       sparse       (k, 6) float32: assign_all_src [mutual s, T mutual s] (:3413-3414); assign_then_nn the rows of
                    refine_dvfs_with_threshold, each match's block twice in a row like the reference appends it (:3427-3434)
@@ -122,24 +133,37 @@ def fine_matching_3d(src_pts, tgt_pts, src_ids, src_off, tgt_ids, tgt_off, corr_
     # Kabsch -> ICP on the mutual points -> rows of all source-patch points, one launch; matches below the minimum are skipped
     rows_src = src_pts[src_ids].contiguous()
     skip_below = max(int(num_min_fine_match), 1)  # (a dropped match has no pairs left: it must not start from the identity)
-    out = engine.patch_loop(cs, coff, ct, coff, cs, ct, coff, weights, 0.0, 1e-6, max_corr_dist=icp_threshold, max_iter=30,
-                            rel_fitness=1e-6, rel_rmse=1e-6, icp_type=icp_type, rows_src=rows_src, rows_off=src_off,
-                            min_corr=skip_below, init_round_f32=init_round_f32)
+    loop_args = dict(src=cs, src_off=coff, tgt=ct, tgt_off=coff, corr_src=cs, corr_ref=ct, corr_off=coff, corr_weights=weights,
+                     rows_src=rows_src, rows_off=src_off)
+    loop_kw = dict(max_corr_dist=icp_threshold, max_iter=30, rel_fitness=1e-6, rel_rmse=1e-6, icp_type=icp_type, min_corr=skip_below,
+                   init_round_f32=init_round_f32)
+    return dict(loop_args=loop_args, loop_kw=loop_kw, P=P, dev=dev, pid_rows=pid_rows, pids=pids, mask_useful=mask_useful,
+                mask_global=mask_global, metric=metric, n3=n3, n2=n2, cs=cs, coff=coff, rows_src=rows_src, src_off=src_off,
+                tgt_pts=tgt_pts, tgt_ids=tgt_ids, tgt_off=tgt_off, output_tgt2src=output_tgt2src, assign_type=assign_type,
+                median_max_resolution=median_max_resolution)
+
+
+def fine_matching_finish(st, out):
+    """What follows the per-patch loop (:3371-3436) for one tile: `out` = the loop's result for this tile's patch matches (T, fitness,
+    rmse, iters, rows -- engine.patch_loop, or this tile's slice of engine.patch_loop_tiles)."""
+    import torch
+    P, dev, pid_rows, pids = st["P"], st["dev"], st["pid_rows"], st["pids"]
+    tgt_pts, tgt_ids, tgt_off = st["tgt_pts"], st["tgt_ids"], st["tgt_off"]
     done = out["iters"] >= 0
     dense = out["rows"][done[pid_rows]]
-    res = dict(dense=dense, mask_useful=mask_useful, mask_global=mask_global, metric=metric, T=out["T"], fitness=out["fitness"],
-               rmse=out["rmse"], iters=out["iters"], tgt2src=None, n_pairs=torch.stack([n3, n2], dim=1))
-    if output_tgt2src:
+    res = dict(dense=dense, mask_useful=st["mask_useful"], mask_global=st["mask_global"], metric=st["metric"], T=out["T"],
+               fitness=out["fitness"], rmse=out["rmse"], iters=out["iters"], tgt2src=None, n_pairs=torch.stack([st["n3"], st["n2"]], dim=1))
+    if st["output_tgt2src"]:
         n_tgt_rows = tgt_off[1:] - tgt_off[:-1]
         pid_t = torch.repeat_interleave(torch.arange(P, device=dev), n_tgt_rows)
         res["tgt2src"] = engine.apply_transform(tgt_pts[tgt_ids].contiguous(), tgt_off, out["T"], inverse=True)[done[pid_t]]
-    if assign_type == "assign_all_src":
-        res["sparse"] = engine.apply_transform(cs, coff, out["T"])[done[pids]]
+    if st["assign_type"] == "assign_all_src":
+        res["sparse"] = engine.apply_transform(st["cs"], st["coff"], out["T"])[done[pids]]
     else:
         thr = out["rmse"] * 2.0  # :3420-3424
-        thr = torch.where(torch.isfinite(thr), thr, torch.full_like(thr, float(median_max_resolution)))
-        thr = torch.clamp(thr, min=float(median_max_resolution))
-        nn, rws = engine.nn_refine(rows_src, src_off, tgt_pts[tgt_ids].contiguous(), tgt_off, out["T"], thr)
+        thr = torch.where(torch.isfinite(thr), thr, torch.full_like(thr, float(st["median_max_resolution"])))
+        thr = torch.clamp(thr, min=float(st["median_max_resolution"]))
+        nn, rws = engine.nn_refine(st["rows_src"], st["src_off"], tgt_pts[tgt_ids].contiguous(), tgt_off, out["T"], thr)
         keep = (nn >= 0) & done[pid_rows]
         rws, pid_k = rws[keep], pid_rows[keep]
         # the reference appends every match's block twice (:3428 and :3434): row l of a match with c rows, o rows before it, goes to

@@ -23,12 +23,39 @@ def prepare_tiles(tile_dir, tiling_config, log):
     return tiles
 
 
-def for_each_tile(cfg, tiles, process, log, first=0):
-    """`process(cfg)` per tile, `first` being the reference's hand-edited `continue_tile`."""
-    for tile_i, src_path in enumerate(tiles[first:]):
+def for_each_tile(cfg, tiles, process, log, first=0, batch=1, stages=None):
+    """`process(cfg)` per tile, `first` being the reference's hand-edited `continue_tile`.
+
+    With `stages = (prepare, launch, finish)` and `batch` > 1 the tiles are worked `batch` at a time around ONE per-patch launch:
+    `prepare(cfg)` per tile (everything before the loop; returns the tile's state), `launch(states)` once for the batch (returns one
+    loop result per state), `finish(state, result)` per tile in tile order.  A <= 1 M-point tile's patch matches fill an MI355X for
+    two rounds of workgroups; merged launches run at 1.5 x the rate (bench.py extras.C2x8_tiles).  Every patch's result is what its
+    own launch gives to rounding (a larger batch may run in another launch shape, whose sums run in another order: 1e-9 m in a
+    transform, tests/test_gpu_parity.py), so a '%.6f' row of the files can differ in its last digit."""
+    def visit(tile_i, src_path):
         log.info(f'Current tile {tile_i + first} of total {len(tiles)} tiles')
         tgt_path = src_path.replace('source_tile_', 'target_tile_')
         assert osp.exists(tgt_path), tgt_path
         cfg.tile_id = re.findall(r'\d+', osp.basename(src_path))[0]
         cfg.src_tile_overlap_path, cfg.tgt_tile_overlap_path = src_path, tgt_path
-        process(cfg)
+
+    if stages is None or batch <= 1:
+        for tile_i, src_path in enumerate(tiles[first:]):
+            visit(tile_i, src_path)
+            process(cfg)
+        return
+    prepare, launch, finish = stages
+    pending = []
+
+    def flush():
+        if pending:
+            for state, result in zip(pending, launch(pending)):
+                finish(state, result)
+            pending.clear()
+
+    for tile_i, src_path in enumerate(tiles[first:]):
+        visit(tile_i, src_path)
+        pending.append(prepare(cfg))
+        if len(pending) >= batch:
+            flush()
+    flush()

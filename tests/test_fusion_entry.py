@@ -98,6 +98,19 @@ def test_main_fusion_entry_runs_the_tiles_and_writes_the_dvf_files(tmp_path, mon
         assert cKDTree(clouds[t]["src"].astype(np.float64)).query(dvfs[:, :3], k=1)[0].max() < 2e-6  # ('%.6f' of float32 coordinates)
         assert np.median(dvfms[:, 3]) < 0.12
         assert os.path.exists(out_root / "supervoxel_partition" / f"partition_of_input_src_tile_{t}.txt")
+    # the tile loop batches tiles around one per-patch launch (--tiles-per-launch, default 8: both tiles above shared one); tile by
+    # tile, the reference's order of work, writes the same files -- rows to the last printed digit
+    cfg1 = dict(cfg, path_name=dict(cfg["path_name"], output_folder="one_by_one"))
+    os.makedirs(tmp_path / "out" / "one_by_one" / "tiled_data" / "overlap")
+    for name in os.listdir(tiles):
+        os.link(tiles / name, tmp_path / "out" / "one_by_one" / "tiled_data" / "overlap" / name)
+    path1 = tmp_path / "fusion_3d_one_by_one.yaml"
+    yaml.safe_dump(cfg1, open(path1, "w"))
+    main_fusion.main(["--config", str(path1), "--partition", "parallel", "--tiles-per-launch", "1"])
+    for t in (0, 1):
+        for name in (f"c2f_dense_dvfs_src2tgt_tile_{t}.txt", f"c2f_sparse_dvfms_src2tgt_visualize_tile_{t}.txt"):
+            a, b = np.loadtxt(res / name), np.loadtxt(tmp_path / "out" / "one_by_one" / "results" / name)
+            assert a.shape == b.shape and np.abs(a - b).max() <= 1.01e-6, name
     # the fusion branch: the same tile with lifted "2D" matches attached to the cfg
     from scipy.spatial import cKDTree
     cfg2, _ = main_fusion.build_config(str(path))
