@@ -222,6 +222,12 @@ __global__ __launch_bounds__(PN_NT) void patch_normals_kernel(const float *__res
 // Open3D's ComputeCovariance) and every lane solves its own 3 x 3 eigenproblem.  A query whose survivors overflow the
 // list is redone by the wave with the exact top-k of the kernel above.
 constexpr int PL_NW = 4, PL_NT = PL_NW * 64, PL_NB = 32, PL_CAP = 43, PL_MAX_K = 36, PL_MAX_N = 8192;
+constexpr float PL_FAR = 1e30f;  // (1e30^2 overflows to +inf)
+// Workgroups per CU the compiler is asked to fit: 3 = 168 VGPRs, three waves per SIMD, ~40 dwords of the register sort spilled --
+// 30.4 ms at C4 against 34.3 ms with the 223 VGPRs / two waves per SIMD it takes unasked (round 5).
+#ifndef PL_MIN_WGS
+#define PL_MIN_WGS 3
+#endif
 __device__ __forceinline__ void pl_covariance_normal(const float *__restrict__ x, const float *__restrict__ y, const float *__restrict__ z,
                                                      const int (&pay)[PL_CAP], int k, double (&nv)[3]) {
     double cum[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -247,7 +253,7 @@ __device__ __forceinline__ void pl_covariance_normal(const float *__restrict__ x
     smallest_eigvec3(Cm, nv);
     if (nv[0] * nv[0] + nv[1] * nv[1] + nv[2] * nv[2] == 0.0) { nv[0] = 0.0; nv[1] = 0.0; nv[2] = 1.0; }
 }
-__global__ __launch_bounds__(PL_NT, 2) void patch_normals_lanes_kernel(const float *__restrict__ pts, const int64_t *__restrict__ off,
+__global__ __launch_bounds__(PL_NT, PL_MIN_WGS) void patch_normals_lanes_kernel(const float *__restrict__ pts, const int64_t *__restrict__ off,
                                                                        int64_t P, int knn, int cap_pad, float *__restrict__ normals,
                                                                        double *__restrict__ normals64) {
     extern __shared__ __attribute__((aligned(16))) unsigned char pl_smem[];
@@ -268,7 +274,9 @@ __global__ __launch_bounds__(PL_NT, 2) void patch_normals_lanes_kernel(const flo
     const int n_pad = (n + 7) & ~7;
     for (int i = tid; i < n_pad; i += PL_NT) {
         const bool real = i < n;
-        const float a = real ? pg[3 * i] : 0.f, b = real ? pg[3 * i + 1] : 0.f, c = real ? pg[3 * i + 2] : 0.f;
+        // (places past the patch hold a point at infinity: d2 = +inf falls into the last bin of pass 1 -- which a threshold only
+        //  reaches when it takes every point anyway -- and below no edge in pass 2, so neither pass asks which candidates are real)
+        const float a = real ? pg[3 * i] : PL_FAR, b = real ? pg[3 * i + 1] : PL_FAR, c = real ? pg[3 * i + 2] : PL_FAR;
         xs[i] = a; ys[i] = b; zs[i] = c;
         if (real) {
             mn[0] = fminf(mn[0], a); mn[1] = fminf(mn[1], b); mn[2] = fminf(mn[2], c);
@@ -318,6 +326,8 @@ __global__ __launch_bounds__(PL_NT, 2) void patch_normals_lanes_kernel(const flo
         for (int b = 0; b < PL_NB / 2; ++b) hist[b * 64] = 0u;
         const unsigned int one = valid ? 1u : 0u;
         // pass 1: per-lane histogram of the approximate d2 (differences of nearby float coordinates are exact or nearly so)
+        // (reading the next eight candidates ahead of this step's atomics, the way knn_lanes_kernel does, was measured: 36.9 ms
+        //  against 30.3 at C4 -- three waves per SIMD hide the LDS latency already and the second register set costs more)
         for (int c = 0; c < n_pad; c += 8) {
             const float4 xa = *reinterpret_cast<const float4 *>(xs + c), xb = *reinterpret_cast<const float4 *>(xs + c + 4);
             const float4 ya = *reinterpret_cast<const float4 *>(ys + c), yb = *reinterpret_cast<const float4 *>(ys + c + 4);
@@ -330,7 +340,7 @@ __global__ __launch_bounds__(PL_NT, 2) void patch_normals_lanes_kernel(const flo
                 const float d2 = dx * dx + dy * dy + dz * dz;
                 int b = (int)(__float_as_uint(d2) >> 21) - bin_base;
                 b = b < 0 ? 0 : (b > PL_NB - 1 ? PL_NB - 1 : b);
-                atomicAdd(&hist[(b >> 1) * 64], (c + w < n ? one : 0u) << ((b & 1) * 16));
+                atomicAdd(&hist[(b >> 1) * 64], one << ((b & 1) * 16));
             }
         }
         // the first bin at which the count reaches k
@@ -357,7 +367,7 @@ __global__ __launch_bounds__(PL_NT, 2) void patch_normals_lanes_kernel(const flo
             for (int w = 0; w < 8; ++w) {
                 const float dx = cx[w] - qx, dy = cy[w] - qy, dz = cz[w] - qz;
                 const float d2 = dx * dx + dy * dy + dz * dz;
-                const bool take = d2 < edge && c + w < n;
+                const bool take = d2 < edge;
                 const int at = cnt < PL_CAP ? cnt : PL_CAP;
                 list[(take ? at : PL_CAP) * 64] = (unsigned short)(c + w);
                 cnt += take ? 1 : 0;
