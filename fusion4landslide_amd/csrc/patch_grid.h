@@ -369,18 +369,20 @@ template <> __device__ __forceinline__ float grid_sqrt<float>(float v) { return 
 template <> __device__ __forceinline__ double grid_sqrt<double>(double v) { return (double)__builtin_amdgcn_sqrtf((float)v); }
 
 // Flat scan of the first `cnt` entries of this lane's row list; idle lanes sit on the dummy slot.  Returns the number
-// of candidates this lane evaluated (profiling builds only use it).
-template <typename F, int NT>
-__device__ __forceinline__ int grid_scan_rows(const PatchGrid<F> &g, const GridPt<F> *__restrict__ tl, int dummy,
-                                              const unsigned int *__restrict__ rl, int cnt, F px, F py, F pz, Best<F> &best) {
+// of candidates this lane evaluated (profiling builds only use it).  `active`: lanes that take part (the others sit on the dummy).
+template <typename F, typename FQ, int NT, class Measure>
+__device__ __forceinline__ int grid_walk_rows(const GridPt<F> *__restrict__ tl, int dummy, const unsigned int *__restrict__ rl, int cnt,
+                                              bool active, Best<FQ> &best, Measure &&measure) {
     const int tid = (int)threadIdx.x;
     int n_steps = 0;
-    unsigned int cur = rl[tid];
+    cnt = active ? cnt : 0;
+    unsigned int cur = active ? rl[tid] : 0u;
     int j = (int)(cur & 0xffffu), e = (int)(cur >> 16);
     int k = cnt < 1 ? cnt : 1;
-    unsigned int nxt = rl[k * NT + tid];
+    // (a lane that sits the walk out must see the END of a list, not its own first row: entry `cnt` is the sentinel only for the lanes
+    //  whose count was not overridden)
+    unsigned int nxt = active ? rl[k * NT + tid] : 0u;
     GridPt<F> q = tl[j < e ? j : dummy];
-    const F Qx = grid_query(px, g.ox), Qy = grid_query(py, g.oy), Qz = grid_query(pz, g.oz);
     while (__any(j < e)) {
         // next position first, so that its loads are in flight while the current candidate is evaluated
         int jn = j + 1;
@@ -389,13 +391,13 @@ __device__ __forceinline__ int grid_scan_rows(const PatchGrid<F> &g, const GridP
         const int en = roll ? (int)(nxt >> 16) : e;
         k = roll ? (k + 1 > cnt ? cnt : k + 1) : k;
         const GridPt<F> qn = tl[jn < en ? jn : dummy];
-        const unsigned int nn = rl[k * NT + tid];
+        const unsigned int nn = active ? rl[k * NT + tid] : 0u;
         // (float32: keep both requests up here -- left alone, the scheduler sinks them to the top of the next trip, a
         //  few instructions before their results are needed; +5 %.  float64: the longer evaluation hides them anyway
         //  and the pinned order costs 6 %, measured.)
-        if (sizeof(F) == 4) __builtin_amdgcn_sched_barrier(0);
+        if (sizeof(FQ) == 4) __builtin_amdgcn_sched_barrier(0);
         // current candidate
-        best.offer(grid_d2(Qx - grid_coord(q.x, Qx), Qy - grid_coord(q.y, Qy), Qz - grid_coord(q.z, Qz)), q.tag);
+        best.offer(measure(q), q.tag);
 #ifdef F4L_ICP_PROF
         n_steps += j < e ? 1 : 0;
 #endif
@@ -403,6 +405,60 @@ __device__ __forceinline__ int grid_scan_rows(const PatchGrid<F> &g, const GridP
         nxt = roll ? nn : nxt;
     }
     return n_steps;
+}
+// float32 records, float32 arithmetic
+template <typename F, int NT>
+__device__ __forceinline__ int grid_scan_rows(const PatchGrid<float> &g, const GridPt<float> *__restrict__ tl, int dummy,
+                                              const unsigned int *__restrict__ rl, int cnt, float px, float py, float pz, Best<float> &best) {
+    return grid_walk_rows<float, float, NT>(tl, dummy, rl, cnt, true, best,
+                                            [&](const GridPt<float> &q) { return grid_d2(px - q.x, py - q.y, pz - q.z); });
+}
+// float64 search (the parity mode).  The product walks the list in double (`exact` below).  -DF4L_GRID_PRESCAN builds the variant
+// VERDICT r4 asked to have measured (item 2c, "float32 scan with a float64 guard band"): 18.50 against 18.59 ms at C4, +2 % at C3,
+// but -9 % on a 1 M-point tile (C2: the 128-VGPR shapes spill what the second walk adds) -- profiles/r5_icp_occupancy_and_registers.log
+// section 7; not enabled.  How it works: the list is walked in FLOAT32 first.  The query is split into its float32 image and
+// a float32 remainder, Q = Qf + Qr to 2^-48 of itself; a record holds float32 coordinates, so (Qf - x) is one rounding of an exact
+// difference (exact outright where it cancels) and (Qf - x) + Qr is dx to 1.2e-7 of itself whatever the magnitude of the coordinates
+// -- d2 to 4e-7.  The walk keeps what the float64 walk keeps, in float32: the best (d2, tag) below the bound and the runner-up
+// distance (Best<float>: the incoming bound counts as a loser once something beats it).  If the runner-up lies beyond the best by
+// more than both errors can explain (a factor 1 + 4e-6), the float32 winner IS the minimiser of (exact d2, index) and beats the
+// bound: its exact d2 is measured once, in double, the way the exact walk measures it; `second`, a LOWER bound on every other
+// scanned target (what the certificates of icp.hip need of it), becomes the float32 runner-up less its error.  Lanes whose two best
+// are closer than that -- duplicates, lattices, a candidate on the bound -- walk their list again in double: the answers are those
+// of the exact walk in every case, only `second` may be lower by 2e-6 of itself.
+template <typename F, int NT>
+__device__ __forceinline__ int grid_scan_rows(const PatchGrid<double> &g, const GridPt<double> *__restrict__ tl, int dummy,
+                                              const unsigned int *__restrict__ rl, int cnt, double px, double py, double pz, Best<double> &best) {
+    const double Qx = grid_query(px, g.ox), Qy = grid_query(py, g.oy), Qz = grid_query(pz, g.oz);
+    auto exact = [&](const GridPt<double> &q) { return grid_d2(Qx - (double)q.x, Qy - (double)q.y, Qz - (double)q.z); };
+#ifndef F4L_GRID_PRESCAN
+    return grid_walk_rows<double, double, NT>(tl, dummy, rl, cnt, true, best, exact);
+#else
+    const float fx = (float)Qx, fy = (float)Qy, fz = (float)Qz;
+    const float rx = (float)(Qx - (double)fx), ry = (float)(Qy - (double)fy), rz = (float)(Qz - (double)fz);
+    Best<float> bf;
+    {
+        const double b0 = best.d2() * 1.000002;  // (rounded up below: nothing at or under the bound is lost)
+        bf.init(b0 < 3.0e38 ? __double2float_ru(b0) : __builtin_inff());
+    }
+    int steps = grid_walk_rows<double, float, NT>(tl, dummy, rl, cnt, true, bf, [&](const GridPt<double> &q) {
+        const float dx = (fx - q.x) + rx, dy = (fy - q.y) + ry, dz = (fz - q.z) + rz;
+        return grid_d2(dx, dy, dz);
+    });
+    const bool found = bf.found();
+    const bool unclear = found && !(bf.second > bf.d2() * 1.000004f + 1e-37f);
+    if (__any(unclear)) steps += grid_walk_rows<double, double, NT>(tl, dummy, rl, cnt, unclear, best, exact);
+    if (!unclear) {
+        const double lower = (double)bf.second * (1.0 - 2e-6);
+        if (found) {
+            const GridPt<double> w = tl[bf.slot()];
+            best.d = exact(w);
+            best.t = bf.tag();
+        }
+        best.second = lower < best.second ? lower : best.second;
+    }
+    return steps;
+#endif
 }
 
 // The rare wide search of grid_nn (points without a previous correspondence on a grid finer than the radius): the
