@@ -953,6 +953,54 @@ def test_apply_transform_and_nn_refine(eng):
     assert mism <= 3e-4 * len(d["src"]) + 2
 
 
+def test_nn_refine_wave_per_small_patch_is_the_grid_search(eng, monkeypatch):
+    """f4l_nn_refine gives patches of up to 128 targets a wave each (all targets measured, no grid; round 5) and the others a
+    workgroup over a grid: the same winner -- the minimiser of (float32 d2, index) below the threshold -- and the same rows, on a
+    mix of supervoxel-sized patches, patches around the limit (127, 128, 129 targets), empty ones on either side, a zero threshold
+    and a patch with duplicated targets; against the KD-tree on top."""
+    rng = np.random.default_rng(77)
+    sizes_t = [0, 1, 5, 37, 60, 64, 65, 100, 127, 128, 129, 300, 0, 50, 800, 33]
+    sizes_s = [12, 0, 70, 64, 1, 130, 65, 40, 200, 128, 90, 310, 0, 75, 500, 64]
+    src, tgt, so, to = [], [], [0], [0]
+    for ns, nt in zip(sizes_s, sizes_t):
+        c = rng.uniform(-40, 40, 3)
+        t = (c + rng.uniform(-0.5, 0.5, (nt, 3)) * [1, 1, 0.05]).astype(np.float32)
+        if nt == 50:
+            t[10:20] = t[0:10]                                       # duplicated targets: the smaller index wins
+        s = (c + rng.uniform(-0.5, 0.5, (ns, 3)) * [1, 1, 0.05]).astype(np.float32)
+        if nt >= 5 and ns >= 5:
+            s[:5] = t[:5]                                            # exact hits (d2 = 0)
+        src.append(s); tgt.append(t); so.append(so[-1] + ns); to.append(to[-1] + nt)
+    src, tgt = np.concatenate(src), np.concatenate(tgt)
+    so, to = np.asarray(so, np.int64), np.asarray(to, np.int64)
+    P = len(sizes_t)
+    T = np.tile(np.eye(4), (P, 1, 1))
+    for p in range(P):
+        T[p, :3, :3] = rot_from_axis_angle(rng.normal(size=3), 0.004)
+        T[p, :3, 3] = rng.uniform(-0.02, 0.02, 3)
+    thr = np.full(P, 0.12)
+    thr[3] = 0.0                                                     # no search at all
+    args = (dev(src), dev(so), dev(tgt), dev(to), dev(T), dev(thr))
+    nn, rows = eng.nn_refine(*args)
+    monkeypatch.setenv("F4L_NN_REFINE_NO_SMALL", "1")
+    nn_g, rows_g = eng.nn_refine(*args)
+    monkeypatch.delenv("F4L_NN_REFINE_NO_SMALL")
+    assert torch.equal(nn, nn_g) and torch.equal(rows, rows_g)
+    nn_only, none = eng.nn_refine(*args, return_rows=False)
+    assert none is None and torch.equal(nn_only, nn)
+    nn = nn.cpu().numpy()
+    assert (nn[so[3]:so[4]] == -1).all() and (nn[so[0]:so[1]] == -1).all()
+    mism = 0
+    for p in range(P):
+        if sizes_t[p] == 0 or sizes_s[p] == 0 or thr[p] == 0:
+            continue
+        moved = src[so[p]:so[p + 1]].astype(np.float64) @ T[p, :3, :3].T + T[p, :3, 3]
+        ref_nn, _ = O.nn_within(moved, tgt[to[p]:to[p + 1]].astype(np.float64), thr[p])
+        mism += int((nn[so[p]:so[p + 1]] != ref_nn).sum())
+    assert mism <= 3
+    assert (nn[so[13]:so[13] + 5] == np.arange(5)).all()            # the duplicates' first copies
+
+
 # ------------------------------------------------------------------------------- supervoxel partition
 def _sv_cases(golden_dir):
     return sorted(glob.glob(os.path.join(golden_dir, "supervoxel_*.npz")))
