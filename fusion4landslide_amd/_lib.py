@@ -67,11 +67,13 @@ SIGNATURES = {
     "f4l_write_partition_txt": (C.c_int, [C.c_char_p, _P, _P, _I64, C.c_int32]),
     "f4l_median_f64_workspace_bytes": (_SZ, [_I64]),
     "f4l_median_f64": (C.c_int, [_P, _I64, _I64, _P, _P, _SZ, _P]),
+    "f4l_median_sqrt_f64": (C.c_int, [_P, _I64, _I64, _P, _P, _SZ, _P]),
     "f4l_labels_to_csr_workspace_bytes": (_SZ, [_I64, _I64]),
     "f4l_labels_to_csr": (C.c_int, [_P, _I64, _I64, _P, _P, _P, _SZ, _P]),
     "f4l_labels_to_csr_via": (C.c_int, [_P, _I64, _P, _I64, _I64, _P, _P, _P, _SZ, _P]),
     "f4l_epoch_join_workspace_bytes": (_SZ, [_I64, _I64]),
     "f4l_epoch_join": (C.c_int, [_P, _I64, _P, _I64, _P, _P, _P, _SZ, _P]),
+    "f4l_match_lists": (C.c_int, [_P, _P, _P, _P, _I64, _P, _P, _P, _P, _P, _P]),
     "f4l_gather_points": (C.c_int, [_P, _P, _I64, _P, _P]),
 }
 

@@ -1951,9 +1951,12 @@ static int csr_ws_layout(int64_t n, int64_t K, CsrWs &w, unsigned char *base) {
 
 // ---- median (the last step of `_compute_median_resolution`) ---------------------------------------------------------------
 namespace f4l {
-__global__ void median_pick_kernel(const double *__restrict__ middle, int64_t n, double *__restrict__ out) {
+__global__ void median_pick_kernel(const double *__restrict__ middle, int64_t n, double *__restrict__ out, int of_sqrt) {
     // numpy.median: mean of the two middle elements (they coincide for odd n); middle = the elements of rank (n - 1) / 2, n / 2
-    out[0] = (n & 1) ? middle[0] : (middle[0] + middle[1]) * 0.5;
+    // (of_sqrt: the values are squares and the median wanted is that of their roots -- the root is monotone, so the middle
+    //  elements are the same; the mean of the pair is taken over the roots)
+    const double a = of_sqrt ? sqrt(middle[0]) : middle[0], b = of_sqrt ? sqrt(middle[1]) : middle[1];
+    out[0] = (n & 1) ? a : (a + b) * 0.5;
 }
 }  // namespace f4l
 
@@ -1962,8 +1965,22 @@ extern "C" size_t f4l_median_f64_workspace_bytes(int64_t n) {
     return f4l::select_workspace_bytes() + 256;
 }
 // The two middle order statistics by radix select (select.hip): six passes that read the values, no sort.
+namespace f4l {
+static int median_impl(const double *values, int64_t n, int64_t stride, double *median_out, void *workspace, size_t workspace_bytes, void *stream,
+                       int of_sqrt);
+}
 extern "C" int f4l_median_f64(const double *values, int64_t n, int64_t stride, double *median_out, void *workspace, size_t workspace_bytes,
                               void *stream) {
+    return f4l::median_impl(values, n, stride, median_out, workspace, workspace_bytes, stream, 0);
+}
+// numpy.median(numpy.sqrt(values)) without the pass that takes the roots: `_compute_median_resolution` wants the median DISTANCE and
+// the searches hand out squared distances (values >= 0).
+extern "C" int f4l_median_sqrt_f64(const double *values, int64_t n, int64_t stride, double *median_out, void *workspace, size_t workspace_bytes,
+                                   void *stream) {
+    return f4l::median_impl(values, n, stride, median_out, workspace, workspace_bytes, stream, 1);
+}
+static int f4l::median_impl(const double *values, int64_t n, int64_t stride, double *median_out, void *workspace, size_t workspace_bytes, void *stream,
+                            int of_sqrt) {
     using namespace f4l;
     if (!values || n <= 0 || stride < 1 || !median_out || !workspace) return F4L_EINVAL;
     if (workspace_bytes < f4l_median_f64_workspace_bytes(n)) return F4L_EWORKSPACE;
@@ -1972,7 +1989,7 @@ extern "C" int f4l_median_f64(const double *values, int64_t n, int64_t stride, d
     const int64_t ranks[2] = {(n - 1) / 2, n / 2};
     const int rc = select_ranks_f64(values, n, stride, 2, ranks, middle, workspace, st);
     if (rc != F4L_OK) return rc;
-    hipLaunchKernelGGL(median_pick_kernel, dim3(1), dim3(1), 0, st, (const double *)middle, n, median_out);
+    hipLaunchKernelGGL(median_pick_kernel, dim3(1), dim3(1), 0, st, (const double *)middle, n, median_out, of_sqrt);
     F4L_LAUNCH_CHECK();
     return F4L_OK;
 }

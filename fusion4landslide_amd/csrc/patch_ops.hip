@@ -657,6 +657,42 @@ extern "C" int f4l_nn_refine(const float *src, const int64_t *src_off, const flo
     return F4L_OK;
 }
 
+// ---- f4l_nn_refine's answers as the correspondence lists of f4l_patch_loop ------------------------------------------------------
+namespace f4l {
+__global__ __launch_bounds__(256) void match_lists_kernel(const float *__restrict__ src, const int64_t *__restrict__ src_off,
+                                                          const float *__restrict__ tgt, const int64_t *__restrict__ tgt_off, int64_t P,
+                                                          const int32_t *__restrict__ nn, const int64_t *__restrict__ kept_before,
+                                                          float *__restrict__ cs, float *__restrict__ ct, int64_t *__restrict__ coff) {
+    const int64_t p = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);  // a wave per patch
+    if (p >= P) return;
+    const int64_t s0 = src_off[p], s1 = src_off[p + 1], t0 = tgt_off[p];
+    for (int64_t i = s0 + lane_id(); i < s1; i += 64) {
+        const int32_t m = nn[i];
+        if (m < 0) continue;
+        const int64_t at = kept_before[i], t = t0 + m;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) { cs[3 * at + d] = src[3 * i + d]; ct[3 * at + d] = tgt[3 * t + d]; }
+    }
+    if (lane_id() == 0) {
+        coff[p] = kept_before[s0];
+        if (p == P - 1) coff[P] = kept_before[s1];
+    }
+}
+}  // namespace f4l
+
+extern "C" int f4l_match_lists(const float *src, const int64_t *src_off, const float *tgt, const int64_t *tgt_off, int64_t P,
+                               const int32_t *nn, const int64_t *kept_before, float *corr_src_out, float *corr_ref_out,
+                               int64_t *corr_off_out, void *stream) {
+    using namespace f4l;
+    if (P < 0 || !src_off || !tgt_off || !corr_off_out || (P > 0 && (!nn || !kept_before))) return F4L_EINVAL;
+    if (P == 0) { F4L_HIP_CHECK(hipMemsetAsync(corr_off_out, 0, 8, (hipStream_t)stream)); return F4L_OK; }
+    if (P > 0x7fffffffLL) return F4L_EUNSUPPORTED;
+    hipLaunchKernelGGL(match_lists_kernel, dim3((unsigned)((P + 3) / 4)), dim3(256), 0, (hipStream_t)stream, src, src_off, tgt, tgt_off, P, nn,
+                       kept_before, corr_src_out, corr_ref_out, corr_off_out);
+    F4L_LAUNCH_CHECK();
+    return F4L_OK;
+}
+
 // ---- the loop body's steps before the rigid fit (src/coarse_to_fine_matching_base.py:3254-3320) ------------------------
 namespace f4l {
 

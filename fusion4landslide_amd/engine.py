@@ -110,11 +110,13 @@ def _median_of_sqrt(d2):
     """Device scalar: numpy's median (mean of the middle pair) of sqrt(d2) -- the square root first: the mean of the middle pair
     is taken over distances."""
     torch = require_gpu()
-    d = torch.sqrt(d2).contiguous()
-    out = torch.empty((1,), dtype=torch.float64, device=d.device)
-    nbytes = lib().f4l_median_f64_workspace_bytes(d.shape[0])
-    ws = torch.empty((max(int(nbytes), 1),), dtype=torch.uint8, device=d.device)
-    check(lib().f4l_median_f64(ptr(d), d.shape[0], 1, ptr(out), ptr(ws), C.c_size_t(nbytes), stream_ptr()), "f4l_median_f64")
+    if d2.dim() != 1:
+        raise ValueError("d2 must be a vector (a column of a distance table: pass its view, the stride is taken from it)")
+    stride = int(d2.stride(0)) if d2.shape[0] > 1 else 1
+    out = torch.empty((1,), dtype=torch.float64, device=d2.device)
+    nbytes = lib().f4l_median_f64_workspace_bytes(d2.shape[0])
+    ws = torch.empty((max(int(nbytes), 1),), dtype=torch.uint8, device=d2.device)
+    check(lib().f4l_median_sqrt_f64(ptr(d2), d2.shape[0], stride, ptr(out), ptr(ws), C.c_size_t(nbytes), stream_ptr()), "f4l_median_sqrt_f64")
     return out
 
 
@@ -460,6 +462,27 @@ def nn_refine(src, src_off, tgt, tgt_off, T, thr, max_tgt_patch=None, return_row
     check(lib().f4l_nn_refine(ptr(src), ptr(src_off), ptr(tgt), ptr(tgt_off), P, ptr(T), ptr(thr),
                               int(max_tgt_patch), ptr(nn), ptr(rows), stream_ptr()), "f4l_nn_refine")
     return nn, rows
+
+
+def match_lists(src, src_off, tgt, tgt_off, nn):
+    """`nn_refine`'s answers (index inside the target patch, -1 for none) as the correspondence lists of :func:`patch_loop`:
+    (corr_src (m, 3), corr_ref (m, 3), corr_off (P + 1,)) -- the rows that found a match, in row order (f4l_match_lists)."""
+    torch = require_gpu()
+    src = _dev(src, torch.float32, "src", (3,))
+    tgt = _dev(tgt, torch.float32, "tgt", (3,))
+    src_off = _dev(src_off, torch.int64, "src_off")
+    tgt_off = _dev(tgt_off, torch.int64, "tgt_off")
+    nn = _dev(nn, torch.int32, "nn")
+    P, n = src_off.shape[0] - 1, src.shape[0]
+    before = torch.zeros((n + 1,), dtype=torch.int64, device=src.device)
+    torch.cumsum(nn >= 0, 0, out=before[1:])
+    m = int(before[-1].item())
+    cs = torch.empty((m, 3), dtype=torch.float32, device=src.device)
+    ct = torch.empty((m, 3), dtype=torch.float32, device=src.device)
+    coff = torch.empty((P + 1,), dtype=torch.int64, device=src.device)
+    check(lib().f4l_match_lists(ptr(src), ptr(src_off), ptr(tgt), ptr(tgt_off), P, ptr(nn), ptr(before), ptr(cs), ptr(ct), ptr(coff),
+                                stream_ptr()), "f4l_match_lists")
+    return cs, ct, coff
 
 
 def knn(xyz, k, return_d2=False):

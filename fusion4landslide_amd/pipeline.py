@@ -102,20 +102,10 @@ def _patches_and_registration(torch, src, tgt, labels, tgt_nn, K, med, icp_thres
     max_s = int((off_s[1:] - off_s[:-1]).max().item()) if P else 0
     m, _ = engine.nn_refine(ps, off_s, pt, off_t, eye, torch.full((P,), 2.0 * icp_threshold, dtype=torch.float64, device=dev),
                             max_tgt_patch=max_t, return_rows=False)
-    # rows that found a match, their targets and the matches' CSR offsets: one compaction (`nonzero`), one running count --
-    # rows are in patch order, so the count of kept rows before a patch's first row is that patch's offset
-    cnt = off_s[1:] - off_s[:-1]
-    keep = m >= 0
-    kept = torch.nonzero(keep).squeeze(1)
-    tbase = torch.repeat_interleave(off_t[:-1], cnt, output_size=ps.shape[0])  # first target row of every source row's patch
-    cs = ps[kept]
-    ct = pt[tbase[kept] + m[kept].to(torch.int64)]
-    running = torch.zeros(ps.shape[0] + 1, dtype=torch.int64, device=dev)
-    torch.cumsum(keep, 0, out=running[1:])
-    coff = running[off_s]
-    del tbase, running
+    # rows that found a match and their targets as the loop's correspondence lists: one running count, one pass (f4l_match_lists)
+    cs, ct, coff = engine.match_lists(ps, off_s, pt, off_t, m)
     mark("point_matches")
-    out = engine.patch_loop(ps, off_s, pt, off_t, cs.contiguous(), ct.contiguous(), coff, None, 0.0, 1e-6, max_corr_dist=icp_threshold,
+    out = engine.patch_loop(ps, off_s, pt, off_t, cs, ct, coff, None, 0.0, 1e-6, max_corr_dist=icp_threshold,
                             max_iter=max_iter, fixed_iters=fixed_iters, max_src_patch=max_s, max_tgt_patch=max_t, search=search)
     mark("patch_loop")
     thr = torch.clamp(2.0 * out["rmse"], min=med)  # base:3420-3424

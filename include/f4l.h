@@ -236,6 +236,16 @@ int f4l_nn_refine(const float *src, const int64_t *src_off, const float *tgt, co
                   const double *T, const double *thr, int64_t max_tgt_patch_host, int32_t *nn_out, float *out6,
                   void *stream);
 
+/* f4l_nn_refine's answers as the CSR correspondence lists f4l_patch_loop takes (the mutual pairs of every patch match,
+ * src/coarse_to_fine_matching_base.py:3259-3274 when the point matches are nearest neighbours inside the matched patch): for
+ * every source row i with nn[i] >= 0, in row order, corr_src_out gets src[i] and corr_ref_out the target row
+ * tgt_off[patch of i] + nn[i]; corr_off_out int64 [P + 1] the lists' offsets.  kept_before int64 [src_off[P] + 1]: the number of
+ * rows j < i with nn[j] >= 0 (an exclusive running count with the total behind it: one scan, the caller's); corr_*_out float32
+ * [kept_before[src_off[P]]][3]. */
+int f4l_match_lists(const float *src, const int64_t *src_off, const float *tgt, const int64_t *tgt_off, int64_t P,
+                    const int32_t *nn, const int64_t *kept_before, float *corr_src_out, float *corr_ref_out,
+                    int64_t *corr_off_out, void *stream);
+
 /* Tile preparation around the hot loop, `_voxel_subsampling` (src/coarse_to_fine_matching_base.py:1012-1057).
  *
  * f4l_voxel_downsample: Open3D `PointCloud.voxel_down_sample(voxel)` as called at :1024-1025 -- voxel index =
@@ -402,6 +412,9 @@ int f4l_epoch_join(const float *src, int64_t n, const float *tgt, int64_t m, dou
 size_t f4l_median_f64_workspace_bytes(int64_t n);
 int f4l_median_f64(const double *values, int64_t n, int64_t stride, double *median_out, void *workspace, size_t workspace_bytes,
                    void *stream);
+/* numpy.median(numpy.sqrt(values)) for values >= 0 (squared distances in, the median distance out) without a pass for the roots. */
+int f4l_median_sqrt_f64(const double *values, int64_t n, int64_t stride, double *median_out, void *workspace,
+                        size_t workspace_bytes, void *stream);
 
 /* Gather rows: out[i] = pts[order[i]] (float32 [n][3]); builds patch-contiguous clouds from a CSR order. */
 int f4l_gather_points(const float *pts, const int32_t *order, int64_t n, float *out, void *stream);

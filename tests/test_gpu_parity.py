@@ -1001,6 +1001,29 @@ def test_nn_refine_wave_per_small_patch_is_the_grid_search(eng, monkeypatch):
     assert (nn[so[13]:so[13] + 5] == np.arange(5)).all()            # the duplicates' first copies
 
 
+def test_match_lists_are_the_matched_rows_in_order(eng):
+    """f4l_match_lists: f4l_nn_refine's answers as the correspondence lists of f4l_patch_loop -- the rows with a match, in row order,
+    against their targets, offsets per patch (empty patches, patches without a match, a patch where every row matches)."""
+    rng = np.random.default_rng(5)
+    ns = [0, 7, 130, 64, 1, 300, 0, 33]
+    nt = [4, 0, 90, 64, 2, 500, 0, 10]
+    so, to = np.concatenate([[0], np.cumsum(ns)]).astype(np.int64), np.concatenate([[0], np.cumsum(nt)]).astype(np.int64)
+    src, tgt = rng.normal(size=(so[-1], 3)).astype(np.float32), rng.normal(size=(to[-1], 3)).astype(np.float32)
+    nn = np.full(so[-1], -1, np.int32)
+    for p in range(len(ns)):
+        if nt[p] == 0:
+            continue
+        pick = rng.random(ns[p]) < (1.0 if p == 3 else 0.0 if p == 7 else 0.6)
+        nn[so[p]:so[p + 1]][pick] = rng.integers(0, nt[p], int(pick.sum()))
+    cs, ct, coff = eng.match_lists(dev(src), dev(so), dev(tgt), dev(to), dev(nn))
+    keep = nn >= 0
+    patch_of = np.repeat(np.arange(len(ns)), ns)
+    assert np.array_equal(cs.cpu().numpy(), src[keep]) and np.array_equal(ct.cpu().numpy(), tgt[to[patch_of[keep]] + nn[keep]])
+    assert np.array_equal(coff.cpu().numpy(), np.concatenate([[0], np.cumsum(np.bincount(patch_of[keep], minlength=len(ns)))]))
+    none = eng.match_lists(dev(src), dev(so), dev(tgt), dev(to), dev(np.full(so[-1], -1, np.int32)))
+    assert none[0].shape == (0, 3) and int(none[2].abs().sum()) == 0
+
+
 # ------------------------------------------------------------------------------- supervoxel partition
 def _sv_cases(golden_dir):
     return sorted(glob.glob(os.path.join(golden_dir, "supervoxel_*.npz")))
