@@ -8,6 +8,7 @@ Ragged patches are CSR: ``pts`` is (n, 3) float32 with the points of patch p in 
 lists of index tensors (src/coarse_to_fine_matching_base.py:3156-3157, 3254).
 """
 import ctypes as C
+import os
 
 from . import _lib
 from ._lib import check, lib, ptr, require_gpu, stream_ptr
@@ -34,6 +35,35 @@ def _dev(t, dtype, name, shape_tail=None):
     if shape_tail is not None and tuple(t.shape[1:]) != tuple(shape_tail):
         raise ValueError(f"{name} must have shape (n, {', '.join(map(str, shape_tail))}), got {tuple(t.shape)}")
     return t
+
+
+_SCRATCH = {}
+
+
+def _scratch(nbytes, device):
+    """Workspace of a stateless call: one buffer per (device, stream), grown when a call needs more and otherwise reused -- the calls
+    of a stream run in order, so the next one may overwrite what the last one left.  (Handing every workspace back to the caching
+    allocator made a 100 M-point path stall for 0.2-0.8 s now and then: the allocator splits a freed 14 GB block for the small
+    tensors that follow and has to get a new one from the driver for the next large request.)  F4L_NO_SCRATCH_CACHE=1: a fresh
+    tensor per call; :func:`release_scratch` drops the buffers."""
+    torch = require_gpu()
+    nbytes = max(int(nbytes), 1)
+    if os.environ.get("F4L_NO_SCRATCH_CACHE") or torch.cuda.is_current_stream_capturing():
+        return torch.empty((nbytes,), dtype=torch.uint8, device=device)
+    key = (torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device(),
+           torch.cuda.current_stream(device).cuda_stream)
+    buf = _SCRATCH.get(key)
+    if buf is None or buf.numel() < nbytes:
+        _SCRATCH.pop(key, None)
+        buf = None  # (free the old one first: the two need not coexist)
+        buf = torch.empty((nbytes,), dtype=torch.uint8, device=device)
+        _SCRATCH[key] = buf
+    return buf
+
+
+def release_scratch():
+    """Drops the cached workspaces (see :func:`_scratch`)."""
+    _SCRATCH.clear()
 
 
 def _max_patch(off):
@@ -115,7 +145,7 @@ def _median_of_sqrt(d2):
     stride = int(d2.stride(0)) if d2.shape[0] > 1 else 1
     out = torch.empty((1,), dtype=torch.float64, device=d2.device)
     nbytes = lib().f4l_median_f64_workspace_bytes(d2.shape[0])
-    ws = torch.empty((max(int(nbytes), 1),), dtype=torch.uint8, device=d2.device)
+    ws = _scratch(nbytes, d2.device)
     check(lib().f4l_median_sqrt_f64(ptr(d2), d2.shape[0], stride, ptr(out), ptr(ws), C.c_size_t(nbytes), stream_ptr()), "f4l_median_sqrt_f64")
     return out
 
@@ -493,7 +523,7 @@ def knn(xyz, k, return_d2=False):
     idx = torch.empty((n, k), dtype=torch.int32, device=xyz.device)
     d2 = torch.empty((n, k), dtype=torch.float64, device=xyz.device) if return_d2 else None
     nbytes = lib().f4l_knn_workspace_bytes(n, k)
-    ws = torch.empty((max(int(nbytes), 1),), dtype=torch.uint8, device=xyz.device)
+    ws = _scratch(nbytes, xyz.device)
     check(lib().f4l_knn(ptr(xyz), n, int(k), ptr(idx), ptr(d2), ptr(ws), C.c_size_t(nbytes), stream_ptr()), "f4l_knn")
     return (idx, d2) if return_d2 else idx
 
@@ -509,7 +539,7 @@ def knn_normals(xyz, k, return_d2=False, return_nn1=False):
     nrm = torch.empty((n, 3), dtype=torch.float64, device=xyz.device)
     d2 = torch.empty((n, k), dtype=torch.float64, device=xyz.device) if return_d2 else None
     nbytes = lib().f4l_knn_workspace_bytes(n, k)
-    ws = torch.empty((max(int(nbytes), 1),), dtype=torch.uint8, device=xyz.device)
+    ws = _scratch(nbytes, xyz.device)
     if return_nn1:
         nn1 = torch.empty((n,), dtype=torch.float64, device=xyz.device)
         check(lib().f4l_knn_normals_nn1(ptr(xyz), n, int(k), ptr(idx), ptr(d2), ptr(nrm), ptr(nn1), ptr(ws), C.c_size_t(nbytes),
@@ -530,7 +560,7 @@ def nn_query(cloud, queries, k=1, return_d2=False):
     idx = torch.empty((m, k), dtype=torch.int32, device=cloud.device)
     d2 = torch.empty((m, k), dtype=torch.float64, device=cloud.device) if return_d2 else None
     nbytes = lib().f4l_nn_query_workspace_bytes(n, m, int(k))
-    ws = torch.empty((max(int(nbytes), 1),), dtype=torch.uint8, device=cloud.device)
+    ws = _scratch(nbytes, cloud.device)
     check(lib().f4l_nn_query(ptr(cloud), n, ptr(queries), m, int(k), ptr(idx), ptr(d2), ptr(ws), C.c_size_t(nbytes),
                              stream_ptr()), "f4l_nn_query")
     return (idx, d2) if return_d2 else idx
@@ -549,7 +579,7 @@ def voxel_downsample(xyz, voxel_size, return_map=False, layout="open3d"):
     vop = torch.empty((n,), dtype=torch.int32, device=xyz.device) if return_map else None
     m = C.c_int64(0)
     nbytes = lib().f4l_voxel_downsample_workspace_bytes(n)
-    ws = torch.empty((max(int(nbytes), 1),), dtype=torch.uint8, device=xyz.device)
+    ws = _scratch(nbytes, xyz.device)
     check(lib().f4l_voxel_downsample(ptr(xyz), n, float(voxel_size), {"open3d": 0, "pcl": 1}[layout], ptr(pts), ptr(cnt),
                                      ptr(vop), C.byref(m), ptr(ws),
                                      C.c_size_t(nbytes), stream_ptr()), "f4l_voxel_downsample")
@@ -727,7 +757,7 @@ def labels_to_csr(labels, K):
     order = torch.empty((n,), dtype=torch.int32, device=labels.device)
     off = torch.empty((K + 1,), dtype=torch.int64, device=labels.device)
     nbytes = lib().f4l_labels_to_csr_workspace_bytes(n, K)
-    ws = torch.empty((max(int(nbytes), 1),), dtype=torch.uint8, device=labels.device)
+    ws = _scratch(nbytes, labels.device)
     check(lib().f4l_labels_to_csr(ptr(labels), n, int(K), ptr(order), ptr(off), ptr(ws), C.c_size_t(nbytes),
                                   stream_ptr()), "f4l_labels_to_csr")
     return order, off
@@ -743,7 +773,7 @@ def labels_to_csr_via(labels, via, K):
     order = torch.empty((m,), dtype=torch.int32, device=labels.device)
     off = torch.empty((K + 1,), dtype=torch.int64, device=labels.device)
     nbytes = lib().f4l_labels_to_csr_workspace_bytes(m, K)
-    ws = torch.empty((max(int(nbytes), 1),), dtype=torch.uint8, device=labels.device)
+    ws = _scratch(nbytes, labels.device)
     check(lib().f4l_labels_to_csr_via(ptr(labels), labels.shape[0], ptr(via), m, int(K), ptr(order), ptr(off), ptr(ws),
                                       C.c_size_t(nbytes), stream_ptr()), "f4l_labels_to_csr_via")
     return order, off
@@ -761,7 +791,7 @@ def epoch_join(src, tgt, return_nn1=True):
     idx = torch.empty((m,), dtype=torch.int32, device=src.device)
     nn1 = torch.empty((m,), dtype=torch.float64, device=src.device) if return_nn1 else None
     nbytes = lib().f4l_epoch_join_workspace_bytes(n, m)
-    ws = torch.empty((max(int(nbytes), 1),), dtype=torch.uint8, device=src.device)
+    ws = _scratch(nbytes, src.device)
     check(lib().f4l_epoch_join(ptr(src), n, ptr(tgt), m, ptr(nn1), ptr(idx), ptr(ws), C.c_size_t(nbytes), stream_ptr()), "f4l_epoch_join")
     return idx, nn1
 
