@@ -12,4 +12,5 @@ cp "$ROOT"/include/*.h "$B/include/"
 make -C "$B/fusion4landslide_amd/csrc" -j6 "$@" > "$B/build.log" 2>&1 || { tail -30 "$B/build.log"; exit 1; }
 mkdir -p "$ROOT/fusion4landslide_amd/lib/variants"
 cp "$B/fusion4landslide_amd/lib/libf4l_hip.so" "$ROOT/fusion4landslide_amd/lib/variants/lib_$name.so"
+cp "$B/build.log" "$ROOT/build/variant_$name.log"; rm -rf "$B"   # (the scratch copy does not travel to the GPU box with the next snapshot)
 echo "built fusion4landslide_amd/lib/variants/lib_$name.so"
