@@ -1044,6 +1044,21 @@ __global__ __launch_bounds__(NW * 64, WIDE ? 3 : (sizeof(F) == 8 ? ICP_WAVES_PER
 
 }  // namespace f4l
 
+// The throughput shapes (WIDE: the bulk class of a large batch, bench.py's headline launch) live in a translation unit of their own,
+// this file compiled again with -DF4L_ICP_BULK_TU and the ILP-first scheduling strategy (csrc/Makefile: icp_bulk.o): that
+// scheduler is worth 1 % there (18.62 -> 18.44 ms at C4) and costs the shapes a 1 M-point tile runs in 7 % (profiles/
+// r5_icp_occupancy_and_registers.log section 8), and the strategy is a per-file compiler option.
+namespace f4l {
+#ifdef F4L_ICP_BULK_TU
+template __global__ void icp_kernel<0, 2, double, true>(IcpArgs);
+template __global__ void icp_kernel<1, 2, double, true>(IcpArgs);
+#else
+extern template __global__ void icp_kernel<0, 2, double, true>(IcpArgs);
+extern template __global__ void icp_kernel<1, 2, double, true>(IcpArgs);
+#endif
+}  // namespace f4l
+
+#ifndef F4L_ICP_BULK_TU
 #include "icp_rows.h"
 
 namespace f4l {
@@ -1539,3 +1554,4 @@ static int f4l::icp_launch_host(const float *src, const int64_t *src_off, const 
     if (buf && hipFreeAsync(buf, st) != hipSuccess && rc == F4L_OK) { f4l_tls_hip_error = (int)hipGetLastError(); rc = F4L_EHIP; }
     return rc;
 }
+#endif  // F4L_ICP_BULK_TU
