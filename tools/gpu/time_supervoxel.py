@@ -22,6 +22,6 @@ print(f"n={n}: knn {ms_knn:.2f} ms, normals {ms_nrm:.2f} ms, device segmentation
 t0 = time.perf_counter(); lab_p, Kp = engine.supervoxel_parallel(xyz, k, res); torch.cuda.synchronize(); t1 = time.perf_counter()
 print(f"f4l_supervoxel_parallel end to end: {1e3*(t1-t0):.1f} ms, K={Kp}")
 t0 = time.perf_counter(); lab_h, Kh = engine.supervoxel(xyz, k, res); torch.cuda.synchronize(); t1 = time.perf_counter()
-print(f"f4l_supervoxel (label-identical, host segmentation) end to end: {1e3*(t1-t0):.1f} ms, K={Kh}")
+print(f"f4l_supervoxel (the reference's labels, on the device) end to end: {1e3*(t1-t0):.1f} ms, K={Kh}")
 cnt_p, cnt_h = torch.bincount(lab_p.long()).float(), torch.bincount(lab_h.long()).float()
 print(f"sizes parallel: min {int(cnt_p.min())} max {int(cnt_p.max())} cv {float(cnt_p.std()/cnt_p.mean()):.3f}; sequential: min {int(cnt_h.min())} max {int(cnt_h.max())} cv {float(cnt_h.std()/cnt_h.mean()):.3f}")
