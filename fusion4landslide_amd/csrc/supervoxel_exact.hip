@@ -58,6 +58,9 @@ struct State {
     int m;                 // entries of the exchange's current generation
     int max_tail;          // the largest closure (visited set) any centre had
     long long total[8];    // per pass: absorptions of the whole estimate (the budget of the last round is switched on by it)
+#ifdef SVX_MEASURE_PREFIX
+    int minchg[8], nchg[8];  // (measurement build: the lowest centre whose output changed in a pass, and how many did)
+#endif
     unsigned long long sub[2][SUBPOOLS];  // bump pointers of the two estimate pools
 };
 
@@ -193,6 +196,9 @@ __global__ void prep_kernel(State *st, int sel, unsigned int *abs_wr, const int3
     if (blockIdx.x == 0) {
         for (int t = (int)threadIdx.x; t < SUBPOOLS; t += (int)blockDim.x) st->sub[sel][t] = 0ULL;
         if (threadIdx.x == 0) { st->changed[pass & 7] = 0; st->total[pass & 7] = 0; }
+#ifdef SVX_MEASURE_PREFIX
+        if (threadIdx.x == 0) { st->minchg[pass & 7] = 0x7fffffff; st->nchg[pass & 7] = 0; }
+#endif
     }
     SVX_FOR(s, nreps) abs_wr[reps[s]] = NONE;
 }
@@ -413,6 +419,9 @@ __global__ __launch_bounds__(EVAL_WAVES * 64, SVX_EVAL_WPE) void eval_kernel(Fus
         a.wr.ns[i] = nsz; a.wr.cnt[i] = cnt; a.wr.off[i] = out_off; a.wr.len[i] = out_len; a.wr.hash[i] = hash;
         a.wr.cnt_slot[s] = cnt;
         if (!same) a.st->changed[pass & 7] = 1;
+#ifdef SVX_MEASURE_PREFIX
+        if (!same) { atomicMin(&a.st->minchg[pass & 7], i); atomicAdd(&a.st->nchg[pass & 7], 1); }
+#endif
     }
 }
 // (the claims: compared after the pass, when all of them are in; and the pass's absorptions in all)
@@ -422,6 +431,12 @@ __global__ void abs_changed_kernel(FuseArgs a, int pass) {
     SVX_FOR(s, a.nreps) {
         const int32_t i = a.reps[s];
         ch = ch || a.rd.abs[i] != a.wr.abs[i];
+#ifdef SVX_MEASURE_PREFIX
+        if (a.rd.abs[i] != a.wr.abs[i]) {  // the claimant(s) whose claim on i came or went
+            const unsigned int c0 = a.rd.abs[i], c1 = a.wr.abs[i], c = c0 < c1 ? c0 : c1;
+            atomicMin(&a.st->minchg[pass & 7], (int)c); atomicAdd(&a.st->nchg[pass & 7], 1);
+        }
+#endif
         tot += a.wr.cnt_slot[s];
     }
     if (__ballot(ch) != 0ULL && lane_id() == 0) a.st->changed[pass & 7] = 1;
@@ -751,6 +766,11 @@ static int segment_exact_run(const float *xyz, const double *normals, const int3
                 hipLaunchKernelGGL(svx::abs_changed_kernel, dim3(nreps > 262144 ? 256 : 64), b, 0, st, fa, it);
                 F4L_LAUNCH_CHECK();
                 rd ^= 1;
+#ifdef SVX_MEASURE_PREFIX
+                if (read_state() == F4L_OK)
+                    fprintf(stderr, "[sv prefix] round %d pass %d: %d of %d centres: lowest changed %.4f of n, %d changes\n", rounds, it, nreps, (int)n,
+                            hs.minchg[it & 7] == 0x7fffffff ? 1.0 : (double)hs.minchg[it & 7] / (double)n, hs.nchg[it & 7]);
+#endif
             }
             rc = read_state();
             if (rc != F4L_OK) return rc;
