@@ -302,6 +302,32 @@ def test_nn_query_vs_kdtree():
     assert engine.nn_query(torch.from_numpy(cloud).cuda(), torch.zeros((0, 3)).cuda(), 1).shape == (0, 1)
 
 
+def test_nn_query_small_k_is_the_ordered_brute_force_on_ties_and_displaced_queries():
+    """The small-k walk (k <= 4: float32 scan, exact re-measurement of the survivors, exact walk on near-ties, later rounds clipped
+    to the ball of the known k-th distance) against the definition: the k smallest by (double d2 from the float coordinates, index)
+    -- on a lattice (every distance tied many times), with duplicated cloud points, queries on lattice points, between them,
+    displaced by several cells and far outside the cloud."""
+    from fusion4landslide_amd import engine
+    rng = np.random.default_rng(101)
+    gx, gy = np.meshgrid(np.arange(60, dtype=np.float32) * 0.25, np.arange(50, dtype=np.float32) * 0.25)
+    cloud = np.stack([gx.ravel(), gy.ravel(), np.zeros(gx.size, np.float32)], axis=1)
+    cloud = np.concatenate([cloud, cloud[::7], rng.uniform(0, 12, (500, 3)).astype(np.float32) * np.float32([1, 1, 0.02])])  # + duplicates + scatter
+    q = np.concatenate([cloud[rng.choice(len(cloud), 400)],                                   # on cloud points (d2 = 0, ties with duplicates)
+                        cloud[rng.choice(len(cloud), 400)] + np.float32([0.125, 0.125, 0]),   # cell centres: four-way ties
+                        cloud[rng.choice(len(cloud), 400)] + np.float32([0.0, 0.0, 0.9]),     # displaced across cells (flat grid: z is free)
+                        rng.uniform(-5, 20, (300, 3)).astype(np.float32),                     # anywhere, also far outside
+                        rng.uniform(0, 12, (500, 3)).astype(np.float32) * np.float32([1, 1, 0.02])])
+    c64, q64 = cloud.astype(np.float64), q.astype(np.float64)
+    d2_all = ((q64[:, None, 0] - c64[None, :, 0]) ** 2 + (q64[:, None, 1] - c64[None, :, 1]) ** 2) + (q64[:, None, 2] - c64[None, :, 2]) ** 2
+    order = np.lexsort((np.broadcast_to(np.arange(len(cloud)), d2_all.shape), d2_all), axis=1)  # by d2, then index
+    for k in (1, 2, 3, 4):
+        idx, d2 = engine.nn_query(torch.from_numpy(cloud).cuda(), torch.from_numpy(q).cuda(), k, return_d2=True)
+        idx, d2 = idx.cpu().numpy(), d2.cpu().numpy()
+        ref = order[:, :k]
+        assert np.array_equal(idx, ref), (k, int((idx != ref).any(axis=1).sum()))
+        assert np.array_equal(d2, np.take_along_axis(d2_all, ref, axis=1))
+
+
 def test_epoch_join_is_the_two_searches_it_replaces():
     """f4l_epoch_join: the second epoch binned once for its two searches.  Bit-equal to f4l_knn(tgt, 2)[:, 1] (what
     `_compute_median_resolution`, src/coarse_to_fine_matching_base.py:2716-2754, takes the median of) and to
