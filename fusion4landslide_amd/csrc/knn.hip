@@ -799,6 +799,11 @@ __global__ __launch_bounds__(KR_NW * 64, 2) void knn_lanes_kernel(KnnLanesArgs r
     __shared__ unsigned int s_hist[KR_NW][KR_NB * 64];
     __shared__ unsigned int s_list[KR_NW][(KR_CAP + 1) * 64];  // (+ 1: the row predicated-off writes of pass 2 land in)
     __shared__ __attribute__((aligned(16))) float s_tile[KR_NW][KR_G * KR_TS];
+#ifdef F4L_KNN_LDS_PAD  // (measurement only: LDS asked for and never used -- one workgroup per CU instead of two: what occupancy is worth)
+    __shared__ unsigned int s_pad[F4L_KNN_LDS_PAD / 4];
+    if (ra.a.n < 0) s_pad[threadIdx.x] = 1u;
+    if (ra.a.n < -1) s_list[0][0] = s_pad[threadIdx.x ^ 1];
+#endif
     KnnArgs a = ra.a;
     int bin_base = ra.bin_base;
     float edge_slack = ra.edge_slack;
