@@ -57,6 +57,7 @@ struct State {
     int changed[8];        // per pass (slot = pass % 8): something differed from the estimate before
     int m;                 // entries of the exchange's current generation
     int max_tail;          // the largest closure (visited set) any centre had
+    int done, done_it;     // the round's estimate has converged (conv_kernel), after this many passes: the passes queued behind it do nothing
     long long total[8];    // per pass: absorptions of the whole estimate (the budget of the last round is switched on by it)
 #ifdef SVX_MEASURE_PREFIX
     int minchg[8], nchg[8];  // (measurement build: the lowest centre whose output changed in a pass, and how many did)
@@ -179,6 +180,7 @@ __global__ void iota_kernel(int32_t *a, int32_t *b, int32_t *sz, int64_t *off, i
     SVX_FOR(i, n) { a[i] = (int32_t)i; b[i] = (int32_t)i; sz[i] = 1; off[i] = i * k; len[i] = k; }
 }
 __global__ void round_init_kernel(FuseArgs a) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) { a.st->done = 0; a.st->done_it = 0; }
     SVX_FOR(s, a.nreps) {
         const int32_t i = a.reps[s];
         a.rd.abs[i] = NONE;
@@ -193,6 +195,7 @@ __global__ void round_init_kernel(FuseArgs a) {
 }
 // before a pass: its pool's bump pointers, its claims, its flag and its total
 __global__ void prep_kernel(State *st, int sel, unsigned int *abs_wr, const int32_t *reps, int nreps, int pass) {
+    if (st->done) return;  // (converged earlier in this batch of passes)
     if (blockIdx.x == 0) {
         for (int t = (int)threadIdx.x; t < SUBPOOLS; t += (int)blockDim.x) st->sub[sel][t] = 0ULL;
         if (threadIdx.x == 0) { st->changed[pass & 7] = 0; st->total[pass & 7] = 0; }
@@ -227,6 +230,7 @@ __global__ __launch_bounds__(EVAL_WAVES * 64, SVX_EVAL_WPE) void eval_kernel(Fus
     const int wave = (int)(threadIdx.x >> 6), lane = lane_id(), h = lane / G, hl = lane % G, hbase = h * G;
     const int64_t s0 = ((int64_t)blockIdx.x * EVAL_WAVES + wave) * CPW;
     if (s0 >= a.nreps) return;  // (whole wave)
+    if (a.st->done) return;     // (converged earlier in this batch of passes)
     const int64_t s = s0 + h;
     const bool valid_c = s < a.nreps;
     int32_t *Q = q_all[wave][h];
@@ -426,6 +430,7 @@ __global__ __launch_bounds__(EVAL_WAVES * 64, SVX_EVAL_WPE) void eval_kernel(Fus
 }
 // (the claims: compared after the pass, when all of them are in; and the pass's absorptions in all)
 __global__ void abs_changed_kernel(FuseArgs a, int pass) {
+    if (a.st->done) return;
     bool ch = false;
     long long tot = 0;
     SVX_FOR(s, a.nreps) {
@@ -442,6 +447,12 @@ __global__ void abs_changed_kernel(FuseArgs a, int pass) {
     if (__ballot(ch) != 0ULL && lane_id() == 0) a.st->changed[pass & 7] = 1;
     int lo = wave_sum((int)(tot & 0xffff)), hi = wave_sum((int)(tot >> 16));  // (a lane's share is far below 2^31)
     if (lane_id() == 0 && (lo || hi)) atomicAdd((unsigned long long *)&a.st->total[pass & 7], (unsigned long long)(((long long)hi << 16) + lo));
+}
+// after a pass: did it change nothing (and did it run with the budget, if the budget binds)?  Then the passes the host has queued
+// behind it return at once -- the host looks at the state only every few passes (a look costs a fifth of a pass).
+__global__ void conv_kernel(State *st, int pass, int budget_on, long long budget_total) {
+    if (st->done) return;
+    if (st->changed[pass & 7] == 0 && (budget_on || st->total[pass & 7] < budget_total)) { st->done = 1; st->done_it = pass + 1; }
 }
 // the converged estimate becomes the state: survivors keep size and list, everybody follows its absorber
 __global__ void commit_kernel(FuseArgs a, int32_t *sz0, int64_t *adj_off, int32_t *adj_len, int32_t *keep_flag) {
@@ -683,7 +694,12 @@ static int segment_exact_run(const float *xyz, const double *normals, const int3
     if (workspace_bytes < w.total) return F4L_EWORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     const dim3 g(2048), b(256), one(1);
-    State hs;
+    // (the looks at the state land in PINNED host memory, one buffer per host thread, kept: a copy into pageable memory goes through
+    //  the runtime's staging path, and there are a hundred looks per call)
+    static thread_local State *hs_pinned = nullptr;
+    if (!hs_pinned && hipHostMalloc((void **)&hs_pinned, sizeof(State), hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); hs_pinned = nullptr; }
+    State hs_pageable;
+    State &hs = hs_pinned ? *hs_pinned : hs_pageable;
     auto read_state = [&]() -> int {
         F4L_HIP_CHECK(hipMemcpyAsync(&hs, w.st, offsetof(State, sub), hipMemcpyDeviceToHost, st));
         F4L_HIP_CHECK(hipStreamSynchronize(st));
@@ -743,8 +759,11 @@ static int segment_exact_run(const float *xyz, const double *normals, const int3
         long long prev_total = 0;
         bool converged = false;
         int it = 0;
-        // passes between two looks at the state: one while a pass takes longer than the look, four in the short late rounds
-        const int batch_len = nreps > 40000 ? 1 : 4;
+        // passes between two looks at the state: two in the long rounds (a look -- copy, synchronise, restart an empty queue -- costs a
+        // fifth of a pass at 1 M centres; per 10 M points 278 ms with one, 260 with two, 282 with three), four in the short late rounds
+        // (round 5: and the passes queued behind the one that converges do nothing -- conv_kernel -- so a batch costs no wasted pass)
+        int batch_len = nreps > 40000 ? 4 : 8;
+        if (const char *e = getenv("F4L_SV_EXACT_BATCH")) { const int v = atoi(e); if (v >= 1 && v <= 16) batch_len = v; }  // (measurement)
         while (!converged) {
             bool budget_on = false;
             for (int batch = 0; batch < batch_len; ++batch, ++it, ++passes) {
@@ -764,6 +783,7 @@ static int segment_exact_run(const float *xyz, const double *normals, const int3
                 if (wide) hipLaunchKernelGGL((svx::eval_kernel<32, QCAP_WIDE>), dim3((unsigned)((nreps + 2 * EVAL_WAVES - 1) / (2 * EVAL_WAVES))), dim3(EVAL_WAVES * 64), 0, st, fa, lambda, budget_total, it);
                 else hipLaunchKernelGGL((svx::eval_kernel<16, 256>), dim3((unsigned)((nreps + 4 * EVAL_WAVES - 1) / (4 * EVAL_WAVES))), dim3(EVAL_WAVES * 64), 0, st, fa, lambda, budget_total, it);
                 hipLaunchKernelGGL(svx::abs_changed_kernel, dim3(nreps > 262144 ? 256 : 64), b, 0, st, fa, it);
+                hipLaunchKernelGGL(svx::conv_kernel, one, one, 0, st, w.st, it, budget_on ? 1 : 0, budget_total);
                 F4L_LAUNCH_CHECK();
                 rd ^= 1;
 #ifdef SVX_MEASURE_PREFIX
@@ -775,10 +795,15 @@ static int segment_exact_run(const float *xyz, const double *normals, const int3
             rc = read_state();
             if (rc != F4L_OK) return rc;
             if (hs.overflow) { queue_outgrown = (hs.overflow & 1) != 0; return F4L_EUNSUPPORTED; }
+            if (hs.done) {  // the passes after number done_it did nothing: the estimate is the one pass done_it - 1 wrote
+                passes -= it - hs.done_it;
+                it = hs.done_it;
+                rd = it & 1;
+            }
             const long long total = hs.total[(it - 1) & 7];
             prev_total = total;
             // converged: the last pass changed nothing -- and it ran with the budget if the budget binds
-            converged = hs.changed[(it - 1) & 7] == 0 && (budget_on || total < budget_total);
+            converged = hs.done != 0;
         }
         // commit (the estimate `rd` = the last one written; its lists are in pool pe[(it - 1) & 1])
         fa.rd = est(rd);
