@@ -57,7 +57,8 @@ struct State {
     int changed[8];        // per pass (slot = pass % 8): something differed from the estimate before
     int m;                 // entries of the exchange's current generation
     int max_tail;          // the largest closure (visited set) any centre had
-    int done, done_it;     // the round's estimate has converged (conv_kernel), after this many passes: the passes queued behind it do nothing
+    int done, done_it;     // the round's estimate has converged (abs_changed_kernel), after this many passes: the passes queued behind it do nothing
+    unsigned int arrive;   // workgroups of abs_changed_kernel that are through (the last one closes the pass)
     long long total[8];    // per pass: absorptions of the whole estimate (the budget of the last round is switched on by it)
 #ifdef SVX_MEASURE_PREFIX
     int minchg[8], nchg[8];  // (measurement build: the lowest centre whose output changed in a pass, and how many did)
@@ -179,10 +180,21 @@ struct FuseArgs {
 __global__ void iota_kernel(int32_t *a, int32_t *b, int32_t *sz, int64_t *off, int32_t *len, int64_t n, int k) {
     SVX_FOR(i, n) { a[i] = (int32_t)i; b[i] = (int32_t)i; sz[i] = 1; off[i] = i * k; len[i] = k; }
 }
+// (and what pass 0 needs prepared: its pool's bump pointers, its claims, its flag and its total -- every later pass is prepared by
+//  the last workgroup of the pass before it, abs_changed_kernel)
 __global__ void round_init_kernel(FuseArgs a) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) { a.st->done = 0; a.st->done_it = 0; }
+    if (blockIdx.x == 0) {
+        for (int t = (int)threadIdx.x; t < SUBPOOLS; t += (int)blockDim.x) a.st->sub[0][t] = 0ULL;
+        if (threadIdx.x == 0) {
+            a.st->done = 0; a.st->done_it = 0; a.st->arrive = 0u; a.st->changed[0] = 0; a.st->total[0] = 0;
+#ifdef SVX_MEASURE_PREFIX
+            a.st->minchg[0] = 0x7fffffff; a.st->nchg[0] = 0;
+#endif
+        }
+    }
     SVX_FOR(s, a.nreps) {
         const int32_t i = a.reps[s];
+        a.wr.abs[i] = NONE;
         a.rd.abs[i] = NONE;
         a.rd.ns[i] = a.sz0[i];
         a.rd.cnt[i] = 0;
@@ -193,19 +205,6 @@ __global__ void round_init_kernel(FuseArgs a) {
 
     }
 }
-// before a pass: its pool's bump pointers, its claims, its flag and its total
-__global__ void prep_kernel(State *st, int sel, unsigned int *abs_wr, const int32_t *reps, int nreps, int pass) {
-    if (st->done) return;  // (converged earlier in this batch of passes)
-    if (blockIdx.x == 0) {
-        for (int t = (int)threadIdx.x; t < SUBPOOLS; t += (int)blockDim.x) st->sub[sel][t] = 0ULL;
-        if (threadIdx.x == 0) { st->changed[pass & 7] = 0; st->total[pass & 7] = 0; }
-#ifdef SVX_MEASURE_PREFIX
-        if (threadIdx.x == 0) { st->minchg[pass & 7] = 0x7fffffff; st->nchg[pass & 7] = 0; }
-#endif
-    }
-    SVX_FOR(s, nreps) abs_wr[reps[s]] = NONE;
-}
-
 // Half a wavefront (32 lanes) = one centre: the lists are a few dozen entries, and two dependent-load chains per wave keep the
 // memory system busier than one.  Q: the closure's queue = its visited set, in the reference's order (:125-134, 151-157), in LDS.
 // Everything "uniform" below is uniform within a half; both halves walk every loop together (a half that is through is
@@ -429,30 +428,54 @@ __global__ __launch_bounds__(EVAL_WAVES * 64, SVX_EVAL_WPE) void eval_kernel(Fus
     }
 }
 // (the claims: compared after the pass, when all of them are in; and the pass's absorptions in all)
-__global__ void abs_changed_kernel(FuseArgs a, int pass) {
-    if (a.st->done) return;
+__global__ void abs_changed_kernel(FuseArgs a, int pass, int budget_on, long long budget_total) {
+    State *st = a.st;
+    if (st->done) return;
     bool ch = false;
     long long tot = 0;
     SVX_FOR(s, a.nreps) {
         const int32_t i = a.reps[s];
-        ch = ch || a.rd.abs[i] != a.wr.abs[i];
+        const unsigned int c0 = a.rd.abs[i], c1 = a.wr.abs[i];
+        ch = ch || c0 != c1;
 #ifdef SVX_MEASURE_PREFIX
-        if (a.rd.abs[i] != a.wr.abs[i]) {  // the claimant(s) whose claim on i came or went
-            const unsigned int c0 = a.rd.abs[i], c1 = a.wr.abs[i], c = c0 < c1 ? c0 : c1;
-            atomicMin(&a.st->minchg[pass & 7], (int)c); atomicAdd(&a.st->nchg[pass & 7], 1);
+        if (c0 != c1) {  // the claimant(s) whose claim on i came or went
+            atomicMin(&st->minchg[pass & 7], (int)(c0 < c1 ? c0 : c1)); atomicAdd(&st->nchg[pass & 7], 1);
         }
 #endif
+        a.rd.abs[i] = NONE;  // (this estimate is the one the NEXT pass writes: its claims start empty)
         tot += a.wr.cnt_slot[s];
     }
-    if (__ballot(ch) != 0ULL && lane_id() == 0) a.st->changed[pass & 7] = 1;
+    if (__ballot(ch) != 0ULL && lane_id() == 0) st->changed[pass & 7] = 1;
     int lo = wave_sum((int)(tot & 0xffff)), hi = wave_sum((int)(tot >> 16));  // (a lane's share is far below 2^31)
-    if (lane_id() == 0 && (lo || hi)) atomicAdd((unsigned long long *)&a.st->total[pass & 7], (unsigned long long)(((long long)hi << 16) + lo));
-}
-// after a pass: did it change nothing (and did it run with the budget, if the budget binds)?  Then the passes the host has queued
-// behind it return at once -- the host looks at the state only every few passes (a look costs a fifth of a pass).
-__global__ void conv_kernel(State *st, int pass, int budget_on, long long budget_total) {
-    if (st->done) return;
-    if (st->changed[pass & 7] == 0 && (budget_on || st->total[pass & 7] < budget_total)) { st->done = 1; st->done_it = pass + 1; }
+    if (lane_id() == 0 && (lo || hi)) atomicAdd((unsigned long long *)&st->total[pass & 7], (unsigned long long)(((long long)hi << 16) + lo));
+    // The last workgroup through closes the pass: did it change nothing (and did it run with the budget, if the budget binds)?  Then
+    // the passes the host has queued behind it return at once -- the host looks at the state only every few passes (a look costs a
+    // fifth of a pass) -- else it prepares the next pass: its pool's bump pointers, its flag and its total.
+    __shared__ int s_last;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        s_last = atomicAdd(&st->arrive, 1u) == gridDim.x - 1 ? 1 : 0;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    const int changed = atomicAdd(&st->changed[pass & 7], 0);
+    const long long total = (long long)atomicAdd((unsigned long long *)&st->total[pass & 7], 0ULL);
+    const bool conv = changed == 0 && (budget_on || total < budget_total);
+    const int next = pass + 1;
+    if (!conv)
+        for (int t = (int)threadIdx.x; t < SUBPOOLS; t += (int)blockDim.x) st->sub[next & 1][t] = 0ULL;
+    if (threadIdx.x == 0) {
+        st->arrive = 0u;
+        if (conv) { st->done = 1; st->done_it = next; }
+        else {
+            st->changed[next & 7] = 0; st->total[next & 7] = 0;
+#ifdef SVX_MEASURE_PREFIX
+            st->minchg[next & 7] = 0x7fffffff; st->nchg[next & 7] = 0;
+#endif
+        }
+    }
 }
 // the converged estimate becomes the state: survivors keep size and list, everybody follows its absorber
 __global__ void commit_kernel(FuseArgs a, int32_t *sz0, int64_t *adj_off, int32_t *adj_len, int32_t *keep_flag) {
@@ -761,7 +784,7 @@ static int segment_exact_run(const float *xyz, const double *normals, const int3
         int it = 0;
         // passes between two looks at the state: two in the long rounds (a look -- copy, synchronise, restart an empty queue -- costs a
         // fifth of a pass at 1 M centres; per 10 M points 278 ms with one, 260 with two, 282 with three), four in the short late rounds
-        // (round 5: and the passes queued behind the one that converges do nothing -- conv_kernel -- so a batch costs no wasted pass)
+        // (round 5: and the passes queued behind the one that converges do nothing -- abs_changed_kernel decides -- so a batch costs no wasted pass)
         int batch_len = nreps > 40000 ? 4 : 8;
         if (const char *e = getenv("F4L_SV_EXACT_BATCH")) { const int v = atoi(e); if (v >= 1 && v <= 16) batch_len = v; }  // (measurement)
         while (!converged) {
@@ -770,7 +793,6 @@ static int segment_exact_run(const float *xyz, const double *normals, const int3
                 if (it >= MAX_ITERS) return F4L_EUNSUPPORTED;
                 fa.rd = est(rd); fa.wr = est(rd ^ 1);
                 fa.pool_sel = it & 1; fa.pool_base = w.pool_off[pe[it & 1]];
-                hipLaunchKernelGGL(svx::prep_kernel, g, b, 0, st, w.st, it & 1, fa.wr.abs, (const int32_t *)reps, nreps, it);
                 // the budget only binds in the round that reaches K: the prefix sum of the absorptions is taken once a pass has
                 // absorbed as much as the budget
                 fa.before = nullptr;
@@ -782,8 +804,7 @@ static int segment_exact_run(const float *xyz, const double *normals, const int3
                 }
                 if (wide) hipLaunchKernelGGL((svx::eval_kernel<32, QCAP_WIDE>), dim3((unsigned)((nreps + 2 * EVAL_WAVES - 1) / (2 * EVAL_WAVES))), dim3(EVAL_WAVES * 64), 0, st, fa, lambda, budget_total, it);
                 else hipLaunchKernelGGL((svx::eval_kernel<16, 256>), dim3((unsigned)((nreps + 4 * EVAL_WAVES - 1) / (4 * EVAL_WAVES))), dim3(EVAL_WAVES * 64), 0, st, fa, lambda, budget_total, it);
-                hipLaunchKernelGGL(svx::abs_changed_kernel, dim3(nreps > 262144 ? 256 : 64), b, 0, st, fa, it);
-                hipLaunchKernelGGL(svx::conv_kernel, one, one, 0, st, w.st, it, budget_on ? 1 : 0, budget_total);
+                hipLaunchKernelGGL(svx::abs_changed_kernel, dim3(nreps > 262144 ? 256 : 64), b, 0, st, fa, it, budget_on ? 1 : 0, budget_total);
                 F4L_LAUNCH_CHECK();
                 rd ^= 1;
 #ifdef SVX_MEASURE_PREFIX
