@@ -65,6 +65,7 @@ SIGNATURES = {
     "f4l_supervoxel_parallel": (C.c_int, [_P, _I64, _I, _D, _P, _P, _P, _P, _P, _P, _SZ, _P]),
     "f4l_supervoxel_segment_host": (C.c_int, [_P, _P, _P, _I64, _I, _D, _P, _P]),
     "f4l_write_partition_txt": (C.c_int, [C.c_char_p, _P, _P, _I64, C.c_int32]),
+    "f4l_write_rows_txt": (C.c_int, [C.c_char_p, _P, _I64, C.c_int]),
     "f4l_median_f64_workspace_bytes": (_SZ, [_I64]),
     "f4l_median_f64": (C.c_int, [_P, _I64, _I64, _P, _P, _SZ, _P]),
     "f4l_median_sqrt_f64": (C.c_int, [_P, _I64, _I64, _P, _P, _SZ, _P]),

@@ -383,6 +383,12 @@ int f4l_supervoxel_segment_host(const float *xyz_host, const double *normals_hos
 int f4l_write_partition_txt(const char *path, const float *xyz_host, const int32_t *labels_host, int64_t n,
                             int32_t n_supervoxels);
 
+/* Host-only: the result files of a tile -- `np.savetxt(path, rows, delimiter=" ", fmt="%.6f")` as `save_process_dvf` calls it
+ * (src/coarse_to_fine_matching_base.py:3477-3537) -- byte for byte: rows_host float32 [n][ncols], one row per line, values
+ * separated by one blank, six decimals rounded as printf rounds the exact value.  (numpy formats a million rows of six in
+ * 2.4 s, four to eight such files per tile; this writer takes 0.1 s.) */
+int f4l_write_rows_txt(const char *path, const float *rows_host, int64_t n, int ncols);
+
 /* Sort-by-label -> CSR (replaces the O(K*N) mask loop of prepare_pts2spt_dict,
  * src/coarse_to_fine_matching_base.py:1327-1332).  labels int32 [n]; order_out int32 [n] = point ids grouped by label
  * (stable); off_out int64 [K+1].  A label outside [0, K) (an "unlabelled" -1, a label beyond the caller's count) belongs to no

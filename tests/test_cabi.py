@@ -122,6 +122,31 @@ def test_partition_text_file_is_byte_identical_to_the_reference_writer(golden_di
         assert ours(tmp_path / "b.txt", c["xyz"], c["labels"], c["n_supervoxels"]) == open(tmp_path / "ref.txt", "rb").read()
 
 
+def test_partition_text_coordinates_are_printf_12g(tmp_path):
+    """The partition file's coordinates are `out << std::setprecision(12) << double(x)` in the reference (xyz_io.h:192-221) =
+    printf("%.12g").  The writer forms the twelve digits itself for 1 <= |x| < 10^12 (round 5: 1.84 -> 0.23 s per million points):
+    every coordinate must be the string Python's '%.12g' gives for the same double -- on magnitudes from 10^-6 to 10^13, values that
+    round up into a new digit, trailing zeros, signed zeros, the float32 extremes."""
+    import ctypes as C
+    from fusion4landslide_amd._lib import check, lib
+    rng = np.random.default_rng(11)
+    n = 60_000
+    pts = (rng.normal(size=(n, 3)) * 10.0 ** rng.integers(-6, 14, (n, 1))).astype(np.float32)
+    edge = np.array([0.0, -0.0, 1.0, -1.0, 9.99999999999, 999999999999.6, 1e12, 0.5, 123456.789, 99999.9999999, 1e11, 2.5, 1 / 128,
+                     16777216.0, 3.4e38, 1e-45, 9.9999998e11, 999999.94, 1000000.06, 7.0000005, 10.0, 100.0, 1e5, -1e5], np.float32)
+    pts.reshape(-1)[:len(edge)] = edge
+    lab = rng.integers(0, 700, n).astype(np.int32)
+    path = tmp_path / "p.txt"
+    check(lib().f4l_write_partition_txt(str(path).encode(), pts.ctypes.data_as(C.c_void_p), lab.ctypes.data_as(C.c_void_p), n, 700),
+          "f4l_write_partition_txt")
+    lines = open(path).read().split("\n")
+    assert len(lines) == n + 1 and lines[-1] == ""
+    for i in range(n):
+        f = lines[i].split(" ")
+        assert len(f) == 7 and f[:3] == ["%.12g" % float(v) for v in pts[i]] and int(f[6]) == lab[i], (i, lines[i])
+    assert lib().f4l_write_partition_txt(str(path).encode(), pts.ctypes.data_as(C.c_void_p), lab.ctypes.data_as(C.c_void_p), n, 5) != 0  # label beyond K
+
+
 def test_sanitizer_run_of_the_oracle_and_the_host_code():
     """`make -C oracle asan`: the C oracle and the product library's host-only code (the sequential segmentation and the
     text writer, csrc/supervoxel_host.cpp) under AddressSanitizer + UndefinedBehaviorSanitizer on the CPU; both

@@ -38,6 +38,30 @@ def test_save_process_dvf_writes_the_reference_files(tmp_path):
     assert np.loadtxt(tmp_path / "rock" / "results" / "c2f_dvfms_src2tgt_visualize_0_5.txt")[1, 3] == pytest.approx(0.06)
 
 
+def test_row_writer_is_numpy_savetxt_byte_for_byte(tmp_path):
+    """f4l_write_rows_txt (what save_process_dvf writes its tables with) against `np.savetxt(path, rows, delimiter=" ", fmt="%.6f")`,
+    the reference's call (src/coarse_to_fine_matching_base.py:3477-3537): every byte, on random rows and on the values where a
+    six-decimal writer can go wrong -- exact ties of the seventh decimal (odd multiples of 1/128: to even, like printf), signed
+    zeros and tiny negatives ('-0.000000'), the float32 extremes, 10^9 and beyond, infinities, NaN."""
+    import ctypes as C
+    from fusion4landslide_amd._lib import check, lib
+    rng = np.random.default_rng(3)
+    edge = np.array([0.0, -0.0, 1 / 128, -1 / 128, 3 / 128, 1e-7, -1e-7, 5e-7, -5e-7, 4.9999997e-7, 1e9, -1e9, 999999999.0, 1.5e9, 3.4e38,
+                     -3.4e38, np.inf, -np.inf, np.nan, 0.9999995, 0.99999994, 123456.789, 2.5e-6, 1.5e-6, 0.5, 1e-45, -1e-45, 65504.0,
+                     16777216.0, 0.1, 0.2, 0.3], np.float32)
+    edge = np.concatenate([edge, (np.arange(1, 4000, 2) / 128.0).astype(np.float32), -(np.arange(1, 4000, 2) / 128.0).astype(np.float32)])
+    for ncols in (6, 4, 1):
+        rows = np.concatenate([np.resize(edge, (len(edge) // ncols * ncols,)).reshape(-1, ncols),
+                               (rng.normal(size=(20_000, ncols)) * 10.0 ** rng.integers(-7, 6, (20_000, 1))).astype(np.float32)])
+        ref, out = tmp_path / f"ref_{ncols}.txt", tmp_path / f"out_{ncols}.txt"
+        np.savetxt(ref, rows, delimiter=" ", fmt="%.6f")
+        check(lib().f4l_write_rows_txt(str(out).encode(), rows.ctypes.data_as(C.c_void_p), rows.shape[0], ncols), "f4l_write_rows_txt")
+        assert open(ref, "rb").read() == open(out, "rb").read(), ncols
+    check(lib().f4l_write_rows_txt(str(tmp_path / "empty.txt").encode(), None, 0, 6), "f4l_write_rows_txt")
+    assert open(tmp_path / "empty.txt", "rb").read() == b""
+    assert lib().f4l_write_rows_txt(str(tmp_path / "no_such_dir" / "x.txt").encode(), rows.ctypes.data_as(C.c_void_p), 1, 1) != 0
+
+
 @pytest.mark.gpu
 def test_main_fusion_entry_runs_the_tiles_and_writes_the_dvf_files(tmp_path, monkeypatch):
     """`python -m fusion4landslide_amd.main_fusion --config <yaml>` on a synthetic two-tile data set already tiled (the tiler
