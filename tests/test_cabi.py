@@ -128,6 +128,7 @@ def test_partition_text_coordinates_are_printf_12g(tmp_path):
     every coordinate must be the string Python's '%.12g' gives for the same double -- on magnitudes from 10^-6 to 10^13, values that
     round up into a new digit, trailing zeros, signed zeros, the float32 extremes."""
     import ctypes as C
+    import numpy as np
     from fusion4landslide_amd._lib import check, lib
     rng = np.random.default_rng(11)
     n = 60_000
