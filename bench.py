@@ -28,7 +28,8 @@ Extra objects on the JSON line:
                  the same committed passes: the kernel is LDS resident, HBM is not what bounds it.
   roofline_knn   the same for the exact kNN-30 kernel of the supervoxel stage (132 B per point), the kernel north_star
                  asks HBM numbers for (N = 1 only).
-  roofline_supervoxel  the same for the whole partition stage, f4l_supervoxel_parallel on 10 M points (160 B per point).
+  roofline_supervoxel  the same for the whole partition stage as the path runs it by default: f4l_supervoxel (the reference's
+                 labels) on 10 M points, 160 B per point; `variant_parallel` inside it: the opt-in f4l_supervoxel_parallel.
   extras         the other single-GPU BASELINE configs (C2 1 M, C3 10 M dense) and the float32 fast mode (N = 1 only).
   cpu_baseline   the C oracle (oracle/f4l_oracle.c, "port") timed on a bounded prefix of the same patches, 1 thread, and
                  with its patch loop on all host cores (rank 0, N = 1 only).
@@ -62,7 +63,8 @@ SV_BYTES_PER_PT = 160        # kNN 132 B + normals 24 B + labels
 VALU_PEAK_GCYC = 256 * 4 * 2.4  # G SIMD-cycles of vector issue per second: 256 CUs x 4 SIMD-32 x 2.4 GHz (MI355X_MICROARCH.md); a wave64
                                 # float32 / integer instruction takes 2 of them, a float64 one 4
 KERNEL_SOURCES = {"icp": ("icp.hip", "icp_rows.h", "ldlt6.h", "patch_grid.h", "f4l_device.h"), "knn": ("knn.hip", "lane_topk.h", "topk.h", "f4l_device.h"),
-                  "supervoxel": ("supervoxel_gpu.hip", "sv_metric.h", "select.hip", "knn.hip", "lane_topk.h", "topk.h", "f4l_device.h")}
+                  "supervoxel": ("supervoxel_gpu.hip", "sv_metric.h", "select.hip", "knn.hip", "lane_topk.h", "topk.h", "f4l_device.h"),
+                  "supervoxel_exact": ("supervoxel_exact.hip", "sv_metric.h", "select.hip", "knn.hip", "lane_topk.h", "topk.h", "f4l_device.h")}
 
 
 def parse_args(argv=None):
@@ -394,26 +396,35 @@ def knn_roofline(torch, engine, xyz, k=30):
 
 
 def supervoxel_roofline(torch, engine, xyz, k=30):
-    """The partition stage of the full path on (up to 10 M points of) the source epoch: f4l_supervoxel_parallel end to end -- exact
-    kNN-30 + PCA normals + the device segmentation -- at the path's own resolution rule (sqrt(3) x 10 x median point spacing,
+    """The partition stage of the full path on (up to 10 M points of) the source epoch, as the path and both entry points run it by
+    default: f4l_supervoxel end to end -- exact kNN-30 + PCA normals + the REFERENCE's segmentation on the device
+    (csrc/supervoxel_exact.hip) -- at the path's own resolution rule (sqrt(3) x 10 x median point spacing,
     src/coarse_to_fine_matching_base.py:2668-2671), timed with events on the launch stream; SURVEY.md 8(d) prices the stage at
-    132 + 24 + 4 = 160 B per point."""
+    132 + 24 + 4 = 160 B per point.  `variant_parallel`: the same for the opt-in f4l_supervoxel_parallel (other labels)."""
     import numpy as np
     n = xyz.shape[0]
     res = float(np.sqrt(3.0) * 10.0 * engine.median_resolution(xyz))
     K = [0]
 
-    def run():
-        K[0] = engine.supervoxel_parallel(xyz, k, res)[1]
-    s = _timed(torch, run, 3)
-    ach = SV_BYTES_PER_PT * n / s / 1e9
-    roof = {"bound": "hbm", "kernel": "f4l_supervoxel_parallel (knn_lanes_kernel + the svg:: kernels of the segmentation, ~270 launches)",
-            "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None,
-            "kernel_ms": round(1e3 * s, 4), "algorithmic_bytes": SV_BYTES_PER_PT * n, "points": n, "k": k, "resolution_m": round(res, 4),
-            "supervoxels": int(K[0]), "Mpts_per_s": round(n / s / 1e6, 2),
-            "note": "a graph contraction: ~14 passes over edge lists that shrink from 30 edges per point; its passes wait for dependent "
-                    "scattered loads (profiles/README.md: TA 50 % busy, HBM 30 %, VALU 30 % in the largest of them)"}
-    attach_counters(roof, "supervoxel_counters.json", "supervoxel", "f4l_supervoxel_parallel k=30", 1e3 * s, units=n)
+    def one(fn, which, fname, workload, what, note, reps):
+        def run():
+            K[0] = fn(xyz, k, res)[1]
+        s = _timed(torch, run, reps)
+        ach = SV_BYTES_PER_PT * n / s / 1e9
+        roof = {"bound": "hbm", "kernel": what, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
+                "traffic": None, "kernel_ms": round(1e3 * s, 4), "algorithmic_bytes": SV_BYTES_PER_PT * n, "points": n, "k": k,
+                "resolution_m": round(res, 4), "supervoxels": int(K[0]), "Mpts_per_s": round(n / s / 1e6, 2), "note": note}
+        attach_counters(roof, fname, which, workload, 1e3 * s, units=n)
+        return roof
+    roof = one(engine.supervoxel, "supervoxel_exact", "supervoxel_exact_counters.json", "f4l_supervoxel k=30",
+               "f4l_supervoxel (knn_lanes_kernel + svx::eval_kernel / xch_eval_kernel passes of the reference's segmentation)",
+               "the reference's sequential fusion and FIFO exchange as fixed points of parallel passes: every pass re-evaluates the "
+               "representatives whose inputs changed, through dependent gathers (list -> root -> claim -> record -> metric); bound by those "
+               "and by the number of passes, not by HBM", 2)
+    roof["variant_parallel"] = one(engine.supervoxel_parallel, "supervoxel", "supervoxel_counters.json", "f4l_supervoxel_parallel k=30",
+                                   "f4l_supervoxel_parallel (knn_lanes_kernel + the svg:: kernels of the segmentation, ~270 launches)",
+                                   "a graph contraction: ~14 passes over edge lists that shrink from 30 edges per point; its passes wait for "
+                                   "dependent scattered loads (profiles/README.md)", 3)
     return roof
 
 
@@ -486,21 +497,17 @@ def extras(torch, engine, synthetic, prob, dev, args):
         c = synthetic.make_patches_device(n_pts, cells, 1.386, dev, seed=0)
         src, tgt = c["src"], c["tgt"]
         del c
-        pipeline.full_path(src, tgt, max_iter=MAX_ITER, fixed_iters=True)  # warm-up
-        r = pipeline.full_path(src, tgt, max_iter=MAX_ITER, fixed_iters=True)
-        out[f"full_path_{n_pts // 1_000_000}M"] = {"value": round(n_pts / r["stage_ms"]["total"] / 1e3, 3), "unit": "Mpts/s", "supervoxels": int(r["K"]),
-                                                    "resolution_m": round(r["resolution"], 4), "stage_ms": {k: round(v, 3) for k, v in r["stage_ms"].items()},
-                                                    "mean_fitness": round(float(r["fitness"].mean().item()), 4),
-                                                    "partition": "parallel variant (f4l_partition_neighbours + f4l_partition_segment)"}
-        if n_pts <= 10_000_000:  # the same path on the REFERENCE's own partition (its labels, computed on the device: supervoxel_exact.hip)
-            pipeline.full_path(src, tgt, max_iter=MAX_ITER, fixed_iters=True, partition="identical")
-            ri = pipeline.full_path(src, tgt, max_iter=MAX_ITER, fixed_iters=True, partition="identical")
-            out[f"full_path_{n_pts // 1_000_000}M_identical_partition"] = {
-                "value": round(n_pts / ri["stage_ms"]["total"] / 1e3, 3), "unit": "Mpts/s", "supervoxels": int(ri["K"]),
-                "stage_ms": {k: round(v, 3) for k, v in ri["stage_ms"].items()}, "mean_fitness": round(float(ri["fitness"].mean().item()), 4),
-                "partition": "the reference's labels (f4l_supervoxel)"}
-            del ri
-        del src, tgt, r
+        for part, note in (("identical", "the reference's labels (f4l_supervoxel: the default of pipeline.full_path and of both entry points)"),
+                           ("parallel", "parallel variant (f4l_partition_neighbours + f4l_partition_segment): the reference's K and criteria, other labels")):
+            pipeline.full_path(src, tgt, max_iter=MAX_ITER, fixed_iters=True, partition=part)  # warm-up
+            r = pipeline.full_path(src, tgt, max_iter=MAX_ITER, fixed_iters=True, partition=part)
+            out[f"full_path_{n_pts // 1_000_000}M_{part}_partition"] = {
+                "value": round(n_pts / r["stage_ms"]["total"] / 1e3, 3), "unit": "Mpts/s", "supervoxels": int(r["K"]), "resolution_m": round(r["resolution"], 4),
+                "stage_ms": {k: round(v, 3) for k, v in r["stage_ms"].items()}, "mean_fitness": round(float(r["fitness"].mean().item()), 4), "partition": note}
+            del r
+            engine.release_scratch()
+            torch.cuda.empty_cache()
+        del src, tgt
         torch.cuda.empty_cache()
     return out
 

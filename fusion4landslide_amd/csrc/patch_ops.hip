@@ -649,7 +649,8 @@ extern "C" int f4l_nn_refine(const float *src, const int64_t *src_off, const flo
     if (small) {
         hipLaunchKernelGGL(nn_refine_small_kernel, dim3((unsigned)((P + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
         F4L_LAUNCH_CHECK();
-        if (max_tgt_patch_host <= NRS_CAP) return F4L_OK;
+        // (the grid kernel is launched even when the caller states no patch beyond NRS_CAP: a bound may be understated, and a patch the
+        //  wave kernel leaves alone must not keep uninitialised rows -- workgroups of small patches return at once)
         a.skip_nt = NRS_CAP;
     }
     hipLaunchKernelGGL(nn_refine_kernel, dim3((unsigned)P), dim3(PN_NT), lds, (hipStream_t)stream, a);

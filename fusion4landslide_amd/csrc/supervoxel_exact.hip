@@ -149,17 +149,46 @@ __global__ void min_metric_kernel(const float *__restrict__ xyz, const double *_
 }
 
 // ---- fusion -------------------------------------------------------------------------------------------------------------
-struct Est {                     // one estimate of "what the centres of this round do" (two of them: read / written)
-    unsigned int *abs;           // [n] the centre that absorbs the node, NONE
-    int32_t *ns, *cnt;           // [n] a centre's size after its turn, the nodes it absorbs
-    int64_t *off;                // [n] its list of rejected neighbours after its turn: offset into `lists` ...
-    int32_t *len;                //     ... and length
-    unsigned long long *hash;    // [n] order-sensitive hash of that list (what "the list did not change" is read from)
-    int32_t *cnt_slot;           // [nreps] cnt in the order of the centres (the budget's prefix sum runs over it)
+// What an evaluation gathers lives in two packed records per node (round 6; before: nine separate arrays, i.e. six to seven 32-byte
+// sectors per visited node and two per list entry -- the passes are bound by exactly those gathers):
+//   NodeS  (64 B, one cache line half)  what a ROUND starts from: position, normal, size, list.  Written by iota / commit.
+//   NodeE  (32 B, one sector)           one ESTIMATE of "what the centres of this round do", two of them (read / written): who
+//                                       absorbs the node (claims by atomicMin, from any centre), and the node's own outcome as a
+//                                       centre: size and kept list after its turn, the nodes it absorbs.  The claim that a chain
+//                                       walk reads and the record the queue reads a moment later share the sector.
+// The lists (neighbour table, then the pools) hold ROUND-START ROOTS: rootlists_kernel maps the survivors' lists through `root`
+// once per round, instead of every evaluation of every pass doing it per entry.
+struct alignas(64) NodeS {
+    float x, y, z;
+    int32_t sz;                  // round-start size
+    double nx, ny, nz;
+    int64_t off;                 // round-start list: offset into `lists` ...
+    int32_t len;                 //                   ... and length
+    int32_t pad_[3];
 };
+struct alignas(32) NodeE {
+    unsigned int abs;            // the centre that absorbs the node, NONE (written by OTHER centres: never stored with the rest)
+    int32_t ns, cnt, len;        // as a centre: its size after its turn, the nodes it absorbs, its kept list's length
+    int64_t off;                 //              ... and offset
+    unsigned long long hash;     // order-sensitive hash of that list (what "the list did not change" is read from)
+};
+static_assert(sizeof(NodeS) == 64 && sizeof(NodeE) == 32, "record sizes");
+__device__ __forceinline__ NodeS load_s(const NodeS *p) {
+    NodeS r;
+    const uint4 *q = reinterpret_cast<const uint4 *>(p);
+    uint4 *o = reinterpret_cast<uint4 *>(&r);
+    o[0] = q[0]; o[1] = q[1]; o[2] = q[2]; o[3] = q[3];
+    return r;
+}
+__device__ __forceinline__ NodeE load_e(const NodeE *p) {
+    NodeE r;
+    const uint4 *q = reinterpret_cast<const uint4 *>(p);
+    uint4 *o = reinterpret_cast<uint4 *>(&r);
+    o[0] = q[0]; o[1] = q[1];
+    return r;
+}
 struct FuseArgs {
-    const float *xyz;
-    const double *nrm;
+    NodeS *S;                    // [n]
     const int32_t *lists;        // the neighbour table followed by the three list pools: one address space
     int64_t n;
     int k;
@@ -167,18 +196,26 @@ struct FuseArgs {
     State *st;
     const int32_t *reps;         // the round's centres, ascending
     int nreps;
-    const int32_t *root;         // [n] round-start representative of every node
-    const int32_t *sz0;          // [n] round-start sizes
-    const int64_t *adj_off;      // [n] round-start lists
-    const int32_t *adj_len;
     const int64_t *before;       // [nreps] absorptions by the centres before each centre (previous estimate), or null
     int64_t pool_base, sub_cap;  // where this pass writes lists: SUBPOOLS regions of sub_cap entries from pool_base
     int pool_sel;                // which set of bump pointers
-    Est rd, wr;
+    NodeE *rd, *wr;              // [n] the estimate read / written
+    int32_t *cnt_slot_rd, *cnt_slot_wr;  // [nreps] cnt in the order of the centres (the budget's prefix sum runs over it)
 };
 
-__global__ void iota_kernel(int32_t *a, int32_t *b, int32_t *sz, int64_t *off, int32_t *len, int64_t n, int k) {
-    SVX_FOR(i, n) { a[i] = (int32_t)i; b[i] = (int32_t)i; sz[i] = 1; off[i] = i * k; len[i] = k; }
+__global__ void iota_kernel(int32_t *root, int32_t *reps, NodeS *S, const float *__restrict__ xyz, const double *__restrict__ nrm, int64_t n, int k) {
+    SVX_FOR(i, n) {
+        root[i] = (int32_t)i; reps[i] = (int32_t)i;
+        NodeS r;
+        r.x = xyz[3 * i]; r.y = xyz[3 * i + 1]; r.z = xyz[3 * i + 2];
+        r.sz = 1;
+        r.nx = nrm[3 * i]; r.ny = nrm[3 * i + 1]; r.nz = nrm[3 * i + 2];
+        r.off = i * k; r.len = k;
+        r.pad_[0] = r.pad_[1] = r.pad_[2] = 0;
+        const uint4 *o = reinterpret_cast<const uint4 *>(&r);
+        uint4 *q = reinterpret_cast<uint4 *>(S + i);
+        q[0] = o[0]; q[1] = o[1]; q[2] = o[2]; q[3] = o[3];
+    }
 }
 // (and what pass 0 needs prepared: its pool's bump pointers, its claims, its flag and its total -- every later pass is prepared by
 //  the last workgroup of the pass before it, abs_changed_kernel)
@@ -194,15 +231,15 @@ __global__ void round_init_kernel(FuseArgs a) {
     }
     SVX_FOR(s, a.nreps) {
         const int32_t i = a.reps[s];
-        a.wr.abs[i] = NONE;
-        a.rd.abs[i] = NONE;
-        a.rd.ns[i] = a.sz0[i];
-        a.rd.cnt[i] = 0;
-        a.rd.off[i] = a.adj_off[i];
-        a.rd.len[i] = a.adj_len[i];
-        a.rd.hash[i] = ~0ULL;   // ("the round-start list": no evaluation writes this value twice in a row unless nothing changes)
-        a.rd.cnt_slot[s] = 0;
-
+        const NodeS si = load_s(a.S + i);
+        a.wr[i].abs = NONE;
+        NodeE e;
+        e.abs = NONE; e.ns = si.sz; e.cnt = 0; e.len = si.len; e.off = si.off;
+        e.hash = ~0ULL;   // ("the round-start list": no evaluation writes this value twice in a row unless nothing changes)
+        const uint4 *o = reinterpret_cast<const uint4 *>(&e);
+        uint4 *q = reinterpret_cast<uint4 *>(a.rd + i);
+        q[0] = o[0]; q[1] = o[1];
+        a.cnt_slot_rd[s] = 0;
     }
 }
 // Half a wavefront (32 lanes) = one centre: the lists are a few dozen entries, and two dependent-load chains per wave keep the
@@ -236,7 +273,7 @@ __global__ __launch_bounds__(EVAL_WAVES * 64, SVX_EVAL_WPE) void eval_kernel(Fus
     unsigned int *ACC = acc_all[wave][h];
     const int32_t i = a.reps[valid_c ? s : s0];
     const unsigned int ui = (unsigned int)i;
-    const unsigned int *__restrict__ abs_rd = a.rd.abs;
+    const NodeE *__restrict__ E = a.rd;
     int32_t *__restrict__ pool = const_cast<int32_t *>(a.lists);
     const unsigned int below = (1u << hl) - 1u;
     auto hb = [&](unsigned long long m) { return (unsigned int)(m >> hbase) & GMASK; };  // this half's bits of a wave-wide ballot
@@ -250,20 +287,19 @@ __global__ __launch_bounds__(EVAL_WAVES * 64, SVX_EVAL_WPE) void eval_kernel(Fus
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     };
-    const unsigned int absi = abs_rd[i];
+    const NodeE ei = load_e(E + i);    // (its claim, and what it did in the pass before: one sector)
+    const NodeS si = load_s(a.S + i);  // (its position and normal -- the metric's first argument, :142 --, its size and list: one line)
+    const unsigned int absi = ei.abs;
     const bool dead = absi != NONE && absi < ui;  // absorbed before its turn: adjacents[i] is empty by then (:121)
-    const int64_t off0 = a.adj_off[i];
-    const int len0 = a.adj_len[i];
+    const int64_t off0 = si.off;
+    const int len0 = si.len;
     long long budget = a.before ? budget_total - (long long)a.before[valid_c ? s : s0] : 0x7fffffffffffLL;
     const bool run = valid_c && !dead && len0 > 0 && budget > 0;
-    int nsz = a.sz0[i], cnt = 0;
+    int nsz = si.sz, cnt = 0;
     int head = 0, tail = 0;
     bool ovf = false;
-    // this centre's own position and normal (the metric's first argument, :142)
-    float pi_[3];
-    double ni_[3];
-#pragma unroll
-    for (int d = 0; d < 3; ++d) { pi_[d] = a.xyz[3 * (int64_t)i + d]; ni_[d] = a.nrm[3 * (int64_t)i + d]; }
+    const float pi_[3] = {si.x, si.y, si.z};
+    const double ni_[3] = {si.nx, si.ny, si.nz};
 
     // appends Find(list entries) that are not yet visited, in list order (:126-133 / :151-157); `act`: this half has a list to append
     auto append_list = [&](bool act, int64_t off, int len) {
@@ -272,13 +308,13 @@ __global__ __launch_bounds__(EVAL_WAVES * 64, SVX_EVAL_WPE) void eval_kernel(Fus
             const bool have = go && c0 + hl < len;
             unsigned int r = NONE;
             if (have) {
-                r = (unsigned int)a.root[pool[off + c0 + hl]];
+                r = (unsigned int)pool[off + c0 + hl];  // (a round-start root: rootlists_kernel)
                 // Find as centre i sees it (set.Find, :127/:152): every absorption by a centre that ran BEFORE i and was alive at its
                 // own turn; honoured claims lead to ever higher centres, so the walk ends
                 for (;;) {
-                    const unsigned int c = abs_rd[r];
+                    const unsigned int c = E[r].abs;
                     if (c == NONE || !(c < ui)) break;
-                    const unsigned int cc = abs_rd[c];
+                    const unsigned int cc = E[c].abs;
                     if (cc != NONE && cc < c) break;
                     r = c;
                 }
@@ -326,20 +362,22 @@ __global__ __launch_bounds__(EVAL_WAVES * 64, SVX_EVAL_WPE) void eval_kernel(Fus
         const int m = go ? (tail - head < G ? tail - head : G) : 0;
         const bool mine = hl < m;
         const int32_t j = mine ? Q[head + hl] : i;
-        // sizes[j] as centre i finds it: j ran before i (and grew) iff j < i
-        const int sj = mine ? ((unsigned int)j < ui ? a.rd.ns[j] : a.sz0[j]) : 0;
+        // sizes[j] and adjacents[j] as centre i finds them (:142, :151): j ran before i -- grew, kept a list of its own -- iff j < i
+        int sj = 0, jlen = 0;
+        int64_t joff = 0;
         bool acc = false;
         if (mine) {
-            float pj[3];
-            double nj[3];
-#pragma unroll
-            for (int d = 0; d < 3; ++d) { pj[d] = a.xyz[3 * (int64_t)j + d]; nj[d] = a.nrm[3 * (int64_t)j + d]; }
+            const NodeS sn = load_s(a.S + j);
+            sj = sn.sz; joff = sn.off; jlen = sn.len;
+            if ((unsigned int)j < ui) {
+                const NodeE en = load_e(E + j);  // (the sector its claim was read from a moment ago)
+                sj = en.ns; joff = en.off; jlen = en.len;
+            }
+            const float pj[3] = {sn.x, sn.y, sn.z};
+            const double nj[3] = {sn.nx, sn.ny, sn.nz};
             const double loss = (double)sj * sv_metric_vals(pi_, ni_, pj, nj, a.resolution);  // :142 `sizes[j] * metric(points[i], points[j])`
             acc = lambda - loss > 0.0;                                                        // :143-144
         }
-        // adjacents[j] as centre i finds it (:151): j's list after its turn iff j < i
-        const int64_t joff = mine ? ((unsigned int)j < ui ? a.rd.off[j] : a.adj_off[j]) : 0;
-        const int jlen = mine ? ((unsigned int)j < ui ? a.rd.len[j] : a.adj_len[j]) : 0;
         unsigned int accm = hb(__ballot(acc));
         int done = m;  // entries of this chunk that the reference's loop reaches
         if (go && (long long)__popc(accm) >= budget) {  // `if (--number_of_supervoxels == n_supervoxels) break;` (:160) inside this chunk
@@ -352,7 +390,7 @@ __global__ __launch_bounds__(EVAL_WAVES * 64, SVX_EVAL_WPE) void eval_kernel(Fus
         }
         const bool take = mine && ((accm >> hl) & 1u);
         if (take) {
-            atomicMin(&a.wr.abs[j], ui);  // set.Link(j, i) (:145); of several centres that claim j in an estimate the lowest counts
+            atomicMin(&a.wr[j].abs, ui);  // set.Link(j, i) (:145); of several centres that claim j in an estimate the lowest counts
             atomicOr(&ACC[(head + hl) >> 5], 1u << ((head + hl) & 31));
         }
         nsz += half_sum(take ? sj : 0);   // sizes[i] += sizes[j] (:147)
@@ -418,9 +456,250 @@ __global__ __launch_bounds__(EVAL_WAVES * 64, SVX_EVAL_WPE) void eval_kernel(Fus
     if (ovf && hl == 0) atomicOr(&a.st->overflow, tail + 68 > QCAP ? 1 : 2);
     if (hl == 0 && tail > a.st->max_tail) atomicMax(&a.st->max_tail, tail);  // (a statistic: rarely more than a few updates per pass)
     if (hl == 0 && valid_c) {
-        const bool same = a.rd.ns[i] == nsz && a.rd.cnt[i] == cnt && a.rd.len[i] == out_len && a.rd.hash[i] == hash;
-        a.wr.ns[i] = nsz; a.wr.cnt[i] = cnt; a.wr.off[i] = out_off; a.wr.len[i] = out_len; a.wr.hash[i] = hash;
-        a.wr.cnt_slot[s] = cnt;
+        const bool same = ei.ns == nsz && ei.cnt == cnt && ei.len == out_len && ei.hash == hash;
+        NodeE *w = a.wr + i;  // (everything but `abs`, which the other centres' claims are landing in)
+        w->ns = nsz; w->cnt = cnt; w->len = out_len;
+        *reinterpret_cast<ulonglong2 *>(&w->off) = make_ulonglong2((unsigned long long)out_off, hash);
+        a.cnt_slot_wr[s] = cnt;
+        if (!same) a.st->changed[pass & 7] = 1;
+#ifdef SVX_MEASURE_PREFIX
+        if (!same) { atomicMin(&a.st->minchg[pass & 7], i); atomicAdd(&a.st->nchg[pass & 7], 1); }
+#endif
+    }
+}
+// ---- the narrow shape, round 6: one DPP row (16 lanes) per centre, the visited set as a HASH SET in LDS ---------------------------------
+// The counters of round 5's kernel (profiles/r6_svx_eval_counters.json) put it at 65 % vector issue with waves parked on memory the rest of
+// the time: ~1200 vector and ~600 scalar instructions per wavefront, three quarters of them the visited-set bookkeeping -- a linear scan of the
+// queue per list chunk (tail / 4 LDS reads and 4 compares each) and a serial first-occurrence loop of ballots and shuffles.  Here: a byte-wide
+// open-addressing table beside the queue (the node's position in the queue, 0xff = empty; a look-up is ~1.1 probes), first occurrences inside a
+// chunk by 15 row_shr compares without a loop, row sums by row_ror.  Same queue order, same visited sets, same outputs as eval_kernel<16, 256>.
+template <int D> __device__ __forceinline__ unsigned int row_shr_u(unsigned int v) {
+    return (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x110 + D, 0xf, 0xf, true);  // (lanes below D of the row read 0)
+}
+template <int D> __device__ __forceinline__ bool dup_below(unsigned int key) {
+    bool d = row_shr_u<D>(key) == key;
+    if constexpr (D < 15) d |= dup_below<D + 1>(key);
+    return d;
+}
+template <int D> __device__ __forceinline__ int row_ror_i(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x120 + D, 0xf, 0xf, true); }
+__device__ __forceinline__ int row_sum16(int v) {
+    v += row_ror_i<8>(v); v += row_ror_i<4>(v); v += row_ror_i<2>(v); v += row_ror_i<1>(v);
+    return v;  // (every lane of the row holds the row's total)
+}
+constexpr int Q16 = 256, H16 = 256;
+__global__ __launch_bounds__(EVAL_WAVES * 64, SVX_EVAL_WPE) void eval16_kernel(FuseArgs a, double lambda, long long budget_total, int pass) {
+    constexpr int G = 16, CPW = 4;
+    __shared__ int32_t q_all[EVAL_WAVES][CPW][Q16];
+    __shared__ unsigned int h_all[EVAL_WAVES][CPW][H16 / 4];
+    __shared__ unsigned int acc_all[EVAL_WAVES][CPW][Q16 / 32];
+    const int wave = (int)(threadIdx.x >> 6), lane = lane_id(), h = lane >> 4, hl = lane & 15, hbase = h * G;
+    const int64_t s0 = ((int64_t)blockIdx.x * EVAL_WAVES + wave) * CPW;
+    if (s0 >= a.nreps) return;  // (whole wave)
+    if (a.st->done) return;     // (converged earlier in this batch of passes)
+    const int64_t s = s0 + h;
+    const bool valid_c = s < a.nreps;
+    int32_t *Q = q_all[wave][h];
+    unsigned int *HW = h_all[wave][h];
+    const unsigned char *HB = reinterpret_cast<const unsigned char *>(HW);
+    unsigned int *ACC = acc_all[wave][h];
+    const int32_t i = a.reps[valid_c ? s : s0];
+    const unsigned int ui = (unsigned int)i;
+    const NodeE *__restrict__ E = a.rd;
+    int32_t *__restrict__ pool = const_cast<int32_t *>(a.lists);
+    const unsigned int below = (1u << hl) - 1u;
+    auto hb = [&](unsigned long long m) { return (unsigned int)(m >> hbase) & 0xffffu; };
+    auto wsync = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    const NodeE ei = load_e(E + i);
+    const NodeS si = load_s(a.S + i);
+    const unsigned int absi = ei.abs;
+    const bool dead = absi != NONE && absi < ui;  // absorbed before its turn: adjacents[i] is empty by then (:121)
+    const int64_t off0 = si.off;
+    const int len0 = si.len;
+    long long budget = a.before ? budget_total - (long long)a.before[valid_c ? s : s0] : 0x7fffffffffffLL;
+    const bool run = valid_c && !dead && len0 > 0 && budget > 0;
+    int nsz = si.sz, cnt = 0;
+    int head = 0, tail = 0;
+    bool ovf = false;
+    const float pi_[3] = {si.x, si.y, si.z};
+    const double ni_[3] = {si.nx, si.ny, si.nz};
+    auto slot_of = [](unsigned int r) { return (r * 0x9E3779B1u) >> 24; };
+    // the node at queue position `pos` enters the table (lanes of a chunk insert side by side: a byte is claimed by a compare-and-swap of its word)
+    auto insert = [&](bool on, unsigned int r, int pos) {
+        unsigned int slot = slot_of(r);
+        while (on) {
+            const unsigned int w = HW[slot >> 2], sh = (slot & 3u) * 8u;
+            if (((w >> sh) & 0xffu) == 0xffu) {
+                if (atomicCAS(&HW[slot >> 2], w, (w & ~(0xffu << sh)) | ((unsigned int)pos << sh)) == w) on = false;
+            } else slot = (slot + 1u) & (unsigned int)(H16 - 1);
+        }
+    };
+    // appends Find(list entries) that are not yet visited, in list order (:126-133 / :151-157); `act`: this row has a list to append
+    auto append_list = [&](bool act, int64_t off, int len) {
+        for (int c0 = 0; __any(act && !ovf && c0 < len); c0 += G) {
+            const bool go = act && !ovf && c0 < len;
+            const bool have = go && c0 + hl < len;
+            unsigned int r = NONE;
+            bool fresh = false;
+            if (have) {
+                r = (unsigned int)pool[off + c0 + hl];  // (a round-start root: rootlists_kernel)
+                // Find as centre i sees it (set.Find, :127/:152): every absorption by a centre that ran BEFORE i and was alive at its
+                // own turn; honoured claims lead to ever higher centres, so the walk ends
+                for (;;) {
+                    const unsigned int c = E[r].abs;
+                    if (c == NONE || !(c < ui)) break;
+                    const unsigned int cc = E[c].abs;
+                    if (cc != NONE && cc < c) break;
+                    r = c;
+                }
+                // visited already?  (the table holds every node of the queue; at most 252 of its 256 bytes are taken)
+                fresh = true;
+                for (unsigned int slot = slot_of(r);; slot = (slot + 1u) & (unsigned int)(H16 - 1)) {
+                    const unsigned int p = HB[slot];
+                    if (p == 0xffu) break;
+                    if ((unsigned int)Q[p] == r) { fresh = false; break; }
+                }
+            }
+            // ... or by a lower lane of this chunk (the first occurrence wins)
+            const bool first = fresh && !dup_below<1>(fresh ? r + 1u : 0u);
+            const unsigned int news = hb(__ballot(first));
+            const int nn = (int)__popc(news);
+            bool put = false;
+            int pos = 0;
+            if (go) {
+                if (tail + nn + 4 > Q16) ovf = true;
+                else {
+                    put = first;
+                    pos = tail + (int)__popc(news & below);
+                    if (put) Q[pos] = (int32_t)r;
+                    tail += nn;
+                }
+            }
+            insert(put, r, pos);
+            wsync();
+        }
+    };
+
+    if (run) {
+        if (hl == 0) Q[0] = i;  // visited[i] = true; queue[front++] = i (:123-125)
+        for (int e = hl; e < Q16 / 32; e += G) ACC[e] = 0u;
+        for (int e = hl; e < H16 / 4; e += G) HW[e] = 0xffffffffu;
+        head = tail = 1;
+    }
+    wsync();
+    insert(run && hl == 0, ui, 0);
+    wsync();
+    append_list(run, off0, len0);
+    bool stop = false;
+    while (__any(run && !stop && !ovf && head < tail)) {  // :137-163, 16 entries of the queue at a time
+        const bool go = run && !stop && !ovf && head < tail;
+        const int m = go ? (tail - head < G ? tail - head : G) : 0;
+        const bool mine = hl < m;
+        const int32_t j = mine ? Q[head + hl] : i;
+        // sizes[j] and adjacents[j] as centre i finds them (:142, :151): j ran before i -- grew, kept a list of its own -- iff j < i
+        int sj = 0, jlen = 0;
+        int64_t joff = 0;
+        bool acc = false;
+        if (mine) {
+            const NodeS sn = load_s(a.S + j);
+            sj = sn.sz; joff = sn.off; jlen = sn.len;
+            if ((unsigned int)j < ui) {
+                const NodeE en = load_e(E + j);  // (the sector its claim was read from a moment ago)
+                sj = en.ns; joff = en.off; jlen = en.len;
+            }
+            const float pj[3] = {sn.x, sn.y, sn.z};
+            const double nj[3] = {sn.nx, sn.ny, sn.nz};
+            const double loss = (double)sj * sv_metric_vals(pi_, ni_, pj, nj, a.resolution);  // :142 `sizes[j] * metric(points[i], points[j])`
+            acc = lambda - loss > 0.0;                                                        // :143-144
+        }
+        unsigned int accm = hb(__ballot(acc));
+        int done = m;  // entries of this chunk that the reference's loop reaches
+        if (go && (long long)__popc(accm) >= budget) {  // `if (--number_of_supervoxels == n_supervoxels) break;` (:160) inside this chunk
+            unsigned int t = accm;
+            for (long long b = 1; b < budget; ++b) t &= t - 1u;
+            const int last = __ffs((int)t) - 1;  // lane of the absorption that reaches K
+            done = last + 1;
+            accm &= (1u << (last + 1)) - 1u;
+            stop = true;
+        }
+        const bool take = mine && ((accm >> hl) & 1u);
+        if (take) {
+            atomicMin(&a.wr[j].abs, ui);  // set.Link(j, i) (:145); of several centres that claim j in an estimate the lowest counts
+            atomicOr(&ACC[(head + hl) >> 5], 1u << ((head + hl) & 31));
+        }
+        nsz += row_sum16(take ? sj : 0);   // sizes[i] += sizes[j] (:147)
+        const int na = (int)__popc(accm);
+        cnt += na;
+        budget -= na;
+        // the absorbed nodes' lists join the queue, in the queue's order (:149-157)
+        unsigned int mm = accm;
+        while (__any(mm != 0u && !ovf)) {
+            const bool ex = mm != 0u && !ovf;
+            const int l = ex ? __ffs((int)mm) - 1 : 0;
+            if (ex) mm &= mm - 1u;
+            const long long o = __shfl((long long)joff, hbase + l, 64);
+            const int ln = __shfl(jlen, hbase + l, 64);
+            append_list(ex, (int64_t)o, ln);
+        }
+        if (go) head += done;
+    }
+    // the centre's list after its turn (:164 `adjacents[i].swap(adjacent)`): the entries it looked at and did not absorb, in order
+    int64_t out_off = dead ? 0 : off0;
+    int out_len = dead ? 0 : len0;  // (a centre that did not run keeps its list; an absorbed one's is cleared, :158)
+    unsigned long long hash = dead ? 1ULL : ~0ULL;
+    wsync();
+    const bool fin = run && !ovf;
+    int kept = 0;
+    for (int e0 = 1; __any(fin && e0 < head); e0 += G) {
+        const int e = e0 + hl;
+        kept += (int)__popc(hb(__ballot(fin && e < head && !((ACC[e >> 5] >> (e & 31)) & 1u))));
+    }
+    if (fin) {
+        out_len = kept;
+        out_off = 0;
+    }
+    {
+        const bool alloc = fin && kept > 0;
+        const int sp = (int)(s & (SUBPOOLS - 1));
+        unsigned long long base = 0ULL;
+        if (alloc && hl == 0) base = atomicAdd(&a.st->sub[a.pool_sel][sp], (unsigned long long)kept);
+        base = (unsigned long long)__shfl((long long)base, hbase, 64);
+        if (alloc) {
+            if ((long long)base + kept > a.sub_cap) ovf = true;
+            out_off = a.pool_base + (int64_t)sp * a.sub_cap + (int64_t)base;
+        }
+    }
+    unsigned long long hsum = 0ULL;
+    {
+        int at = 0;
+        const bool wr = fin && !ovf;
+        for (int e0 = 1; __any(wr && e0 < head); e0 += G) {
+            const int e = e0 + hl;
+            const bool keep = wr && e < head && !((ACC[e >> 5] >> (e & 31)) & 1u);
+            const unsigned int km = hb(__ballot(keep));
+            if (keep) {
+                const int p = at + (int)__popc(km & below);
+                pool[out_off + p] = Q[e];
+                hsum += mix64(((unsigned long long)(unsigned int)Q[e] << 32) | (unsigned int)p);
+            }
+            at += (int)__popc(km);
+        }
+    }
+    {
+        const int h0 = row_sum16((int)(hsum & 0x7fffffffULL)), h1 = row_sum16((int)((hsum >> 31) & 0x7fffffffULL));
+        if (run) hash = 2ULL + (unsigned long long)h0 + (unsigned long long)h1 * 0x9E3779B1ULL + (unsigned long long)kept * 0x85EBCA6BULL;
+    }
+    if (ovf && hl == 0) atomicOr(&a.st->overflow, tail + 68 > Q16 ? 1 : 2);
+    if (hl == 0 && tail > a.st->max_tail) atomicMax(&a.st->max_tail, tail);  // (a statistic: rarely more than a few updates per pass)
+    if (hl == 0 && valid_c) {
+        const bool same = ei.ns == nsz && ei.cnt == cnt && ei.len == out_len && ei.hash == hash;
+        NodeE *w = a.wr + i;  // (everything but `abs`, which the other centres' claims are landing in)
+        w->ns = nsz; w->cnt = cnt; w->len = out_len;
+        *reinterpret_cast<ulonglong2 *>(&w->off) = make_ulonglong2((unsigned long long)out_off, hash);
+        a.cnt_slot_wr[s] = cnt;
         if (!same) a.st->changed[pass & 7] = 1;
 #ifdef SVX_MEASURE_PREFIX
         if (!same) { atomicMin(&a.st->minchg[pass & 7], i); atomicAdd(&a.st->nchg[pass & 7], 1); }
@@ -435,15 +714,15 @@ __global__ void abs_changed_kernel(FuseArgs a, int pass, int budget_on, long lon
     long long tot = 0;
     SVX_FOR(s, a.nreps) {
         const int32_t i = a.reps[s];
-        const unsigned int c0 = a.rd.abs[i], c1 = a.wr.abs[i];
+        const unsigned int c0 = a.rd[i].abs, c1 = a.wr[i].abs;
         ch = ch || c0 != c1;
 #ifdef SVX_MEASURE_PREFIX
         if (c0 != c1) {  // the claimant(s) whose claim on i came or went
             atomicMin(&st->minchg[pass & 7], (int)(c0 < c1 ? c0 : c1)); atomicAdd(&st->nchg[pass & 7], 1);
         }
 #endif
-        a.rd.abs[i] = NONE;  // (this estimate is the one the NEXT pass writes: its claims start empty)
-        tot += a.wr.cnt_slot[s];
+        a.rd[i].abs = NONE;  // (this estimate is the one the NEXT pass writes: its claims start empty)
+        tot += a.cnt_slot_wr[s];
     }
     if (__ballot(ch) != 0ULL && lane_id() == 0) st->changed[pass & 7] = 1;
     int lo = wave_sum((int)(tot & 0xffff)), hi = wave_sum((int)(tot >> 16));  // (a lane's share is far below 2^31)
@@ -478,20 +757,38 @@ __global__ void abs_changed_kernel(FuseArgs a, int pass, int budget_on, long lon
     }
 }
 // the converged estimate becomes the state: survivors keep size and list, everybody follows its absorber
-__global__ void commit_kernel(FuseArgs a, int32_t *sz0, int64_t *adj_off, int32_t *adj_len, int32_t *keep_flag) {
+__global__ void commit_kernel(FuseArgs a, int32_t *keep_flag) {
     SVX_FOR(s, a.nreps) {
         const int32_t i = a.reps[s];
-        const bool survives = a.rd.abs[i] == NONE;
+        const NodeE e = load_e(a.rd + i);
+        const bool survives = e.abs == NONE;
         keep_flag[s] = survives ? 1 : 0;
-        if (survives) { sz0[i] = a.rd.ns[i]; adj_off[i] = a.rd.off[i]; adj_len[i] = a.rd.len[i]; }
-        else adj_len[i] = 0;
+        NodeS *si = a.S + i;
+        if (survives) { si->sz = e.ns; si->off = e.off; si->len = e.len; }
+        else si->len = 0;
     }
 }
-__global__ void reroot_kernel(int32_t *root, const unsigned int *__restrict__ abs, int64_t n) {
+__global__ void reroot_kernel(int32_t *root, const NodeE *__restrict__ E, int64_t n) {
     SVX_FOR(x, n) {
         unsigned int r = (unsigned int)root[x];
-        while (abs[r] != NONE) r = abs[r];  // (a converged estimate: every claim real, chains ascend in time)
+        for (;;) {  // (a converged estimate: every claim real, chains ascend in time)
+            const unsigned int c = E[r].abs;
+            if (c == NONE) break;
+            r = c;
+        }
         root[x] = (int32_t)r;
+    }
+}
+// the survivors' lists for the next round: every entry replaced by its representative (Find at the start of the round: what every
+// evaluation of every pass would otherwise look up per entry).  16 lanes per list; in place (a list has one owner).
+__global__ __launch_bounds__(256) void rootlists_kernel(const NodeS *__restrict__ S, int32_t *__restrict__ lists, const int32_t *__restrict__ root,
+                                                        const int32_t *__restrict__ reps, int nreps) {
+    const int sub = (int)(threadIdx.x & 15);
+    for (int64_t s = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4; s < nreps; s += ((int64_t)gridDim.x * blockDim.x) >> 4) {
+        const NodeS *si = S + reps[s];
+        const int64_t off = si->off;
+        const int len = si->len;
+        for (int e = sub; e < len; e += 16) lists[off + e] = root[lists[off + e]];
     }
 }
 __global__ void compact_kernel(const int32_t *reps, const int32_t *keep_flag, const int32_t *keep_pos, int nreps, int32_t *reps_out) {
@@ -634,12 +931,10 @@ struct Ws {
     State *st;
     int32_t *lists;  // [n k] the neighbour table (a copy: one address space with the pools) + 3 pools
     int64_t pool_off[3], pool_cap;
-    int32_t *root, *sz0, *adj_len, *reps_a, *reps_b, *keep_flag, *keep_pos;
-    int64_t *adj_off, *before;
-    unsigned int *abs[2];
-    int32_t *ns[2], *cnt[2], *len[2], *cnt_slot[2];
-    int64_t *off[2];
-    unsigned long long *hash[2];
+    NodeS *S;
+    NodeE *E[2];
+    int32_t *root, *reps_a, *reps_b, *keep_flag, *keep_pos, *cnt_slot[2];
+    int64_t *before;
     double *dis, *dis2[2], *median;
     void *sel;
     unsigned long long *key, *key_s_in, *key_s_out;
@@ -660,33 +955,38 @@ static int layout(int64_t n, int k, Ws &w, unsigned char *base) {
     prim = prim > scan64_b ? prim : scan64_b;
     size_t o = 0;
     auto carve = [&](size_t bytes) { size_t at = o; o += align_up(bytes); return base ? base + at : (unsigned char *)nullptr; };
-    const size_t nk = (size_t)n * (size_t)k;
+    const size_t nk = (size_t)n * (size_t)k, N = (size_t)n;
     w.st = (State *)carve(sizeof(State));
     // the pools: a centre's list is inherited by ONE absorber in a consistent estimate, so the lists of a pass sum to at most the
     // lists before it (n k at the start); an inconsistent estimate may count some twice: room for 2 n k, in SUBPOOLS slices
-    w.pool_cap = (int64_t)(((2 * nk + 2 * (size_t)n) / SUBPOOLS + 64) * SUBPOOLS);  // (+ what was absorbed and passed through: at most a few per centre)
+    w.pool_cap = (int64_t)(((2 * nk + 2 * N) / SUBPOOLS + 64) * SUBPOOLS);  // (+ what was absorbed and passed through: at most a few per centre)
     w.lists = (int32_t *)carve((nk + 3 * (size_t)w.pool_cap) * 4);
     for (int p = 0; p < 3; ++p) w.pool_off[p] = (int64_t)nk + (int64_t)p * w.pool_cap;
-    w.root = (int32_t *)carve((size_t)n * 4); w.sz0 = (int32_t *)carve((size_t)n * 4); w.adj_len = (int32_t *)carve((size_t)n * 4);
-    w.reps_a = (int32_t *)carve((size_t)n * 4); w.reps_b = (int32_t *)carve((size_t)n * 4);
-    w.keep_flag = (int32_t *)carve((size_t)n * 4); w.keep_pos = (int32_t *)carve((size_t)n * 4);
-    w.adj_off = (int64_t *)carve((size_t)n * 8); w.before = (int64_t *)carve((size_t)n * 8);
-    for (int e = 0; e < 2; ++e) {
-        w.abs[e] = (unsigned int *)carve((size_t)n * 4); w.ns[e] = (int32_t *)carve((size_t)n * 4); w.cnt[e] = (int32_t *)carve((size_t)n * 4);
-        w.len[e] = (int32_t *)carve((size_t)n * 4); w.cnt_slot[e] = (int32_t *)carve((size_t)n * 4);
-        w.off[e] = (int64_t *)carve((size_t)n * 8); w.hash[e] = (unsigned long long *)carve((size_t)n * 8);
-    }
-    w.dis = (double *)carve((size_t)n * 8);
-    w.dis2[0] = (double *)carve((size_t)n * 8); w.dis2[1] = (double *)carve((size_t)n * 8);
+    w.root = (int32_t *)carve(N * 4);
+    w.reps_a = (int32_t *)carve(N * 4); w.reps_b = (int32_t *)carve(N * 4);
+    w.dis = (double *)carve(N * 8);
+    w.dis2[0] = (double *)carve(N * 8); w.dis2[1] = (double *)carve(N * 8);
     w.median = (double *)carve(16);
     w.sel = carve(select_workspace_bytes());
-    // (the exchange's arrays alias the fusion's estimates: the fusion is over when the exchange starts)
-    w.key = (unsigned long long *)w.off[0]; w.key_s_in = (unsigned long long *)w.off[1]; w.key_s_out = (unsigned long long *)w.hash[0];
-    w.node_s_in = w.ns[0]; w.node_s_out = w.ns[1]; w.pos = w.cnt[0]; w.lab = w.cnt[1]; w.out[0] = w.len[0]; w.out[1] = w.len[1];
-    w.rank = w.cnt_slot[0];
-    w.ch[0] = (unsigned char *)w.abs[0]; w.ch[1] = (unsigned char *)w.abs[1];
     w.prim = carve(prim);
     w.prim_bytes = prim;
+    // what only the fusion needs and what only the exchange needs share one region (the fusion is over when the exchange starts;
+    // `root`, the representatives and `dis` live on through both)
+    const size_t region = o;
+    w.S = (NodeS *)carve(N * sizeof(NodeS));
+    w.E[0] = (NodeE *)carve(N * sizeof(NodeE)); w.E[1] = (NodeE *)carve(N * sizeof(NodeE));
+    w.keep_flag = (int32_t *)carve(N * 4); w.keep_pos = (int32_t *)carve(N * 4);
+    w.cnt_slot[0] = (int32_t *)carve(N * 4); w.cnt_slot[1] = (int32_t *)carve(N * 4);
+    w.before = (int64_t *)carve(N * 8);
+    const size_t fusion_end = o;
+    o = region;
+    w.key = (unsigned long long *)carve(N * 8); w.key_s_in = (unsigned long long *)carve(N * 8); w.key_s_out = (unsigned long long *)carve(N * 8);
+    w.node_s_in = (int32_t *)carve(N * 4); w.node_s_out = (int32_t *)carve(N * 4);
+    w.pos = (int32_t *)carve(N * 4); w.lab = (int32_t *)carve(N * 4);
+    w.out[0] = (int32_t *)carve(N * 4); w.out[1] = (int32_t *)carve(N * 4);
+    w.rank = (int32_t *)carve(N * 4);
+    w.ch[0] = carve(N); w.ch[1] = carve(N);
+    o = o > fusion_end ? o : fusion_end;
     w.total = o;
     return F4L_OK;
 }
@@ -755,25 +1055,31 @@ static int segment_exact_run(const float *xyz, const double *normals, const int3
     double lambda0 = 0.0;
     F4L_HIP_CHECK(hipMemcpyAsync(&lambda0, w.median, 8, hipMemcpyDeviceToHost, st));
     F4L_HIP_CHECK(hipMemcpyAsync(w.lists, knn, (size_t)n * k * 4, hipMemcpyDeviceToDevice, st));
-    hipLaunchKernelGGL(svx::iota_kernel, g, b, 0, st, w.root, w.reps_a, w.sz0, w.adj_off, w.adj_len, n, k);
+    hipLaunchKernelGGL(svx::iota_kernel, g, b, 0, st, w.root, w.reps_a, w.S, xyz, normals, n, k);
     rc = read_state();
     if (rc != F4L_OK) return rc;
     const int K = hs.K;
+    // K == n (a resolution below the point spacing: every point in a cell of its own): the reference's `--number == n_supervoxels`
+    // (:160) never fires once a first absorption took the count below K -- it then fuses on to ONE supervoxel -- while its check
+    // after a centre's turn (:169) stops everything at once when the first centre absorbs nothing (n singletons).  Neither is what
+    // a budget of (live - K) = 0 describes: left to the host replay (tests/test_gpu_supervoxel_exact.py).
+    if ((int64_t)K >= n) return F4L_EUNSUPPORTED;
     double lambda = lambda0 > DBL_EPSILON ? lambda0 : DBL_EPSILON;
 
     FuseArgs fa;
-    fa.xyz = xyz; fa.nrm = normals; fa.lists = w.lists; fa.n = n; fa.k = k; fa.resolution = resolution; fa.st = w.st;
-    fa.root = w.root; fa.sz0 = w.sz0; fa.adj_off = w.adj_off; fa.adj_len = w.adj_len; fa.sub_cap = w.pool_cap / SUBPOOLS;
+    fa.S = w.S; fa.lists = w.lists; fa.n = n; fa.k = k; fa.resolution = resolution; fa.st = w.st;
+    fa.sub_cap = w.pool_cap / SUBPOOLS;
     int32_t *reps = w.reps_a, *reps_next = w.reps_b;
     int nreps = (int)n, live = (int)n;
     int committed_pool = -1;  // (the pool the round-start lists live in; -1: the neighbour table)
+    const bool old16 = getenv("F4L_SV_EXACT_SCAN") != nullptr;  // (A/B: the narrow shape with round 5's linear visited scan)
     int rounds = 0, passes = 0;
-    auto est = [&](int e) { Est x; x.abs = w.abs[e]; x.ns = w.ns[e]; x.cnt = w.cnt[e]; x.off = w.off[e]; x.len = w.len[e]; x.hash = w.hash[e]; x.cnt_slot = w.cnt_slot[e]; return x; };
+    auto set_est = [&](int rd) { fa.rd = w.E[rd]; fa.wr = w.E[rd ^ 1]; fa.cnt_slot_rd = w.cnt_slot[rd]; fa.cnt_slot_wr = w.cnt_slot[rd ^ 1]; };
     for (; rounds < MAX_ROUNDS; lambda *= 2.0, ++rounds) {
         if (nreps <= 1) break;  // :118
         fa.reps = reps; fa.nreps = nreps;
         int rd = 0;
-        fa.rd = est(0); fa.wr = est(1);
+        set_est(0);
         hipLaunchKernelGGL(svx::round_init_kernel, g, b, 0, st, fa);
         const long long budget_total = (long long)live - K;
         // the two pools the estimates' lists alternate between: the ones the round-start lists are not in
@@ -791,7 +1097,7 @@ static int segment_exact_run(const float *xyz, const double *normals, const int3
             bool budget_on = false;
             for (int batch = 0; batch < batch_len; ++batch, ++it, ++passes) {
                 if (it >= MAX_ITERS) return F4L_EUNSUPPORTED;
-                fa.rd = est(rd); fa.wr = est(rd ^ 1);
+                set_est(rd);
                 fa.pool_sel = it & 1; fa.pool_base = w.pool_off[pe[it & 1]];
                 // the budget only binds in the round that reaches K: the prefix sum of the absorptions is taken once a pass has
                 // absorbed as much as the budget
@@ -799,11 +1105,12 @@ static int segment_exact_run(const float *xyz, const double *normals, const int3
                 budget_on = prev_total >= budget_total;
                 if (budget_on) {
                     size_t tb = w.prim_bytes;
-                    F4L_HIP_CHECK(rocprim::exclusive_scan(w.prim, tb, fa.rd.cnt_slot, w.before, (int64_t)0, (size_t)nreps, rocprim::plus<int64_t>(), st, false));
+                    F4L_HIP_CHECK(rocprim::exclusive_scan(w.prim, tb, fa.cnt_slot_rd, w.before, (int64_t)0, (size_t)nreps, rocprim::plus<int64_t>(), st, false));
                     fa.before = w.before;
                 }
                 if (wide) hipLaunchKernelGGL((svx::eval_kernel<32, QCAP_WIDE>), dim3((unsigned)((nreps + 2 * EVAL_WAVES - 1) / (2 * EVAL_WAVES))), dim3(EVAL_WAVES * 64), 0, st, fa, lambda, budget_total, it);
-                else hipLaunchKernelGGL((svx::eval_kernel<16, 256>), dim3((unsigned)((nreps + 4 * EVAL_WAVES - 1) / (4 * EVAL_WAVES))), dim3(EVAL_WAVES * 64), 0, st, fa, lambda, budget_total, it);
+                else if (old16) hipLaunchKernelGGL((svx::eval_kernel<16, 256>), dim3((unsigned)((nreps + 4 * EVAL_WAVES - 1) / (4 * EVAL_WAVES))), dim3(EVAL_WAVES * 64), 0, st, fa, lambda, budget_total, it);
+                else hipLaunchKernelGGL(svx::eval16_kernel, dim3((unsigned)((nreps + 4 * EVAL_WAVES - 1) / (4 * EVAL_WAVES))), dim3(EVAL_WAVES * 64), 0, st, fa, lambda, budget_total, it);
                 hipLaunchKernelGGL(svx::abs_changed_kernel, dim3(nreps > 262144 ? 256 : 64), b, 0, st, fa, it, budget_on ? 1 : 0, budget_total);
                 F4L_LAUNCH_CHECK();
                 rd ^= 1;
@@ -827,9 +1134,9 @@ static int segment_exact_run(const float *xyz, const double *normals, const int3
             converged = hs.done != 0;
         }
         // commit (the estimate `rd` = the last one written; its lists are in pool pe[(it - 1) & 1])
-        fa.rd = est(rd);
-        hipLaunchKernelGGL(svx::commit_kernel, g, b, 0, st, fa, w.sz0, w.adj_off, w.adj_len, w.keep_flag);
-        hipLaunchKernelGGL(svx::reroot_kernel, g, b, 0, st, w.root, (const unsigned int *)fa.rd.abs, n);
+        set_est(rd);
+        hipLaunchKernelGGL(svx::commit_kernel, g, b, 0, st, fa, w.keep_flag);
+        hipLaunchKernelGGL(svx::reroot_kernel, g, b, 0, st, w.root, (const svx::NodeE *)fa.rd, n);
         {
             size_t tb = w.prim_bytes;
             F4L_HIP_CHECK(rocprim::exclusive_scan(w.prim, tb, w.keep_flag, w.keep_pos, 0, (size_t)nreps, rocprim::plus<int32_t>(), st, false));
@@ -844,6 +1151,9 @@ static int segment_exact_run(const float *xyz, const double *normals, const int3
         nreps = lastp + lastf;
         live = nreps;
         { int32_t *t = reps; reps = reps_next; reps_next = t; }
+        if (nreps > 1 && nreps != K)  // (another round follows: its lists hold this round's representatives)
+            hipLaunchKernelGGL(svx::rootlists_kernel, dim3((unsigned)((nreps + 15) / 16 < 4096 ? (nreps + 15) / 16 : 4096)), b, 0, st, (const svx::NodeS *)w.S, w.lists,
+                               (const int32_t *)w.root, (const int32_t *)reps, nreps);
         if (getenv("F4L_SV_EXACT_DEBUG")) fprintf(stderr, "[sv exact] round %d lambda %.6g: %d passes, %d representatives left (K %d)\n", rounds, lambda, it, nreps, K);
         if (nreps == K) { ++rounds; break; }  // :175
     }

@@ -9,6 +9,7 @@ lists of index tensors (src/coarse_to_fine_matching_base.py:3156-3157, 3254).
 """
 import ctypes as C
 import os
+import threading
 
 from . import _lib
 from ._lib import check, lib, ptr, require_gpu, stream_ptr
@@ -38,6 +39,7 @@ def _dev(t, dtype, name, shape_tail=None):
 
 
 _SCRATCH = {}
+_SCRATCH_LOCK = threading.Lock()
 
 
 def _scratch(nbytes, device):
@@ -50,20 +52,25 @@ def _scratch(nbytes, device):
     nbytes = max(int(nbytes), 1)
     if os.environ.get("F4L_NO_SCRATCH_CACHE") or torch.cuda.is_current_stream_capturing():
         return torch.empty((nbytes,), dtype=torch.uint8, device=device)
+    # (the host thread is part of the key: f4l_knn and f4l_epoch_join synchronise in mid-call with the GIL released, so two threads
+    #  on one stream must not share a buffer -- ADVICE r5)
     key = (torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device(),
-           torch.cuda.current_stream(device).cuda_stream)
-    buf = _SCRATCH.get(key)
-    if buf is None or buf.numel() < nbytes:
-        _SCRATCH.pop(key, None)
-        buf = None  # (free the old one first: the two need not coexist)
-        buf = torch.empty((nbytes,), dtype=torch.uint8, device=device)
-        _SCRATCH[key] = buf
+           torch.cuda.current_stream(device).cuda_stream, threading.get_ident())
+    with _SCRATCH_LOCK:
+        buf = _SCRATCH.get(key)
+        if buf is None or buf.numel() < nbytes:
+            _SCRATCH.pop(key, None)
+            buf = None  # (free the old one first: the two need not coexist)
+            buf = torch.empty((nbytes,), dtype=torch.uint8, device=device)
+            _SCRATCH[key] = buf
     return buf
 
 
 def release_scratch():
-    """Drops the cached workspaces (see :func:`_scratch`)."""
-    _SCRATCH.clear()
+    """Drops the cached workspaces (see :func:`_scratch`): the entry points call it when a run is over, so that the peak workspace
+    (about 14 GB at 100 M points) does not stay allocated for the life of the process."""
+    with _SCRATCH_LOCK:
+        _SCRATCH.clear()
 
 
 def _max_patch(off):

@@ -6,7 +6,8 @@ matches and patch matches) is taken here by nearest neighbours:
     _compute_median_resolution            base:2716-2754   engine.median_resolution (exact 2-NN, f4l_knn)
     implement_partition                   base:2658-2694   supervoxel partition of the source epoch, resolution =
                                                            max(sqrt(3) * 10 * median_res, voxel) (:2668-2671)
-                                                           (f4l_supervoxel_parallel, or the label-identical f4l_supervoxel)
+                                                           (f4l_supervoxel: the reference's labels, the default; or the
+                                                            parallel variant f4l_supervoxel_parallel)
     load_partition / prepare_pts2spt_dict base:1237-1332   f4l_labels_to_csr + f4l_gather_points
     (patch matches: every target point joins the patch of its nearest source point -- f4l_nn_query; point matches: 1-NN of
      each source point inside its target patch within 2 x icp_threshold -- f4l_nn_refine at the identity)
@@ -20,9 +21,11 @@ import numpy as np
 from . import engine
 
 
-def full_path(src, tgt, k=30, icp_threshold=0.1, voxel_size=0.0, partition="parallel", max_iter=30, fixed_iters=False,
+def full_path(src, tgt, k=30, icp_threshold=0.1, voxel_size=0.0, partition="identical", max_iter=30, fixed_iters=False,
               search="f64", resolution=None, keep_inputs=False):
-    """src, tgt: (n, 3) float32 CUDA tensors (two epochs of one tile).  Returns dict(rows (n_src, 6) dense displacement
+    """src, tgt: (n, 3) float32 CUDA tensors (two epochs of one tile).  `partition`: "identical" (default, like the entry points:
+    the reference's own supervoxel labels, f4l_supervoxel) or "parallel" (the all-device variant: same K and criteria, other
+    labels).  Returns dict(rows (n_src, 6) dense displacement
     rows in patch order, sparse (m, 6), labels, K, T, fitness, rmse, iters, order (patch-contiguous source order),
     resolution, stage_ms {name: milliseconds}[, with keep_inputs: what the per-patch loop was given -- patch_src, patch_tgt (the
     two epochs in patch order), corr_src, corr_ref, corr_off (the point matches of every patch)])."""

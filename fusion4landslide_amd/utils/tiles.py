@@ -53,9 +53,13 @@ def for_each_tile(cfg, tiles, process, log, first=0, batch=1, stages=None):
                 finish(state, result)
             pending.clear()
 
-    for tile_i, src_path in enumerate(tiles[first:]):
-        visit(tile_i, src_path)
-        pending.append(prepare(cfg))
-        if len(pending) >= batch:
-            flush()
-    flush()
+    try:
+        for tile_i, src_path in enumerate(tiles[first:]):
+            visit(tile_i, src_path)
+            pending.append(prepare(cfg))
+            if len(pending) >= batch:
+                flush()
+    finally:
+        # (also when prepare() raises at tile i: the tiles prepared before it are finished and written, as the reference's
+        #  tile-by-tile loop would have written them before failing at i -- ADVICE r5)
+        flush()

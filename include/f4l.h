@@ -231,7 +231,9 @@ int f4l_apply_transform(const float *pts, const int64_t *off, int64_t P, int64_t
 /* a15: `refine_dvfs_with_threshold` (src/coarse_to_fine_matching_base.py:48-97) for all patches at once:
  * for each source point, transform by T_p, take the nearest point of the target patch; valid when
  * d^2 < thr_p^2.  thr double [P].  nn_out int32 [n_src] (index inside the target patch, or -1);
- * out6 float32 [n_src][6] = [s, nearest target] (rows of invalid points are zero filled); both nullable. */
+ * out6 float32 [n_src][6] = [s, nearest target] (rows of invalid points are zero filled); both nullable.
+ * max_tgt_patch_host sizes LDS and picks the path; it may be understated (a larger patch streams its targets from
+ * global memory: slower, same answers) -- every row of every patch is written either way. */
 int f4l_nn_refine(const float *src, const int64_t *src_off, const float *tgt, const int64_t *tgt_off, int64_t P,
                   const double *T, const double *thr, int64_t max_tgt_patch_host, int32_t *nn_out, float *out6,
                   void *stream);

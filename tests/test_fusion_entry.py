@@ -96,19 +96,24 @@ def test_main_fusion_entry_runs_the_tiles_and_writes_the_dvf_files(tmp_path, mon
     from fusion4landslide_amd.cpp_core.supervoxel_segmentation.build import supervoxel
     seen = []
     run_before = main_fusion.run
-    main_fusion.run = lambda *a, **k: (seen.append(supervoxel.SEGMENTATION), run_before(*a, **k))[1]
+    main_fusion.run = lambda *a, **k: (seen.append((supervoxel.SEGMENTATION, a[2] if len(a) > 2 else k.get("tiles_per_launch"))), run_before(*a, **k))[1]
+    calls = []
+    compute_before = supervoxel.computeSupervoxel
+    monkeypatch.setattr(supervoxel, "computeSupervoxel", lambda f, k, r, out="None": (calls.append((f, k, r, out, compute_before(f, k, r, out))), calls[-1][4])[1])
     try:
-        main_fusion.main(["--config", str(path), "--partition", "parallel"])  # (opt-in: the all-device segmentation)
-        main_fusion.run = lambda *a, **k: seen.append(supervoxel.SEGMENTATION)
-        main_fusion.main(["--config", str(path)])  # (no --partition: the entry's default is the reference's labels)
+        # the DEFAULT mode, un-stubbed: no --partition = the reference's labels, no --tiles-per-launch = tile by tile
+        main_fusion.main(["--config", str(path)])
+        monkeypatch.setattr(supervoxel, "computeSupervoxel", compute_before)
         monkeypatch.setenv("F4L_SV_MODE", "fast")
         with pytest.raises(SystemExit):            # an invalid mode is refused before anything runs
             main_fusion.main(["--config", str(path)])
         monkeypatch.delenv("F4L_SV_MODE")
     finally:
         main_fusion.run = run_before
-    assert seen == ["parallel", "identical"] and supervoxel.SEGMENTATION == "identical"
+    assert seen == [("identical", 1)] and supervoxel.SEGMENTATION == "identical"
     res = out_root / "results"
+    from scipy.spatial import cKDTree
+    from fusion4landslide_amd import engine
     for t in (0, 1):
         dvfs = np.loadtxt(res / f"c2f_dense_dvfs_src2tgt_tile_{t}.txt")
         dvfms = np.loadtxt(res / f"c2f_dense_dvfms_src2tgt_tile_{t}.txt")
@@ -118,25 +123,38 @@ def test_main_fusion_entry_runs_the_tiles_and_writes_the_dvf_files(tmp_path, mon
         assert 30_000 < len(dvfs) <= 60_000 and vis[0, 3] == 0 and vis[1, 3] == 5
         assert np.allclose(dvfms[:, 3], np.linalg.norm(dvfs[:, 3:] - dvfs[:, :3], axis=1), atol=2e-6)
         # every row starts at a point of the tile's source epoch; the field of the stable blocks is a few centimetres
-        from scipy.spatial import cKDTree
         assert cKDTree(clouds[t]["src"].astype(np.float64)).query(dvfs[:, :3], k=1)[0].max() < 2e-6  # ('%.6f' of float32 coordinates)
         assert np.median(dvfms[:, 3]) < 0.12
-        assert os.path.exists(out_root / "supervoxel_partition" / f"partition_of_input_src_tile_{t}.txt")
-    # the tile loop batches tiles around one per-patch launch (--tiles-per-launch, default 8: both tiles above shared one); tile by
-    # tile, the reference's order of work, writes the same files -- rows to the last printed digit
-    cfg1 = dict(cfg, path_name=dict(cfg["path_name"], output_folder="one_by_one"))
-    os.makedirs(tmp_path / "out" / "one_by_one" / "tiled_data" / "overlap")
-    for name in os.listdir(tiles):
-        os.link(tiles / name, tmp_path / "out" / "one_by_one" / "tiled_data" / "overlap" / name)
-    path1 = tmp_path / "fusion_3d_one_by_one.yaml"
-    yaml.safe_dump(cfg1, open(path1, "w"))
-    main_fusion.main(["--config", str(path1), "--partition", "parallel", "--tiles-per-launch", "1"])
+    # the partition files of the default mode carry the REFERENCE's labels: column 6 of each is what the one-core replay of
+    # supervoxel_segmentation.h:117-237 (csrc/supervoxel_host.cpp, pinned by the reference-compiled fixtures) gives for the same call
+    assert len(calls) == 4 and all(c[1] == 30 for c in calls)
+    from fusion4landslide_amd.utils.ply import read_ply
+    monkeypatch.setenv("F4L_SV_EXACT_HOST", "1")
+    for f, k, r, out, lab in calls:
+        replay, K = supervoxel.computeSupervoxelArray(read_ply(f)[0], k, r)
+        assert np.array_equal(replay, lab) and lab.max() + 1 == K
+        part = np.loadtxt(out)
+        assert part.shape == (len(lab), 7) and np.array_equal(part[:, 6].astype(np.int64), lab)
+    monkeypatch.delenv("F4L_SV_EXACT_HOST")
+    # the same tiles with the all-device segmentation (opt-in) and 8 tiles around one per-patch launch: every file again; and for
+    # one partition the batching moves a row by at most the last printed digit (1e-9 m in a transform, whatever the batch)
+    def run_into(folder, argv):
+        cfgx = dict(cfg, path_name=dict(cfg["path_name"], output_folder=folder))
+        os.makedirs(tmp_path / "out" / folder / "tiled_data" / "overlap")
+        for name in os.listdir(tiles):
+            os.link(tiles / name, tmp_path / "out" / folder / "tiled_data" / "overlap" / name)
+        px = tmp_path / f"fusion_3d_{folder}.yaml"
+        yaml.safe_dump(cfgx, open(px, "w"))
+        main_fusion.main(["--config", str(px)] + argv)
+        return tmp_path / "out" / folder / "results"
+    res_p1 = run_into("parallel_one_by_one", ["--partition", "parallel"])
+    res_p8 = run_into("parallel_batched", ["--partition", "parallel", "--tiles-per-launch", "8"])
     for t in (0, 1):
         for name in (f"c2f_dense_dvfs_src2tgt_tile_{t}.txt", f"c2f_sparse_dvfms_src2tgt_visualize_tile_{t}.txt"):
-            a, b = np.loadtxt(res / name), np.loadtxt(tmp_path / "out" / "one_by_one" / "results" / name)
+            a, b = np.loadtxt(res_p1 / name), np.loadtxt(res_p8 / name)
             assert a.shape == b.shape and np.abs(a - b).max() <= 1.01e-6, name
+        assert os.path.exists(tmp_path / "out" / "parallel_batched" / "supervoxel_partition" / f"partition_of_input_src_tile_{t}.txt")
     # the fusion branch: the same tile with lifted "2D" matches attached to the cfg
-    from scipy.spatial import cKDTree
     cfg2, _ = main_fusion.build_config(str(path))
     cfg2.method.fine_matching_only_3d, cfg2.method.fine_matching_fusion, cfg2.method.weighting_svd = False, True, True
     cfg2.path_name.output_root = str(tmp_path / "out" / "fusion_run")

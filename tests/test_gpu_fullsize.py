@@ -182,12 +182,18 @@ def _occupied_cells_device(xyz, res):
     return int(torch.unique(key).shape[0])
 
 
-def test_full_size_C5_100M_full_path(eng):
+@pytest.mark.parametrize("partition", ["identical", "parallel"])
+def test_full_size_C5_100M_full_path(eng, partition, monkeypatch):
     """BASELINE.json configs[4] on ONE GPU: the whole hot path -- median resolution, supervoxel partition on the device,
     patches, point matches, per-patch Kabsch + 20-iteration ICP + rows, nearest-neighbour refinement -- on 100 M points per
-    epoch (pipeline.full_path, what bench.py's `full_path_100M` extra times).  Size-independent properties of the whole result,
-    and >= 30 sampled patches of its per-patch stage against the CPU oracle to 1e-9 m."""
+    epoch (pipeline.full_path, what bench.py's `full_path_100M_*_partition` extras time).  `identical` is the path's default and
+    the entry points': the REFERENCE's supervoxel labels (supervoxel_segmentation.h:117-237 on the device, f4l_supervoxel);
+    `parallel` the opt-in variant.  Size-independent properties of the whole result, >= 30 sampled patches of the per-patch stage
+    against the CPU oracle to 1e-9 m, and -- for the reference's labels -- every label of a 2 M-point sub-tile against the one-core
+    replay of the reference's sequence (the whole 100 M against the replay: tools/gpu/svx_100M_vs_host.py, profiles/r6_*)."""
     from fusion4landslide_amd import pipeline, synthetic
+    monkeypatch.delenv("F4L_SV_EXACT_HOST", raising=False)
+    assert pipeline.full_path.__defaults__[3] == "identical"  # (the default of the path = the default of main_fusion / main_piecewise_icp)
     c = synthetic.CONFIGS["C5_100M_full"]
     n = c["n"]
     dev = torch.device("cuda")
@@ -195,7 +201,7 @@ def test_full_size_C5_100M_full_path(eng):
     src, tgt = d["src"], d["tgt"]
     del d
     torch.cuda.empty_cache()
-    r = pipeline.full_path(src, tgt, max_iter=MAX_ITER, fixed_iters=True, keep_inputs=True)
+    r = pipeline.full_path(src, tgt, max_iter=MAX_ITER, fixed_iters=True, keep_inputs=True, partition=partition)
     K, labels = r["K"], r["labels"]
     # the partition: K = occupied cells of the resolution grid exactly (grid_sample.h:48-68), labels 0 .. K-1 all non-empty
     assert K == _occupied_cells_device(src, r["resolution"])
@@ -248,6 +254,19 @@ def test_full_size_C5_100M_full_path(eng):
     keep = dict(labels=labels.clone(), T=T.clone(), K=K)
     del r, rows, ps, dd, T, R
     torch.cuda.empty_cache()
-    r2 = pipeline.full_path(src, tgt, max_iter=MAX_ITER, fixed_iters=True)
+    r2 = pipeline.full_path(src, tgt, max_iter=MAX_ITER, fixed_iters=True, partition=partition)
     assert r2["K"] == keep["K"] and torch.equal(r2["labels"], keep["labels"]) and torch.equal(r2["T"], keep["T"])
-    print(f"C5 100 M points: K = {K}, stages (ms) " + ", ".join(f"{k_} {v:.1f}" for k_, v in r2["stage_ms"].items()))
+    print(f"C5 100 M points, {partition} partition: K = {K}, stages (ms) " + ", ".join(f"{k_} {v:.1f}" for k_, v in r2["stage_ms"].items()))
+    if partition != "identical":
+        return
+    res = r2["resolution"]
+    del r2
+    eng.release_scratch()
+    torch.cuda.empty_cache()
+    # the reference's labels: every label of a 2 M-point sub-tile (a compact strip of the same cloud, at the run's resolution) against the one-core
+    # replay of the reference's sequence (csrc/supervoxel_host.cpp, itself pinned by the reference-compiled fixtures)
+    sub = src[:2_000_000].contiguous()
+    lab_d, K_d = eng.supervoxel(sub, 30, res)
+    monkeypatch.setenv("F4L_SV_EXACT_HOST", "1")
+    lab_h, K_h = eng.supervoxel(sub, 30, res)
+    assert K_d == K_h and torch.equal(lab_d, lab_h), f"{int((lab_d != lab_h).sum())} of 2 M labels differ from the host replay"

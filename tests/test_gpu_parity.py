@@ -988,6 +988,9 @@ def test_nn_refine_wave_per_small_patch_is_the_grid_search(eng, monkeypatch):
     assert torch.equal(nn, nn_g) and torch.equal(rows, rows_g)
     nn_only, none = eng.nn_refine(*args, return_rows=False)
     assert none is None and torch.equal(nn_only, nn)
+    # an UNDERSTATED bound (64 for patches of up to 800 targets): every row is still written, with the same answers
+    nn_u, rows_u = eng.nn_refine(*args, max_tgt_patch=64)
+    assert torch.equal(nn_u, nn) and torch.equal(rows_u, rows)
     nn = nn.cpu().numpy()
     assert (nn[so[3]:so[4]] == -1).all() and (nn[so[0]:so[1]] == -1).all()
     mism = 0

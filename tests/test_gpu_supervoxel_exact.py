@@ -117,3 +117,35 @@ def test_segment_exact_entry_reports_its_passes_and_refuses_what_it_cannot_hold(
     ws1 = torch.empty(nb1, dtype=torch.uint8, device="cuda")
     rc = lib().f4l_supervoxel_segment_exact(ptr(xyz), ptr(nrm), ptr(knn1), n, 1, 1.0, ptr(labels), C.byref(K), stats, ptr(ws1), C.c_size_t(nb1), stream_ptr())
     assert rc == -4 or rc != 0  # F4L_EUNSUPPORTED
+
+
+def test_every_point_in_a_cell_of_its_own_follows_the_reference(eng, monkeypatch):
+    """K == n (a resolution below the point spacing).  The reference's `--number == n_supervoxels` (:160) can no longer
+    fire once a first absorption took the count below K, and its check after a centre's turn (:169) fires at once when the FIRST
+    centre absorbs nothing: n singletons in one order of the points, ONE supervoxel in another.  The device path leaves this case to
+    the host replay (f4l_supervoxel_segment_exact returns F4L_EUNSUPPORTED); f4l_supervoxel equals the live reference in both."""
+    import ctypes as C
+    import torch
+    from fusion4landslide_amd._lib import lib, ptr, stream_ptr
+    from oracle import oracle as O
+    rng = np.random.default_rng(5)
+    gx, gy = np.meshgrid(np.arange(25) * 0.1, np.arange(25) * 0.1)
+    p = (np.c_[gx.ravel(), gy.ravel(), np.zeros(625)] + rng.normal(0, 0.01, (625, 3))).astype(np.float32)
+    monkeypatch.delenv("F4L_SV_EXACT_HOST", raising=False)
+    for cloud, want in ((p, 625), (np.roll(p, -1, axis=0), 1)):
+        xyz = torch.from_numpy(np.ascontiguousarray(cloud)).cuda()
+        lab, K = eng.supervoxel(xyz, 8, 0.02)
+        assert K == want and len(torch.unique(lab)) == want
+        if O.have_ref():
+            r = O.ref_supervoxel(cloud, 8, 0.02)
+            assert r["n_grid_cells"] == 625 and r["n_supervoxels"] == want and np.array_equal(r["labels"], lab.cpu().numpy())
+        else:
+            r = O.supervoxel(cloud, 8, 0.02)
+            assert r["n_supervoxels"] == want and np.array_equal(r["labels"], lab.cpu().numpy())
+    knn, nrm = eng.knn_normals(xyz, 8)
+    labels = torch.empty(625, dtype=torch.int32, device="cuda")
+    nb = lib().f4l_supervoxel_segment_exact_workspace_bytes(625, 8)
+    ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
+    K = C.c_int32(0)
+    rc = lib().f4l_supervoxel_segment_exact(ptr(xyz), ptr(nrm), ptr(knn), 625, 8, 0.02, ptr(labels), C.byref(K), None, ptr(ws), C.c_size_t(nb), stream_ptr())
+    assert rc == -4  # F4L_EUNSUPPORTED

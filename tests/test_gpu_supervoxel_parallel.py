@@ -97,14 +97,19 @@ def test_partition_against_the_large_reference_fixture(eng, golden_dir):
     rms, dvn, cv = partition_quality(xyz, nrm_h, par.cpu().numpy())
     assert rms <= 1.10 * rms_ref and dvn <= 1.15 * dev_ref + 1e-4 and cv <= 1.3 * cv_ref, ((rms, dvn, cv), (rms_ref, dev_ref, cv_ref))
     if O.have_ref():  # the live reference, on a cloud no fixture has seen
-        fresh = large_surface_cloud(c["seed"] + int(time.time()) % 1000 + 1, 200_000, 4.0)
+        seed = c["seed"] + int(time.time()) % 1000 + 1
+        fresh = large_surface_cloud(seed, 200_000, 4.0)
         r = O.ref_supervoxel(fresh, c["k"], c["resolution"])
         lab2, K2 = eng.supervoxel(dev(fresh), c["k"], c["resolution"])
         assert K2 == r["n_supervoxels"] and np.array_equal(lab2.cpu().numpy(), r["labels"])
         par2, Kp2, _, nrm2, _, info2 = eng.supervoxel_parallel(dev(fresh), c["k"], c["resolution"], return_intermediates=True)
         info2 = info2.cpu().numpy() if hasattr(info2, "cpu") else np.asarray(info2)
         assert Kp2 == r["n_grid_cells"]
-        assert eng.supervoxel_lambda0(info2) == O.ref_lambda0(fresh, r["normals"], r["knn_idx"], c["resolution"])
+        # (lambda0 is the metric of ONE pair of points, the median: bit-equal when the device's normal of that pair equals the
+        #  reference's to the last bit -- the fixtures' case --; the normals are only pinned to 1e-9, so on a cloud drawn from the
+        #  clock the last bits of 1 - |n . n'| may differ: seen once in six rounds, 1.1e-16 absolute at seed-of-the-day)
+        l0, l0_ref = eng.supervoxel_lambda0(info2), O.ref_lambda0(fresh, r["normals"], r["knn_idx"], c["resolution"])
+        assert abs(l0 - l0_ref) <= 1e-12 * l0_ref, (seed, l0, l0_ref)
         q_ref, q_par = partition_quality(fresh, r["normals"], r["labels"]), partition_quality(fresh, r["normals"], par2.cpu().numpy())
         assert q_par[0] <= 1.10 * q_ref[0] and q_par[1] <= 1.15 * q_ref[1] + 1e-4 and q_par[2] <= 1.3 * q_ref[2], (q_par, q_ref)
 

@@ -5,6 +5,7 @@ files bench.py reads for `roofline*.traffic` and `roofline*.valu`:
     profiles/icp_kernel_counters.json   <- gpurun_out/<dir>/icp.json    (bench.py --config C4_50M_100k, kernel `icp_kernel`)
     profiles/knn_counters.json          <- gpurun_out/<dir>/knn.json    (tools/gpu/knn_only.py 10000000, every f4l:: / rocprim kernel of f4l_knn)
     profiles/supervoxel_counters.json   <- gpurun_out/<dir>/svp.json    (tools/gpu/svp_only.py 10000000 3)
+    profiles/supervoxel_exact_counters.json <- gpurun_out/<dir>/svx.json (tools/gpu/svx_only.py 10000000 3: the default partition)
 
 HBM bytes: FETCH_SIZE (KB) x 1024 x 2 (the gfx950 correction of MI355X_MICROARCH.md: the counter tallies 128-byte requests at
 64 B) + WRITE_SIZE (KB) x 1024.  Vector issue: SQ_INSTS_VALU wave-instructions, of which the float64 ones (ADD / MUL / FMA /
@@ -41,7 +42,9 @@ def main():
             ("knn.json", "ALL", "knn_counters.json", "knn", "f4l_knn k=30", 10_000_000, None,
              "every kernel of one f4l_knn call on 10 M points (binning sorts, cell tables, knn_lanes_kernel, knn_listed_kernel)"),
             ("svp.json", "ALL", "supervoxel_counters.json", "supervoxel", "f4l_supervoxel_parallel k=30", 10_000_000, None,
-             "every kernel of one f4l_supervoxel_parallel call on 10 M points (kNN + normals + the ~270 launches of the segmentation)")]
+             "every kernel of one f4l_supervoxel_parallel call on 10 M points (kNN + normals + the ~270 launches of the segmentation)"),
+            ("svx.json", "ALL", "supervoxel_exact_counters.json", "supervoxel_exact", "f4l_supervoxel k=30", 10_000_000, None,
+             "every kernel of one f4l_supervoxel call on 10 M points (kNN + normals + the passes of the reference's segmentation: svx::)")]
     for raw_name, key, out_name, which, workload, units, group, what in jobs:
         path = os.path.join(src, raw_name)
         if not os.path.exists(path):
