@@ -76,6 +76,8 @@ SIGNATURES = {
     "f4l_epoch_join": (C.c_int, [_P, _I64, _P, _I64, _P, _P, _P, _SZ, _P]),
     "f4l_match_lists": (C.c_int, [_P, _P, _P, _P, _I64, _P, _P, _P, _P, _P, _P]),
     "f4l_gather_points": (C.c_int, [_P, _P, _I64, _P, _P]),
+    "f4l_tile_point_clouds": (C.c_int, [C.c_char_p, C.c_char_p, _I, _I, _I, C.c_float, C.c_float, _I, C.c_char_p, _I, _P, _P]),
+    "f4l_resave_point_cloud": (C.c_int, [C.c_char_p, C.c_char_p, _I, _P]),
 }
 
 _lib = None

@@ -1104,6 +1104,11 @@ static int launch_icp_one(const IcpArgs &a, size_t lds, hipStream_t st) {
 
 template <typename F>
 static int launch_icp(const IcpArgs &a, int mode, int nw, size_t lds, hipStream_t st, bool wide = false) {
+    // (measured and not kept, round 6: a second kernel for point-to-point / float64 patches that keeps the correspondence sums LAZILY --
+    //  moments of the counted pairs in original coordinates, per-point deadlines in units of the patch-wide motion bound, only status
+    //  changes touch the sums: tools/experiments/icp_lazy.h.  C4 18.25 against 18.25 ms, C2 0.80 against 0.69, C3 17.7 against 15.0:
+    //  the benchmark's patches never go quiet -- 8 % of a patch's points are still searched in pass 20, profiles/r4_f_searches_per_pass.log
+    //  -- so the sweep it saves is paid back by the bookkeeping of the points that do change.)
     if (mode == F4L_ICP_POINT2POINT) {
         if (nw == 1) return launch_icp_one<0, 1, F>(a, lds, st);
         if (nw == 2) return wide ? launch_icp_one<0, 2, F, true>(a, lds, st) : launch_icp_one<0, 2, F>(a, lds, st);

@@ -132,30 +132,15 @@ __global__ void grid_count_kernel(const float *__restrict__ xyz, int64_t n, doub
     cnt = wave_sum(cnt);
     if (lane_id() == 0 && cnt) atomicAdd(&st->K, cnt);
 }
-#pragma clang fp contract(off)
-__global__ void min_metric_kernel(const float *__restrict__ xyz, const double *__restrict__ nrm, const int32_t *__restrict__ knn, int64_t n,
-                                  int k, double resolution, double *__restrict__ dis0) {
-    SVX_FOR(i, n) {
-        double best = DBL_MAX;
-        for (int j = 0; j < k; ++j) {
-            const int64_t q = knn[i * k + j];
-            if (q != i) {
-                const double m = sv_metric(xyz, nrm, i, q, resolution);
-                best = m < best ? m : best;
-            }
-        }
-        dis0[i] = best;
-    }
-}
-
 // ---- fusion -------------------------------------------------------------------------------------------------------------
 // What an evaluation gathers lives in two packed records per node (round 6; before: nine separate arrays, i.e. six to seven 32-byte
 // sectors per visited node and two per list entry -- the passes are bound by exactly those gathers):
 //   NodeS  (64 B, one cache line half)  what a ROUND starts from: position, normal, size, list.  Written by iota / commit.
-//   NodeE  (32 B, one sector)           one ESTIMATE of "what the centres of this round do", two of them (read / written): who
-//                                       absorbs the node (claims by atomicMin, from any centre), and the node's own outcome as a
-//                                       centre: size and kept list after its turn, the nodes it absorbs.  The claim that a chain
-//                                       walk reads and the record the queue reads a moment later share the sector.
+//   NodeE  (32 B, one sector)           one ESTIMATE of "what the centres of this round do", two of them (read / written): the
+//                                       node's own outcome as a centre -- size and kept list after its turn, the nodes it absorbs.
+//   abs    (4 B, dense)                 ... and who absorbs the node (claims by atomicMin, from any centre): what every list entry's
+//                                       chain walk reads, sixteen nodes to a sector (inside the records it cost a sector each and
+//                                       the pass's comparison read 64 bytes per centre for 8).
 // The lists (neighbour table, then the pools) hold ROUND-START ROOTS: rootlists_kernel maps the survivors' lists through `root`
 // once per round, instead of every evaluation of every pass doing it per entry.
 struct alignas(64) NodeS {
@@ -166,8 +151,10 @@ struct alignas(64) NodeS {
     int32_t len;                 //                   ... and length
     int32_t pad_[3];
 };
+// (measured and not kept, round 6: the record as two arrays, {x, y, z, size} 16 B and {normal, offset | length} 32 B, so that more
+//  neighbours share a cache line: 228 against 215 ms per 10 M points -- the second gather per visited node costs more than the lines save)
 struct alignas(32) NodeE {
-    unsigned int abs;            // the centre that absorbs the node, NONE (written by OTHER centres: never stored with the rest)
+    int32_t pad0_;
     int32_t ns, cnt, len;        // as a centre: its size after its turn, the nodes it absorbs, its kept list's length
     int64_t off;                 //              ... and offset
     unsigned long long hash;     // order-sensitive hash of that list (what "the list did not change" is read from)
@@ -200,6 +187,7 @@ struct FuseArgs {
     int64_t pool_base, sub_cap;  // where this pass writes lists: SUBPOOLS regions of sub_cap entries from pool_base
     int pool_sel;                // which set of bump pointers
     NodeE *rd, *wr;              // [n] the estimate read / written
+    unsigned int *abs_rd, *abs_wr;  // [n] its claims
     int32_t *cnt_slot_rd, *cnt_slot_wr;  // [nreps] cnt in the order of the centres (the budget's prefix sum runs over it)
 };
 
@@ -217,6 +205,28 @@ __global__ void iota_kernel(int32_t *root, int32_t *reps, NodeS *S, const float 
         q[0] = o[0]; q[1] = o[1]; q[2] = o[2]; q[3] = o[3];
     }
 }
+// lambda0's sweep (:105-113): every point's smallest metric to a neighbour, from the packed records (one line per neighbour instead of
+// the coordinate array's and the normal array's)
+#pragma clang fp contract(off)
+__global__ void min_metric_kernel(const NodeS *__restrict__ S, const int32_t *__restrict__ knn, int64_t n, int k, double resolution, double *__restrict__ dis0) {
+    SVX_FOR(i, n) {
+        const NodeS si = load_s(S + i);
+        const float pi_[3] = {si.x, si.y, si.z};
+        const double ni_[3] = {si.nx, si.ny, si.nz};
+        double best = DBL_MAX;
+        for (int j = 0; j < k; ++j) {
+            const int64_t q = knn[i * k + j];
+            if (q != i) {
+                const NodeS sq = load_s(S + q);
+                const float pq[3] = {sq.x, sq.y, sq.z};
+                const double nq[3] = {sq.nx, sq.ny, sq.nz};
+                const double m = sv_metric_vals(pi_, ni_, pq, nq, resolution);
+                best = m < best ? m : best;
+            }
+        }
+        dis0[i] = best;
+    }
+}
 // (and what pass 0 needs prepared: its pool's bump pointers, its claims, its flag and its total -- every later pass is prepared by
 //  the last workgroup of the pass before it, abs_changed_kernel)
 __global__ void round_init_kernel(FuseArgs a) {
@@ -232,9 +242,10 @@ __global__ void round_init_kernel(FuseArgs a) {
     SVX_FOR(s, a.nreps) {
         const int32_t i = a.reps[s];
         const NodeS si = load_s(a.S + i);
-        a.wr[i].abs = NONE;
+        a.abs_wr[i] = NONE;
+        a.abs_rd[i] = NONE;
         NodeE e;
-        e.abs = NONE; e.ns = si.sz; e.cnt = 0; e.len = si.len; e.off = si.off;
+        e.pad0_ = 0; e.ns = si.sz; e.cnt = 0; e.len = si.len; e.off = si.off;
         e.hash = ~0ULL;   // ("the round-start list": no evaluation writes this value twice in a row unless nothing changes)
         const uint4 *o = reinterpret_cast<const uint4 *>(&e);
         uint4 *q = reinterpret_cast<uint4 *>(a.rd + i);
@@ -252,7 +263,7 @@ __global__ void round_init_kernel(FuseArgs a) {
 //  or not their outcome moves, so fewer than half are skipped until the last passes, and the bookkeeping costs every evaluation:
 //  51.4 ms of passes per 1 M points against 41.7 without.  One centre per wavefront, the first version: 41.7 ms.)
 #ifndef SVX_EVAL_WPE
-#define SVX_EVAL_WPE 8
+#define SVX_EVAL_WPE 6  // (round 6: 80 VGPRs and no spill beat 64 with; 6 waves per SIMD are what the LDS leaves anyway)
 #endif
 // G lanes per centre (64 / G centres per wavefront), QCAP entries of queue: <16, 256> is the shape clouds normally take (closures
 // of 45-76 nodes on surfaces, up to 216 in volumes; 16 KB of LDS per workgroup: full occupancy; 31 ms per 1 M points against 37
@@ -274,6 +285,7 @@ __global__ __launch_bounds__(EVAL_WAVES * 64, SVX_EVAL_WPE) void eval_kernel(Fus
     const int32_t i = a.reps[valid_c ? s : s0];
     const unsigned int ui = (unsigned int)i;
     const NodeE *__restrict__ E = a.rd;
+    const unsigned int *__restrict__ ABS = a.abs_rd;
     int32_t *__restrict__ pool = const_cast<int32_t *>(a.lists);
     const unsigned int below = (1u << hl) - 1u;
     auto hb = [&](unsigned long long m) { return (unsigned int)(m >> hbase) & GMASK; };  // this half's bits of a wave-wide ballot
@@ -289,7 +301,7 @@ __global__ __launch_bounds__(EVAL_WAVES * 64, SVX_EVAL_WPE) void eval_kernel(Fus
     };
     const NodeE ei = load_e(E + i);    // (its claim, and what it did in the pass before: one sector)
     const NodeS si = load_s(a.S + i);  // (its position and normal -- the metric's first argument, :142 --, its size and list: one line)
-    const unsigned int absi = ei.abs;
+    const unsigned int absi = a.abs_rd[i];
     const bool dead = absi != NONE && absi < ui;  // absorbed before its turn: adjacents[i] is empty by then (:121)
     const int64_t off0 = si.off;
     const int len0 = si.len;
@@ -312,9 +324,9 @@ __global__ __launch_bounds__(EVAL_WAVES * 64, SVX_EVAL_WPE) void eval_kernel(Fus
                 // Find as centre i sees it (set.Find, :127/:152): every absorption by a centre that ran BEFORE i and was alive at its
                 // own turn; honoured claims lead to ever higher centres, so the walk ends
                 for (;;) {
-                    const unsigned int c = E[r].abs;
+                    const unsigned int c = ABS[r];
                     if (c == NONE || !(c < ui)) break;
-                    const unsigned int cc = E[c].abs;
+                    const unsigned int cc = ABS[c];
                     if (cc != NONE && cc < c) break;
                     r = c;
                 }
@@ -390,7 +402,7 @@ __global__ __launch_bounds__(EVAL_WAVES * 64, SVX_EVAL_WPE) void eval_kernel(Fus
         }
         const bool take = mine && ((accm >> hl) & 1u);
         if (take) {
-            atomicMin(&a.wr[j].abs, ui);  // set.Link(j, i) (:145); of several centres that claim j in an estimate the lowest counts
+            atomicMin(&a.abs_wr[j], ui);  // set.Link(j, i) (:145); of several centres that claim j in an estimate the lowest counts
             atomicOr(&ACC[(head + hl) >> 5], 1u << ((head + hl) & 31));
         }
         nsz += half_sum(take ? sj : 0);   // sizes[i] += sizes[j] (:147)
@@ -457,7 +469,7 @@ __global__ __launch_bounds__(EVAL_WAVES * 64, SVX_EVAL_WPE) void eval_kernel(Fus
     if (hl == 0 && tail > a.st->max_tail) atomicMax(&a.st->max_tail, tail);  // (a statistic: rarely more than a few updates per pass)
     if (hl == 0 && valid_c) {
         const bool same = ei.ns == nsz && ei.cnt == cnt && ei.len == out_len && ei.hash == hash;
-        NodeE *w = a.wr + i;  // (everything but `abs`, which the other centres' claims are landing in)
+        NodeE *w = a.wr + i;
         w->ns = nsz; w->cnt = cnt; w->len = out_len;
         *reinterpret_cast<ulonglong2 *>(&w->off) = make_ulonglong2((unsigned long long)out_off, hash);
         a.cnt_slot_wr[s] = cnt;
@@ -493,7 +505,17 @@ __global__ __launch_bounds__(EVAL_WAVES * 64, SVX_EVAL_WPE) void eval16_kernel(F
     __shared__ unsigned int h_all[EVAL_WAVES][CPW][H16 / 4];
     __shared__ unsigned int acc_all[EVAL_WAVES][CPW][Q16 / 32];
     const int wave = (int)(threadIdx.x >> 6), lane = lane_id(), h = lane >> 4, hl = lane & 15, hbase = h * G;
-    const int64_t s0 = ((int64_t)blockIdx.x * EVAL_WAVES + wave) * CPW;
+#ifndef SVX_NO_XCD_MAP
+    // Workgroups are handed to the 8 XCDs round robin, and each XCD has an L2 of its own: with the plain mapping the sixteen centres of
+    // a workgroup -- neighbours in space wherever the cloud's order is coherent (tiles as PCL's voxel filter or a scanner leave them) --
+    // have their neighbourhood's records pulled into EIGHT caches.  Here an XCD works through ONE contiguous eighth of the centres.
+    // (block 8 q + x is the q-th block of XCD x; XCD x owns nb / 8 blocks, one more when x < nb % 8: a bijection onto [0, nb))
+    const unsigned int nb = gridDim.x, x8 = blockIdx.x & 7u, rem = nb & 7u;
+    const unsigned int blk = x8 * (nb >> 3) + (x8 < rem ? x8 : rem) + (blockIdx.x >> 3);
+#else
+    const unsigned int blk = blockIdx.x;
+#endif
+    const int64_t s0 = ((int64_t)blk * EVAL_WAVES + wave) * CPW;
     if (s0 >= a.nreps) return;  // (whole wave)
     if (a.st->done) return;     // (converged earlier in this batch of passes)
     const int64_t s = s0 + h;
@@ -505,6 +527,7 @@ __global__ __launch_bounds__(EVAL_WAVES * 64, SVX_EVAL_WPE) void eval16_kernel(F
     const int32_t i = a.reps[valid_c ? s : s0];
     const unsigned int ui = (unsigned int)i;
     const NodeE *__restrict__ E = a.rd;
+    const unsigned int *__restrict__ ABS = a.abs_rd;
     int32_t *__restrict__ pool = const_cast<int32_t *>(a.lists);
     const unsigned int below = (1u << hl) - 1u;
     auto hb = [&](unsigned long long m) { return (unsigned int)(m >> hbase) & 0xffffu; };
@@ -515,7 +538,7 @@ __global__ __launch_bounds__(EVAL_WAVES * 64, SVX_EVAL_WPE) void eval16_kernel(F
     };
     const NodeE ei = load_e(E + i);
     const NodeS si = load_s(a.S + i);
-    const unsigned int absi = ei.abs;
+    const unsigned int absi = a.abs_rd[i];
     const bool dead = absi != NONE && absi < ui;  // absorbed before its turn: adjacents[i] is empty by then (:121)
     const int64_t off0 = si.off;
     const int len0 = si.len;
@@ -549,9 +572,9 @@ __global__ __launch_bounds__(EVAL_WAVES * 64, SVX_EVAL_WPE) void eval16_kernel(F
                 // Find as centre i sees it (set.Find, :127/:152): every absorption by a centre that ran BEFORE i and was alive at its
                 // own turn; honoured claims lead to ever higher centres, so the walk ends
                 for (;;) {
-                    const unsigned int c = E[r].abs;
+                    const unsigned int c = ABS[r];
                     if (c == NONE || !(c < ui)) break;
-                    const unsigned int cc = E[c].abs;
+                    const unsigned int cc = ABS[c];
                     if (cc != NONE && cc < c) break;
                     r = c;
                 }
@@ -627,7 +650,7 @@ __global__ __launch_bounds__(EVAL_WAVES * 64, SVX_EVAL_WPE) void eval16_kernel(F
         }
         const bool take = mine && ((accm >> hl) & 1u);
         if (take) {
-            atomicMin(&a.wr[j].abs, ui);  // set.Link(j, i) (:145); of several centres that claim j in an estimate the lowest counts
+            atomicMin(&a.abs_wr[j], ui);  // set.Link(j, i) (:145); of several centres that claim j in an estimate the lowest counts
             atomicOr(&ACC[(head + hl) >> 5], 1u << ((head + hl) & 31));
         }
         nsz += row_sum16(take ? sj : 0);   // sizes[i] += sizes[j] (:147)
@@ -696,7 +719,7 @@ __global__ __launch_bounds__(EVAL_WAVES * 64, SVX_EVAL_WPE) void eval16_kernel(F
     if (hl == 0 && tail > a.st->max_tail) atomicMax(&a.st->max_tail, tail);  // (a statistic: rarely more than a few updates per pass)
     if (hl == 0 && valid_c) {
         const bool same = ei.ns == nsz && ei.cnt == cnt && ei.len == out_len && ei.hash == hash;
-        NodeE *w = a.wr + i;  // (everything but `abs`, which the other centres' claims are landing in)
+        NodeE *w = a.wr + i;
         w->ns = nsz; w->cnt = cnt; w->len = out_len;
         *reinterpret_cast<ulonglong2 *>(&w->off) = make_ulonglong2((unsigned long long)out_off, hash);
         a.cnt_slot_wr[s] = cnt;
@@ -714,14 +737,14 @@ __global__ void abs_changed_kernel(FuseArgs a, int pass, int budget_on, long lon
     long long tot = 0;
     SVX_FOR(s, a.nreps) {
         const int32_t i = a.reps[s];
-        const unsigned int c0 = a.rd[i].abs, c1 = a.wr[i].abs;
+        const unsigned int c0 = a.abs_rd[i], c1 = a.abs_wr[i];
         ch = ch || c0 != c1;
 #ifdef SVX_MEASURE_PREFIX
         if (c0 != c1) {  // the claimant(s) whose claim on i came or went
             atomicMin(&st->minchg[pass & 7], (int)(c0 < c1 ? c0 : c1)); atomicAdd(&st->nchg[pass & 7], 1);
         }
 #endif
-        a.rd[i].abs = NONE;  // (this estimate is the one the NEXT pass writes: its claims start empty)
+        a.abs_rd[i] = NONE;  // (this estimate is the one the NEXT pass writes: its claims start empty)
         tot += a.cnt_slot_wr[s];
     }
     if (__ballot(ch) != 0ULL && lane_id() == 0) st->changed[pass & 7] = 1;
@@ -761,18 +784,18 @@ __global__ void commit_kernel(FuseArgs a, int32_t *keep_flag) {
     SVX_FOR(s, a.nreps) {
         const int32_t i = a.reps[s];
         const NodeE e = load_e(a.rd + i);
-        const bool survives = e.abs == NONE;
+        const bool survives = a.abs_rd[i] == NONE;
         keep_flag[s] = survives ? 1 : 0;
         NodeS *si = a.S + i;
         if (survives) { si->sz = e.ns; si->off = e.off; si->len = e.len; }
         else si->len = 0;
     }
 }
-__global__ void reroot_kernel(int32_t *root, const NodeE *__restrict__ E, int64_t n) {
+__global__ void reroot_kernel(int32_t *root, const unsigned int *__restrict__ abs, int64_t n) {
     SVX_FOR(x, n) {
         unsigned int r = (unsigned int)root[x];
         for (;;) {  // (a converged estimate: every claim real, chains ascend in time)
-            const unsigned int c = E[r].abs;
+            const unsigned int c = abs[r];
             if (c == NONE) break;
             r = c;
         }
@@ -804,6 +827,8 @@ struct XchArgs {
     int k;
     double resolution;
     State *st;
+    // (measured and not kept, round 6: position, label and the two estimates as ONE 16-byte record per node -- a neighbour costs one
+    //  gather instead of two, but 8 nodes share a cache line instead of 32: xch_eval_kernel 37.0 against 28.6 ms per 10 M points)
     int32_t *lab;                 // [n] label = representative point (the generation's starting state)
     double *dis;                  // [n] metric to it
     int32_t *pos;                 // [n] position in the current generation, POS_INF
@@ -860,9 +885,13 @@ __global__ void xch_generation_kernel(XchArgs a, const unsigned long long *__res
 // coalesced 4 k-byte row per entry, four entries per wavefront) and reduced across them.
 __global__ __launch_bounds__(256) void xch_eval_kernel(XchArgs a, int m, int pass) {
     const int lane = lane_id(), sub = lane & 15;
-    const int64_t per_pass = (int64_t)gridDim.x * (blockDim.x >> 6) * 4;
     bool differs = false;
-    for (int64_t t0 = ((int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 4; t0 < m; t0 += per_pass) {  // (whole waves iterate together)
+    // (a workgroup takes one contiguous stretch of the generation, and an XCD -- whose L2 is its own -- one contiguous eighth of it:
+    //  the generation is in (position of the pusher, slot) order, i.e. neighbours in the cloud's order sit side by side; see eval16_kernel)
+    const unsigned int nb = gridDim.x, x8 = blockIdx.x & 7u, rem = nb & 7u;
+    const int64_t blk = (int64_t)(x8 * (nb >> 3) + (x8 < rem ? x8 : rem) + (blockIdx.x >> 3));
+    const int64_t per_wg = ((((int64_t)m + nb - 1) / nb + 15) / 16) * 16, w_lo = blk * per_wg, w_hi = w_lo + per_wg < m ? w_lo + per_wg : (int64_t)m;
+    for (int64_t t0 = w_lo + (int64_t)(threadIdx.x >> 6) * 4; t0 < w_hi; t0 += (int64_t)(blockDim.x >> 6) * 4) {  // (whole waves iterate together)
         const int64_t t = t0 + (lane >> 4);
         const bool valid = t < m;
         const int32_t i = a.Q[valid ? t : 0];
@@ -933,6 +962,7 @@ struct Ws {
     int64_t pool_off[3], pool_cap;
     NodeS *S;
     NodeE *E[2];
+    unsigned int *abs[2];
     int32_t *root, *reps_a, *reps_b, *keep_flag, *keep_pos, *cnt_slot[2];
     int64_t *before;
     double *dis, *dis2[2], *median;
@@ -975,6 +1005,7 @@ static int layout(int64_t n, int k, Ws &w, unsigned char *base) {
     const size_t region = o;
     w.S = (NodeS *)carve(N * sizeof(NodeS));
     w.E[0] = (NodeE *)carve(N * sizeof(NodeE)); w.E[1] = (NodeE *)carve(N * sizeof(NodeE));
+    w.abs[0] = (unsigned int *)carve(N * 4); w.abs[1] = (unsigned int *)carve(N * 4);
     w.keep_flag = (int32_t *)carve(N * 4); w.keep_pos = (int32_t *)carve(N * 4);
     w.cnt_slot[0] = (int32_t *)carve(N * 4); w.cnt_slot[1] = (int32_t *)carve(N * 4);
     w.before = (int64_t *)carve(N * 8);
@@ -1045,7 +1076,8 @@ static int segment_exact_run(const float *xyz, const double *normals, const int3
         hipLaunchKernelGGL(svx::grid_count_kernel, g, b, 0, st, xyz, n, resolution, w.st, set, slots);
     }
     // lambda0 (:105-113)
-    hipLaunchKernelGGL(svx::min_metric_kernel, g, b, 0, st, xyz, normals, knn, n, k, resolution, w.dis);
+    hipLaunchKernelGGL(svx::iota_kernel, g, b, 0, st, w.root, w.reps_a, w.S, xyz, normals, n, k);
+    hipLaunchKernelGGL(svx::min_metric_kernel, g, b, 0, st, (const svx::NodeS *)w.S, knn, n, k, resolution, w.dis);
     F4L_LAUNCH_CHECK();
     {
         const int64_t rank = n / 2;
@@ -1055,7 +1087,6 @@ static int segment_exact_run(const float *xyz, const double *normals, const int3
     double lambda0 = 0.0;
     F4L_HIP_CHECK(hipMemcpyAsync(&lambda0, w.median, 8, hipMemcpyDeviceToHost, st));
     F4L_HIP_CHECK(hipMemcpyAsync(w.lists, knn, (size_t)n * k * 4, hipMemcpyDeviceToDevice, st));
-    hipLaunchKernelGGL(svx::iota_kernel, g, b, 0, st, w.root, w.reps_a, w.S, xyz, normals, n, k);
     rc = read_state();
     if (rc != F4L_OK) return rc;
     const int K = hs.K;
@@ -1074,7 +1105,7 @@ static int segment_exact_run(const float *xyz, const double *normals, const int3
     int committed_pool = -1;  // (the pool the round-start lists live in; -1: the neighbour table)
     const bool old16 = getenv("F4L_SV_EXACT_SCAN") != nullptr;  // (A/B: the narrow shape with round 5's linear visited scan)
     int rounds = 0, passes = 0;
-    auto set_est = [&](int rd) { fa.rd = w.E[rd]; fa.wr = w.E[rd ^ 1]; fa.cnt_slot_rd = w.cnt_slot[rd]; fa.cnt_slot_wr = w.cnt_slot[rd ^ 1]; };
+    auto set_est = [&](int rd) { fa.rd = w.E[rd]; fa.wr = w.E[rd ^ 1]; fa.abs_rd = w.abs[rd]; fa.abs_wr = w.abs[rd ^ 1]; fa.cnt_slot_rd = w.cnt_slot[rd]; fa.cnt_slot_wr = w.cnt_slot[rd ^ 1]; };
     for (; rounds < MAX_ROUNDS; lambda *= 2.0, ++rounds) {
         if (nreps <= 1) break;  // :118
         fa.reps = reps; fa.nreps = nreps;
@@ -1136,7 +1167,7 @@ static int segment_exact_run(const float *xyz, const double *normals, const int3
         // commit (the estimate `rd` = the last one written; its lists are in pool pe[(it - 1) & 1])
         set_est(rd);
         hipLaunchKernelGGL(svx::commit_kernel, g, b, 0, st, fa, w.keep_flag);
-        hipLaunchKernelGGL(svx::reroot_kernel, g, b, 0, st, w.root, (const svx::NodeE *)fa.rd, n);
+        hipLaunchKernelGGL(svx::reroot_kernel, g, b, 0, st, w.root, (const unsigned int *)fa.abs_rd, n);
         {
             size_t tb = w.prim_bytes;
             F4L_HIP_CHECK(rocprim::exclusive_scan(w.prim, tb, w.keep_flag, w.keep_pos, 0, (size_t)nreps, rocprim::plus<int32_t>(), st, false));

@@ -18,6 +18,7 @@
 #include <fstream>
 #include <iomanip>
 #include <random>
+#include <thread>
 #include <vector>
 
 #include "../../include/f4l.h"
@@ -333,6 +334,59 @@ static inline char *put_uint(char *p, unsigned int v) {
 }
 }  // namespace f4l
 
+
+namespace f4l {
+// Formatting split over cores (round 6): rows are formatted in blocks of `block` rows by up to `threads` workers at a time, each into
+// a buffer of its own, and the blocks are written in order -- the same bytes as one thread writes, at a multiple of its rate (a
+// 1 M-point tile's partition file: 0.18 s on one core).  F4L_WRITER_THREADS caps the workers (default: the cores, at most 8).
+static int writer_threads() {
+    int t = (int)std::thread::hardware_concurrency();
+    if (t < 1) t = 1;
+    if (t > 8) t = 8;
+    if (const char *e = getenv("F4L_WRITER_THREADS")) { const int v = atoi(e); if (v >= 1 && v <= 64) t = v; }
+    return t;
+}
+// fmt(r0, r1, out) formats rows [r0, r1) at `out` and returns the end (or nullptr on bad input); bytes_per_row bounds a row.
+template <class Fmt>
+static int write_rows_parallel(FILE *fp, int64_t n, size_t bytes_per_row, const Fmt &fmt) {
+    const int64_t block = 16384;
+    const int T = (int)std::min<int64_t>(writer_threads(), (n + block - 1) / block > 0 ? (n + block - 1) / block : 1);
+    std::vector<std::vector<char>> buf((size_t)T);
+    std::vector<size_t> len((size_t)T);
+    try {
+        for (auto &b : buf) b.resize((size_t)block * bytes_per_row);
+    } catch (const std::bad_alloc &) {
+        return F4L_ENOMEM;
+    }
+    int rc = F4L_OK;
+    for (int64_t base = 0; base < n && rc == F4L_OK; base += block * T) {
+        const int live = (int)std::min<int64_t>(T, (n - base + block - 1) / block);
+        auto work = [&](int t) {
+            const int64_t r0 = base + (int64_t)t * block, r1 = std::min<int64_t>(n, r0 + block);
+            char *end = fmt(r0, r1, buf[(size_t)t].data());
+            len[(size_t)t] = end ? (size_t)(end - buf[(size_t)t].data()) : (size_t)-1;
+        };
+        if (live == 1) work(0);
+        else {
+            std::vector<std::thread> th;
+            th.reserve((size_t)live - 1);
+            try {
+                for (int t = 1; t < live; ++t) th.emplace_back(work, t);
+            } catch (...) {  // (no more threads to be had: the rest on this one)
+                for (int t = (int)th.size() + 1; t < live; ++t) work(t);
+            }
+            work(0);
+            for (auto &x : th) x.join();
+        }
+        for (int t = 0; t < live && rc == F4L_OK; ++t) {
+            if (len[(size_t)t] == (size_t)-1) rc = F4L_EINVAL;
+            else if (fwrite(buf[(size_t)t].data(), 1, len[(size_t)t], fp) != len[(size_t)t]) rc = F4L_EINVAL;
+        }
+    }
+    return rc;
+}
+}  // namespace f4l
+
 extern "C" int f4l_write_partition_txt(const char *path, const float *xyz_host, const int32_t *labels_host, int64_t n,
                                        int32_t n_supervoxels) {
     if (!path || n < 0 || n_supervoxels < 0 || (n > 0 && (!xyz_host || !labels_host))) return F4L_EINVAL;
@@ -341,16 +395,10 @@ extern "C" int f4l_write_partition_txt(const char *path, const float *xyz_host, 
     for (int32_t i = 0; i < n_supervoxels; ++i) colour[(size_t)i] = (uint32_t)random();
     FILE *fp = fopen(path, "wb");
     if (!fp) return F4L_EINVAL;
-    const int64_t chunk = 4096;
-    std::vector<char> buf((size_t)chunk * 208);
-    bool ok = true;
-    int rc = F4L_OK;
-    for (int64_t i0 = 0; i0 < n && ok; i0 += chunk) {
-        const int64_t i1 = i0 + chunk < n ? i0 + chunk : n;
-        char *p = buf.data();
+    int rc = f4l::write_rows_parallel(fp, n, 208, [&](int64_t i0, int64_t i1, char *p) -> char * {
         for (int64_t i = i0; i < i1; ++i) {
             const int32_t l = labels_host[i];
-            if (l < 0 || l >= n_supervoxels) { rc = F4L_EINVAL; ok = false; break; }
+            if (l < 0 || l >= n_supervoxels) return nullptr;
             const uint32_t c = colour[(size_t)l];
             p = f4l::put_g12(p, xyz_host[3 * i]); *p++ = ' ';
             p = f4l::put_g12(p, xyz_host[3 * i + 1]); *p++ = ' ';
@@ -360,10 +408,10 @@ extern "C" int f4l_write_partition_txt(const char *path, const float *xyz_host, 
             p = f4l::put_uint(p, c & 0xffu); *p++ = ' ';
             p = f4l::put_uint(p, (unsigned int)l); *p++ = '\n';
         }
-        if (fwrite(buf.data(), 1, (size_t)(p - buf.data()), fp) != (size_t)(p - buf.data())) ok = false;
-    }
-    ok = (fclose(fp) == 0) && ok;
-    return rc != F4L_OK ? rc : (ok ? F4L_OK : F4L_EINVAL);
+        return p;
+    });
+    if (fclose(fp) != 0 && rc == F4L_OK) rc = F4L_EINVAL;
+    return rc;
 }
 
 // The result files of a tile -- `np.savetxt(path, rows, delimiter=" ", fmt="%.6f")` of save_process_dvf
@@ -399,18 +447,7 @@ extern "C" int f4l_write_rows_txt(const char *path, const float *rows_host, int6
     if (!path || n < 0 || ncols < 1 || (n > 0 && !rows_host)) return F4L_EINVAL;
     FILE *fp = fopen(path, "wb");
     if (!fp) return F4L_EINVAL;
-    const size_t chunk_rows = 4096;
-    std::vector<char> buf;
-    try {
-        buf.resize(chunk_rows * ((size_t)ncols * 66 + 1));
-    } catch (const std::bad_alloc &) {
-        fclose(fp);
-        return F4L_ENOMEM;
-    }
-    bool ok = true;
-    for (int64_t r0 = 0; r0 < n && ok; r0 += (int64_t)chunk_rows) {
-        const int64_t r1 = r0 + (int64_t)chunk_rows < n ? r0 + (int64_t)chunk_rows : n;
-        char *p = buf.data();
+    int rc = f4l::write_rows_parallel(fp, n, (size_t)ncols * 66 + 1, [&](int64_t r0, int64_t r1, char *p) -> char * {
         for (int64_t r = r0; r < r1; ++r) {
             const float *row = rows_host + (size_t)r * (size_t)ncols;
             for (int c = 0; c < ncols; ++c) {
@@ -419,8 +456,8 @@ extern "C" int f4l_write_rows_txt(const char *path, const float *rows_host, int6
             }
             *p++ = '\n';
         }
-        ok = fwrite(buf.data(), 1, (size_t)(p - buf.data()), fp) == (size_t)(p - buf.data());
-    }
-    ok = (fclose(fp) == 0) && ok;
-    return ok ? F4L_OK : F4L_EINVAL;
+        return p;
+    });
+    if (fclose(fp) != 0 && rc == F4L_OK) rc = F4L_EINVAL;
+    return rc;
 }

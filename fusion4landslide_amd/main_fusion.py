@@ -27,6 +27,7 @@ import time
 
 from . import engine
 from .src.coarse_to_fine_matching import Coarse2Fine
+from .utils import async_io
 from .utils.common import AttrDict, access_device, get_logger, load_yaml, setup_seed
 from .utils.tiles import for_each_tile, prepare_tiles
 
@@ -59,16 +60,29 @@ def run(cfg, first_tile=0, tiles_per_launch=1):
         c.voxel_size, c.tile_dir = cfg.method.voxel_size_init, tile_dir
         return c
 
-    with torch.no_grad():
-        tiles = prepare_tiles(tile_dir, tiling_config, cfg.logging)
-        def launch(states):
-            kw = states[0].fine_state["loop_kw"]
-            assert all(s.fine_state["loop_kw"] == kw for s in states)  # (one config: one set of loop parameters)
-            return engine.patch_loop_tiles([s.fine_state["loop_args"] for s in states], **kw)
-
-        for_each_tile(cfg, tiles, lambda c: Coarse2Fine(c).implement_c2f_matching(), cfg.logging, first=first_tile, batch=int(tiles_per_launch),
-                      stages=(lambda c: Coarse2Fine(c).prepare_c2f(), launch, lambda s, out: s.finish_c2f(out)))
+    # host files next to device work (utils/async_io.py): the partition and result files of a tile are written by writer threads
+    # while the next tile computes, and the next tile's PLY files are read ahead; the same bytes land on disk, and every writer is
+    # through (or has raised) before this function returns.  F4L_ASYNC_IO=0: the reference's serial order of work.
+    cfg.defer_files = async_io.enabled()
+    try:
+        with torch.no_grad():
+            tiles = _run_tiles(cfg, tile_dir, tiling_config, first_tile, tiles_per_launch)
+    finally:
+        async_io.drain()
     engine.release_scratch()  # (the run's peak workspace does not outlive it)
+    return tiles
+
+
+def _run_tiles(cfg, tile_dir, tiling_config, first_tile, tiles_per_launch):
+    tiles = prepare_tiles(tile_dir, tiling_config, cfg.logging)
+
+    def launch(states):
+        kw = states[0].fine_state["loop_kw"]
+        assert all(s.fine_state["loop_kw"] == kw for s in states)  # (one config: one set of loop parameters)
+        return engine.patch_loop_tiles([s.fine_state["loop_args"] for s in states], **kw)
+
+    for_each_tile(cfg, tiles, lambda c: Coarse2Fine(c).implement_c2f_matching(), cfg.logging, first=first_tile, batch=int(tiles_per_launch),
+                  stages=(lambda c: Coarse2Fine(c).prepare_c2f(), launch, lambda s, out: s.finish_c2f(out)))
     return tiles
 
 

@@ -30,8 +30,9 @@ import numpy as np
 from .. import engine
 from .._lib import check, lib
 from ..cpp_core.supervoxel_segmentation.build import supervoxel as supervoxel_partition
+from ..utils import async_io
 from ..utils.common import AttrDict, dir_exist
-from ..utils.ply import read_ply
+from ..utils.ply import read_xyz32
 from .fine_matching import fine_matching_3d, fine_matching_finish, fine_matching_prepare  # noqa: F401
 
 
@@ -39,15 +40,20 @@ def _get(d, key, default=None):
     return d[key] if (d is not None and key in d and d[key] is not None) else default
 
 
+def _write_rows(path, rows):
+    check(lib().f4l_write_rows_txt(path.encode(), rows.ctypes.data_as(C.c_void_p), rows.shape[0], rows.shape[1]), "f4l_write_rows_txt")
+
+
 def max_mag_visualize(dataset):
     """The upper end of the colour scale the reference plants into row 1 of every *_visualize file (base:3480-3489)."""
     return {"rockfall_simulator": 0.06, "brienz_tls": 5, "mattertal": 10}.get(dataset, 10)
 
 
-def save_process_dvf(output_root, tile_id, dataset, dense, sparse=None, tgt2src=None, multiple_case=True, voxel_size=None):
+def save_process_dvf(output_root, tile_id, dataset, dense, sparse=None, tgt2src=None, multiple_case=True, voxel_size=None, defer=False):
     """`save_process_dvf` (src/coarse_to_fine_matching_base.py:3459-3600): the result files of a tile under <output_root>/results,
     with the reference's names, '%.6f', and -- in the *_visualize files -- magnitudes 0 and max_mag_visualize planted into rows 0
-    and 1.  dense / sparse / tgt2src: (m, 6) arrays or tensors [from xyz, to xyz].  Returns the list of files written."""
+    and 1.  dense / sparse / tgt2src: (m, 6) arrays or tensors [from xyz, to xyz].  Returns the list of files written -- with
+    `defer`, of files BEING written by the writer threads (utils/async_io; the tile loop drains them before the run returns)."""
     def host(a):
         if a is None:
             return None
@@ -62,21 +68,31 @@ def save_process_dvf(output_root, tile_id, dataset, dense, sparse=None, tgt2src=
 
     def save(name, arr):
         # np.savetxt(path, arr, delimiter=" ", fmt="%.6f") byte for byte (f4l_write_rows_txt: numpy formats value by value in
-        # Python -- 2.4 s per million rows of six, four to eight such files per tile, against 30 ms of device work for the tile)
+        # Python -- 2.4 s per million rows of six, four to eight such files per tile, against 30 ms of device work for the tile).
+        # `arr`: the table, or a function that makes it (the magnitude tables: 30 ms of numpy per million rows, which a deferred
+        # file leaves to its writer thread)
         path = osp.join(res_dir, name)
-        rows = np.ascontiguousarray(arr, dtype=np.float32)
-        if rows.ndim != 2:
-            raise ValueError("save_process_dvf writes tables")
-        check(lib().f4l_write_rows_txt(path.encode(), rows.ctypes.data_as(C.c_void_p), rows.shape[0], rows.shape[1]), "f4l_write_rows_txt")
+
+        def job():
+            rows = np.ascontiguousarray(arr() if callable(arr) else arr, dtype=np.float32)
+            if rows.ndim != 2:
+                raise ValueError("save_process_dvf writes tables")
+            _write_rows(path, rows)
+        if defer:  # (the inputs are this call's own arrays: nobody touches them until the writer is through)
+            async_io.submit(job)
+        else:
+            job()
         written.append(path)
 
     def xyz_mag(rows, planted):
-        mag = np.linalg.norm(rows[:, 3:6] - rows[:, :3], axis=1).astype(np.float32)[:, None]  # torch.linalg.norm on float32 (:3463-3465)
-        if planted:
-            mag = mag.copy()
-            mag[0] = 0
-            mag[1] = cap
-        return np.hstack((rows[:, :3], mag))
+        def make():
+            mag = np.linalg.norm(rows[:, 3:6] - rows[:, :3], axis=1).astype(np.float32)[:, None]  # torch.linalg.norm on float32 (:3463-3465)
+            if planted:
+                mag = mag.copy()
+                mag[0] = 0
+                mag[1] = cap
+            return np.hstack((rows[:, :3], mag))
+        return make
 
     if multiple_case:
         save(f"c2f_dense_dvfs_src2tgt_tile_{tile_id}.txt", dense)                                   # :3477-3479
@@ -99,7 +115,7 @@ def save_process_dvf(output_root, tile_id, dataset, dense, sparse=None, tgt2src=
                 idx = idx[:, 0].cpu().numpy()
                 remain = np.ones(len(tgt2src), dtype=bool)
                 remain[idx[hit]] = False
-                vis = xyz_mag(tgt2src, True)  # (the reference indexes the already planted magnitudes, then plants again)
+                vis = xyz_mag(tgt2src, True)()  # (the reference indexes the already planted magnitudes, then plants again)
                 for name, sel in ((f"c2f_dvfms_tgt2src_mutual_intersect_with_src2tgt_visualize_tile_{tile_id}.txt", idx[hit]),
                                   (f"c2f_dvfms_tgt2src_mutual_remain_with_src2tgt_visualize_tile_{tile_id}.txt", np.nonzero(remain)[0])):
                     part = vis[sel].copy()
@@ -129,6 +145,7 @@ class Coarse2Fine:
         self.output_root = config.path_name.output_root
         self.device = _get(config, "device")
         self.tile_id = _get(config, "tile_id", 0)  # (captured now: the tile loop moves the config on before a batched tile is finished)
+        self.defer_files = bool(_get(config, "defer_files", False))  # (the tile loop's: partition / result files by the writer threads)
         self.data_input_3d, self.data_interim, self.data_output = AttrDict(), AttrDict(), AttrDict()
         if self.method.partition_type != "supervoxel":
             raise NotImplementedError(f"partition_type {self.method.partition_type!r}: only 'supervoxel' is built here (the superpoint "
@@ -149,8 +166,10 @@ class Coarse2Fine:
             root = self.config.path_name.input_root
             self.src_pcd_path, self.tgt_pcd_path = osp.join(root, "raw_pcd", self.data.src_pcd), osp.join(root, "raw_pcd", self.data.tgt_pcd)
         dev = torch.device("cuda", torch.cuda.current_device())
-        self.data_input_3d.src_pts = torch.from_numpy(np.ascontiguousarray(read_ply(self.src_pcd_path)[0], dtype=np.float32)).to(dev)
-        self.data_input_3d.tgt_pts = torch.from_numpy(np.ascontiguousarray(read_ply(self.tgt_pcd_path)[0], dtype=np.float32)).to(dev)
+        # (the tile loop may have started these reads while the tile before was on the device: utils/tiles.py, utils/async_io.py)
+        self._host_xyz = {"src": async_io.take(self.src_pcd_path, read_xyz32), "tgt": async_io.take(self.tgt_pcd_path, read_xyz32)}
+        self.data_input_3d.src_pts = torch.from_numpy(self._host_xyz["src"]).to(dev)
+        self.data_input_3d.tgt_pts = torch.from_numpy(self._host_xyz["tgt"]).to(dev)
 
     # ---- base:1012-1057 -----------------------------------------------------------------------------------------------------
     def _voxel_subsampling(self):
@@ -179,10 +198,14 @@ class Coarse2Fine:
         tag = f"_tile_{self.tile_id}" if self.data.multiple_case else ""
         save = bool(_get(self.method, "save_partition", True))
         labels = []
-        for which, path in (("src", self.src_pcd_path), ("tgt", self.tgt_pcd_path)):
+        # `computeSupervoxel(path, k, radius, out)` of base:2680-2694 without its second read of the same PLY and without the labels'
+        # trip to the host and back: the cloud `_read_data` put on the device, the partition file by the writer threads
+        for which, pts in (("src", self.data_input_3d.src_pts), ("tgt", self.data_input_3d.tgt_pts)):
             out = osp.join(partition_path, f"partition_of_input_{which}{tag}.txt") if save else "None"
-            lab = supervoxel_partition.computeSupervoxel(path, int(self.para.n_normals), float(svl_radius), out)
-            labels.append(torch.from_numpy(np.asarray(lab, dtype=np.int32)).to(self.data_input_3d.src_pts.device))
+            lab, _ = supervoxel_partition.computeSupervoxelDevice(pts, int(self.para.n_normals), float(svl_radius), out,
+                                                                  xyz_host=self._host_xyz.get(which), defer=self.defer_files)
+            labels.append(lab)
+        self._host_xyz = {}
         self.data_interim.idx_pts2spt_src, self.data_interim.idx_pts2spt_tgt = labels
 
     def load_partition(self):
@@ -305,7 +328,7 @@ class Coarse2Fine:
         O = self.data_output
         return save_process_dvf(self.output_root, self.tile_id, self.data.dataset, O.corres_3d_refine_apply_icp,
                                 O.corres_3d_refine_apply_icp_discrete, O.corres_3d_refine_apply_icp_tgt2src,
-                                multiple_case=bool(self.data.multiple_case), voxel_size=_get(self.method, "voxel_size"))
+                                multiple_case=bool(self.data.multiple_case), voxel_size=_get(self.method, "voxel_size"), defer=self.defer_files)
 
     # ---- src/coarse_to_fine_matching.py:201-290 -------------------------------------------------------------------------------
     def implement_c2f_matching(self):

@@ -45,6 +45,49 @@ def read_ply(path):
     return xyz, {k: v for k, v in cols.items() if k not in ("x", "y", "z")}
 
 
+def read_xyz32(path):
+    """The vertex coordinates as a contiguous float32 (n, 3) array -- what `pcl::PointXYZ` (supervoxel.cpp:88-91) and the device
+    keep of a tile.  Binary files whose x, y, z are float32 are sliced out of the record buffer without the float64 detour of
+    `read_ply` (a third of its time on a 1 M-point tile); everything else goes through it."""
+    with open(path, "rb") as f:
+        if f.readline().strip() != b"ply":
+            raise ValueError(f"{path}: not a PLY file")
+        fmt, n, props, in_vertex, first = None, 0, [], False, None
+        while True:
+            line = f.readline()
+            if not line:
+                raise ValueError(f"{path}: truncated header")
+            tok = line.decode("ascii", "replace").split()
+            if not tok:
+                continue
+            if tok[0] == "format":
+                fmt = tok[1]
+            elif tok[0] == "element":
+                if first is None:
+                    first = tok[1]
+                in_vertex = tok[1] == "vertex"
+                if in_vertex:
+                    n = int(tok[2])
+            elif tok[0] == "property" and in_vertex:
+                if tok[1] == "list":
+                    props = None
+                    break
+                props.append((tok[2], _TYPES.get(tok[1])))
+            elif tok[0] == "end_header":
+                break
+        fast = (props and fmt in ("binary_little_endian", "binary_big_endian") and first == "vertex"
+                and all(t is not None for _, t in props) and all(dict(props).get(k) == "f4" for k in ("x", "y", "z")))
+        if fast:
+            end = "<" if fmt == "binary_little_endian" else ">"
+            dt = np.dtype([(name, end + t) for name, t in props])
+            rec = np.frombuffer(f.read(n * dt.itemsize), dtype=dt, count=n)
+            out = np.empty((n, 3), dtype=np.float32)
+            for d, k in enumerate(("x", "y", "z")):
+                out[:, d] = rec[k]
+            return out
+    return np.ascontiguousarray(read_ply(path)[0], dtype=np.float32)
+
+
 def write_ply(path, xyz, dtype="float32"):
     xyz = np.ascontiguousarray(xyz, dtype=dtype)
     t = "float" if dtype == "float32" else "double"

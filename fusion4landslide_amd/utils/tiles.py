@@ -6,7 +6,9 @@ import os
 import os.path as osp
 import re
 
+from . import async_io
 from .common import dir_exist
+from .ply import read_xyz32
 
 
 def prepare_tiles(tile_dir, tiling_config, log):
@@ -32,17 +34,28 @@ def for_each_tile(cfg, tiles, process, log, first=0, batch=1, stages=None):
     two rounds of workgroups; merged launches run at 1.5 x the rate (bench.py extras.C2x8_tiles).  Every patch's result is what its
     own launch gives to rounding (a larger batch may run in another launch shape, whose sums run in another order: 1e-9 m in a
     transform, tests/test_gpu_parity.py), so a '%.6f' row of the files can differ in its last digit."""
+    todo = tiles[first:]
+    ahead = bool(getattr(cfg, "defer_files", False))  # (the fusion entry: the next tile's PLY files are read while this one computes)
+
     def visit(tile_i, src_path):
         log.info(f'Current tile {tile_i + first} of total {len(tiles)} tiles')
         tgt_path = src_path.replace('source_tile_', 'target_tile_')
         assert osp.exists(tgt_path), tgt_path
         cfg.tile_id = re.findall(r'\d+', osp.basename(src_path))[0]
         cfg.src_tile_overlap_path, cfg.tgt_tile_overlap_path = src_path, tgt_path
+        if ahead and tile_i + 1 < len(todo):
+            nxt = todo[tile_i + 1]
+            for path in (nxt, nxt.replace('source_tile_', 'target_tile_')):
+                if osp.exists(path):
+                    async_io.prefetch(path, read_xyz32)
 
     if stages is None or batch <= 1:
-        for tile_i, src_path in enumerate(tiles[first:]):
-            visit(tile_i, src_path)
-            process(cfg)
+        try:
+            for tile_i, src_path in enumerate(todo):
+                visit(tile_i, src_path)
+                process(cfg)
+        finally:
+            async_io.forget_prefetched()
         return
     prepare, launch, finish = stages
     pending = []
@@ -54,12 +67,13 @@ def for_each_tile(cfg, tiles, process, log, first=0, batch=1, stages=None):
             pending.clear()
 
     try:
-        for tile_i, src_path in enumerate(tiles[first:]):
+        for tile_i, src_path in enumerate(todo):
             visit(tile_i, src_path)
             pending.append(prepare(cfg))
             if len(pending) >= batch:
                 flush()
     finally:
+        async_io.forget_prefetched()
         # (also when prepare() raises at tile i: the tiles prepared before it are finished and written, as the reference's
         #  tile-by-tile loop would have written them before failing at i -- ADVICE r5)
         flush()

@@ -424,6 +424,30 @@ int f4l_median_f64(const double *values, int64_t n, int64_t stride, double *medi
 int f4l_median_sqrt_f64(const double *values, int64_t n, int64_t stride, double *median_out, void *workspace,
                         size_t workspace_bytes, void *stream);
 
+/* The tiling front end of both entry scripts (main_piecewise_icp.py:60-83, main_fusion.py:112-125 -> src/functions.py:147-177 ->
+ * the SWIG module cpp_core/pcd_tiling/pcd_tiling.i), `tile_point_clouds` of cpp_core/pcd_tiling/pcd_tiling.h:3-12, body
+ * cpp_core/pcd_tiling/pcd_tiling.cpp:709-871 -- the same ten arguments in the same order: crop both epochs to the overlap of their
+ * bounding boxes (:73-116), optionally thin them with a voxel grid (pcl::VoxelGrid, :118-227; voxel_grid_filter_size == 0: the median
+ * nearest-neighbour spacing of the smaller cloud, :37-54), halve the box along the longer side of the projection plane until both
+ * halves hold fewer than max_points_per_tile points (:231-655), and write every leaf as
+ *   <save_dir>/non_overlap/{source,target}_tile_<i>.ply and <save_dir>/overlap/{source,target}_tile_<i>_overlap.ply
+ * (binary little-endian PLY, float x y z [+ uchar red green blue]; the overlap twin: the leaf's box grown by 20 m in the projection
+ * plane -- hard coded in the reference, which accepts and ignores min_points_per_tile and overlap_tiles: so does this).
+ * projection_direction: -1 (the axis whose face of the overlap box is largest), 0, 1 or 2.
+ * Both clouds live on the device from the read to the leaves: boxes, crops (stable compaction), the voxel grid with its colour
+ * averages, the spacing estimate and the counts that steer the recursion are kernels; the host walks the tree of boxes and writes
+ * the files.  A FILE-LEVEL entry: paths in, files out; it allocates its own device memory and synchronises `stream`.
+ * *n_tiles_host (HOST int, nullable): the tiles written per epoch; -2 when an input file does not exist (the reference prints and
+ * returns false there, :735-738: the return value is F4L_OK).  F4L_EUNSUPPORTED: more than max_points_per_tile coincident points
+ * (the reference recurses until its stack overflows), or list properties on the vertex element.  PCL's filter semantics are restated
+ * from its documentation [parity unpinned]; file for file the output equals oracle/pcd_tiling_ref.py (tests/test_pcd_tiling.py). */
+int f4l_tile_point_clouds(const char *first_ply, const char *second_ply, int max_points_per_tile, int min_points_per_tile,
+                          int voxel_grid_flag, float voxel_grid_filter_size, float overlap_tiles, int projection_direction,
+                          const char *save_dir, int verbose, int32_t *n_tiles_host, void *stream);
+/* `resave_point_cloud` (pcd_tiling.h:15-17, pcd_tiling.cpp:662-707): both files re-written as binary PLY (host only).
+ * *ok_host: 1 done, 0 an input file does not exist. */
+int f4l_resave_point_cloud(const char *first_ply, const char *second_ply, int verbose, int32_t *ok_host);
+
 /* Gather rows: out[i] = pts[order[i]] (float32 [n][3]); builds patch-contiguous clouds from a CSR order. */
 int f4l_gather_points(const float *pts, const int32_t *order, int64_t n, float *out, void *stream);
 

@@ -222,7 +222,7 @@ def test_full_path_over_slabs_single_rank_equals_the_tile_path(eng):
     c = synthetic.two_epoch_cloud(60_000, 9, 1.386, seed=4)
     src, tgt = dev(c["src"]), dev(c["tgt"])
     res = 0.9
-    whole = pipeline.full_path(src, tgt, resolution=res, max_iter=20, fixed_iters=True)
+    whole = pipeline.full_path(src, tgt, resolution=res, max_iter=20, fixed_iters=True, partition="parallel")  # (the slab partition is the parallel variant)
     part = pipeline.full_path_slabs(src, torch.arange(src.shape[0], device="cuda"), tgt, None, 0, 1, halo=0.5, resolution=res, max_iter=20,
                                     fixed_iters=True)
     assert part["K_local"] == part["K_total"] == whole["K"] and part["offset"] == 0 and part["n_uncertified"] == 0

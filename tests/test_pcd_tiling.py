@@ -1,17 +1,18 @@
-"""The tiling front end (cpp_core/pcd_tiling/pcd_tiling.cpp -> fusion4landslide_amd/cpp_core/pcd_tiling/build/pcd_tiling.py).
-PCL is not available here, so these are structural checks of the restated recursion (CPU) and of the GPU voxel filter
-against its numpy restatement."""
+"""The tiling front end: cpp_core/pcd_tiling/pcd_tiling.cpp:709-871 -> f4l_tile_point_clouds (fusion4landslide_amd/csrc/tiling.hip) behind
+the shim fusion4landslide_amd/cpp_core/pcd_tiling/build/pcd_tiling.py.  PCL is not available here, so the checker is a numpy
+restatement of the reference's steps (oracle/pcd_tiling_ref.py; parity unpinned): CPU tests pin the restatement's structure, GPU tests
+compare the library entry with it FILE FOR FILE, byte for byte, on the reference's ten-argument call."""
 import os
 
 import numpy as np
 import pytest
 
-from fusion4landslide_amd.cpp_core.pcd_tiling.build import pcd_tiling as T
 from fusion4landslide_amd.utils.ply import read_ply
+from oracle import pcd_tiling_ref as R
 
 
 def _write_cloud(path, xyz, rgb=None):
-    T._write(path, T._Cloud(xyz, rgb))
+    R._write(path, R._Cloud(xyz, rgb))
 
 
 def _surface(rng, n, x0, x1, y0, y1):
@@ -21,19 +22,21 @@ def _surface(rng, n, x0, x1, y0, y1):
 
 def test_split_boxes_halve_the_longer_in_plane_side():
     lo, hi = np.array([0, 0, 0], np.float32), np.array([10, 4, 1], np.float32)
-    (t1lo, t1hi, o1lo, o1hi), (t2lo, t2hi, o2lo, o2hi) = T._split_boxes(lo, hi, 2)
+    (t1lo, t1hi, o1lo, o1hi), (t2lo, t2hi, o2lo, o2hi) = R._split_boxes(lo, hi, 2)
     assert t1lo.tolist() == [5, 0, 0] and t1hi.tolist() == [10, 4, 1]      # upper half first
     assert t2lo.tolist() == [0, 0, 0] and t2hi.tolist() == [5, 4, 1]
     assert o1lo.tolist() == [-15, -20, 0] and o1hi.tolist() == [30, 24, 1]  # 20 m pad in the projection plane only
     assert o2lo.tolist() == [-20, -20, 0] and o2hi.tolist() == [25, 24, 1]
     # projection along x: the plane is (y, z); z is longer here
-    (t1lo, t1hi, _, _), _ = T._split_boxes(np.array([0, 0, 0], np.float32), np.array([1, 2, 8], np.float32), 0)
+    (t1lo, t1hi, _, _), _ = R._split_boxes(np.array([0, 0, 0], np.float32), np.array([1, 2, 8], np.float32), 0)
     assert t1lo.tolist() == [0, 0, 4] and t1hi.tolist() == [1, 2, 8]
-    c = T._Cloud(np.array([[5, 1, 0.5], [4.999, 1, 0.5], [5.001, 1, 0.5]], np.float32))
-    assert len(T._crop(c, [5, 0, 0], [10, 4, 1])) == 2 and len(T._crop(c, [0, 0, 0], [5, 4, 1])) == 2  # inclusive both ways
+    c = R._Cloud(np.array([[5, 1, 0.5], [4.999, 1, 0.5], [5.001, 1, 0.5]], np.float32))
+    assert len(R._crop(c, [5, 0, 0], [10, 4, 1])) == 2 and len(R._crop(c, [0, 0, 0], [5, 4, 1])) == 2  # inclusive both ways
 
 
-def test_tile_point_clouds_structure(tmp_path):
+def test_restatement_structure(tmp_path):
+    """The checker itself (host only): every tile below the limit, the overlap twin contains its tile and everything within 20 m of it
+    in the projection plane, the tiles cover the cropped cloud, tile 0 is the upper-most half of every split."""
     rng = np.random.default_rng(5)
     a = _surface(rng, 6000, 0, 100, 0, 60)
     b = _surface(rng, 5000, 10, 120, -5, 55)                     # overlap box: x 10..100, y 0..55
@@ -41,8 +44,12 @@ def test_tile_point_clouds_structure(tmp_path):
     pa, pb, out = str(tmp_path / "a.ply"), str(tmp_path / "b.ply"), str(tmp_path / "tiles")
     _write_cloud(pa, a, rgb)
     _write_cloud(pb, b)
-    assert T.tile_point_clouds(pa, pb, 1000, 0, False, 0.0, 0.0, -1, out, False) is True
-    assert T.tile_point_clouds(str(tmp_path / "missing.ply"), pb, 1000, 0, False, 0.0, 0.0, -1, out, False) is False
+    assert R.tile_point_clouds(pa, pb, 1000, 0, False, 0.0, 0.0, -1, out, False) is True
+    assert R.tile_point_clouds(str(tmp_path / "missing.ply"), pb, 1000, 0, False, 0.0, 0.0, -1, out, False) is False
+    _check_structure(out, a, b, 1000)
+
+
+def _check_structure(out, a, b, limit):
     names = sorted(os.listdir(os.path.join(out, "non_overlap")))
     n_tiles = len(names) // 2
     assert n_tiles >= 5 and names == sorted([f"{k}_tile_{i}.ply" for k in ("source", "target") for i in range(n_tiles)])
@@ -53,7 +60,7 @@ def test_tile_point_clouds_structure(tmp_path):
         for i in range(n_tiles):
             t, f = read_ply(os.path.join(out, "non_overlap", f"{kind}_tile_{i}.ply"))
             o, _ = read_ply(os.path.join(out, "overlap", f"{kind}_tile_{i}_overlap.ply"))
-            assert len(t) < 1000 and len(t) > 1
+            assert len(t) < limit and len(t) > 1
             assert (kind == "source") == ("red" in f)                       # colours travel with the cloud that has them
             tset = {tuple(r) for r in t.astype(np.float32)}
             assert tset <= {tuple(r) for r in o.astype(np.float32)}        # the overlap twin contains its tile
@@ -71,7 +78,80 @@ def test_tile_point_clouds_structure(tmp_path):
     assert t0[:, 0].max() == inside(a)[:, 0].max()
 
 
-def test_resave_point_cloud(tmp_path):
+def _same_files(dir_a, dir_b):
+    for sub in ("non_overlap", "overlap"):
+        na, nb = sorted(os.listdir(os.path.join(dir_a, sub))), sorted(os.listdir(os.path.join(dir_b, sub)))
+        assert na == nb and len(na) >= 2, (sub, na, nb)
+        for name in na:
+            assert open(os.path.join(dir_a, sub, name), "rb").read() == open(os.path.join(dir_b, sub, name), "rb").read(), (sub, name)
+    return len(os.listdir(os.path.join(dir_a, "non_overlap"))) // 2
+
+
+@pytest.mark.gpu
+def test_library_tiler_equals_the_restatement_file_for_file(tmp_path):
+    """f4l_tile_point_clouds through the drop-in module, on the reference's ten-argument call, against oracle/pcd_tiling_ref.py: the same
+    files with the same bytes -- without and with the voxel grid (given leaf, and leaf = median spacing), colours on one epoch, every
+    projection direction, georeferenced coordinates (float32 cell arithmetic), points exactly on a cut, ascii and double-precision
+    inputs; the missing-file and the too-many-coincident-points answers; `resave_point_cloud`."""
+    from fusion4landslide_amd.cpp_core.pcd_tiling.build import pcd_tiling as T
+    rng = np.random.default_rng(5)
+    a = _surface(rng, 6000, 0, 100, 0, 60)
+    b = _surface(rng, 5000, 10, 120, -5, 55)
+    a[:40, 0] = 55.0                                               # points exactly on the first cut of the overlap box (x 10..100)
+    rgb = rng.integers(0, 256, (len(a), 3)).astype(np.uint8)
+    pa, pb = str(tmp_path / "a.ply"), str(tmp_path / "b.ply")
+    _write_cloud(pa, a, rgb)
+    _write_cloud(pb, b)
+    for tag, args in (("plain", (1000, 0, False, 0.0, 0.0, -1)), ("dir0", (1500, 100, False, 0.05, 0.0, 0)), ("dir1", (1500, 100, False, 0.05, 0.0, 1)),
+                      ("dir2", (800, 100, False, 0.05, 5.0, 2)), ("grid", (700, 0, True, 1.5, 0.0, -1)), ("grid_auto", (900, 0, True, 0.0, 0.0, -1))):
+        got, ref = str(tmp_path / f"got_{tag}"), str(tmp_path / f"ref_{tag}")
+        assert T.tile_point_clouds(pa, pb, *args, got, False) is True
+        assert R.tile_point_clouds(pa, pb, *args, ref, False) is True
+        n_tiles = _same_files(got, ref)
+        assert n_tiles >= 2, tag
+    _check_structure(str(tmp_path / "got_plain"), a, b, 1000)
+    assert T.tile_point_clouds(str(tmp_path / "missing.ply"), pb, 1000, 0, False, 0.0, 0.0, -1, str(tmp_path / "none"), False) is False
+    # georeferenced clouds, colours, the voxel grid from the median spacing (the configuration main_fusion.py:113-123 asks for)
+    g1 = _surface(rng, 40000, 2600000, 2600060, 1200000, 1200040)
+    g1[:, 2] += 1500
+    g2 = _surface(rng, 30000, 2600010, 2600070, 1199995, 1200035)
+    g2[:, 2] += 1500
+    p1, p2 = str(tmp_path / "g1.ply"), str(tmp_path / "g2.ply")
+    _write_cloud(p1, g1, rng.integers(0, 256, (len(g1), 3)).astype(np.uint8))
+    _write_cloud(p2, g2)
+    got, ref = str(tmp_path / "got_geo"), str(tmp_path / "ref_geo")
+    assert T.tile_point_clouds(p1, p2, 4000, 0, True, 0.0, 0.0, -1, got, False) is True
+    assert R.tile_point_clouds(p1, p2, 4000, 0, True, 0.0, 0.0, -1, ref, False) is True
+    n_tiles = _same_files(got, ref)
+    total = sum(len(read_ply(os.path.join(got, "non_overlap", f"source_tile_{i}.ply"))[0]) for i in range(n_tiles))
+    lo = np.maximum(g1.min(0), g2.min(0)); hi = np.minimum(g1.max(0), g2.max(0))
+    assert n_tiles >= 2 and total < int(np.all((g1 >= lo) & (g1 <= hi), axis=1).sum())  # thinned
+    # an ascii PLY and a double-precision one: the same tiles as their float32 binary twins
+    pa_ascii, pb_double = str(tmp_path / "a_ascii.ply"), str(tmp_path / "b_double.ply")
+    with open(pa_ascii, "w") as f:
+        f.write(f"ply\nformat ascii 1.0\nelement vertex {len(a)}\nproperty float x\nproperty float y\nproperty float z\nproperty uchar red\n"
+                "property uchar green\nproperty uchar blue\nend_header\n")
+        for p, c in zip(a, rgb):
+            f.write("%.9g %.9g %.9g %d %d %d\n" % (p[0], p[1], p[2], c[0], c[1], c[2]))
+    from fusion4landslide_amd.utils.ply import write_ply
+    write_ply(pb_double, b, dtype="float64")
+    got2 = str(tmp_path / "got_ascii")
+    assert T.tile_point_clouds(pa_ascii, pb_double, 1000, 0, False, 0.0, 0.0, -1, got2, False) is True
+    _same_files(got2, str(tmp_path / "ref_plain"))
+    # more than maxPointsPerTile coincident points: refused (the reference recurses until its stack overflows)
+    same = np.tile(np.array([[1.0, 2.0, 3.0]], np.float32), (50, 1))
+    ps = str(tmp_path / "same.ply")
+    _write_cloud(ps, same)
+    with pytest.raises(ValueError):
+        T.tile_point_clouds(ps, ps, 10, 0, False, 0.0, 0.0, -1, str(tmp_path / "stuck"), False)
+    # resave_point_cloud: ascii in, binary out, same coordinates
+    assert T.resave_point_cloud(pa_ascii, pb_double, False) is True
+    assert b"binary_little_endian" in open(pa_ascii, "rb").read(64)
+    assert np.array_equal(read_ply(pa_ascii)[0].astype(np.float32), a) and np.array_equal(read_ply(pb_double)[0].astype(np.float32), b)
+    assert T.resave_point_cloud(str(tmp_path / "missing.ply"), pb, False) is False
+
+
+def test_resave_point_cloud_of_the_restatement(tmp_path):
     rng = np.random.default_rng(6)
     a = _surface(rng, 50, 0, 1, 0, 1)
     p1, p2 = str(tmp_path / "a.ply"), str(tmp_path / "b.ply")
@@ -79,13 +159,13 @@ def test_resave_point_cloud(tmp_path):
         f.write("ply\nformat ascii 1.0\nelement vertex 50\nproperty float x\nproperty float y\nproperty float z\nend_header\n")
         np.savetxt(f, a, fmt="%.9g")
     _write_cloud(p2, a)
-    assert T.resave_point_cloud(p1, p2, False) is True
+    assert R.resave_point_cloud(p1, p2, False) is True
     assert b"binary_little_endian" in open(p1, "rb").read(64)
     assert np.array_equal(read_ply(p1)[0].astype(np.float32), a)
 
 
 @pytest.mark.gpu
-def test_voxel_grid_pcl_layout_vs_numpy_and_full_tiling(tmp_path):
+def test_voxel_grid_pcl_layout_vs_numpy():
     import torch
     from fusion4landslide_amd import engine
     from oracle import oracle as O
@@ -97,20 +177,3 @@ def test_voxel_grid_pcl_layout_vs_numpy_and_full_tiling(tmp_path):
         rp, rc, rv = O.voxel_grid_pcl(a, leaf)
         assert len(rp) == pts.shape[0] and np.array_equal(cnt.cpu().numpy(), rc) and np.array_equal(vop.cpu().numpy(), rv)
         assert np.abs(pts.cpu().numpy() - rp).max() <= 1e-6
-    b = _surface(rng, 30000, 2600010, 2600070, 1199995, 1200035)
-    b[:, 2] += 1500
-    pa, pb, out = str(tmp_path / "a.ply"), str(tmp_path / "b.ply"), str(tmp_path / "tiles")
-    _write_cloud(pa, a, rng.integers(0, 256, (len(a), 3)).astype(np.uint8))
-    _write_cloud(pb, b)
-    assert T.tile_point_clouds(pa, pb, 4000, 0, True, 0.0, 0.0, -1, out, False) is True   # leaf from the median spacing
-    n_tiles = len(os.listdir(os.path.join(out, "non_overlap"))) // 2
-    assert n_tiles >= 2
-    total = 0
-    for i in range(n_tiles):
-        t, f = read_ply(os.path.join(out, "non_overlap", f"source_tile_{i}.ply"))
-        assert 1 < len(t) < 4000 and "red" in f
-        total += len(t)
-    # thinned: fewer points than went in, none lost to the recursion
-    lo = np.maximum(a.min(0), b.min(0)); hi = np.minimum(a.max(0), b.max(0))
-    n_in = int(np.all((a >= lo) & (a <= hi), axis=1).sum())
-    assert total < n_in

@@ -45,8 +45,8 @@ mine = dict(gid=out["gid"].cpu(), disp=(rows[:, 3:] - rows[:, :3]).cpu(), fit=ou
 allr = [None] * world
 dist.all_gather_object(allr, mine)
 if rank == 0:
-    whole = pipeline.full_path(src, tgt, resolution=RES, max_iter=20, fixed_iters=True)
-    whole = pipeline.full_path(src, tgt, resolution=RES, max_iter=20, fixed_iters=True)
+    whole = pipeline.full_path(src, tgt, resolution=RES, max_iter=20, fixed_iters=True, partition="parallel")
+    whole = pipeline.full_path(src, tgt, resolution=RES, max_iter=20, fixed_iters=True, partition="parallel")
     wd = torch.zeros((src.shape[0], 3), dtype=torch.float64)
     wr = whole["rows"].double().cpu()
     wd[whole["order"].to(torch.int64).cpu()] = wr[:, 3:] - wr[:, :3]

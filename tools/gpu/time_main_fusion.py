@@ -35,3 +35,4 @@ wall = time.perf_counter() - t0
 print(f"main_fusion: {T} tiles of {n} points: {wall:.2f} s wall = {wall / T:.2f} s per tile")
 st = pstats.Stats(pr); st.sort_stats("cumulative")
 import io; s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("cumulative").print_stats(28); print("\n".join(l[:150] for l in s.getvalue().split("\n")[6:40]))
+s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(22); print("\n".join(l[:150] for l in s.getvalue().split("\n")[6:34]))
