@@ -229,7 +229,8 @@ def run_rank(args, world):
         line = {
             "metric": "M-points/sec piecewise ICP (20 iters, two-epoch cloud)",
             "value": None if dry else round(n / (ms_per_step * 1e-3) / 1e6, 3), "unit": "Mpts/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "timed_region_s": round(elapsed, 4),
+            "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": args.config, "points_per_epoch": n, "patches": P_total,
                        "points_on_rank0": n_mine, "patches_on_rank0": P,

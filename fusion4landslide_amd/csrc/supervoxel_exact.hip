@@ -635,6 +635,10 @@ __global__ __launch_bounds__(EVAL_WAVES * 64, SVX_EVAL_WPE) void eval16_kernel(F
             }
             const float pj[3] = {sn.x, sn.y, sn.z};
             const double nj[3] = {sn.nx, sn.ny, sn.nz};
+            // (measured and not kept, round 6: the test decided in float32 wherever it is clear of the threshold by more than float32 can be
+            //  off, the double metric -- a double sqrt and division -- only in the band around it: 224.5 against 216.4 ms per 10 M points;
+            //  the kernel waits on its gathers, and the seven registers the second path costs weigh more than the ~65 double-rate
+            //  instructions it saves)
             const double loss = (double)sj * sv_metric_vals(pi_, ni_, pj, nj, a.resolution);  // :142 `sizes[j] * metric(points[i], points[j])`
             acc = lambda - loss > 0.0;                                                        // :143-144
         }
