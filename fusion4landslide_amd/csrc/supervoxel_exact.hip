@@ -60,6 +60,7 @@ struct State {
     int done, done_it;     // the round's estimate has converged (abs_changed_kernel), after this many passes: the passes queued behind it do nothing
     unsigned int arrive;   // workgroups of abs_changed_kernel that are through (the last one closes the pass)
     long long total[8];    // per pass: absorptions of the whole estimate (the budget of the last round is switched on by it)
+    unsigned long long pool_max, pool_sum;  // (statistics: the fullest slice of a list pool any pass left, and the most entries a pass wrote)
 #ifdef SVX_MEASURE_PREFIX
     int minchg[8], nchg[8];  // (measurement build: the lowest centre whose output changed in a pass, and how many did)
 #endif
@@ -766,6 +767,17 @@ __global__ void abs_changed_kernel(FuseArgs a, int pass, int budget_on, long lon
     __syncthreads();
     if (!s_last) return;
     __threadfence();
+    {   // (statistics of the pass's list pool, for F4L_SV_EXACT_DEBUG and the sizing of the pools)
+        unsigned long long mx = 0ULL, sm = 0ULL;
+        for (int t = (int)threadIdx.x; t < SUBPOOLS; t += (int)blockDim.x) { const unsigned long long v = st->sub[pass & 1][t]; mx = v > mx ? v : mx; sm += v; }
+        atomicMax(&st->pool_max, mx);
+        __shared__ unsigned long long s_sum;
+        if (threadIdx.x == 0) s_sum = 0ULL;
+        __syncthreads();
+        atomicAdd(&s_sum, sm);
+        __syncthreads();
+        if (threadIdx.x == 0) atomicMax(&st->pool_sum, s_sum);
+    }
     const int changed = atomicAdd(&st->changed[pass & 7], 0);
     const long long total = (long long)atomicAdd((unsigned long long *)&st->total[pass & 7], 0ULL);
     const bool conv = changed == 0 && (budget_on || total < budget_total);
@@ -1189,7 +1201,9 @@ static int segment_exact_run(const float *xyz, const double *normals, const int3
         if (nreps > 1 && nreps != K)  // (another round follows: its lists hold this round's representatives)
             hipLaunchKernelGGL(svx::rootlists_kernel, dim3((unsigned)((nreps + 15) / 16 < 4096 ? (nreps + 15) / 16 : 4096)), b, 0, st, (const svx::NodeS *)w.S, w.lists,
                                (const int32_t *)w.root, (const int32_t *)reps, nreps);
-        if (getenv("F4L_SV_EXACT_DEBUG")) fprintf(stderr, "[sv exact] round %d lambda %.6g: %d passes, %d representatives left (K %d)\n", rounds, lambda, it, nreps, K);
+        if (getenv("F4L_SV_EXACT_DEBUG"))
+            fprintf(stderr, "[sv exact] round %d lambda %.6g: %d passes, %d representatives left (K %d); list pools so far: fullest slice %.3f of its capacity, "
+                            "largest pass %.3f n k entries\n", rounds, lambda, it, nreps, K, (double)hs.pool_max / (double)fa.sub_cap, (double)hs.pool_sum / ((double)n * k));
         if (nreps == K) { ++rounds; break; }  // :175
     }
     if (rounds >= MAX_ROUNDS && nreps != K && nreps > 1) return F4L_EUNSUPPORTED;

@@ -131,8 +131,25 @@ int segment_host(const float *xyz, const double *nrm, const int32_t *knn, int64_
     // step 1 (:117-176): greedy fusion, lambda doubling until exactly n_target representatives remain
     int32_t n_reps = n, live = n;
     std::vector<int32_t> kept;
+    // The reference's loop has no exit for a neighbour graph with more connected components than the target count (k = 4 on a strip:
+    // the fuzz case that found it): lambda doubles for ever and no round absorbs anything any more -- the call never returns.  A loss
+    // is at most sizes * metric <= n (1 + 0.4 diagonal / resolution); a round that absorbs nothing with lambda beyond that proves that
+    // none ever will: reported (F4L_EUNSUPPORTED) instead of replayed.
+    double loss_cap;
+    {
+        double mn[3] = {DBL_MAX, DBL_MAX, DBL_MAX}, mx[3] = {-DBL_MAX, -DBL_MAX, -DBL_MAX};
+        for (int32_t i = 0; i < n; ++i)
+            for (int d = 0; d < 3; ++d) {
+                const double v = xyz[3 * (size_t)i + d];
+                mn[d] = std::min(mn[d], v);
+                mx[d] = std::max(mx[d], v);
+            }
+        const double diag = std::sqrt((mx[0] - mn[0]) * (mx[0] - mn[0]) + (mx[1] - mn[1]) * (mx[1] - mn[1]) + (mx[2] - mn[2]) * (mx[2] - mn[2]));
+        loss_cap = (double)n * (1.0 + 0.4 * diag / resolution) * 1.0001;
+    }
     for (;; lambda *= 2.0) {
         if (n_reps <= 1) break;
+        const int32_t live_before = live;
         if (pool.size() > (size_t)n * 16) {  // compact the pool: keep only lists still referenced
             std::vector<int32_t> fresh;
             fresh.reserve((size_t)n * 4);
@@ -212,6 +229,7 @@ int segment_host(const float *xyz, const double *nrm, const int32_t *knn, int64_
             if (find_root(parent.data(), i) == i) reps[(size_t)m++] = i;
         }
         n_reps = m;
+        if (live == live_before && !(lambda <= loss_cap)) return F4L_EUNSUPPORTED;  // (also a NaN lambda: never)
         live = m;
         if (n_reps == n_target) break;
     }

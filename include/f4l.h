@@ -281,10 +281,14 @@ int f4l_nn_query(const float *cloud, int64_t n, const float *queries, int64_t m,
  *   ties are ordered by point index.  idx_out int32 [n][k]; d2_out double [n][k] or NULL.  1 <= k <= 64, k <= n.
  * f4l_normals: PCA normal of each point's neighbour list (codelibrary/geometry/point_cloud/
  *   pca_estimate_normals.h:43-108, unit weights), double [n][3].
- * f4l_supervoxel: kNN + normals on the device, then the sequential boundary-preserving segmentation
- *   (codelibrary/geometry/point_cloud/supervoxel_segmentation.h:65-265, metric supervoxel.cpp:27-40) on the
- *   host: this call SYNCHRONISES `stream`.  labels_out int32 [n] (device); n_supervoxels_host is a HOST int.
- *   knn_out / normals_out (device, nullable) receive the intermediate products.
+ * f4l_supervoxel: kNN + normals on the device, then the reference's sequential boundary-preserving segmentation
+ *   (codelibrary/geometry/point_cloud/supervoxel_segmentation.h:65-265, metric supervoxel.cpp:27-40), label for label: on the
+ *   device too since round 5 (f4l_supervoxel_segment_exact below; a one-core host replay of the same sequence is the fall-back
+ *   for clouds that outgrow the device's buffers).  SYNCHRONISES `stream`.  labels_out int32 [n] (device); n_supervoxels_host
+ *   is a HOST int.  knn_out / normals_out (device, nullable) receive the intermediate products.
+ *   F4L_EUNSUPPORTED: the neighbour graph has more connected components than the resolution grid has occupied cells (e.g. k = 4
+ *   on a thin strip): no lambda ever reaches the target count and the reference's loop (:117-176) never returns on such a cloud;
+ *   this call does, with nothing written to labels_out.
  * ---------------------------------------------------------------------------------------------- */
 size_t f4l_knn_workspace_bytes(int64_t n, int k);
 int f4l_knn(const float *xyz, int64_t n, int k, int32_t *idx_out, double *d2_out, void *workspace,
