@@ -160,10 +160,12 @@ def test_a_neighbour_graph_that_cannot_reach_the_target_count_is_reported(eng):
     import torch
     from fusion4landslide_amd._lib import F4LError
     rng = np.random.default_rng(1003)
-    n = 400
-    p = np.c_[rng.uniform(0, 8 * 40.0, n), rng.uniform(0, 4.0, n), rng.normal(0, 0.12, n)].astype(np.float32)
+    # two clumps 100 m apart, 8 neighbours each: two components; one cell of the resolution grid holds both: K = 1 is out of reach
+    a = rng.normal(0, 0.5, (60, 3)) * [1, 1, 0.05]
+    p = np.r_[a, a[::-1] + [100.0, 0, 0]].astype(np.float32)
     with pytest.raises(F4LError):
-        eng.supervoxel(torch.from_numpy(p).cuda(), 4, 6.0)
-    q = np.c_[rng.uniform(0, 20.0, n), rng.uniform(0, 20.0, n), rng.normal(0, 0.05, n)].astype(np.float32)
-    lab, K = eng.supervoxel(torch.from_numpy(q).cuda(), 12, 6.0)
-    assert K >= 4 and int(lab.max()) == K - 1
+        eng.supervoxel(torch.from_numpy(p).cuda(), 8, 1000.0)
+    # (the same two clumps with a cell each: K = 2 is reached, every clump one supervoxel)
+    lab, K = eng.supervoxel(torch.from_numpy(p).cuda(), 8, 50.0)
+    lab = lab.cpu().numpy()
+    assert K == 2 and len(set(lab[:60])) == 1 and len(set(lab[60:])) == 1 and lab[0] != lab[60]
