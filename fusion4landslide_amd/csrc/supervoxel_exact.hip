@@ -561,49 +561,62 @@ __global__ __launch_bounds__(EVAL_WAVES * 64, SVX_EVAL_WPE) void eval16_kernel(F
             } else slot = (slot + 1u) & (unsigned int)(H16 - 1);
         }
     };
-    // appends Find(list entries) that are not yet visited, in list order (:126-133 / :151-157); `act`: this row has a list to append
+    // one chunk of resolved entries joins the queue: the ones not yet visited, in list order (:126-133 / :151-157)
+    auto commit = [&](bool go, bool have, unsigned int r) {
+        bool fresh = false;
+        if (have) {  // visited already?  (the table holds every node of the queue; at most 252 of its 256 bytes are taken)
+            fresh = true;
+            for (unsigned int slot = slot_of(r);; slot = (slot + 1u) & (unsigned int)(H16 - 1)) {
+                const unsigned int p = HB[slot];
+                if (p == 0xffu) break;
+                if ((unsigned int)Q[p] == r) { fresh = false; break; }
+            }
+        }
+        // ... or by a lower lane of this chunk (the first occurrence wins)
+        const bool first = fresh && !dup_below<1>(fresh ? r + 1u : 0u);
+        const unsigned int news = hb(__ballot(first));
+        const int nn = (int)__popc(news);
+        bool put = false;
+        int pos = 0;
+        if (go) {
+            if (tail + nn + 4 > Q16) ovf = true;
+            else {
+                put = first;
+                pos = tail + (int)__popc(news & below);
+                if (put) Q[pos] = (int32_t)r;
+                tail += nn;
+            }
+        }
+        insert(put, r, pos);
+        wsync();
+    };
+    // appends Find(list entries) that are not yet visited; `act`: this row has a list to append.  TWO chunks of 16 entries per trip:
+    // the kernel waits on its dependent gathers (entry -> claim -> claim ...), and the two chunks' chains do not depend on each other --
+    // only their order in the queue does, which the commits keep -- so their loads are in flight together.
     auto append_list = [&](bool act, int64_t off, int len) {
-        for (int c0 = 0; __any(act && !ovf && c0 < len); c0 += G) {
+        for (int c0 = 0; __any(act && !ovf && c0 < len); c0 += 2 * G) {
             const bool go = act && !ovf && c0 < len;
-            const bool have = go && c0 + hl < len;
-            unsigned int r = NONE;
-            bool fresh = false;
-            if (have) {
-                r = (unsigned int)pool[off + c0 + hl];  // (a round-start root: rootlists_kernel)
-                // Find as centre i sees it (set.Find, :127/:152): every absorption by a centre that ran BEFORE i and was alive at its
-                // own turn; honoured claims lead to ever higher centres, so the walk ends
-                for (;;) {
-                    const unsigned int c = ABS[r];
-                    if (c == NONE || !(c < ui)) break;
-                    const unsigned int cc = ABS[c];
-                    if (cc != NONE && cc < c) break;
-                    r = c;
+            const bool haveA = go && c0 + hl < len, haveB = go && c0 + G + hl < len;
+            unsigned int rA = NONE, rB = NONE;
+            if (haveA) rA = (unsigned int)pool[off + c0 + hl];  // (round-start roots: rootlists_kernel)
+            if (haveB) rB = (unsigned int)pool[off + c0 + G + hl];
+            // Find as centre i sees it (set.Find, :127/:152): every absorption by a centre that ran BEFORE i and was alive at its own
+            // turn; honoured claims lead to ever higher centres, so the walk ends
+            unsigned int cA = haveA ? ABS[rA] : NONE, cB = haveB ? ABS[rB] : NONE;
+            bool wA = cA != NONE && cA < ui, wB = cB != NONE && cB < ui;
+            while (wA || wB) {
+                const unsigned int ccA = wA ? ABS[cA] : NONE, ccB = wB ? ABS[cB] : NONE;
+                if (wA) {
+                    if (ccA != NONE && ccA < cA) wA = false;  // (cA was absorbed before its own turn: its claim does not count)
+                    else { rA = cA; cA = ccA; wA = cA != NONE && cA < ui; }
                 }
-                // visited already?  (the table holds every node of the queue; at most 252 of its 256 bytes are taken)
-                fresh = true;
-                for (unsigned int slot = slot_of(r);; slot = (slot + 1u) & (unsigned int)(H16 - 1)) {
-                    const unsigned int p = HB[slot];
-                    if (p == 0xffu) break;
-                    if ((unsigned int)Q[p] == r) { fresh = false; break; }
+                if (wB) {
+                    if (ccB != NONE && ccB < cB) wB = false;
+                    else { rB = cB; cB = ccB; wB = cB != NONE && cB < ui; }
                 }
             }
-            // ... or by a lower lane of this chunk (the first occurrence wins)
-            const bool first = fresh && !dup_below<1>(fresh ? r + 1u : 0u);
-            const unsigned int news = hb(__ballot(first));
-            const int nn = (int)__popc(news);
-            bool put = false;
-            int pos = 0;
-            if (go) {
-                if (tail + nn + 4 > Q16) ovf = true;
-                else {
-                    put = first;
-                    pos = tail + (int)__popc(news & below);
-                    if (put) Q[pos] = (int32_t)r;
-                    tail += nn;
-                }
-            }
-            insert(put, r, pos);
-            wsync();
+            commit(go, haveA, rA);
+            if (__any(go && !ovf && c0 + G < len)) commit(go && !ovf && c0 + G < len, haveB && !ovf, rB);
         }
     };
 
