@@ -228,6 +228,17 @@ constexpr float PL_FAR = 1e30f;  // (1e30^2 overflows to +inf)
 #ifndef PL_MIN_WGS
 #define PL_MIN_WGS 3
 #endif
+// (time-only ablations for tools/build_variant.sh: results are wrong with any of them set)
+#ifdef PL_ABL_NOPASS1
+#define PL_ABL_N1(n) ((n) < 64 ? (n) : 64)
+#else
+#define PL_ABL_N1(n) (n)
+#endif
+#ifdef PL_ABL_NOPASS2
+#define PL_ABL_N2(n) ((n) < 40 ? (n) : 40)
+#else
+#define PL_ABL_N2(n) (n)
+#endif
 __device__ __forceinline__ void pl_covariance_normal(const float *__restrict__ x, const float *__restrict__ y, const float *__restrict__ z,
                                                      const int (&pay)[PL_CAP], int k, double (&nv)[3]) {
     double cum[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -328,7 +339,7 @@ __global__ __launch_bounds__(PL_NT, PL_MIN_WGS) void patch_normals_lanes_kernel(
         // pass 1: per-lane histogram of the approximate d2 (differences of nearby float coordinates are exact or nearly so)
         // (reading the next eight candidates ahead of this step's atomics, the way knn_lanes_kernel does, was measured: 36.9 ms
         //  against 30.3 at C4 -- three waves per SIMD hide the LDS latency already and the second register set costs more)
-        for (int c = 0; c < n_pad; c += 8) {
+        for (int c = 0; c < PL_ABL_N1(n_pad); c += 8) {
             const float4 xa = *reinterpret_cast<const float4 *>(xs + c), xb = *reinterpret_cast<const float4 *>(xs + c + 4);
             const float4 ya = *reinterpret_cast<const float4 *>(ys + c), yb = *reinterpret_cast<const float4 *>(ys + c + 4);
             const float4 za = *reinterpret_cast<const float4 *>(zs + c), zb = *reinterpret_cast<const float4 *>(zs + c + 4);
@@ -357,7 +368,7 @@ __global__ __launch_bounds__(PL_NT, PL_MIN_WGS) void patch_normals_lanes_kernel(
         edge = valid ? edge : -1.0f;
         // pass 2: the candidates below the threshold go to the lane's list (a lane that does not take one writes the spare row)
         int cnt = 0;
-        for (int c = 0; c < n_pad; c += 8) {
+        for (int c = 0; c < PL_ABL_N2(n_pad); c += 8) {
             const float4 xa = *reinterpret_cast<const float4 *>(xs + c), xb = *reinterpret_cast<const float4 *>(xs + c + 4);
             const float4 ya = *reinterpret_cast<const float4 *>(ys + c), yb = *reinterpret_cast<const float4 *>(ys + c + 4);
             const float4 za = *reinterpret_cast<const float4 *>(zs + c), zb = *reinterpret_cast<const float4 *>(zs + c + 4);
@@ -374,6 +385,9 @@ __global__ __launch_bounds__(PL_NT, PL_MIN_WGS) void patch_normals_lanes_kernel(
             }
         }
         if (cnt > PL_CAP) { fb = true; cnt = PL_CAP; }
+#if defined(PL_ABL_NOPASS1) || defined(PL_ABL_NOPASS2)
+        fb = false;
+#endif
         // the survivors, exact d2 from the float coordinates, sorted on registers
         double key[PL_CAP];
         int pay[PL_CAP];
@@ -384,10 +398,16 @@ __global__ __launch_bounds__(PL_NT, PL_MIN_WGS) void patch_normals_lanes_kernel(
             key[j] = ok ? dist2_exact(xs[id], ys[id], zs[id], qx, qy, qz) : __builtin_inf();
             pay[j] = ok ? id : 0x7fffffff;
         }
+#ifndef PL_ABL_NOSORT
         lane_sort_ascending<PL_CAP>(key, pay);
         lane_order_ties<PL_CAP>(key, pay);
+#endif
         double nv[3];
+#ifdef PL_ABL_NOEIG
+        nv[0] = key[0] + key[PL_CAP - 1] + key[20]; nv[1] = pay[0] + pay[PL_CAP - 1] + pay[20]; nv[2] = 1.0;
+#else
         pl_covariance_normal(xs, ys, zs, pay, k, nv);
+#endif
         if (valid && !fb) {
             store_normal(normals, normals64, o + q, nv);
         }
