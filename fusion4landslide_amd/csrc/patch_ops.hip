@@ -141,6 +141,36 @@ __device__ __forceinline__ void smallest_eigvec3(const double *C, double *out) {
     }
 }
 
+// The covariance of a point's k neighbours (itself included) and its smallest eigenvector: Open3D's ComputeCovariance sums the
+// cumulants in the order of the search result (ascending distance), and so does every kernel here -- one lane walking its sorted
+// list, or a wave reading its sorted slots lane by lane -- so a query's normal does not depend on which kernel or path took it
+// (round 6: the wave paths used a butterfly sum before, equal to the last bits only).
+__device__ __forceinline__ void cov_add(double (&cum)[9], double a, double b, double c) {
+    cum[0] += a; cum[1] += b; cum[2] += c;
+    cum[3] += a * a; cum[4] += a * b; cum[5] += a * c; cum[6] += b * b; cum[7] += b * c; cum[8] += c * c;
+}
+__device__ __forceinline__ void cov_normal(double (&cum)[9], int k, double (&nv)[3]) {
+    if (k < 3) { nv[0] = 0.0; nv[1] = 0.0; nv[2] = 1.0; return; }  // identity covariance -> no preferred axis -> (0,0,1)
+    const double ik = 1.0 / (double)k;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) cum[i] *= ik;
+    double Cm[6];
+    Cm[0] = cum[3] - cum[0] * cum[0];
+    Cm[1] = cum[4] - cum[0] * cum[1];
+    Cm[2] = cum[5] - cum[0] * cum[2];
+    Cm[3] = cum[6] - cum[1] * cum[1];
+    Cm[4] = cum[7] - cum[1] * cum[2];
+    Cm[5] = cum[8] - cum[2] * cum[2];
+    smallest_eigvec3(Cm, nv);
+    if (nv[0] * nv[0] + nv[1] * nv[1] + nv[2] * nv[2] == 0.0) { nv[0] = 0.0; nv[1] = 0.0; nv[2] = 1.0; }
+}
+// (a wave's sorted slots: lane j holds the j-th neighbour's coordinates)
+__device__ __forceinline__ void wave_covariance_normal(double a, double b, double c, int k, double (&nv)[3]) {
+    double cum[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int j = 0; j < k; ++j) cov_add(cum, readlane_f64(a, j), readlane_f64(b, j), readlane_f64(c, j));
+    cov_normal(cum, k, nv);
+}
+
 // One workgroup per patch, one wave per query point (queries strided over the 4 waves).
 __global__ __launch_bounds__(PN_NT) void patch_normals_kernel(const float *__restrict__ pts,
                                                                const int64_t *__restrict__ off, int64_t P, int knn,
@@ -176,34 +206,12 @@ __global__ __launch_bounds__(PN_NT) void patch_normals_kernel(const float *__res
             if (c0 == 0) best.fill_sorted(cd, ci);  // first batch: sort in place instead of 64 insertions
             else best.offer(cd, ci, k);
         }
-        // cumulants of the k neighbours (self included), Open3D ComputeCovariance
-        double cum[9];
+        // the k neighbours (self included) in the order of the list
+        double nv[3];
         {
             const bool have = lane < k;
             const int j = have ? best.i : q;
-            const double x = have ? (double)base[3 * j] : 0.0, y = have ? (double)base[3 * j + 1] : 0.0,
-                         z = have ? (double)base[3 * j + 2] : 0.0;
-            cum[0] = x; cum[1] = y; cum[2] = z;
-            cum[3] = x * x; cum[4] = x * y; cum[5] = x * z; cum[6] = y * y; cum[7] = y * z; cum[8] = z * z;
-        }
-#pragma unroll
-        for (int i = 0; i < 9; ++i) cum[i] = wave_sum(cum[i]);
-        double nv[3];
-        if (k < 3) {
-            nv[0] = 0.0; nv[1] = 0.0; nv[2] = 1.0;  // identity covariance -> no preferred axis -> (0,0,1)
-        } else {
-            const double ik = 1.0 / (double)k;
-#pragma unroll
-            for (int i = 0; i < 9; ++i) cum[i] *= ik;
-            double Cm[6];
-            Cm[0] = cum[3] - cum[0] * cum[0];
-            Cm[1] = cum[4] - cum[0] * cum[1];
-            Cm[2] = cum[5] - cum[0] * cum[2];
-            Cm[3] = cum[6] - cum[1] * cum[1];
-            Cm[4] = cum[7] - cum[1] * cum[2];
-            Cm[5] = cum[8] - cum[2] * cum[2];
-            smallest_eigvec3(Cm, nv);
-            if (nv[0] * nv[0] + nv[1] * nv[1] + nv[2] * nv[2] == 0.0) { nv[0] = 0.0; nv[1] = 0.0; nv[2] = 1.0; }
+            wave_covariance_normal((double)base[3 * j], (double)base[3 * j + 1], (double)base[3 * j + 2], k, nv);
         }
         if (lane == 0) {
             store_normal(normals, normals64, o + q, nv);
@@ -223,6 +231,7 @@ __global__ __launch_bounds__(PN_NT) void patch_normals_kernel(const float *__res
 // list is redone by the wave with the exact top-k of the kernel above.
 constexpr int PL_NW = 4, PL_NT = PL_NW * 64, PL_NB = 32, PL_CAP = 43, PL_MAX_K = 36, PL_MAX_N = 8192;
 constexpr float PL_FAR = 1e30f;  // (1e30^2 overflows to +inf)
+typedef float pl_f2 __attribute__((ext_vector_type(2)));  // (two candidates per v_pk_* instruction)
 // Workgroups per CU the compiler is asked to fit: 3 = 168 VGPRs, three waves per SIMD, ~40 dwords of the register sort spilled --
 // 30.4 ms at C4 against 34.3 ms with the 223 VGPRs / two waves per SIMD it takes unasked (round 5).
 #ifndef PL_MIN_WGS
@@ -246,23 +255,9 @@ __device__ __forceinline__ void pl_covariance_normal(const float *__restrict__ x
     for (int j = 0; j < PL_MAX_K; ++j)
         if (j < k) {
             const int id = pay[j];
-            const double a = (double)x[id], b = (double)y[id], c = (double)z[id];
-            cum[0] += a; cum[1] += b; cum[2] += c;
-            cum[3] += a * a; cum[4] += a * b; cum[5] += a * c; cum[6] += b * b; cum[7] += b * c; cum[8] += c * c;
+            cov_add(cum, (double)x[id], (double)y[id], (double)z[id]);
         }
-    if (k < 3) { nv[0] = 0.0; nv[1] = 0.0; nv[2] = 1.0; return; }  // identity covariance -> no preferred axis -> (0,0,1)
-    const double ik = 1.0 / (double)k;
-#pragma unroll
-    for (int i = 0; i < 9; ++i) cum[i] *= ik;
-    double Cm[6];
-    Cm[0] = cum[3] - cum[0] * cum[0];
-    Cm[1] = cum[4] - cum[0] * cum[1];
-    Cm[2] = cum[5] - cum[0] * cum[2];
-    Cm[3] = cum[6] - cum[1] * cum[1];
-    Cm[4] = cum[7] - cum[1] * cum[2];
-    Cm[5] = cum[8] - cum[2] * cum[2];
-    smallest_eigvec3(Cm, nv);
-    if (nv[0] * nv[0] + nv[1] * nv[1] + nv[2] * nv[2] == 0.0) { nv[0] = 0.0; nv[1] = 0.0; nv[2] = 1.0; }
+    cov_normal(cum, k, nv);
 }
 __global__ __launch_bounds__(PL_NT, PL_MIN_WGS) void patch_normals_lanes_kernel(const float *__restrict__ pts, const int64_t *__restrict__ off,
                                                                        int64_t P, int knn, int cap_pad, float *__restrict__ normals,
@@ -326,32 +321,43 @@ __global__ __launch_bounds__(PL_NT, PL_MIN_WGS) void patch_normals_lanes_kernel(
         float top = area > 0.f ? 16.f * (float)k * area / (3.14159265f * (float)n) : diag2;
         top = top < diag2 ? top : diag2;
         top = top > 1e-30f ? top : 1e-30f;
-        bin_base = (int)(__float_as_uint(top) >> 21) - (PL_NB - 1);
+        bin_base = ((int)(__float_as_uint(top) >> 21) - (PL_NB - 1)) & ~1;  // (top >= 1e-30: positive; even: a counter word = two bins)
         slack = 1e-6f * top;
     }
+    const float range_lo = __uint_as_float((unsigned int)bin_base << 21), range_hi = __uint_as_float((((unsigned int)bin_base + PL_NB) << 21) - 1u);
+    // (the lane's counters as an LDS address, shifted so that + (bits of d2 >> 22) << 8 is the counter's word)
+    const unsigned int hist_addr = (unsigned int)(size_t)((__attribute__((address_space(3))) unsigned int *)hist) - (((unsigned int)bin_base >> 1) << 8);
     for (int q0 = 0; q0 < n; q0 += PL_NT) {  // (whole waves iterate together)
         const int q = q0 + tid;
         const bool valid = q < n;
         const float qx = xs[valid ? q : 0], qy = ys[valid ? q : 0], qz = zs[valid ? q : 0];
 #pragma unroll
         for (int b = 0; b < PL_NB / 2; ++b) hist[b * 64] = 0u;
-        const unsigned int one = valid ? 1u : 0u;
-        // pass 1: per-lane histogram of the approximate d2 (differences of nearby float coordinates are exact or nearly so)
+        // pass 1: per-lane histogram of the approximate d2 (differences of nearby float coordinates are exact or nearly so), two
+        // candidates per packed instruction.  d2 is clamped as a FLOAT to the histogram's range, so its bits give the counter's
+        // word (bits 22.. : bin_base is even) and half (bit 21) directly: 5 integer instructions per candidate where clamping the bin
+        // index took 8 (round 6).  (Lanes past the patch's last query count too: nobody reads their counters.)
         // (reading the next eight candidates ahead of this step's atomics, the way knn_lanes_kernel does, was measured: 36.9 ms
         //  against 30.3 at C4 -- three waves per SIMD hide the LDS latency already and the second register set costs more)
+        const pl_f2 qx2 = {qx, qx}, qy2 = {qy, qy}, qz2 = {qz, qz};
         for (int c = 0; c < PL_ABL_N1(n_pad); c += 8) {
             const float4 xa = *reinterpret_cast<const float4 *>(xs + c), xb = *reinterpret_cast<const float4 *>(xs + c + 4);
             const float4 ya = *reinterpret_cast<const float4 *>(ys + c), yb = *reinterpret_cast<const float4 *>(ys + c + 4);
             const float4 za = *reinterpret_cast<const float4 *>(zs + c), zb = *reinterpret_cast<const float4 *>(zs + c + 4);
-            const float cx[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w}, cy[8] = {ya.x, ya.y, ya.z, ya.w, yb.x, yb.y, yb.z, yb.w},
-                        cz[8] = {za.x, za.y, za.z, za.w, zb.x, zb.y, zb.z, zb.w};
+            const pl_f2 cx[4] = {{xa.x, xa.y}, {xa.z, xa.w}, {xb.x, xb.y}, {xb.z, xb.w}}, cy[4] = {{ya.x, ya.y}, {ya.z, ya.w}, {yb.x, yb.y}, {yb.z, yb.w}},
+                        cz[4] = {{za.x, za.y}, {za.z, za.w}, {zb.x, zb.y}, {zb.z, zb.w}};
 #pragma unroll
-            for (int w = 0; w < 8; ++w) {
-                const float dx = cx[w] - qx, dy = cy[w] - qy, dz = cz[w] - qz;
-                const float d2 = dx * dx + dy * dy + dz * dz;
-                int b = (int)(__float_as_uint(d2) >> 21) - bin_base;
-                b = b < 0 ? 0 : (b > PL_NB - 1 ? PL_NB - 1 : b);
-                atomicAdd(&hist[(b >> 1) * 64], one << ((b & 1) * 16));
+            for (int w = 0; w < 4; ++w) {
+                const pl_f2 dx = cx[w] - qx2, dy = cy[w] - qy2, dz = cz[w] - qz2;
+                const pl_f2 d2 = dx * dx + dy * dy + dz * dz;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const float t = __builtin_amdgcn_fmed3f(d2[h], range_lo, range_hi);
+                    unsigned int at, by;
+                    asm("v_lshrrev_b32 %0, 22, %1\n\tv_lshl_add_u32 %0, %0, 8, %2" : "=&v"(at) : "v"(t), "v"(hist_addr));
+                    asm("v_bfe_u32 %0, %1, 21, 1\n\tv_mad_u32_u24 %0, %0, %2, 1" : "=&v"(by) : "v"(t), "s"(65535u));
+                    __hip_atomic_fetch_add((__attribute__((address_space(3))) unsigned int *)(size_t)at, by, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
             }
         }
         // the first bin at which the count reaches k
@@ -366,22 +372,37 @@ __global__ __launch_bounds__(PL_NT, PL_MIN_WGS) void patch_normals_lanes_kernel(
         bool fb = valid && T == PL_NB;  // (cannot happen: every point of the patch lands in a bin)
         float edge = T >= PL_NB - 1 ? __builtin_inff() : __uint_as_float((unsigned int)(T + bin_base + 1) << 21) * 1.0001f + slack;
         edge = valid ? edge : -1.0f;
-        // pass 2: the candidates below the threshold go to the lane's list (a lane that does not take one writes the spare row)
+        // pass 2: the candidates below the threshold, 32 at a time as a bit mask (a compare and an add-with-carry per candidate), and
+        // the few set bits of a mask go to the lane's list (round 6; before: a conditional list write per candidate, 15 instructions)
         int cnt = 0;
-        for (int c = 0; c < PL_ABL_N2(n_pad); c += 8) {
-            const float4 xa = *reinterpret_cast<const float4 *>(xs + c), xb = *reinterpret_cast<const float4 *>(xs + c + 4);
-            const float4 ya = *reinterpret_cast<const float4 *>(ys + c), yb = *reinterpret_cast<const float4 *>(ys + c + 4);
-            const float4 za = *reinterpret_cast<const float4 *>(zs + c), zb = *reinterpret_cast<const float4 *>(zs + c + 4);
-            const float cx[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w}, cy[8] = {ya.x, ya.y, ya.z, ya.w, yb.x, yb.y, yb.z, yb.w},
-                        cz[8] = {za.x, za.y, za.z, za.w, zb.x, zb.y, zb.z, zb.w};
+        for (int c = 0; c < PL_ABL_N2(n_pad); c += 32) {
+            unsigned int mask = 0u;
 #pragma unroll
-            for (int w = 0; w < 8; ++w) {
-                const float dx = cx[w] - qx, dy = cy[w] - qy, dz = cz[w] - qz;
-                const float d2 = dx * dx + dy * dy + dz * dz;
-                const bool take = d2 < edge;
-                const int at = cnt < PL_CAP ? cnt : PL_CAP;
-                list[(take ? at : PL_CAP) * 64] = (unsigned short)(c + w);
-                cnt += take ? 1 : 0;
+            for (int g = 0; g < 32; g += 8) {
+                if (c + g < n_pad) {  // (uniform)
+                    const float4 xa = *reinterpret_cast<const float4 *>(xs + c + g), xb = *reinterpret_cast<const float4 *>(xs + c + g + 4);
+                    const float4 ya = *reinterpret_cast<const float4 *>(ys + c + g), yb = *reinterpret_cast<const float4 *>(ys + c + g + 4);
+                    const float4 za = *reinterpret_cast<const float4 *>(zs + c + g), zb = *reinterpret_cast<const float4 *>(zs + c + g + 4);
+                    const pl_f2 cx[4] = {{xa.x, xa.y}, {xa.z, xa.w}, {xb.x, xb.y}, {xb.z, xb.w}}, cy[4] = {{ya.x, ya.y}, {ya.z, ya.w}, {yb.x, yb.y}, {yb.z, yb.w}},
+                                cz[4] = {{za.x, za.y}, {za.z, za.w}, {zb.x, zb.y}, {zb.z, zb.w}};
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) {
+                        const pl_f2 dx = cx[w] - qx2, dy = cy[w] - qy2, dz = cz[w] - qz2;
+                        const pl_f2 d2 = dx * dx + dy * dy + dz * dz;
+                        // mask = 2 * mask + (d2 < edge): candidate c + j of the block ends at bit 31 - j
+                        asm("v_cmp_lt_f32 vcc, %1, %3\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc\n\t"
+                            "v_cmp_lt_f32 vcc, %2, %3\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc"
+                            : "+v"(mask) : "v"(d2[0]), "v"(d2[1]), "v"(edge) : "vcc");
+                    }
+                } else {
+                    mask <<= 8;
+                }
+            }
+            while (mask != 0u) {
+                const int j = __clz((int)mask);
+                mask &= ~(0x80000000u >> j);
+                list[(cnt < PL_CAP ? cnt : PL_CAP) * 64] = (unsigned short)(c + j);
+                ++cnt;
             }
         }
         if (cnt > PL_CAP) { fb = true; cnt = PL_CAP; }
@@ -428,27 +449,11 @@ __global__ __launch_bounds__(PL_NT, PL_MIN_WGS) void patch_normals_lanes_kernel(
                 if (c0 == 0) best.fill_sorted(cd, ci);
                 else best.offer(cd, ci, k);
             }
-            double cum[9];
+            double rn[3];
             {
                 const bool have = lane < k;
                 const int j = have ? best.i : rq;
-                const double a = have ? (double)xs[j] : 0.0, b = have ? (double)ys[j] : 0.0, c = have ? (double)zs[j] : 0.0;
-                cum[0] = a; cum[1] = b; cum[2] = c;
-                cum[3] = a * a; cum[4] = a * b; cum[5] = a * c; cum[6] = b * b; cum[7] = b * c; cum[8] = c * c;
-            }
-#pragma unroll
-            for (int i = 0; i < 9; ++i) cum[i] = wave_sum(cum[i]);
-            double rn[3];
-            if (k < 3) { rn[0] = 0.0; rn[1] = 0.0; rn[2] = 1.0; }
-            else {
-                const double ik = 1.0 / (double)k;
-#pragma unroll
-                for (int i = 0; i < 9; ++i) cum[i] *= ik;
-                double Cm[6];
-                Cm[0] = cum[3] - cum[0] * cum[0]; Cm[1] = cum[4] - cum[0] * cum[1]; Cm[2] = cum[5] - cum[0] * cum[2];
-                Cm[3] = cum[6] - cum[1] * cum[1]; Cm[4] = cum[7] - cum[1] * cum[2]; Cm[5] = cum[8] - cum[2] * cum[2];
-                smallest_eigvec3(Cm, rn);
-                if (rn[0] * rn[0] + rn[1] * rn[1] + rn[2] * rn[2] == 0.0) { rn[0] = 0.0; rn[1] = 0.0; rn[2] = 1.0; }
+                wave_covariance_normal((double)xs[j], (double)ys[j], (double)zs[j], k, rn);
             }
             if (lane == 0) {
                 store_normal(normals, normals64, o + rq, rn);

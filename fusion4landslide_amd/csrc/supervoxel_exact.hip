@@ -77,6 +77,20 @@ __device__ __forceinline__ unsigned long long mix64(unsigned long long x) {
     return x;
 }
 #define SVX_FOR(i, n) for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (int64_t)(n); i += (int64_t)gridDim.x * blockDim.x)
+// The same for kernels that GATHER around the points they own (neighbours, representatives).  Workgroups are dealt to the 8 XCDs
+// round robin and an XCD's L2 is its own: under the plain grid stride every XCD sees every eighth chunk of the window the grid
+// is in -- 0.5 M points, 33 MB of node records at 64 bytes -- and their neighbours all over it, eight times what its 4 MB hold.
+// Here an XCD walks one contiguous eighth of the range with its own workgroups side by side in it (a window of 64 k points),
+// so a record fetched for one point is still there for the thirty that share it (round 6; gridDim.x: a multiple of 8).
+#ifndef SVX_NO_XCD_MAP
+#define SVX_FOR_XCD(i, n)                                                                                                                  \
+    for (int64_t i##_per = ((((int64_t)(n) + 7) >> 3) + blockDim.x - 1) / blockDim.x * blockDim.x, i##_lo = (int64_t)(blockIdx.x & 7u) * i##_per, \
+                 i##_hi = i##_lo + i##_per < (int64_t)(n) ? i##_lo + i##_per : (int64_t)(n),                                               \
+                 i = i##_lo + (int64_t)(blockIdx.x >> 3) * blockDim.x + threadIdx.x;                                                       \
+         i < i##_hi; i += (int64_t)(gridDim.x >> 3) * blockDim.x)
+#else
+#define SVX_FOR_XCD(i, n) SVX_FOR(i, n)
+#endif
 
 // ---- K = occupied cells of the resolution grid (grid_sample.h:48-68), lambda0's metric sweep ------------------------------------
 __global__ void bbox_kernel(const float *__restrict__ xyz, int64_t n, State *st) {
@@ -210,7 +224,7 @@ __global__ void iota_kernel(int32_t *root, int32_t *reps, NodeS *S, const float 
 // the coordinate array's and the normal array's)
 #pragma clang fp contract(off)
 __global__ void min_metric_kernel(const NodeS *__restrict__ S, const int32_t *__restrict__ knn, int64_t n, int k, double resolution, double *__restrict__ dis0) {
-    SVX_FOR(i, n) {
+    SVX_FOR_XCD(i, n) {
         const NodeS si = load_s(S + i);
         const float pi_[3] = {si.x, si.y, si.z};
         const double ni_[3] = {si.nx, si.ny, si.nz};
@@ -836,7 +850,12 @@ __global__ void reroot_kernel(int32_t *root, const unsigned int *__restrict__ ab
 __global__ __launch_bounds__(256) void rootlists_kernel(const NodeS *__restrict__ S, int32_t *__restrict__ lists, const int32_t *__restrict__ root,
                                                         const int32_t *__restrict__ reps, int nreps) {
     const int sub = (int)(threadIdx.x & 15);
+#ifndef SVX_NO_XCD_MAP  // (an XCD: one contiguous eighth of the representatives -- see SVX_FOR_XCD)
+    const int64_t per = (((int64_t)nreps + 7) >> 3), s_lo = (int64_t)(blockIdx.x & 7u) * per, s_hi = s_lo + per < nreps ? s_lo + per : (int64_t)nreps;
+    for (int64_t s = s_lo + (((int64_t)(blockIdx.x >> 3) * blockDim.x + threadIdx.x) >> 4); s < s_hi; s += ((int64_t)(gridDim.x >> 3) * blockDim.x) >> 4) {
+#else
     for (int64_t s = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4; s < nreps; s += ((int64_t)gridDim.x * blockDim.x) >> 4) {
+#endif
         const NodeS *si = S + reps[s];
         const int64_t off = si->off;
         const int len = si->len;
@@ -869,7 +888,7 @@ struct XchArgs {
 };
 #pragma clang fp contract(off)
 __global__ void xch_init_kernel(XchArgs a, const int32_t *__restrict__ root) {
-    SVX_FOR(i, a.n) {
+    SVX_FOR_XCD(i, a.n) {
         const int32_t l = root[i];
         a.lab[i] = l;
         a.dis[i] = sv_metric(a.xyz, a.nrm, i, (int64_t)l, a.resolution);  // :186-189
@@ -879,7 +898,7 @@ __global__ void xch_init_kernel(XchArgs a, const int32_t *__restrict__ root) {
 }
 // the scan of :194-207: a point enters the queue at the first event that touches it
 __global__ void xch_first_keys_kernel(XchArgs a, const int32_t *__restrict__ root) {
-    SVX_FOR(i, a.n) {
+    SVX_FOR_XCD(i, a.n) {
         const int32_t li = root[i];
         for (int j = 0; j < a.k; ++j) {
             const int32_t q = a.knn[i * a.k + j];
@@ -912,14 +931,24 @@ __global__ void xch_generation_kernel(XchArgs a, const unsigned long long *__res
 // a label whose representative is STRICTLY closer than the best so far: the result is the label of smallest metric below the
 // point's own, the first neighbour slot among equal minima -- a (metric, slot) minimum, taken here by 16 lanes per entry (a
 // coalesced 4 k-byte row per entry, four entries per wavefront) and reduced across them.
+constexpr int XCH_PER_WG = 64;  // entries of a generation per workgroup of xch_eval_kernel
 __global__ __launch_bounds__(256) void xch_eval_kernel(XchArgs a, int m, int pass) {
     const int lane = lane_id(), sub = lane & 15;
     bool differs = false;
-    // (a workgroup takes one contiguous stretch of the generation, and an XCD -- whose L2 is its own -- one contiguous eighth of it:
-    //  the generation is in (position of the pusher, slot) order, i.e. neighbours in the cloud's order sit side by side; see eval16_kernel)
+    // (a workgroup takes 64 consecutive entries of the generation, and an XCD -- whose L2 is its own -- one contiguous eighth of it with
+    //  its resident workgroups side by side: the generation is in (position of the pusher, slot) order, i.e. neighbours in the cloud's
+    //  order sit side by side; see eval16_kernel.  Before round 6's last change a workgroup walked a 2048th of the generation:
+    //  an XCD's 256 resident workgroups in 256 different places, 167 GB fetched per 10 M points at 5.4 TB/s)
+#ifndef SVX_NO_XCD_MAP
     const unsigned int nb = gridDim.x, x8 = blockIdx.x & 7u, rem = nb & 7u;
     const int64_t blk = (int64_t)(x8 * (nb >> 3) + (x8 < rem ? x8 : rem) + (blockIdx.x >> 3));
-    const int64_t per_wg = ((((int64_t)m + nb - 1) / nb + 15) / 16) * 16, w_lo = blk * per_wg, w_hi = w_lo + per_wg < m ? w_lo + per_wg : (int64_t)m;
+    const int64_t per_wg = XCH_PER_WG;
+#else
+    const unsigned int nb = gridDim.x;
+    const int64_t blk = blockIdx.x;
+    const int64_t per_wg = ((((int64_t)m + nb - 1) / nb + 15) / 16) * 16;
+#endif
+    const int64_t w_lo = blk * per_wg, w_hi = w_lo + per_wg < m ? w_lo + per_wg : (int64_t)m;
     for (int64_t t0 = w_lo + (int64_t)(threadIdx.x >> 6) * 4; t0 < w_hi; t0 += (int64_t)(blockDim.x >> 6) * 4) {  // (whole waves iterate together)
         const int64_t t = t0 + (lane >> 4);
         const bool valid = t < m;
@@ -956,7 +985,7 @@ __global__ __launch_bounds__(256) void xch_eval_kernel(XchArgs a, int m, int pas
 }
 // the pushes of the generation (:228-236) and its labels
 __global__ void xch_push_kernel(XchArgs a, int m) {
-    SVX_FOR(t, m) {
+    SVX_FOR_XCD(t, m) {
         const int32_t i = a.Q[t];
         const int32_t li = a.out_rd[i];
         if (!a.ch_rd[i]) continue;
@@ -1253,7 +1282,11 @@ static int segment_exact_run(const float *xyz, const double *normals, const int3
                 if (it >= MAX_ITERS) return F4L_EUNSUPPORTED;
                 xa.out_rd = w.out[rd]; xa.out_wr = w.out[rd ^ 1]; xa.ch_rd = w.ch[rd]; xa.ch_wr = w.ch[rd ^ 1]; xa.dis_wr = w.dis2[rd ^ 1];
                 F4L_HIP_CHECK(hipMemsetAsync(&w.st->changed[it & 7], 0, 4, st));
+#ifndef SVX_NO_XCD_MAP
+                hipLaunchKernelGGL(svx::xch_eval_kernel, dim3((unsigned)((m + svx::XCH_PER_WG - 1) / svx::XCH_PER_WG)), b, 0, st, xa, m, it);
+#else
                 hipLaunchKernelGGL(svx::xch_eval_kernel, g, b, 0, st, xa, m, it);
+#endif
                 F4L_LAUNCH_CHECK();
                 rd ^= 1;
             }
