@@ -83,11 +83,15 @@ __device__ __forceinline__ unsigned long long mix64(unsigned long long x) {
 // Here an XCD walks one contiguous eighth of the range with its own workgroups side by side in it (a window of 64 k points),
 // so a record fetched for one point is still there for the thirty that share it (round 6; gridDim.x: a multiple of 8).
 #ifndef SVX_NO_XCD_MAP
+__device__ __forceinline__ bool xcd_grid() { return (gridDim.x & 7u) == 0u; }  // (else -- a grid below 8 or ragged -- the plain stride)
 #define SVX_FOR_XCD(i, n)                                                                                                                  \
-    for (int64_t i##_per = ((((int64_t)(n) + 7) >> 3) + blockDim.x - 1) / blockDim.x * blockDim.x, i##_lo = (int64_t)(blockIdx.x & 7u) * i##_per, \
+    for (int64_t i##_x = xcd_grid() ? 1 : 0,                                                                                               \
+                 i##_per = i##_x ? ((((int64_t)(n) + 7) >> 3) + blockDim.x - 1) / blockDim.x * blockDim.x : (int64_t)(n),                   \
+                 i##_lo = i##_x ? (int64_t)(blockIdx.x & 7u) * i##_per : 0,                                                                \
                  i##_hi = i##_lo + i##_per < (int64_t)(n) ? i##_lo + i##_per : (int64_t)(n),                                               \
-                 i = i##_lo + (int64_t)(blockIdx.x >> 3) * blockDim.x + threadIdx.x;                                                       \
-         i < i##_hi; i += (int64_t)(gridDim.x >> 3) * blockDim.x)
+                 i##_st = (int64_t)(i##_x ? gridDim.x >> 3 : gridDim.x) * blockDim.x,                                                      \
+                 i = i##_lo + (int64_t)(i##_x ? blockIdx.x >> 3 : blockIdx.x) * blockDim.x + threadIdx.x;                                  \
+         i < i##_hi; i += i##_st)
 #else
 #define SVX_FOR_XCD(i, n) SVX_FOR(i, n)
 #endif
@@ -851,8 +855,10 @@ __global__ __launch_bounds__(256) void rootlists_kernel(const NodeS *__restrict_
                                                         const int32_t *__restrict__ reps, int nreps) {
     const int sub = (int)(threadIdx.x & 15);
 #ifndef SVX_NO_XCD_MAP  // (an XCD: one contiguous eighth of the representatives -- see SVX_FOR_XCD)
-    const int64_t per = (((int64_t)nreps + 7) >> 3), s_lo = (int64_t)(blockIdx.x & 7u) * per, s_hi = s_lo + per < nreps ? s_lo + per : (int64_t)nreps;
-    for (int64_t s = s_lo + (((int64_t)(blockIdx.x >> 3) * blockDim.x + threadIdx.x) >> 4); s < s_hi; s += ((int64_t)(gridDim.x >> 3) * blockDim.x) >> 4) {
+    const bool x = xcd_grid();
+    const int64_t per = x ? (((int64_t)nreps + 7) >> 3) : (int64_t)nreps, s_lo = x ? (int64_t)(blockIdx.x & 7u) * per : 0,
+                  s_hi = s_lo + per < nreps ? s_lo + per : (int64_t)nreps, s_st = ((int64_t)(x ? gridDim.x >> 3 : gridDim.x) * blockDim.x) >> 4;
+    for (int64_t s = s_lo + (((int64_t)(x ? blockIdx.x >> 3 : blockIdx.x) * blockDim.x + threadIdx.x) >> 4); s < s_hi; s += s_st) {
 #else
     for (int64_t s = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4; s < nreps; s += ((int64_t)gridDim.x * blockDim.x) >> 4) {
 #endif
@@ -1241,7 +1247,7 @@ static int segment_exact_run(const float *xyz, const double *normals, const int3
         live = nreps;
         { int32_t *t = reps; reps = reps_next; reps_next = t; }
         if (nreps > 1 && nreps != K)  // (another round follows: its lists hold this round's representatives)
-            hipLaunchKernelGGL(svx::rootlists_kernel, dim3((unsigned)((nreps + 15) / 16 < 4096 ? (nreps + 15) / 16 : 4096)), b, 0, st, (const svx::NodeS *)w.S, w.lists,
+            hipLaunchKernelGGL(svx::rootlists_kernel, dim3((unsigned)((((nreps + 15) / 16 < 4096 ? (nreps + 15) / 16 : 4096) + 7) & ~7)), b, 0, st, (const svx::NodeS *)w.S, w.lists,
                                (const int32_t *)w.root, (const int32_t *)reps, nreps);
         if (getenv("F4L_SV_EXACT_DEBUG"))
             fprintf(stderr, "[sv exact] round %d lambda %.6g: %d passes, %d representatives left (K %d); list pools so far: fullest slice %.3f of its capacity, "
