@@ -93,8 +93,19 @@ __device__ __forceinline__ bool xcd_grid() { return (gridDim.x & 7u) == 0u; }  /
                  i = i##_lo + (int64_t)(i##_x ? blockIdx.x >> 3 : blockIdx.x) * blockDim.x + threadIdx.x;                                  \
          i < i##_hi; i += i##_st)
 #else
+__device__ __forceinline__ bool xcd_grid() { return false; }
 #define SVX_FOR_XCD(i, n) SVX_FOR(i, n)
 #endif
+// ... and with a DPP row of 16 lanes per item (blockDim.x / 16 items per workgroup and trip): 16 gathers in flight per item where a
+// thread per item walks its neighbours one dependent load after the other
+#define SVX_FOR_XCD_ROWS(i, n)                                                                                                             \
+    for (int64_t i##_x = xcd_grid() ? 1 : 0, i##_r = (int64_t)(blockDim.x >> 4),                                                           \
+                 i##_per = i##_x ? ((((int64_t)(n) + 7) >> 3) + i##_r - 1) / i##_r * i##_r : (int64_t)(n),                                  \
+                 i##_lo = i##_x ? (int64_t)(blockIdx.x & 7u) * i##_per : 0,                                                                \
+                 i##_hi = i##_lo + i##_per < (int64_t)(n) ? i##_lo + i##_per : (int64_t)(n),                                               \
+                 i##_st = (int64_t)(i##_x ? gridDim.x >> 3 : gridDim.x) * i##_r,                                                           \
+                 i = i##_lo + (int64_t)(i##_x ? blockIdx.x >> 3 : blockIdx.x) * i##_r + (threadIdx.x >> 4);                                \
+         i < i##_hi; i += i##_st)
 
 // ---- K = occupied cells of the resolution grid (grid_sample.h:48-68), lambda0's metric sweep ------------------------------------
 __global__ void bbox_kernel(const float *__restrict__ xyz, int64_t n, State *st) {
@@ -227,13 +238,14 @@ __global__ void iota_kernel(int32_t *root, int32_t *reps, NodeS *S, const float 
 // lambda0's sweep (:105-113): every point's smallest metric to a neighbour, from the packed records (one line per neighbour instead of
 // the coordinate array's and the normal array's)
 #pragma clang fp contract(off)
-__global__ void min_metric_kernel(const NodeS *__restrict__ S, const int32_t *__restrict__ knn, int64_t n, int k, double resolution, double *__restrict__ dis0) {
-    SVX_FOR_XCD(i, n) {
+__global__ __launch_bounds__(256) void min_metric_kernel(const NodeS *__restrict__ S, const int32_t *__restrict__ knn, int64_t n, int k, double resolution, double *__restrict__ dis0) {
+    const int sub = (int)(threadIdx.x & 15);
+    SVX_FOR_XCD_ROWS(i, n) {  // (16 lanes per point: the minimum of a set does not depend on the order it is taken in)
         const NodeS si = load_s(S + i);
         const float pi_[3] = {si.x, si.y, si.z};
         const double ni_[3] = {si.nx, si.ny, si.nz};
         double best = DBL_MAX;
-        for (int j = 0; j < k; ++j) {
+        for (int j = sub; j < k; j += 16) {
             const int64_t q = knn[i * k + j];
             if (q != i) {
                 const NodeS sq = load_s(S + q);
@@ -243,7 +255,12 @@ __global__ void min_metric_kernel(const NodeS *__restrict__ S, const int32_t *__
                 best = m < best ? m : best;
             }
         }
-        dis0[i] = best;
+#pragma unroll
+        for (int x = 1; x < 16; x <<= 1) {
+            const double o = __shfl_xor(best, x, 64);
+            best = o < best ? o : best;
+        }
+        if (sub == 0) dis0[i] = best;
     }
 }
 // (and what pass 0 needs prepared: its pool's bump pointers, its claims, its flag and its total -- every later pass is prepared by
@@ -881,8 +898,9 @@ struct XchArgs {
     int k;
     double resolution;
     State *st;
-    // (measured and not kept, round 6: position, label and the two estimates as ONE 16-byte record per node -- a neighbour costs one
-    //  gather instead of two, but 8 nodes share a cache line instead of 32: xch_eval_kernel 37.0 against 28.6 ms per 10 M points)
+    // (measured twice and not kept, round 6: position, label and the two estimates as ONE 16-byte record per node -- a neighbour costs
+    //  one gather instead of two dependent ones, but 4 nodes share a 64-byte line instead of 16: xch_eval_kernel 37.0 against 28.6 ms per
+    //  10 M points under the plain grid stride (HBM bound), and 27.8 against 24.0 ms with an XCD's workgroups side by side (L2 hits))
     int32_t *lab;                 // [n] label = representative point (the generation's starting state)
     double *dis;                  // [n] metric to it
     int32_t *pos;                 // [n] position in the current generation, POS_INF
@@ -903,17 +921,25 @@ __global__ void xch_init_kernel(XchArgs a, const int32_t *__restrict__ root) {
     }
 }
 // the scan of :194-207: a point enters the queue at the first event that touches it
-__global__ void xch_first_keys_kernel(XchArgs a, const int32_t *__restrict__ root) {
-    SVX_FOR_XCD(i, a.n) {
+__global__ __launch_bounds__(256) void xch_first_keys_kernel(XchArgs a, const int32_t *__restrict__ root) {
+    const int sub = (int)(threadIdx.x & 15);
+    SVX_FOR_XCD_ROWS(i, a.n) {  // (16 lanes per point; the keys are minima: any order -- the point's own key: one atomic per row)
         const int32_t li = root[i];
-        for (int j = 0; j < a.k; ++j) {
+        unsigned long long mine = KEY_INF;
+        for (int j = sub; j < a.k; j += 16) {
             const int32_t q = a.knn[i * a.k + j];
             if (li != root[q]) {
                 const unsigned long long e = ((unsigned long long)i * 64ULL + (unsigned long long)j) * 2ULL;
-                atomicMin(&a.key[i], e);
+                mine = e < mine ? e : mine;
                 atomicMin(&a.key[q], e + 1ULL);
             }
         }
+#pragma unroll
+        for (int x = 1; x < 16; x <<= 1) {
+            const unsigned long long o = __shfl_xor(mine, x, 64);
+            mine = o < mine ? o : mine;
+        }
+        if (sub == 0 && mine != KEY_INF) atomicMin(&a.key[i], mine);
     }
 }
 __global__ void xch_pairs_kernel(const unsigned long long *__restrict__ key, int64_t n, unsigned long long *__restrict__ k_out, int32_t *__restrict__ v_out) {
