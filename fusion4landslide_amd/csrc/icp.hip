@@ -48,6 +48,9 @@ namespace f4l {
 #ifndef ICP_WAVES_PER_EU
 #define ICP_WAVES_PER_EU 4
 #endif
+#ifndef ICP_WIDE_PLANE_WPE
+#define ICP_WIDE_PLANE_WPE 3  // (the plane estimators' bulk shape; 2 = 256 registers: measured)
+#endif
 #ifndef ICP_WAVES_PER_EU_F64
 #define ICP_WAVES_PER_EU_F64 4
 #endif
@@ -352,7 +355,7 @@ __device__ __noinline__ void icp_prepass(const PrepassArgs<F, NT> &q) {
 // WIDE = the register budget of three waves per SIMD (170 VGPRs) instead of four (128): the float64 build keeps ~50 VGPRs
 // in scratch at 128.  Worth it only for two-wave workgroups in the throughput regime (see icp_shape).
 template <int MODE, int NW, typename F, bool WIDE = false>
-__global__ __launch_bounds__(NW * 64, WIDE ? 3 : (sizeof(F) == 8 ? ICP_WAVES_PER_EU_F64 : ICP_WAVES_PER_EU)) void icp_kernel(IcpArgs a) {
+__global__ __launch_bounds__(NW * 64, WIDE ? (MODE == F4L_ICP_POINT2POINT ? 3 : ICP_WIDE_PLANE_WPE) : (sizeof(F) == 8 ? ICP_WAVES_PER_EU_F64 : ICP_WAVES_PER_EU)) void icp_kernel(IcpArgs a) {
     constexpr int NV = (MODE == F4L_ICP_POINT2POINT) ? 17 : 29;
     constexpr int NT = NW * 64;
     // Correspondence sums.  float32 search + point-to-point: per-lane partial sums and the in-wave reduction are
@@ -575,7 +578,7 @@ __global__ __launch_bounds__(NW * 64, WIDE ? 3 : (sizeof(F) == 8 ? ICP_WAVES_PER
 
         // one accepted correspondence (p: moved source point, q: target, d: squared distance, bj: target index)
         // (si: the source point's index inside its patch -- generalized ICP reads its normal)
-        auto accumulate = [&](F px, F py, F pz, F qx, F qy, F qz, F d, int bj, int si) {
+        auto accumulate = [&](A (&acc)[NV], F px, F py, F pz, F qx, F qy, F qz, F d, int bj, int si) {
             (void)si;
             const A dpx = (A)(px - cpx), dpy = (A)(py - cpy), dpz = (A)(pz - cpz);
             const A dqx = (A)(qx - cpx), dqy = (A)(qy - cpy), dqz = (A)(qz - cpz);
@@ -656,134 +659,180 @@ __global__ __launch_bounds__(NW * 64, WIDE ? 3 : (sizeof(F) == 8 ? ICP_WAVES_PER
             }
         };
 
-        int n_search = ns;  // source points that need a search in this pass
-        if (use_cert) {
-            // ---- phase 1: re-measure last pass's correspondence of every source point; certify or queue
-            unsigned short *myq = queue + wave * seg;
-            int nq = 0;
-            for (int base = 0; base < ns; base += NT) {
-                const int i = base + tid;
-                const bool valid = i < ns;
-                const int ii = valid ? i : ns - 1;  // idle lanes recompute the last point (keeps loads in bounds)
-                F x, y, z;
-                if (src_in_lds) { x = sl[3 * ii]; y = sl[3 * ii + 1]; z = sl[3 * ii + 2]; }
-                else {
-                    // sources that are not staged in LDS come from global memory one batch ahead: (nfx, nfy, nfz) was
-                    // requested while the previous batch (or, for the first batch, the previous pass) was at work
-                    const float cx_ = nfx, cy_ = nfy, cz_ = nfz;
-                    int in = base + NT + tid;  // this thread's point in the next batch; past the end: the first batch again
-                    in = base + NT < ns ? (in < ns ? in : ns - 1) : (tid < ns ? tid : ns - 1);
-                    nfx = sg[3 * in]; nfy = sg[3 * in + 1]; nfz = sg[3 * in + 2];
-                    x = (F)cx_ - (F)ox; y = (F)cy_ - (F)oy; z = (F)cz_ - (F)oz;
+        // The two phases, once for each way of summing.  DEFER (point-to-plane with certificates, round 6): the correspondences are
+        // only FOUND here -- every source point's is in `prev` afterwards -- and summed in a loop of their own below.  The plane
+        // estimator carries 29 double sums per lane (58 registers): live across the search they left the bulk shape with 976 bytes
+        // of scratch per lane and ~170 reloads per batch of 64 points (46 ms at C4 against 18.5 for point-to-point); summed where
+        // nothing else is live they stay in registers.  The sums meet other lanes in another order: the same trajectories to
+        // rounding (tests: the shapes against each other and the oracle).
+        auto sweep = [&](auto defer_tag) {
+            constexpr bool DEFER = decltype(defer_tag)::value;
+            int n_search = ns;  // source points that need a search in this pass
+            if (use_cert) {
+                // ---- phase 1: re-measure last pass's correspondence of every source point; certify or queue
+                unsigned short *myq = queue + wave * seg;
+                int nq = 0;
+                for (int base = 0; base < ns; base += NT) {
+                    const int i = base + tid;
+                    const bool valid = i < ns;
+                    const int ii = valid ? i : ns - 1;  // idle lanes recompute the last point (keeps loads in bounds)
+                    F x, y, z;
+                    if (src_in_lds) { x = sl[3 * ii]; y = sl[3 * ii + 1]; z = sl[3 * ii + 2]; }
+                    else {
+                        // sources that are not staged in LDS come from global memory one batch ahead: (nfx, nfy, nfz) was
+                        // requested while the previous batch (or, for the first batch, the previous pass) was at work
+                        const float cx_ = nfx, cy_ = nfy, cz_ = nfz;
+                        int in = base + NT + tid;  // this thread's point in the next batch; past the end: the first batch again
+                        in = base + NT < ns ? (in < ns ? in : ns - 1) : (tid < ns ? tid : ns - 1);
+                        nfx = sg[3 * in]; nfy = sg[3 * in + 1]; nfz = sg[3 * in + 2];
+                        x = (F)cx_ - (F)ox; y = (F)cy_ - (F)oy; z = (F)cz_ - (F)oz;
+                    }
+                    const F px = R0 * x + R1 * y + R2 * z + t0f;
+                    const F py = R3 * x + R4 * y + R5 * z + t1f;
+                    const F pz = R6 * x + R7 * y + R8 * z + t2f;
+                    const int pv = (int)prev[ii];  // 0xffff: never searched, 0xfffe: nothing within the search radius
+                    // distance every OTHER target is still known to keep.  The certificate arrays are float32 in both modes:
+                    // bounds stored rounded down, positions with an allowance for their rounding.
+                    F room = (F)mabs[ii] - dsum;
+                    if (per_point) {
+                        const F mx = px - (F)ps[3 * ii], my = py - (F)ps[3 * ii + 1], mz = pz - (F)ps[3 * ii + 2];
+                        F moved = grid_sqrt<F>(grid_d2(mx, my, mz)) * (F)1.000001;
+                        if (sizeof(F) == 8) moved += (F)2e-7 * (fabs(px) + fabs(py) + fabs(pz));
+                        room = (F)mabs[ii] - moved;
+                    }
+                    const GridPt<F> q = tl[pv < 0xfffe ? pv : 0];
+                    F qx, qy, qz;
+                    grid_rel(g, q, qx, qy, qz);
+                    // (the same expression the search evaluates: certified and searched distances are the same bits)
+                    const F d = grid_d2(grid_query(px, g.ox) - grid_coord(q.x, px), grid_query(py, g.oy) - grid_coord(q.y, py),
+                                        grid_query(pz, g.oz) - grid_coord(q.z, pz));
+                    bool cert = pv < 0xfffe ? grid_sqrt<F>(d) * (F)1.000001 < room : (pv == 0xfffe && room > rF * (F)1.000001);
+                    cert = cert && valid;
+                    const bool hit = cert && pv < 0xfffe && d < r2;
+                    const int qid = (int)(q.tag >> 16);
+                    if (!DEFER && hit) accumulate(acc, px, py, pz, qx, qy, qz, d, qid, ii);
+                    if (a.corr_out && cert) a.corr_out[s0 + i] = hit ? qid : -1;
+                    const bool need = valid && !cert;
+                    const unsigned long long m = __ballot(need);
+                    if (need)  // position among the wave's queued lanes: set bits of m below this lane
+                        myq[nq + (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u))] =
+                            (unsigned short)i;
+                    nq += __builtin_popcountll(m);
                 }
+                if (lane == 0) qcnt[wave] = nq;
+                __syncthreads();
+                n_search = 0;
+    #pragma unroll
+                for (int w = 0; w < NW; ++w) n_search += qcnt[w];
+            }
+            PROF_T(pt_p0b);
+            PROF_ADD(15, pt_p0b, pt_p0);
+
+            // ---- phase 2: search the queued points (all points without certificates), 64 per wave
+            for (int base = wave * 64; base < n_search; base += NT) {  // a wave without queued points skips the batch
+                const int k = base + lane;
+                const bool valid = k < n_search;
+                int i = valid ? k : n_search - 1;
+                if (use_cert) {
+                    int w = 0, loc = i;
+    #pragma unroll
+                    for (int u = 0; u < NW - 1; ++u) {
+                        const int c = qcnt[u];
+                        const bool beyond = (w == u) && loc >= c;
+                        loc = beyond ? loc - c : loc;
+                        w = beyond ? w + 1 : w;
+                    }
+                    i = (int)queue[w * seg + loc];
+                }
+                F x, y, z;
+                if (src_in_lds) { x = sl[3 * i]; y = sl[3 * i + 1]; z = sl[3 * i + 2]; }
+                else { x = (F)sg[3 * i] - (F)ox; y = (F)sg[3 * i + 1] - (F)oy; z = (F)sg[3 * i + 2] - (F)oz; }
                 const F px = R0 * x + R1 * y + R2 * z + t0f;
                 const F py = R3 * x + R4 * y + R5 * z + t1f;
                 const F pz = R6 * x + R7 * y + R8 * z + t2f;
-                const int pv = (int)prev[ii];  // 0xffff: never searched, 0xfffe: nothing within the search radius
-                // distance every OTHER target is still known to keep.  The certificate arrays are float32 in both modes:
-                // bounds stored rounded down, positions with an allowance for their rounding.
-                F room = (F)mabs[ii] - dsum;
-                if (per_point) {
-                    const F mx = px - (F)ps[3 * ii], my = py - (F)ps[3 * ii + 1], mz = pz - (F)ps[3 * ii + 2];
-                    F moved = grid_sqrt<F>(grid_d2(mx, my, mz)) * (F)1.000001;
-                    if (sizeof(F) == 8) moved += (F)2e-7 * (fabs(px) + fabs(py) + fabs(pz));
-                    room = (F)mabs[ii] - moved;
-                }
-                const GridPt<F> q = tl[pv < 0xfffe ? pv : 0];
-                F qx, qy, qz;
-                grid_rel(g, q, qx, qy, qz);
-                // (the same expression the search evaluates: certified and searched distances are the same bits)
-                const F d = grid_d2(grid_query(px, g.ox) - grid_coord(q.x, px), grid_query(py, g.oy) - grid_coord(q.y, py),
-                                    grid_query(pz, g.oz) - grid_coord(q.z, pz));
-                bool cert = pv < 0xfffe ? grid_sqrt<F>(d) * (F)1.000001 < room : (pv == 0xfffe && room > rF * (F)1.000001);
-                cert = cert && valid;
-                const bool hit = cert && pv < 0xfffe && d < r2;
-                const int qid = (int)(q.tag >> 16);
-                if (hit) accumulate(px, py, pz, qx, qy, qz, d, qid, ii);
-                if (a.corr_out && cert) a.corr_out[s0 + i] = hit ? qid : -1;
-                const bool need = valid && !cert;
-                const unsigned long long m = __ballot(need);
-                if (need)  // position among the wave's queued lanes: set bits of m below this lane
-                    myq[nq + (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u))] =
-                        (unsigned short)i;
-                nq += __builtin_popcountll(m);
-            }
-            if (lane == 0) qcnt[wave] = nq;
-            __syncthreads();
-            n_search = 0;
-#pragma unroll
-            for (int w = 0; w < NW; ++w) n_search += qcnt[w];
-        }
-        PROF_T(pt_p0b);
-        PROF_ADD(15, pt_p0b, pt_p0);
-
-        // ---- phase 2: search the queued points (all points without certificates), 64 per wave
-        for (int base = wave * 64; base < n_search; base += NT) {  // a wave without queued points skips the batch
-            const int k = base + lane;
-            const bool valid = k < n_search;
-            int i = valid ? k : n_search - 1;
-            if (use_cert) {
-                int w = 0, loc = i;
-#pragma unroll
-                for (int u = 0; u < NW - 1; ++u) {
-                    const int c = qcnt[u];
-                    const bool beyond = (w == u) && loc >= c;
-                    loc = beyond ? loc - c : loc;
-                    w = beyond ? w + 1 : w;
-                }
-                i = (int)queue[w * seg + loc];
-            }
-            F x, y, z;
-            if (src_in_lds) { x = sl[3 * i]; y = sl[3 * i + 1]; z = sl[3 * i + 2]; }
-            else { x = (F)sg[3 * i] - (F)ox; y = (F)sg[3 * i + 1] - (F)oy; z = (F)sg[3 * i + 2] - (F)oz; }
-            const F px = R0 * x + R1 * y + R2 * z + t0f;
-            const F py = R3 * x + R4 * y + R5 * z + t1f;
-            const F pz = R6 * x + R7 * y + R8 * z + t2f;
-            Best<F> best;
-            F b0 = rs2;
-            if (tgt_in_lds) {
-                if (use_cert) {
-                    // last pass's correspondence, re-measured, bounds the search from the start
-                    const int pv = (int)prev[i];
-                    if (pv < 0xfffe && !(a.debug & 8)) {
-                        const GridPt<F> q = tl[pv];
-                        const F bb = grid_sqrt<F>(grid_d2(grid_query(px, g.ox) - grid_coord(q.x, px), grid_query(py, g.oy) - grid_coord(q.y, py),
-                                                          grid_query(pz, g.oz) - grid_coord(q.z, pz))) * (F)1.000001 + mu;
-                        b0 = bb * bb < rs2 ? bb * bb : rs2;
+                Best<F> best;
+                F b0 = rs2;
+                if (tgt_in_lds) {
+                    if (use_cert) {
+                        // last pass's correspondence, re-measured, bounds the search from the start
+                        const int pv = (int)prev[i];
+                        if (pv < 0xfffe && !(a.debug & 8)) {
+                            const GridPt<F> q = tl[pv];
+                            const F bb = grid_sqrt<F>(grid_d2(grid_query(px, g.ox) - grid_coord(q.x, px), grid_query(py, g.oy) - grid_coord(q.y, py),
+                                                              grid_query(pz, g.oz) - grid_coord(q.z, pz))) * (F)1.000001 + mu;
+                            b0 = bb * bb < rs2 ? bb * bb : rs2;
+                        }
                     }
+                    best.init(b0);
+    #ifdef F4L_ICP_PROF
+                    grid_nn<F, NT>(g, tl, nt, E, rl, valid, px, py, pz, best,
+                                   ((a.debug & 64) && ns <= a.prof_max_n && nt <= a.prof_max_n) ? a.prof : nullptr);
+    #else
+                    grid_nn<F, NT>(g, tl, nt, E, rl, valid, px, py, pz, best);
+    #endif
+                    if (use_cert && valid) {
+                        const F m2 = best.second < b0 ? best.second : b0;
+                        prev[i] = (unsigned short)(best.found() ? best.slot() : 0xfffe);
+                        if (per_point) {
+                            mabs[i] = (float)(grid_sqrt<F>(m2) * (F)0.999999);
+                            ps[3 * i] = (float)px; ps[3 * i + 1] = (float)py; ps[3 * i + 2] = (float)pz;
+                        } else mabs[i] = (float)((grid_sqrt<F>(m2) * (F)0.999999 + dsum) * (F)0.9999998);
+                    }
+                } else {
+                    best.init(r2);
+                    nn_global<F>(tg, nt, ox, oy, oz, px, py, pz, best);
                 }
-                best.init(b0);
+                const bool hit = valid && best.found() && best.d2() < r2;  // SearchHybrid: d2 < r^2
+                const int bj = tgt_in_lds ? best.id() : (int)best.tag();  // index inside the target patch
+                if (a.corr_out && valid) a.corr_out[s0 + i] = hit ? bj : -1;
+                if (!DEFER && hit) {
+                    F qx, qy, qz;
+                    if (tgt_in_lds) { const GridPt<F> q = tl[best.slot()]; grid_rel(g, q, qx, qy, qz); }
+                    else { qx = (F)tg[3 * bj] - (F)ox; qy = (F)tg[3 * bj + 1] - (F)oy; qz = (F)tg[3 * bj + 2] - (F)oz; }
+                    accumulate(acc, px, py, pz, qx, qy, qz, best.d2(), bj, i);
+                }
+            }
+
+            if constexpr (DEFER) {
+                __syncthreads();  // (a searched point's correspondence was written by the lane that searched it)
+                A sums[NV];        // (the pass's sums start to exist here: nothing of them is live across the search)
+#pragma unroll
+                for (int v = 0; v < NV; ++v) sums[v] = (A)0;
+                for (int base = 0; base < ns; base += NT) {
+                    const int i = base + tid;
+                    const bool valid = i < ns;
+                    const int ii = valid ? i : ns - 1;
+                    F x, y, z;
+                    if (src_in_lds) { x = sl[3 * ii]; y = sl[3 * ii + 1]; z = sl[3 * ii + 2]; }
+                    else { x = (F)sg[3 * ii] - (F)ox; y = (F)sg[3 * ii + 1] - (F)oy; z = (F)sg[3 * ii + 2] - (F)oz; }
+                    const F px = R0 * x + R1 * y + R2 * z + t0f;
+                    const F py = R3 * x + R4 * y + R5 * z + t1f;
+                    const F pz = R6 * x + R7 * y + R8 * z + t2f;
+                    const int pv = (int)prev[ii];
+                    const GridPt<F> q = tl[pv < 0xfffe ? pv : 0];
+                    F qx, qy, qz;
+                    grid_rel(g, q, qx, qy, qz);
+                    // (the expression of phase 1 and of the search: the same bits, so the same `d < r2`)
+                    const F d = grid_d2(grid_query(px, g.ox) - grid_coord(q.x, px), grid_query(py, g.oy) - grid_coord(q.y, py),
+                                        grid_query(pz, g.oz) - grid_coord(q.z, pz));
+                    if (valid && pv < 0xfffe && d < r2) accumulate(sums, px, py, pz, qx, qy, qz, d, (int)(q.tag >> 16), ii);
+                }
+#pragma unroll
+                for (int v = 0; v < NV; ++v) acc[v] = sums[v];
+            }
 #ifdef F4L_ICP_PROF
-                grid_nn<F, NT>(g, tl, nt, E, rl, valid, px, py, pz, best,
-                               ((a.debug & 64) && ns <= a.prof_max_n && nt <= a.prof_max_n) ? a.prof : nullptr);
-#else
-                grid_nn<F, NT>(g, tl, nt, E, rl, valid, px, py, pz, best);
+            PROF_T(pt_p1_);
+            PROF_ADD(2, pt_p1_, pt_p0b);
 #endif
-                if (use_cert && valid) {
-                    const F m2 = best.second < b0 ? best.second : b0;
-                    prev[i] = (unsigned short)(best.found() ? best.slot() : 0xfffe);
-                    if (per_point) {
-                        mabs[i] = (float)(grid_sqrt<F>(m2) * (F)0.999999);
-                        ps[3 * i] = (float)px; ps[3 * i + 1] = (float)py; ps[3 * i + 2] = (float)pz;
-                    } else mabs[i] = (float)((grid_sqrt<F>(m2) * (F)0.999999 + dsum) * (F)0.9999998);
-                }
-            } else {
-                best.init(r2);
-                nn_global<F>(tg, nt, ox, oy, oz, px, py, pz, best);
-            }
-            const bool hit = valid && best.found() && best.d2() < r2;  // SearchHybrid: d2 < r^2
-            const int bj = tgt_in_lds ? best.id() : (int)best.tag();  // index inside the target patch
-            if (a.corr_out && valid) a.corr_out[s0 + i] = hit ? bj : -1;
-            if (hit) {
-                F qx, qy, qz;
-                if (tgt_in_lds) { const GridPt<F> q = tl[best.slot()]; grid_rel(g, q, qx, qy, qz); }
-                else { qx = (F)tg[3 * bj] - (F)ox; qy = (F)tg[3 * bj + 1] - (F)oy; qz = (F)tg[3 * bj + 2] - (F)oz; }
-                accumulate(px, py, pz, qx, qy, qz, best.d2(), bj, i);
-            }
+        };
+        if constexpr (MODE == F4L_ICP_POINT2PLANE) {
+            if (use_cert && !(a.debug & 2048)) sweep(std::true_type{});  // (F4L_ICP_DEBUG bit 2048: sum where the points are found, the A/B)
+            else sweep(std::false_type{});
+        } else {
+            sweep(std::false_type{});
         }
 
         PROF_T(pt_p1);
-        PROF_ADD(2, pt_p1, pt_p0b);
         // DPP reduction inside the wave, then the NW partials (as double) through LDS; one wave solves
         {
             A xs[NV / 4], ys[NV % 4 > 0 ? NV % 4 : 1];
