@@ -354,6 +354,22 @@ __device__ __noinline__ void icp_prepass(const PrepassArgs<F, NT> &q) {
 
 // WIDE = the register budget of three waves per SIMD (170 VGPRs) instead of four (128): the float64 build keeps ~50 VGPRs
 // in scratch at 128.  Worth it only for two-wave workgroups in the throughput regime (see icp_shape).
+// The sweep of a pass (phases 1 and 2 of icp_kernel) as a block, or -- in the throughput shapes' translation units -- as a generic lambda
+// instantiated for both ways of summing (DEFER: see the kernel).  F4L_ICP_DEBUG bit 2048: sum where the points are found (the A/B).
+#ifdef F4L_ICP_BULK_TU
+#define ICP_SWEEP_OPEN auto sweep = [&](auto defer_tag) { constexpr bool DEFER = decltype(defer_tag)::value;
+#define ICP_SWEEP_CLOSE                                                                   \
+    };                                                                                    \
+    if constexpr (MODE == F4L_ICP_POINT2PLANE) {                                          \
+        if (use_cert && !(a.debug & 2048)) sweep(std::true_type{});                       \
+        else sweep(std::false_type{});                                                    \
+    } else {                                                                              \
+        sweep(std::false_type{});                                                         \
+    }
+#else
+#define ICP_SWEEP_OPEN { constexpr bool DEFER = false;
+#define ICP_SWEEP_CLOSE }
+#endif
 template <int MODE, int NW, typename F, bool WIDE = false>
 __global__ __launch_bounds__(NW * 64, WIDE ? (MODE == F4L_ICP_POINT2POINT ? 3 : ICP_WIDE_PLANE_WPE) : (sizeof(F) == 8 ? ICP_WAVES_PER_EU_F64 : ICP_WAVES_PER_EU)) void icp_kernel(IcpArgs a) {
     constexpr int NV = (MODE == F4L_ICP_POINT2POINT) ? 17 : 29;
@@ -665,8 +681,9 @@ __global__ __launch_bounds__(NW * 64, WIDE ? (MODE == F4L_ICP_POINT2POINT ? 3 : 
         // of scratch per lane and ~170 reloads per batch of 64 points (46 ms at C4 against 18.5 for point-to-point); summed where
         // nothing else is live they stay in registers.  The sums meet other lanes in another order: the same trajectories to
         // rounding (tests: the shapes against each other and the oracle).
-        auto sweep = [&](auto defer_tag) {
-            constexpr bool DEFER = decltype(defer_tag)::value;
+        // (Only the throughput shapes' translation units take this form: as a generic lambda the sweep schedules 1 % better there under the
+        //  default scheduler and 2-4 % worse in the shapes a 1 M-point tile runs in -- C2 0.688 against 0.660 ms -- which keep the plain block.)
+        ICP_SWEEP_OPEN
             int n_search = ns;  // source points that need a search in this pass
             if (use_cert) {
                 // ---- phase 1: re-measure last pass's correspondence of every source point; certify or queue
@@ -824,13 +841,7 @@ __global__ __launch_bounds__(NW * 64, WIDE ? (MODE == F4L_ICP_POINT2POINT ? 3 : 
             PROF_T(pt_p1_);
             PROF_ADD(2, pt_p1_, pt_p0b);
 #endif
-        };
-        if constexpr (MODE == F4L_ICP_POINT2PLANE) {
-            if (use_cert && !(a.debug & 2048)) sweep(std::true_type{});  // (F4L_ICP_DEBUG bit 2048: sum where the points are found, the A/B)
-            else sweep(std::false_type{});
-        } else {
-            sweep(std::false_type{});
-        }
+        ICP_SWEEP_CLOSE
 
         PROF_T(pt_p1);
         // DPP reduction inside the wave, then the NW partials (as double) through LDS; one wave solves
@@ -1093,14 +1104,17 @@ __global__ __launch_bounds__(NW * 64, WIDE ? (MODE == F4L_ICP_POINT2POINT ? 3 : 
 
 }  // namespace f4l
 
-// The throughput shapes (WIDE: the bulk class of a large batch, bench.py's headline launch) live in a translation unit of their own,
-// this file compiled again with -DF4L_ICP_BULK_TU and the ILP-first scheduling strategy (csrc/Makefile: icp_bulk.o): that
-// scheduler is worth 1 % there (18.62 -> 18.44 ms at C4) and costs the shapes a 1 M-point tile runs in 7 % (profiles/
-// r5_icp_occupancy_and_registers.log section 8), and the strategy is a per-file compiler option.
+// The throughput shapes (WIDE: the bulk class of a large batch, bench.py's headline launch) live in translation units of their own,
+// this file compiled again with -DF4L_ICP_BULK_TU=1 (point-to-point) and -DF4L_ICP_BULK_TU=2 (point-to-plane): the instruction
+// scheduler is a per-file compiler option and the shapes want different ones (csrc/Makefile: icp_bulk.o, icp_bulk_plane.o;
+// profiles/r6_aa_icp_bulk_schedulers.log).
 namespace f4l {
 #ifdef F4L_ICP_BULK_TU
-template __global__ void icp_kernel<0, 2, double, true>(IcpArgs);
+#if F4L_ICP_BULK_TU == 2  // (icp_bulk_plane.o: the plane estimator's shape, under the scheduler that suits it -- csrc/Makefile)
 template __global__ void icp_kernel<1, 2, double, true>(IcpArgs);
+#else
+template __global__ void icp_kernel<0, 2, double, true>(IcpArgs);
+#endif
 #else
 extern template __global__ void icp_kernel<0, 2, double, true>(IcpArgs);
 extern template __global__ void icp_kernel<1, 2, double, true>(IcpArgs);
