@@ -1,6 +1,6 @@
 #!/bin/bash
 # Usage (GPU box, repo root): bash tools/gpu/profile_r6.sh <outdir> -- the rocprofv3 --kernel-trace --stats summaries and un-profiled timings committed
-# under profiles/r6_v_* (the state at the end of round 6): profile_r5.sh's commands with the default (identical) partition in the lead.
+# under profiles/r6_ae_* (the state at the end of round 6): profile_r5.sh's commands with the default (identical) partition in the lead.
 OUT="${1:?usage: $0 <outdir>}"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp; cd "${GRAFT_REPO_ROOT:?set GRAFT_REPO_ROOT (gpurun exports it: the root of the snapshot)}"
 run() {  # name, command...
