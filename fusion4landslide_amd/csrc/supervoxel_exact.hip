@@ -965,6 +965,8 @@ __global__ void xch_generation_kernel(XchArgs a, const unsigned long long *__res
 // coalesced 4 k-byte row per entry, four entries per wavefront) and reduced across them.
 constexpr int XCH_PER_WG = 64;  // entries of a generation per workgroup of xch_eval_kernel
 __global__ __launch_bounds__(256) void xch_eval_kernel(XchArgs a, int m, int pass) {
+    // (the host looks at the flags every second pass: a pass queued behind the one that changed nothing returns at once)
+    if (pass > 0 && a.st->changed[(pass - 1) & 7] == 0) return;
     const int lane = lane_id(), sub = lane & 15;
     bool differs = false;
     // (a workgroup takes 64 consecutive entries of the generation, and an XCD -- whose L2 is its own -- one contiguous eighth of it with
@@ -1290,6 +1292,7 @@ static int segment_exact_run(const float *xyz, const double *normals, const int3
     hipLaunchKernelGGL(svx::xch_first_keys_kernel, g, b, 0, st, xa, (const int32_t *)w.root);
     F4L_LAUNCH_CHECK();
     int generations = 0, xpasses = 0;
+    const bool xch_jacobi = getenv("F4L_SV_EXACT_XCH_JACOBI") != nullptr;
     for (;; ++generations) {
         if (generations >= MAX_GENERATIONS) return F4L_EUNSUPPORTED;
         // the next generation: the nodes with a key, in key order
@@ -1312,7 +1315,13 @@ static int segment_exact_run(const float *xyz, const double *normals, const int3
         while (!converged) {
             for (int batch = 0; batch < 2; ++batch, ++it, ++xpasses) {
                 if (it >= MAX_ITERS) return F4L_EUNSUPPORTED;
-                xa.out_rd = w.out[rd]; xa.out_wr = w.out[rd ^ 1]; xa.ch_rd = w.ch[rd]; xa.ch_wr = w.ch[rd ^ 1]; xa.dis_wr = w.dis2[rd ^ 1];
+                // (the estimate is updated IN PLACE since round 6: an entry's label is one word, so a reader sees the old or the new one,
+                //  and either is an estimate -- the fixed point is unique, recursion on the position in the generation -- while entries whose
+                //  earlier neighbours were through before them see their final labels in the same pass: fewer passes.  A pass that changes
+                //  nothing wrote nothing, so it read the state every entry agrees with.  F4L_SV_EXACT_XCH_JACOBI=1: two buffers, as before.)
+                if (xch_jacobi) { xa.out_rd = w.out[rd]; xa.out_wr = w.out[rd ^ 1]; xa.ch_rd = w.ch[rd]; xa.ch_wr = w.ch[rd ^ 1]; }
+                else { xa.out_rd = w.out[0]; xa.out_wr = w.out[0]; xa.ch_rd = w.ch[0]; xa.ch_wr = w.ch[0]; }
+                xa.dis_wr = w.dis2[0];  // (written by every pass that runs, read by the commit only)
                 F4L_HIP_CHECK(hipMemsetAsync(&w.st->changed[it & 7], 0, 4, st));
 #ifndef SVX_NO_XCD_MAP
                 hipLaunchKernelGGL(svx::xch_eval_kernel, dim3((unsigned)((m + svx::XCH_PER_WG - 1) / svx::XCH_PER_WG)), b, 0, st, xa, m, it);
@@ -1325,10 +1334,12 @@ static int segment_exact_run(const float *xyz, const double *normals, const int3
             rc = read_state();
             if (rc != F4L_OK) return rc;
             converged = hs.changed[(it - 1) & 7] == 0;
+            if (getenv("F4L_SV_EXACT_DEBUG")) fprintf(stderr, "[sv exact] generation %d (%d entries): passes %d and %d changed something: %d, %d\n", generations, m, it - 2, it - 1, hs.changed[(it - 2) & 7], hs.changed[(it - 1) & 7]);
         }
-        xa.out_rd = w.out[rd]; xa.ch_rd = w.ch[rd];
+        if (xch_jacobi) { xa.out_rd = w.out[rd]; xa.ch_rd = w.ch[rd]; }
+        else { xa.out_rd = w.out[0]; xa.ch_rd = w.ch[0]; }
         hipLaunchKernelGGL(svx::xch_push_kernel, g, b, 0, st, xa, m);
-        hipLaunchKernelGGL(svx::xch_commit_kernel, g, b, 0, st, xa, m, (const double *)w.dis2[rd]);
+        hipLaunchKernelGGL(svx::xch_commit_kernel, g, b, 0, st, xa, m, (const double *)w.dis2[0]);
         F4L_LAUNCH_CHECK();
     }
     // ---- relabel (:241-247)
