@@ -508,6 +508,30 @@ def extras(torch, engine, synthetic, prob, dev, args):
             del r
             engine.release_scratch()
             torch.cuda.empty_cache()
+        if n_pts == 1_000_000:
+            # The reference's labels depend on the ORDER of the points (the sequential fusion visits them by index), and so does the
+            # number of passes the fixed-point form needs.  The clouds above are patch by patch (random inside a patch): the
+            # favourable case.  The same cloud in the order a voxel-grid filter or the tiler writes, in Morton order and shuffled:
+            res_m = float((3.0 ** 0.5) * 10.0 * engine.median_resolution(src))
+            cell = ((src - src.min(0).values) / 0.05).floor().to(torch.int64)
+            nx, ny = int(cell[:, 0].max()) + 1, int(cell[:, 1].max()) + 1
+
+            def spread(v):
+                v = v & 0xFFFF; v = (v | (v << 8)) & 0x00FF00FF; v = (v | (v << 4)) & 0x0F0F0F0F
+                v = (v | (v << 2)) & 0x33333333; return (v | (v << 1)) & 0x55555555
+            orders = {"patch_by_patch": None,
+                      "voxel_index_x_fastest": torch.argsort((cell[:, 2] * ny + cell[:, 1]) * nx + cell[:, 0], stable=True),
+                      "morton_xy": torch.argsort(spread(cell[:, 0]) | (spread(cell[:, 1]) << 1), stable=True),
+                      "shuffled": torch.randperm(n_pts, device=dev, generator=torch.Generator(device=dev).manual_seed(1))}
+            ms = {}
+            for name, o in orders.items():
+                pts = src if o is None else src[o].contiguous()
+                engine.supervoxel(pts, 30, res_m)
+                ms[name] = round(1e3 * _timed(torch, lambda: engine.supervoxel(pts, 30, res_m), 3), 2)
+                del pts
+            out["partition_1M_by_point_order_ms"] = dict(ms, note="f4l_supervoxel (the reference's labels) of the same 1 M points in four orders: the "
+                                                         "sequential algorithm's dependency chains, hence the passes, follow the index order")
+            del cell, orders
         del src, tgt
         torch.cuda.empty_cache()
     return out
