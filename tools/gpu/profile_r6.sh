@@ -1,6 +1,6 @@
 #!/bin/bash
 # Usage (GPU box, repo root): bash tools/gpu/profile_r6.sh <outdir> -- the rocprofv3 --kernel-trace --stats summaries and un-profiled timings committed
-# under profiles/r6_ae_* (the state at the end of round 6): profile_r5.sh's commands with the default (identical) partition in the lead.
+# under profiles/r6_am_* (the state at the end of round 6): profile_r5.sh's commands with the default (identical) partition in the lead.
 OUT="${1:?usage: $0 <outdir>}"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp; cd "${GRAFT_REPO_ROOT:?set GRAFT_REPO_ROOT (gpurun exports it: the root of the snapshot)}"
 run() {  # name, command...
@@ -9,7 +9,6 @@ run() {  # name, command...
   cp $OUT/$name/*/*_kernel_stats.csv $OUT/${name}_kernel_stats.csv
   rm -rf $OUT/$name
 }
-python3 bench.py > $OUT/bench_C4.json.log 2> $OUT/bench_C4.err
 run C4_50M_100k python3 bench.py --config C4_50M_100k --cpu-seconds 0 --extras 0 --steps 50 --warmup 5
 run C3_10M_20k python3 bench.py --config C3_10M_20k --cpu-seconds 0 --extras 0 --steps 50 --warmup 5
 run C2_1M_2k python3 bench.py --config C2_1M_2k --cpu-seconds 0 --extras 0 --steps 50 --warmup 5
@@ -24,3 +23,7 @@ F4L_SV_EXACT_DEBUG=1 python3 tools/gpu/svx_sizes.py > $OUT/sv_exact_sizes.log 2>
 timeout 900 python3 tools/gpu/svx_100M_vs_host.py 100000000 > $OUT/svx_100M_vs_host.log 2>&1
 bash tools/gpu/roofline_pmc.sh $OUT/pmc > $OUT/pmc.log 2>&1
 ls $OUT
+# (the bench line last: bench.py reads the traffic of its roofline objects from profiles/*_counters.json, which are hash-guarded to the kernel
+#  sources -- after a kernel change they are stale until tools/make_roofline_profiles.py has turned the passes above into new ones)
+python3 tools/make_roofline_profiles.py $OUT/pmc r6_tmp > /dev/null 2>&1
+python3 bench.py > $OUT/bench_C4.json.log 2>> $OUT/bench_C4.err
