@@ -48,6 +48,9 @@ namespace f4l {
 #ifndef ICP_WAVES_PER_EU
 #define ICP_WAVES_PER_EU 4
 #endif
+#ifndef ICP_WIDE_WPE
+#define ICP_WIDE_WPE 3  // (the headline shape: 168 registers; 2 and 4 measured in round 6, profiles/r6_an_*)
+#endif
 #ifndef ICP_WIDE_PLANE_WPE
 #define ICP_WIDE_PLANE_WPE 3  // (the plane estimators' bulk shape; 2 = 256 registers: measured)
 #endif
@@ -371,7 +374,7 @@ __device__ __noinline__ void icp_prepass(const PrepassArgs<F, NT> &q) {
 #define ICP_SWEEP_CLOSE }
 #endif
 template <int MODE, int NW, typename F, bool WIDE = false>
-__global__ __launch_bounds__(NW * 64, WIDE ? (MODE == F4L_ICP_POINT2POINT ? 3 : ICP_WIDE_PLANE_WPE) : (sizeof(F) == 8 ? ICP_WAVES_PER_EU_F64 : ICP_WAVES_PER_EU)) void icp_kernel(IcpArgs a) {
+__global__ __launch_bounds__(NW * 64, WIDE ? (MODE == F4L_ICP_POINT2POINT ? ICP_WIDE_WPE : ICP_WIDE_PLANE_WPE) : (sizeof(F) == 8 ? ICP_WAVES_PER_EU_F64 : ICP_WAVES_PER_EU)) void icp_kernel(IcpArgs a) {
     constexpr int NV = (MODE == F4L_ICP_POINT2POINT) ? 17 : 29;
     constexpr int NT = NW * 64;
     // Correspondence sums.  float32 search + point-to-point: per-lane partial sums and the in-wave reduction are
